@@ -1,0 +1,9 @@
+"""MI355X-native MINTIME hot path: EfficientNet-B0 feature extractor + Size-Invariant TimeSformer.
+
+Host side is Python on PyTorch-ROCm (tensors, autograd plumbing); all arithmetic runs in the
+hand-written HIP library `csrc/libmintime_hip.so` (C ABI declared in include/mintime_hip.h).
+There is no CPU or eager-PyTorch fallback: every op raises if the library is missing.
+"""
+from . import arch, synth  # noqa: F401
+
+__all__ = ["arch", "synth"]

@@ -1,0 +1,245 @@
+"""CPU ORACLE for the MINTIME hot path -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+A plain-PyTorch-CPU (fp32 or fp64) functional restatement of the reference's forward for
+  * EfficientNet-B0 feature extractor (reference models/efficientnet/efficientnet_pytorch/model.py:267-288,
+    MBConvBlock.forward model.py:89-128, TF-SAME conv utils.py:248-276, swish utils.py:64-80,
+    drop_connect utils.py:129-154)
+  * SizeInvariantTimeSformer (reference models/size_invariant_timesformer.py:224-276, Attention.forward
+    :109-144, attn() :80-87, GEGLU/FeedForward :60-76, PreNorm :18-26)
+written from the op graph, operating on a state-dict with the reference's keys.  Backward comes from
+torch autograd over these same ops.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; the product
+path (the HIP library and its Python host) never does and has no CPU fallback.
+
+PARITY PIN: the reference holds no golden vectors or numerical tests for this path, so
+this oracle is pinned against outputs of the reference itself, generated in the build container by
+tools/make_golden.py (imports /root/reference, loads the same seeded state-dicts) and committed as
+tests/golden/*.npz; tests/test_oracle_golden.py checks every one of them.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+FLT_MAX = torch.finfo(torch.float32).max
+
+
+# --------------------------------------------------------------------------------------------
+# EfficientNet-B0
+# --------------------------------------------------------------------------------------------
+_B0_STAGES = [  # (repeats, k, s, e, cin, cout)   utils.py:502-510
+    (1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+    (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
+_BN_EPS = 1e-3      # utils.py:521
+_BN_MOM = 0.01      # model.py:51
+_DROP_CONNECT = 0.2  # utils.py:522
+
+
+def _b0_blocks():
+    out = []
+    for (r, k, s, e, cin, cout) in _B0_STAGES:
+        for j in range(r):
+            out.append(dict(k=k, s=s if j == 0 else 1, e=e, cin=cin if j == 0 else cout, cout=cout,
+                            skip=(j > 0)))   # model.py:123 (+ utils.py:394: stage-first stride is a list)
+    return out
+
+
+def _same_conv(x, w, stride, groups=1):
+    """TF-SAME zero padding then conv with padding 0 (utils.py:248-276)."""
+    ih, iw = x.shape[-2:]
+    kh, kw = w.shape[-2:]
+    oh, ow = -(-ih // stride), -(-iw // stride)
+    ph = max((oh - 1) * stride + kh - ih, 0)
+    pw = max((ow - 1) * stride + kw - iw, 0)
+    if ph > 0 or pw > 0:
+        x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+    return F.conv2d(x, w, None, stride, 0, 1, groups)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)   # utils.py:67
+
+
+class BNState:
+    """Collects train-mode running-stat updates (the reference updates module buffers in place)."""
+
+    def __init__(self):
+        self.updates = {}
+
+
+def _bn(x, sd, prefix, training, bn_state: Optional[BNState]):
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    if not training:
+        return F.batch_norm(x, rm, rv, w, b, False, _BN_MOM, _BN_EPS)
+    rm2, rv2 = rm.detach().clone(), rv.detach().clone()
+    y = F.batch_norm(x, rm2, rv2, w, b, True, _BN_MOM, _BN_EPS)
+    if bn_state is not None:
+        bn_state.updates[prefix + ".running_mean"] = rm2
+        bn_state.updates[prefix + ".running_var"] = rv2
+    return y
+
+
+def effnet_b0_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool = False,
+                      drop_connect_rate: float = 0.0, bn_state: Optional[BNState] = None,
+                      taps: Optional[dict] = None):
+    """x [N,3,224,224] (any strides) -> features [N,1280,7,7].  model.py:267-288.
+
+    training=True uses batch statistics in every BN (train.py:157).  drop_connect_rate must be 0 for
+    parity runs (the reference's per-sample Bernoulli gate, utils.py:129-154, is RNG-dependent).
+    """
+    assert drop_connect_rate == 0.0 or not training, "oracle parity is defined for drop_connect_rate=0"
+    x = _swish(_bn(_same_conv(x, sd["_conv_stem.weight"], 2), sd, "_bn0", training, bn_state))  # model.py:276
+    if taps is not None:
+        taps["stem"] = x
+    for i, b in enumerate(_b0_blocks()):
+        p = f"_blocks.{i}."
+        inp = x
+        if b["e"] != 1:                                                    # model.py:98-101
+            x = _swish(_bn(F.conv2d(x, sd[p + "_expand_conv.weight"]), sd, p + "_bn0", training, bn_state))
+        cexp = x.shape[1]
+        x = _same_conv(x, sd[p + "_depthwise_conv.weight"], b["s"], groups=cexp)   # model.py:103
+        x = _swish(_bn(x, sd, p + "_bn1", training, bn_state))
+        s = F.adaptive_avg_pool2d(x, 1)                                     # model.py:108-113
+        s = _swish(F.conv2d(s, sd[p + "_se_reduce.weight"], sd[p + "_se_reduce.bias"]))
+        s = F.conv2d(s, sd[p + "_se_expand.weight"], sd[p + "_se_expand.bias"])
+        x = torch.sigmoid(s) * x
+        x = _bn(F.conv2d(x, sd[p + "_project_conv.weight"]), sd, p + "_bn2", training, bn_state)  # :116-117
+        if b["skip"] and b["cin"] == b["cout"]:
+            x = x + inp                                                     # model.py:123-127 (drop_connect = id)
+        if taps is not None:
+            taps[f"block{i}"] = x
+    x = _swish(_bn(F.conv2d(x, sd["_conv_head.weight"]), sd, "_bn1", training, bn_state))   # model.py:286
+    return x
+
+
+# --------------------------------------------------------------------------------------------
+# Size-Invariant TimeSformer
+# --------------------------------------------------------------------------------------------
+
+def _attn_core(q, k, v, mask=None):
+    """size_invariant_timesformer.py:80-87: fill (not add) with -FLT_MAX, softmax, weighted sum."""
+    sim = torch.einsum("bid,bjd->bij", q, k)
+    if mask is not None:
+        sim = sim.masked_fill(~mask, -torch.finfo(sim.dtype).max)
+    p = sim.softmax(dim=-1)
+    return torch.einsum("bij,bjd->bid", p, v), p
+
+
+def _attention(x, sd, prefix, heads, dim_head, mode, n, f, frame_mask, cls_mask):
+    """Attention.forward (:109-144).  mode 'time' regroups tokens '(b n) f d', 'space' '(b f) n d'."""
+    B, N, D = x.shape
+    qkv = F.linear(x, sd[prefix + "to_qkv.weight"])                         # :111 (no bias)
+    q, k, v = qkv.chunk(3, dim=-1)
+
+    def heads_split(t):                                                     # :112  b n (h d) -> (b h) n d
+        return t.reshape(B, N, heads, dim_head).permute(0, 2, 1, 3).reshape(B * heads, N, dim_head)
+
+    q, k, v = map(heads_split, (q, k, v))
+    q = q * (dim_head ** -0.5)                                              # :114 (cls query scaled too)
+    cls_q, q_ = q[:, :1], q[:, 1:]
+    cls_k, k_ = k[:, :1], k[:, 1:]
+    cls_v, v_ = v[:, :1], v[:, 1:]
+    cls_out, cls_att = _attn_core(cls_q, k, v, cls_mask)                    # :120  cls attends to all N keys
+    BH = B * heads
+
+    def regroup(t):                                                         # :122
+        t = t.reshape(BH, f, n, dim_head)
+        if mode == "time":
+            return t.permute(0, 2, 1, 3).reshape(BH * n, f, dim_head)
+        return t.reshape(BH * f, n, dim_head)
+
+    q_, k_, v_ = map(regroup, (q_, k_, v_))
+    r = q_.shape[0] // BH
+    ck = cls_k.repeat_interleave(r, dim=0)                                  # :125-126  (b r) () d
+    cv = cls_v.repeat_interleave(r, dim=0)
+    k_ = torch.cat((ck, k_), dim=1)                                         # :128-129
+    v_ = torch.cat((cv, v_), dim=1)
+    out, _ = _attn_core(q_, k_, v_, frame_mask if mode == "time" else None)  # :132
+    if mode == "time":                                                      # :135
+        out = out.reshape(BH, n, f, dim_head).permute(0, 2, 1, 3).reshape(BH, f * n, dim_head)
+    else:
+        out = out.reshape(BH, f * n, dim_head)
+    out = torch.cat((cls_out, out), dim=1)                                  # :138
+    out = out.reshape(B, heads, N, dim_head).permute(0, 2, 1, 3).reshape(B, N, heads * dim_head)  # :141
+    out = F.linear(out, sd[prefix + "to_out.0.weight"], sd[prefix + "to_out.0.bias"])            # :144
+    return out, cls_att
+
+
+def tsf_forward(sd: Dict[str, torch.Tensor], cfg: dict, x: torch.Tensor, mask: torch.Tensor,
+                identities_mask: torch.Tensor, size_embedding: torch.Tensor, positions: torch.Tensor,
+                require_attention: bool = False, taps: Optional[dict] = None):
+    """x [B,F,C,7,7] -> logits [B,1] (and [space_cls_att, time_cls_att] of the last layer).  :224-276."""
+    m = cfg["model"]
+    heads, dim_head, depth, dim = m["heads"], m["dim-head"], m["depth"], m["dim"]
+    b, f, c, h, w = x.shape
+    n = h * w
+    x = x.permute(0, 1, 3, 4, 2).reshape(b, f * n, c)                       # :227  b f c h w -> b (f h w) c
+    tok = F.linear(x, sd["to_patch_embedding.weight"], sd["to_patch_embedding.bias"])   # :228
+    cls = sd["cls_token"].unsqueeze(0).expand(b, -1, -1)                    # :231
+    x = torch.cat((cls, tok), dim=1)                                        # :232
+    x = x + F.embedding(positions, sd["pos_emb.weight"])                    # :235-236
+    if m["enable-size-emb"]:                                                # :241-248
+        se = size_embedding.to(x.device).repeat_interleave(n, dim=1)
+        se = torch.cat((torch.zeros(b, 1, dtype=se.dtype), se), dim=1).int()
+        x = x + F.embedding(se, sd["size_emb.weight"])
+    if taps is not None:
+        taps["tokens"] = x
+    fm = mask.unsqueeze(1).expand(b, f, f) & identities_mask               # :252-253
+    fm = F.pad(fm, (1, 0), value=True)                                      # :254
+    frame_mask = fm.reshape(b, 1, 1, f, f + 1).expand(b, heads, n, f, f + 1).reshape(b * heads * n, f, f + 1)  # :255
+    cm = mask.repeat_interleave(n, dim=1)                                   # :259  b (f n)
+    cm = F.pad(cm, (1, 0), value=True)                                      # :260
+    cls_mask = cm.reshape(b, 1, 1, -1).expand(b, heads, 1, cm.shape[-1]).reshape(b * heads, 1, -1)
+
+    def ln(t, prefix):
+        return F.layer_norm(t, (dim,), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
+
+    cls_rows = []
+    for i in range(depth):                                                  # :263-268
+        p = f"layers.{i}."
+        y, t_att = _attention(ln(x, p + "0.norm"), sd, p + "0.fn.", heads, dim_head, "time", n, f, frame_mask, cls_mask)
+        x = x + y
+        y, s_att = _attention(ln(x, p + "1.norm"), sd, p + "1.fn.", heads, dim_head, "space", n, f, None, cls_mask)
+        x = x + y
+        hdn = F.linear(ln(x, p + "2.norm"), sd[p + "2.fn.net.0.weight"], sd[p + "2.fn.net.0.bias"])
+        a, g = hdn.chunk(2, dim=-1)                                         # :61-63 GEGLU, exact-erf gelu
+        hdn = a * F.gelu(g)
+        x = F.linear(hdn, sd[p + "2.fn.net.3.weight"], sd[p + "2.fn.net.3.bias"]) + x
+        cls_rows.append(x[:, 0])
+    if taps is not None:
+        taps["cls_rows"] = torch.stack(cls_rows)
+        taps["x_final"] = x
+    out = F.linear(ln(x[:, 0], "to_out.0"), sd["to_out.1.weight"], sd["to_out.1.bias"])   # :270-276
+    if require_attention:
+        return out, [s_att, t_att]                                          # :271 order [space, time]
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# The caller's step (train.py:332-378, test.py:235-247) restated for synthetic inputs
+# --------------------------------------------------------------------------------------------
+
+def clip_forward(ef_sd, tsf_sd, cfg, batch, training_extractor=False, require_attention=False,
+                 bn_state=None, taps=None):
+    v = batch["videos"]
+    b, f, h, w, c = v.shape
+    vid = v.reshape(b * f, h, w, c).permute(0, 3, 1, 2)                     # train.py:341 (view; NHWC strides)
+    feats = effnet_b0_forward(ef_sd, vid, training=training_extractor, bn_state=bn_state, taps=taps)
+    if taps is not None:
+        taps["features"] = feats
+    feats = feats.reshape(b, f, *feats.shape[1:])                           # train.py:354
+    return tsf_forward(tsf_sd, cfg, feats, batch["mask"], batch["identities_mask"],
+                       batch["size_embedding"], batch["positions"], require_attention, taps)
+
+
+def bce_with_logits(logits, labels, pos_weight=None):
+    """train.py:261,367-368: BCEWithLogitsLoss(pos_weight) on [B,1] logits vs [B,1] float labels."""
+    pw = None if pos_weight is None else torch.as_tensor([pos_weight], dtype=logits.dtype)
+    return F.binary_cross_entropy_with_logits(logits, labels.reshape(-1, 1).to(logits.dtype), pos_weight=pw)
+
+
+def to_dtype(sd, dtype):
+    return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}

@@ -1,0 +1,33 @@
+"""Shared helpers for the parity tests."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# north_star tolerance: outputs within 1e-3 relative, fp32.
+REL_TOL = 1e-3
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def rel_err(got, ref):
+    """max|got-ref| / max|ref|  (the per-tensor gate of SURVEY.md §8c)."""
+    got = torch.as_tensor(np.asarray(got)).double() if not torch.is_tensor(got) else got.detach().cpu().double()
+    ref = torch.as_tensor(np.asarray(ref)).double() if not torch.is_tensor(ref) else ref.detach().cpu().double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    den = ref.abs().max().item()
+    return (got - ref).abs().max().item() / max(den, 1e-30)
+
+
+def assert_close(got, ref, tol=REL_TOL, what=""):
+    e = rel_err(got, ref)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+    return e
+
+
+def checksum(t):
+    return float(t.double().sum())

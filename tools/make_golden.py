@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE implementation (imported from /root/reference,
+CPU, fp32 + one fp64 pass) on this repo's seeded weights and synthetic inputs.
+
+Runs only in the build container (the reference does not exist on the GPU box).  Nothing from the
+reference's source enters the repo: the fixtures are inputs' checksums and output tensors.
+
+    python tools/make_golden.py            # writes every fixture
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import mintime_amd  # noqa: E402  (alias of the hyphen-named package)
+from mintime_amd import arch, synth  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))   # size_invariant_timesformer.py:8 imports it, unused
+    # the reference's `models` package must win over this repo's drop-in `models/`
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[k]
+    sys.path.insert(0, REF)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from models.size_invariant_timesformer import SizeInvariantTimeSformer
+        from models.efficientnet.efficientnet_pytorch import EfficientNet
+    assert SizeInvariantTimeSformer.__module__ == "models.size_invariant_timesformer"
+    import models
+    assert models.__path__[0].startswith(REF), models.__path__
+    return EfficientNet, SizeInvariantTimeSformer
+
+
+def checksum(t):
+    return float(t.double().sum())
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def build_tsf(TSF, cfg, seed, require_attention, dtype=torch.float32):
+    model = TSF(config=cfg, require_attention=require_attention)
+    sd = synth.tsf_state(cfg, seed)
+    missing = model.load_state_dict(sd, strict=True)
+    model.eval()
+    return model.to(dtype), sd
+
+
+def tsf_case(TSF, name, batch, frames, channels, identities, ragged, seed):
+    cfg = arch.default_tsf_config(channels=channels, num_frames=frames)
+    model, sd = build_tsf(TSF, cfg, seed, True)
+    feats = synth.features(batch, frames, channels, seed)
+    aux = synth.clip_inputs(batch, frames, identities, seed, ragged=ragged, with_video=False)
+    rows = []
+    hooks = []
+    for i in range(1, cfg["model"]["depth"]):
+        hooks.append(model.layers[i][0].register_forward_pre_hook(lambda m, a: rows.append(a[0][:, 0].detach().clone())))
+    hooks.append(model.to_out.register_forward_pre_hook(lambda m, a: rows.append(a[0].detach().clone())))
+    tok = []
+    hooks.append(model.layers[0][0].register_forward_pre_hook(lambda m, a: tok.append(a[0].detach().clone())))
+    with torch.no_grad():
+        logits, (s_att, t_att) = model(feats, mask=aux["mask"], identities_mask=aux["identities_mask"],
+                                       size_embedding=aux["size_embedding"], positions=aux["positions"])
+        for h in hooks:
+            h.remove()
+        m64, _ = build_tsf(TSF, cfg, seed, True, torch.float64)
+        logits64, _ = m64(feats.double(), mask=aux["mask"], identities_mask=aux["identities_mask"],
+                          size_embedding=aux["size_embedding"], positions=aux["positions"])
+    # backward: d(sum of logits * labels-ish weights) for a few parameters
+    model.zero_grad()
+    feats_g = feats.clone().requires_grad_(True)
+    out, _ = model(feats_g, mask=aux["mask"], identities_mask=aux["identities_mask"],
+                   size_embedding=aux["size_embedding"], positions=aux["positions"])
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out, aux["labels"].reshape(-1, 1))
+    loss.backward()
+    grads = {}
+    named = dict(model.named_parameters())
+    for key in GRAD_KEYS_TSF:
+        g = named[key].grad
+        grads["gnorm." + key] = g.norm()
+        grads["gslice." + key] = g.reshape(-1)[:256].clone()
+    # live rows of the embedding tables
+    grads["gslice.pos_emb.rows"] = named["pos_emb.weight"].grad[:8].clone()
+    grads["gslice.size_emb.rows"] = named["size_emb.weight"].grad[:21].clone()
+    save(name, logits=logits, logits64=logits64, space_att=s_att, time_att=t_att,
+         cls_rows=torch.stack(rows), tokens_head=tok[0][:, :60].clone(), tokens_sum=checksum(tok[0]),
+         feats_sum=checksum(feats), loss=loss.detach(), dfeats_norm=feats_g.grad.norm(),
+         dfeats_slice=feats_g.grad.permute(0, 1, 3, 4, 2).reshape(-1)[:512].clone(),
+         batch=batch, frames=frames, channels=channels, identities=identities, ragged=int(ragged), seed=seed,
+         **grads)
+
+
+GRAD_KEYS_TSF = ["cls_token", "to_patch_embedding.weight", "to_patch_embedding.bias",
+                 "layers.0.0.fn.to_qkv.weight", "layers.0.0.fn.to_out.0.weight", "layers.0.0.fn.to_out.0.bias",
+                 "layers.0.0.norm.weight", "layers.0.0.norm.bias", "layers.4.1.fn.to_qkv.weight",
+                 "layers.4.2.fn.net.0.weight", "layers.4.2.fn.net.0.bias", "layers.4.2.fn.net.3.weight",
+                 "layers.8.2.fn.net.3.bias", "layers.8.1.fn.to_out.0.weight", "to_out.0.weight", "to_out.1.weight",
+                 "to_out.1.bias"]
+
+GRAD_KEYS_EF = ["_conv_stem.weight", "_bn0.weight", "_bn0.bias", "_blocks.0._depthwise_conv.weight",
+                "_blocks.0._se_reduce.weight", "_blocks.0._se_expand.bias", "_blocks.0._project_conv.weight",
+                "_blocks.1._expand_conv.weight", "_blocks.3._depthwise_conv.weight", "_blocks.3._bn1.weight",
+                "_blocks.5._bn2.weight", "_blocks.10._se_expand.weight", "_blocks.10._project_conv.weight",
+                "_blocks.15._expand_conv.weight", "_conv_head.weight", "_bn1.weight"]
+
+
+def build_ef(EF, seed, training, dtype=torch.float32):
+    model = EF.from_name("efficientnet-b0", drop_connect_rate=0.0)
+    sd = synth.effnet_b0_state(seed)
+    model.load_state_dict(sd, strict=True)
+    model.train(training)
+    return model.to(dtype), sd
+
+
+def ef_case(EF, name, n_img, training, seed):
+    model, sd = build_ef(EF, seed, training)
+    vid = synth.clip_inputs(1, n_img, 1, seed)["videos"]            # [1,n,224,224,3]
+    x = vid.reshape(n_img, 224, 224, 3).permute(0, 3, 1, 2)         # NHWC-strided NCHW view (train.py:341)
+    taps = {}
+    hooks = [model._blocks[i].register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(i, o.detach()))
+             for i in (0, 2, 5, 10, 15)]
+    with torch.no_grad():
+        feats = model(x)
+    for h in hooks:
+        h.remove()
+    extra = {}
+    if training:
+        msd = model.state_dict()
+        for k in ("_bn0.running_mean", "_bn0.running_var", "_blocks.3._bn1.running_mean", "_blocks.3._bn1.running_var",
+                  "_blocks.15._bn2.running_var", "_bn1.running_mean", "_bn1.running_var"):
+            extra["stat." + k] = msd[k].clone()
+        extra["nbt"] = msd["_bn0.num_batches_tracked"].clone()
+    m64, _ = build_ef(EF, seed, training, torch.float64)
+    with torch.no_grad():
+        feats64 = m64(x.double())
+    save(name, features=feats, feat64_slice=feats64[:, :64].clone(), input_sum=checksum(x),
+         **{f"block{i}_mean": taps[i].mean(dim=(0, 2, 3)) for i in taps},
+         **{f"block{i}_absmax": taps[i].abs().amax(dim=(0, 2, 3)) for i in taps},
+         **{f"block{i}_slice": taps[i][0, :, :4, :4].clone() for i in taps},
+         n_img=n_img, training=int(training), seed=seed, **extra)
+
+
+def e2e_case(EF, TSF, name, batch, frames, identities, ragged, training, seed):
+    cfg = arch.default_tsf_config(channels=1280, num_frames=frames)
+    ef, _ = build_ef(EF, seed, training)
+    tsf, _ = build_tsf(TSF, cfg, seed, True)
+    inp = synth.clip_inputs(batch, frames, identities, seed, ragged=ragged)
+    v = inp["videos"]
+    b, f, h, w, c = v.shape
+    vid = v.reshape(b * f, h, w, c).permute(0, 3, 1, 2)
+    ef.zero_grad(); tsf.zero_grad()
+    feats = ef(vid)
+    logits, (s_att, t_att) = tsf(feats.reshape(b, f, *feats.shape[1:]), mask=inp["mask"],
+                                 identities_mask=inp["identities_mask"], size_embedding=inp["size_embedding"],
+                                 positions=inp["positions"])
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, inp["labels"].reshape(-1, 1))
+    loss.backward()
+    grads = {}
+    for model, keys, tag in ((ef, GRAD_KEYS_EF, "ef."), (tsf, GRAD_KEYS_TSF, "tsf.")):
+        named = dict(model.named_parameters())
+        for key in keys:
+            g = named[key].grad
+            grads["gnorm." + tag + key] = g.norm()
+            grads["gslice." + tag + key] = g.reshape(-1)[:256].clone()
+    save(name, logits=logits, space_att=s_att, time_att=t_att, loss=loss.detach(),
+         feat_mean=feats.mean(dim=(0, 2, 3)), feat_absmax=feats.abs().amax(dim=(0, 2, 3)),
+         feat_slice=feats[:2, :, :2, :2].clone(), input_sum=checksum(v),
+         batch=batch, frames=frames, identities=identities, ragged=int(ragged), training=int(training), seed=seed,
+         **grads)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    EF, TSF = import_reference()
+    # key/shape manifests of the reference modules (state-dict compatibility contract)
+    ef = EF.from_name("efficientnet-b0")
+    man = {"efficientnet-b0": [[k, list(v.shape), str(v.dtype)] for k, v in ef.state_dict().items()]}
+    for (c, fr) in ((1280, 8), (2048, 16)):
+        t = TSF(config=arch.default_tsf_config(c, fr))
+        man[f"tsf_c{c}_f{fr}"] = [[k, list(v.shape), str(v.dtype)] for k, v in t.state_dict().items()]
+        man[f"tsf_c{c}_f{fr}_no_weight_decay"] = sorted(t.no_weight_decay())
+    with open(os.path.join(OUT, "state_manifest.json"), "w") as fh:
+        json.dump(man, fh)
+    print("wrote state_manifest.json")
+
+    tsf_case(TSF, "tsf_cfg1", batch=2, frames=8, channels=1280, identities=1, ragged=False, seed=0)
+    tsf_case(TSF, "tsf_2id_ragged", batch=2, frames=8, channels=1280, identities=2, ragged=True, seed=1)
+    tsf_case(TSF, "tsf_xs_3id", batch=1, frames=16, channels=2048, identities=3, ragged=True, seed=2)
+    ef_case(EF, "ef_eval", n_img=2, training=False, seed=0)
+    ef_case(EF, "ef_train", n_img=4, training=True, seed=1)
+    e2e_case(EF, TSF, "e2e_cfg1_eval", batch=2, frames=8, identities=1, ragged=False, training=False, seed=0)
+    e2e_case(EF, TSF, "e2e_2id_train", batch=2, frames=8, identities=2, ragged=True, training=True, seed=1)
+
+
+if __name__ == "__main__":
+    main()
