@@ -1,0 +1,88 @@
+/* libmintime_hip.so -- C ABI of the MI355X-native MINTIME hot path.
+ *
+ * The reference (davide-coccomini/MINTIME...) is pure Python on PyTorch and has NO FFI / plugin layer
+ * (SURVEY.md §8b); its "operator API" for this path is the nn.Module surface
+ *   models/efficientnet/efficientnet_pytorch/model.py:267  EfficientNet.forward
+ *   models/size_invariant_timesformer.py:224               SizeInvariantTimeSformer.forward
+ * and the tensor ops those call.  Each entry point below replaces the group of reference ops cited
+ * next to it.  The Python host (package dir `mintime-..._amd/`) binds these with ctypes; a reference
+ * maintainer would bind them the same way.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (fp32 unless stated; masks uint8; indices int32/int64)
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*), never synchronises,
+ *     never allocates; scratch comes from the caller
+ *   - return 0 on success, negative on error; mt_last_error() gives a thread-local message
+ *   - re-entrant: no global mutable state, launches go to the caller's stream on the current device
+ */
+#ifndef MINTIME_HIP_H
+#define MINTIME_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MT_VERSION 100
+
+int mt_version(void);
+const char* mt_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense contraction family (fp32 MFMA).  Replaces every nn.Linear / 1x1 Conv2d / their autograd:
+ *   size_invariant_timesformer.py:111,144 (to_qkv, to_out), :69-74 (FeedForward), :228 (to_patch_embedding)
+ *   efficientnet_pytorch/model.py:98,116,286 (_expand_conv, _project_conv, _conv_head)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { int gin, gout, off; } mt_rowmap;   /* row' = (r/gin)*gout + off + r%gin ; gin==0: identity */
+
+enum { MT_OP_NT = 0,    /* C[M,N] = A[M,K] * B[N,K]^T      forward (torch weight layout)             */
+       MT_OP_NN = 1,    /* C[M,N] = A[M,K] * B[K,N]        dgrad                                      */
+       MT_OP_TN = 2 };  /* C[M,N] = A[K,M]^T * B[K,N]      wgrad (split-K + fp32 atomics, C pre-zeroed) */
+
+enum { MT_PRO_NONE = 0, MT_PRO_BN_SWISH_GATE = 1, MT_PRO_BN_SWISH = 2, MT_PRO_AFFINE = 3 };
+enum { MT_EPI_STORE = 0, MT_EPI_BIAS_RES = 1, MT_EPI_GEGLU = 2, MT_EPI_STATS = 3, MT_EPI_ATOMIC = 4,
+       MT_EPI_GEGLU_BWD = 5, MT_EPI_ACCUM = 6 };
+
+typedef struct {
+  int op, prologue, epilogue;
+  const float* A; const float* B; float* C;
+  int M, N, K;                      /* GEGLU: N = full width of the weight (2*n_half)                   */
+  int64_t lda, ldb, ldc;
+  mt_rowmap a_map, b_map, c_map;
+  const float* bias;
+  const float* R; int64_t ldr;      /* residual (BIAS_RES)                                               */
+  const float* scale; const float* shift; const float* gate; int hw;   /* prologue vectors               */
+  float* C2; int64_t ldc2;          /* GEGLU: optional pre-activation store; GEGLU_BWD: pre-activations  */
+  double* stats; int stats_slots;   /* STATS: [slots][2][N] fp64 accumulators (sum, sum of squares)      */
+  int n_half;
+  int split_k;                      /* TN: number of K splits (>=1)                                      */
+} mt_gemm_desc;
+
+int mt_gemm(const mt_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Size-Invariant TimeSformer forward, non-GEMM pieces
+ * ------------------------------------------------------------------------------------------------ */
+
+/* nn.LayerNorm over the last dim (size_invariant_timesformer.py:18-26).  stats (optional) [rows,2] = mean, rstd. */
+int mt_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                     int rows, int dim, float eps, void* stream);
+
+/* cls token + positional + size embeddings (:231-248), in place on x [B, 1+F*n, dim] whose rows 1.. hold the
+ * patch-embedding output.  positions int64 [B,1+F*n]; sizes int32 [B,F] (NULL size_emb: enable-size-emb False). */
+int mt_embed_fwd(float* x, const float* cls, const float* pos_emb, const float* size_emb,
+                 const int64_t* positions, const int32_t* sizes, int B, int F, int n, int dim, void* stream);
+
+/* Divided attention core (:80-87 attn(), :112-141 of Attention.forward) on the QKV GEMM output
+ * qkv [B, 1+F*n, 3*H*64] -> out [B, 1+F*n, H*64] (merged heads).  mode 0 = time (identity-masked), 1 = space.
+ * mask uint8 [B,F], ident uint8 [B,F,F]; cls_att (optional) [(B*H), 1+F*n] = the cls query's probabilities. */
+int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const uint8_t* mask, const uint8_t* ident,
+                int B, int H, int F, int n, int mode, float scale, void* stream);
+
+/* to_out: LayerNorm + Linear(dim, classes) on the cls row x[:,0] (:270-276). x [B,N,dim] -> logits [B,classes]. */
+int mt_head_fwd(const float* x, const float* gamma, const float* beta, const float* w, const float* bias,
+                float* logits, int B, int N, int dim, int classes, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -4,6 +4,8 @@ Host side is Python on PyTorch-ROCm (tensors, autograd plumbing); all arithmetic
 hand-written HIP library `csrc/libmintime_hip.so` (C ABI declared in include/mintime_hip.h).
 There is no CPU or eager-PyTorch fallback: every op raises if the library is missing.
 """
-from . import arch, synth  # noqa: F401
+from . import arch, synth, lib  # noqa: F401
+from . import timesformer, tsf_engine  # noqa: F401
+from .timesformer import SizeInvariantTimeSformer  # noqa: F401
 
-__all__ = ["arch", "synth"]
+__all__ = ["arch", "synth", "lib", "timesformer", "tsf_engine", "SizeInvariantTimeSformer"]

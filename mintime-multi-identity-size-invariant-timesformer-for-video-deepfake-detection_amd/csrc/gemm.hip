@@ -1,0 +1,106 @@
+// C-ABI dispatch for the fp32 MFMA GEMM family (see gemm_core.hpp, include/mintime_hip.h).
+#include "../../include/mintime_hip.h"
+#include "common.hpp"
+#include "gemm_core.hpp"
+
+using namespace mt;
+
+namespace {
+
+enum { CFG_BIG = 0, CFG_MID = 1, CFG_NARROW = 2 };
+
+struct Cfg { int bm, bn, threads; };
+constexpr Cfg kCfg[3] = {{128, 128, 256}, {128, 64, 256}, {256, 32, 256}};
+
+int pick_cfg(int N, int epilogue) {
+  if (epilogue == MT_EPI_GEGLU) return CFG_BIG;
+  if (N <= 32) return CFG_NARROW;
+  const int pad_big = (N + 127) / 128 * 128;
+  const int pad_mid = (N + 63) / 64 * 64;
+  return pad_mid < pad_big ? CFG_MID : CFG_BIG;
+}
+
+template <int AL, int BL, int PRO, int EPI>
+int launch(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
+  switch (cfg) {
+    case CFG_BIG:
+      hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, AL, BL, PRO, EPI>), grid, dim3(256), 0, s, a);
+      break;
+    case CFG_MID:
+      if constexpr (EPI == EPI_GEGLU) return fail(MT_ERR_UNSUPPORTED, "GEGLU needs the 128x128 tile");
+      else hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 1, AL, BL, PRO, EPI>), grid, dim3(256), 0, s, a);
+      break;
+    case CFG_NARROW:
+      if constexpr (EPI == EPI_GEGLU) return fail(MT_ERR_UNSUPPORTED, "GEGLU needs the 128x128 tile");
+      else hipLaunchKernelGGL((gemm_kernel<4, 1, 2, 1, AL, BL, PRO, EPI>), grid, dim3(256), 0, s, a);
+      break;
+  }
+  return check_launch("mt_gemm");
+}
+
+}  // namespace
+
+extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->B || !d->C) return fail(MT_ERR_ARG, "mt_gemm: null pointer");
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0) return fail(MT_ERR_ARG, "mt_gemm: bad shape %d %d %d", d->M, d->N, d->K);
+  if ((d->lda & 3) || (d->ldb & 3)) return fail(MT_ERR_ARG, "mt_gemm: lda/ldb must be multiples of 4 floats");
+  if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15)) return fail(MT_ERR_ARG, "mt_gemm: A/B must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+
+  GemmArgs a;
+  a.A = d->A; a.B = d->B; a.C = d->C;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
+  a.a_map = {d->a_map.gin, d->a_map.gout, d->a_map.off};
+  a.b_map = {d->b_map.gin, d->b_map.gout, d->b_map.off};
+  a.c_map = {d->c_map.gin, d->c_map.gout, d->c_map.off};
+  a.bias = d->bias; a.R = d->R; a.ldr = d->ldr;
+  a.scale = d->scale; a.shift = d->shift; a.gate = d->gate; a.hw = d->hw > 0 ? d->hw : 1;
+  a.C2 = d->C2; a.ldc2 = d->ldc2; a.stats = d->stats; a.stats_slots = d->stats_slots > 0 ? d->stats_slots : 1;
+  a.n_half = d->n_half; a.k_chunk = 0;
+
+  // K-contiguous operands need K % 4 == 0 (float4 along K); k-major operands need M resp. N % 4 == 0
+  if (d->op == MT_OP_NT && (d->K & 3)) return fail(MT_ERR_ARG, "mt_gemm NT: K %% 4 != 0");
+  if (d->op == MT_OP_NN && ((d->K & 3) || (d->N & 3))) return fail(MT_ERR_ARG, "mt_gemm NN: K,N %% 4 != 0");
+  if (d->op == MT_OP_TN && ((d->M & 3) || (d->N & 3))) return fail(MT_ERR_ARG, "mt_gemm TN: M,N %% 4 != 0");
+  if (d->epilogue == MT_EPI_GEGLU && (d->n_half * 2 != d->N || (d->n_half & 63)))
+    return fail(MT_ERR_ARG, "mt_gemm GEGLU: N must be 2*n_half, n_half %% 64 == 0");
+  if (d->epilogue == MT_EPI_BIAS_RES && !d->R) return fail(MT_ERR_ARG, "mt_gemm: BIAS_RES needs R");
+  if (d->epilogue == MT_EPI_STATS && !d->stats) return fail(MT_ERR_ARG, "mt_gemm: STATS needs stats");
+  if (d->epilogue == MT_EPI_GEGLU_BWD && !d->C2) return fail(MT_ERR_ARG, "mt_gemm: GEGLU_BWD needs C2 (pre-activations)");
+  if (d->prologue != MT_PRO_NONE && (!d->scale || !d->shift)) return fail(MT_ERR_ARG, "mt_gemm: prologue needs scale/shift");
+  if (d->prologue == MT_PRO_BN_SWISH_GATE && !d->gate) return fail(MT_ERR_ARG, "mt_gemm: gate prologue needs gate");
+
+  const int cfg = pick_cfg(d->N, d->epilogue);
+  const int m_tiles = (d->M + kCfg[cfg].bm - 1) / kCfg[cfg].bm;
+  const int n_tiles = (d->N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
+  dim3 grid(m_tiles * n_tiles, 1, 1);
+
+#define COMBO(OP, AL, BL, PRO, EPI)                                                        \
+  if (d->op == OP && d->prologue == PRO && d->epilogue == EPI)                             \
+    return launch<AL, BL, PRO, EPI>(cfg, a, grid, s);
+
+  if (d->op == MT_OP_TN) {
+    int splits = d->split_k > 0 ? d->split_k : 1;
+    int chunk = (d->K + splits - 1) / splits;
+    chunk = (chunk + 15) / 16 * 16;
+    splits = (d->K + chunk - 1) / chunk;
+    a.k_chunk = chunk;
+    grid.y = splits;
+    COMBO(MT_OP_TN, LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_NONE, EPI_ATOMIC)
+    return fail(MT_ERR_UNSUPPORTED, "mt_gemm TN: unsupported prologue/epilogue %d/%d", d->prologue, d->epilogue);
+  }
+  COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_NONE, EPI_STORE)
+  COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_NONE, EPI_BIAS_RES)
+  COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_NONE, EPI_GEGLU)
+  COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_NONE, EPI_STATS)
+  COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_BN_SWISH_GATE, EPI_STATS)
+  COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_STORE)
+  COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_ACCUM)
+  COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_GEGLU_BWD)
+#undef COMBO
+  return fail(MT_ERR_UNSUPPORTED, "mt_gemm: unsupported op/prologue/epilogue %d/%d/%d", d->op, d->prologue, d->epilogue);
+}
+
+extern "C" int mt_version(void) { return MT_VERSION; }
+extern "C" const char* mt_last_error(void) { return mt::err_buf(); }

@@ -1,0 +1,360 @@
+// fp32 MFMA GEMM family for gfx950 (MI355X).
+//
+//   C[M,N] (+)= op(A)[M,K] * op(B)[K,N]      exact fp32: v_mfma_f32_32x32x2_f32 (157 TF peak, no TF32 on CDNA4)
+//
+// One template covers every dense contraction of the MINTIME hot path:
+//   * Linear / 1x1-conv forward   (A rows k-contiguous, B = torch weight [N,K] k-contiguous)
+//   * dgrad                        (A = dY k-contiguous, B = weight [Kc,N] n-contiguous)
+//   * wgrad (split-K, atomics)     (A = dY^T m-contiguous, B = X n-contiguous)
+// with the elementwise work of the reference's separate passes folded into the operand load
+// (prologue: BN-affine + swish + squeeze-excite gate, ...) and the accumulator store
+// (epilogue: bias, residual, GEGLU, BN batch-statistics, ...).
+//
+// Tiling: block = WAVES_M x WAVES_N wavefronts (64 lanes), each owning TM x TN 32x32 MFMA tiles.
+// LDS tiles are k-major ([BK][rows+pad]): lane l reads As[k0 + (l>>5)][row0 + (l&31)] -> 32 consecutive
+// floats per half-wave = conflict-free ds_read_b32, exactly the 32x32x2 operand layout
+// (A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]).  fp32 MFMA issues once per 64 cycles per SIMD, so one b32
+// read per operand per MFMA is far below LDS bandwidth; the design effort goes into the global side:
+// register-staged double buffering (next tile's global loads in flight under the MFMAs), float4
+// global accesses, XCD-aware block order so an A row-panel is reused out of one XCD's L2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum : int { LAYOUT_KCONTIG = 0, LAYOUT_KMAJOR = 1 };
+
+// prologues applied to A elements on the global->LDS path
+enum : int {
+  PRO_NONE = 0,
+  PRO_BN_SWISH_GATE = 1,   // a = swish(z*scale[k]+shift[k]) * gate[(m/hw)*K + k]      (MBConv project conv input)
+  PRO_BN_SWISH = 2,        // a = swish(z*scale[k]+shift[k])
+  PRO_AFFINE = 3,          // a = z*scale[k]+shift[k]
+};
+
+// epilogues
+enum : int {
+  EPI_STORE = 0,        // C = acc (+bias[n])
+  EPI_BIAS_RES = 1,     // C = acc + bias[n] + R[m,n]
+  EPI_GEGLU = 2,        // h[m,j] = (acc_a+ba[j]) * gelu(acc_g+bg[j]);  optional u store (pre-activations)
+  EPI_STATS = 3,        // C = acc ; per-column sum / sum-of-squares accumulated in fp64 (BatchNorm batch statistics)
+  EPI_ATOMIC = 4,       // C += acc via fp32 atomics (split-K wgrad); C must be pre-zeroed or hold a partial
+  EPI_GEGLU_BWD = 5,    // acc = dh[m,j]; du[m,j] = dh*gelu(g), du[m,Nh+j] = dh*a*gelu'(g)   (a,g from u)
+  EPI_ACCUM = 6,        // C = C + acc (+bias)  -- gradient accumulation into an existing tensor
+};
+
+struct RowMap {   // out_row = (r / gin) * gout + off + r % gin   (gin == 0 -> identity)
+  int gin, gout, off;
+};
+
+__device__ __forceinline__ int64_t map_row(const RowMap& rm, int r) {
+  if (rm.gin == 0) return r;
+  int g = r / rm.gin;
+  return (int64_t)g * rm.gout + rm.off + (r - g * rm.gin);
+}
+
+struct GemmArgs {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  RowMap a_map;        // applied to A's row index (KCONTIG: m ; KMAJOR: k)
+  RowMap b_map;        // applied to B's row index when B is KMAJOR (k)
+  RowMap c_map;        // applied to C's / R's row index
+  const float* bias;   // [N] or null
+  const float* R; int64_t ldr;          // residual
+  // prologue
+  const float* scale; const float* shift; const float* gate; int hw;
+  // epilogue extras
+  float* C2; int64_t ldc2;              // GEGLU: u store (may be null) ; GEGLU_BWD: u (read)
+  double* stats; int stats_slots;       // EPI_STATS: [slots][2][N] fp64
+  int n_half;                           // GEGLU: N/2 of the weight (h width)
+  int k_chunk;                          // split-K: contraction length per blockIdx.y (0 = whole K)
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+void gemm_kernel(const GemmArgs p) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int BK = 16;
+  constexpr int LDA_S = BM + 4;
+  constexpr int LDB_S = BN + 4;
+  constexpr int A_UNITS = (BM * BK / 4 + NT - 1) / NT;   // float4 units per thread
+  constexpr int B_UNITS = (BN * BK / 4 + NT - 1) / NT;
+  constexpr bool A_EXACT = (BM * BK / 4) % NT == 0;
+  constexpr bool B_EXACT = (BN * BK / 4) % NT == 0;
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA_S + LDB_S)];
+  float* As = smem;                       // [2][BK][LDA_S]
+  float* Bs = smem + 2 * BK * LDA_S;      // [2][BK][LDB_S]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+
+  // ---- XCD-aware block order: consecutive logical tiles (sharing an A row-panel) land on one XCD's L2
+  const int n_tiles = (p.N + BN - 1) / BN;     // for GEGLU p.N is the full GEMM width (2*n_half)
+  const int m_tiles = (p.M + BM - 1) / BM;
+  const int nblk = n_tiles * m_tiles;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt_ = bid / n_tiles;
+  const int nt_ = bid - mt_ * n_tiles;
+  const int m0 = mt_ * BM;
+  const int n0 = nt_ * BN;
+
+  int k_begin = 0, k_end = p.K;
+  if (p.k_chunk > 0) {
+    k_begin = blockIdx.y * p.k_chunk;
+    k_end = min(p.K, k_begin + p.k_chunk);
+    if (k_begin >= k_end) return;
+  }
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+
+  // B-tile row -> global weight row (GEGLU interleaves the 'a' and 'gate' halves so one lane holds both)
+  auto b_row = [&](int r) -> int {
+    if constexpr (EPI == EPI_GEGLU) {
+      static_assert(EPI != EPI_GEGLU || TN == 2, "GEGLU wants TN == 2");
+      const int w = r / 64, sel = (r >> 5) & 1, c = r & 31;
+      const int j = (n0 >> 1) + w * 32 + c;
+      return j < p.n_half ? sel * p.n_half + j : -1;
+    } else {
+      const int n = n0 + r;
+      return n < p.N ? n : -1;
+    }
+  };
+
+  float4 ra[A_UNITS], rb[B_UNITS];
+
+  auto load_tiles = [&](int kt) {
+    const int k0 = k_begin + kt * BK;
+#pragma unroll
+    for (int i = 0; i < A_UNITS; ++i) {
+      const int u = tid + i * NT;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (A_EXACT || u < BM * BK / 4) {
+        if constexpr (AL == LAYOUT_KCONTIG) {
+          const int row = u >> 2, kq = u & 3;
+          const int m = m0 + row, k = k0 + kq * 4;
+          if (m < p.M && k < k_end) {
+            v = *reinterpret_cast<const float4*>(p.A + map_row(p.a_map, m) * p.lda + k);
+            if constexpr (PRO == PRO_BN_SWISH_GATE || PRO == PRO_BN_SWISH || PRO == PRO_AFFINE) {
+              const float4 sc = *reinterpret_cast<const float4*>(p.scale + k);
+              const float4 sh = *reinterpret_cast<const float4*>(p.shift + k);
+              v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+              if constexpr (PRO != PRO_AFFINE) {
+                v.x = swishf_(v.x); v.y = swishf_(v.y); v.z = swishf_(v.z); v.w = swishf_(v.w);
+              }
+              if constexpr (PRO == PRO_BN_SWISH_GATE) {
+                const float4 g = *reinterpret_cast<const float4*>(p.gate + (int64_t)(m / p.hw) * p.K + k);
+                v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+              }
+            }
+          }
+        } else {
+          constexpr int QPR = BM / 4;
+          const int kk = u / QPR, mq = u - kk * QPR;
+          const int k = k0 + kk, m = m0 + mq * 4;
+          if (k < k_end && m < p.M)
+            v = *reinterpret_cast<const float4*>(p.A + map_row(p.a_map, k) * p.lda + m);
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_UNITS; ++i) {
+      const int u = tid + i * NT;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (B_EXACT || u < BN * BK / 4) {
+        if constexpr (BL == LAYOUT_KCONTIG) {
+          const int row = u >> 2, kq = u & 3;
+          const int n = b_row(row), k = k0 + kq * 4;
+          if (n >= 0 && k < k_end) v = *reinterpret_cast<const float4*>(p.B + (int64_t)n * p.ldb + k);
+        } else {
+          constexpr int QPR = BN / 4;
+          const int kk = u / QPR, nq = u - kk * QPR;
+          const int k = k0 + kk, n = n0 + nq * 4;
+          if (k < k_end && n < p.N) v = *reinterpret_cast<const float4*>(p.B + map_row(p.b_map, k) * p.ldb + n);
+        }
+      }
+      rb[i] = v;
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    float* as = As + buf * BK * LDA_S;
+    float* bs = Bs + buf * BK * LDB_S;
+#pragma unroll
+    for (int i = 0; i < A_UNITS; ++i) {
+      const int u = tid + i * NT;
+      if (A_EXACT || u < BM * BK / 4) {
+        if constexpr (AL == LAYOUT_KCONTIG) {
+          const int row = u >> 2, kq = u & 3;
+          as[(kq * 4 + 0) * LDA_S + row] = ra[i].x;
+          as[(kq * 4 + 1) * LDA_S + row] = ra[i].y;
+          as[(kq * 4 + 2) * LDA_S + row] = ra[i].z;
+          as[(kq * 4 + 3) * LDA_S + row] = ra[i].w;
+        } else {
+          constexpr int QPR = BM / 4;
+          const int kk = u / QPR, mq = u - kk * QPR;
+          *reinterpret_cast<float4*>(as + kk * LDA_S + mq * 4) = ra[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_UNITS; ++i) {
+      const int u = tid + i * NT;
+      if (B_EXACT || u < BN * BK / 4) {
+        if constexpr (BL == LAYOUT_KCONTIG) {
+          const int row = u >> 2, kq = u & 3;
+          bs[(kq * 4 + 0) * LDB_S + row] = rb[i].x;
+          bs[(kq * 4 + 1) * LDB_S + row] = rb[i].y;
+          bs[(kq * 4 + 2) * LDB_S + row] = rb[i].z;
+          bs[(kq * 4 + 3) * LDB_S + row] = rb[i].w;
+        } else {
+          constexpr int QPR = BN / 4;
+          const int kk = u / QPR, nq = u - kk * QPR;
+          *reinterpret_cast<float4*>(bs + kk * LDB_S + nq * 4) = rb[i];
+        }
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  const int a_off = wm * TM * 32 + (lane & 31);
+  const int b_off = wn * TN * 32 + (lane & 31);
+  const int khalf = lane >> 5;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const float* as = As + buf * BK * LDA_S + khalf * LDA_S + a_off;
+    const float* bs = Bs + buf * BK * LDB_S + khalf * LDB_S + b_off;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = as[ks * 2 * LDA_S + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = bs[ks * 2 * LDB_S + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col_l = lane & 31;
+  const int row_h = (lane >> 5) * 4;
+
+  if constexpr (EPI == EPI_GEGLU) {
+    // acc[i][0] = 'a' pre-activation, acc[i][1] = gate pre-activation, same (row, col) in one lane
+    const int j = (n0 >> 1) + wn * 32 + col_l;
+    const bool jok = j < p.n_half;
+    const float ba = (jok && p.bias) ? p.bias[j] : 0.f;
+    const float bg = (jok && p.bias) ? p.bias[p.n_half + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        if (m < p.M && jok) {
+          const float a = acc[i][0][r] + ba;
+          const float g = acc[i][1][r] + bg;
+          p.C[(int64_t)m * p.ldc + j] = a * gelu_erf(g);
+          if (p.C2) {
+            p.C2[(int64_t)m * p.ldc2 + j] = a;
+            p.C2[(int64_t)m * p.ldc2 + p.n_half + j] = g;
+          }
+        }
+      }
+    }
+    return;
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+      const bool nok = n < p.N;
+      float bias = 0.f;
+      if constexpr (EPI == EPI_STORE || EPI == EPI_BIAS_RES || EPI == EPI_ACCUM)
+        bias = (nok && p.bias) ? p.bias[n] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+          if (m < p.M && nok) {
+            float v = acc[i][j][r];
+            const int64_t crow = map_row(p.c_map, m);
+            if constexpr (EPI == EPI_STORE) {
+              p.C[crow * p.ldc + n] = v + bias;
+            } else if constexpr (EPI == EPI_BIAS_RES) {
+              p.C[crow * p.ldc + n] = v + bias + p.R[crow * p.ldr + n];
+            } else if constexpr (EPI == EPI_ACCUM) {
+              p.C[crow * p.ldc + n] += v + bias;
+            } else if constexpr (EPI == EPI_STATS) {
+              p.C[crow * p.ldc + n] = v;
+              s1 += v; s2 += v * v;
+            } else if constexpr (EPI == EPI_ATOMIC) {
+              atomicAdd(p.C + crow * p.ldc + n, v);
+            } else if constexpr (EPI == EPI_GEGLU_BWD) {
+              // n indexes h columns [0, n_half); u = [a | g] pre-activations
+              const float a = p.C2[(int64_t)m * p.ldc2 + n];
+              const float g = p.C2[(int64_t)m * p.ldc2 + p.n_half + n];
+              p.C[crow * p.ldc + n] = v * gelu_erf(g);
+              p.C[crow * p.ldc + p.n_half + n] = v * a * gelu_erf_grad(g);
+            }
+          }
+        }
+      }
+      if constexpr (EPI == EPI_STATS) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lane < 32 && nok) {
+          double* st = p.stats + (int64_t)(blockIdx.x % p.stats_slots) * 2 * p.N;
+          atomicAdd(st + n, (double)s1);
+          atomicAdd(st + p.N + n, (double)s2);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace mt

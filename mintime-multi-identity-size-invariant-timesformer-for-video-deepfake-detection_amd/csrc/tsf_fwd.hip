@@ -1,0 +1,383 @@
+// Size-Invariant TimeSformer forward kernels other than the dense contractions (gfx950).
+//
+//   mt_layernorm_fwd      PreNorm's nn.LayerNorm                (size_invariant_timesformer.py:18-26)
+//   mt_embed_fwd          cls token + pos_emb + size_emb        (:231-248)
+//   mt_attn_fwd           divided space/time attention core incl. the cls query (:80-87, :112-141)
+//   mt_head_fwd           to_out = LayerNorm + Linear(dim,1) on the cls row (:270-276)
+//
+// Attention layout decisions (MI355X-first, not a translation of the reference's rearranges):
+//   * q/k/v are consumed straight out of the QKV GEMM's [B, N, 3*H*64] buffer and the result is written
+//     in merged-head [B, N, H*64] layout -> none of the reference's chunk/rearrange/cat/repeat copies exist.
+//   * groups are tiny (9 keys for time, 50 for space, d=64): at fp32 the MFMA rate equals the VALU rate on
+//     CDNA4, and a 32x32 tile would be mostly padding, so one LANE owns one query row: scores, softmax and
+//     P.V are lane-local (no cross-lane reduction at all); K/V rows are staged once per wavefront in LDS
+//     and read as broadcast / conflict-free ds_read_b128.
+//   * masks are read from mask[B,F] / identities_mask[B,F,F] directly; the reference's materialised
+//     [(B*H*49), F, F+1] frame mask (:252-255) never exists.  Masked logits are FILLED with -FLT_MAX (:82-85).
+#include "../../include/mintime_hip.h"
+#include "common.hpp"
+#include <float.h>
+
+using namespace mt;
+
+namespace {
+
+constexpr int DH = 64;   // dim_head (config: dim-head 64)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------- LayerNorm
+// one wavefront per row; D % 4 == 0, D <= 1024
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ stats, int rows, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+  const int nq = D >> 2;
+  float4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + i * 64;
+    v[i] = q < nq ? xr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + i * 64;
+    if (q < nq) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      ss += a * a + b * b + c * c + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+  float4* yr = reinterpret_cast<float4*>(y + (int64_t)row * D);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + i * 64;
+    if (q < nq) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[q];
+      const float4 b = reinterpret_cast<const float4*>(beta)[q];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      yr[q] = o;
+    }
+  }
+  if (stats && lane == 0) {
+    stats[2 * (int64_t)row] = mean;
+    stats[2 * (int64_t)row + 1] = rstd;
+  }
+}
+
+// ---------------------------------------------------------------------------------------- embeddings
+// x[b,0,:]   = cls + pos_emb[positions[b,0]] + size_emb[0]
+// x[b,1+t,:] += pos_emb[positions[b,1+t]] + size_emb[size[b, t / n]]        (x holds the patch-embedding GEMM output)
+__global__ __launch_bounds__(256) void embed_fwd_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                                        const float* __restrict__ pos_emb, const float* __restrict__ size_emb,
+                                                        const int64_t* __restrict__ positions, const int* __restrict__ sizes,
+                                                        int B, int N, int n, int F, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= B * N) return;
+  const int b = row / N, t = row - b * N;
+  const int64_t pi = positions ? positions[row] : (int64_t)t;
+  int si = 0;
+  if (t > 0 && sizes) si = sizes[b * F + (t - 1) / n];
+  float4* xr = reinterpret_cast<float4*>(x + (int64_t)row * D);
+  const float4* pr = reinterpret_cast<const float4*>(pos_emb + pi * D);
+  const float4* sr = size_emb ? reinterpret_cast<const float4*>(size_emb + (int64_t)si * D) : nullptr;
+  for (int q = lane; q < (D >> 2); q += 64) {
+    float4 v = t == 0 ? reinterpret_cast<const float4*>(cls)[q] : xr[q];
+    const float4 p = pr[q];
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    if (sr) { const float4 s = sr[q]; v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+    xr[q] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------- attention: patch queries
+// MODE 0 = time  : group = (b,h,patch p): F queries (tokens 1+f*n+p), keys = cls + the same F tokens, identity mask
+// MODE 1 = space : group = (b,h,frame f): n queries (tokens 1+f*n+p), keys = cls + the same n tokens, no mask
+// One lane per query. NKEYS = keys per query (F+1 or n+1).  PPW = patches per wavefront in time mode.
+// Per wavefront LDS: a [ROWS][STRIDE] K tile (re-used for V) + a [NKEYS][64] score tile (lane-contiguous).
+template <int MODE, int NKEYS, int PPW, int STRIDE, int WPB>
+__global__ __launch_bounds__(WPB * 64) void attn_patch_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                 const uint8_t* __restrict__ mask,
+                                                                 const uint8_t* __restrict__ ident,
+                                                                 int B, int H, int F, int n, float scale) {
+  constexpr int ROWS = MODE == 0 ? 1 + PPW * (NKEYS - 1) : NKEYS;
+  constexpr int WAVE_LDS = ROWS * STRIDE + NKEYS * 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* kv = lds + wave * WAVE_LDS;
+  float* sc = kv + ROWS * STRIDE + lane;
+
+  const int N = 1 + F * n;
+  const int inner = H * DH;
+  const int ld = 3 * inner;
+  const int chunks = MODE == 0 ? (n + PPW - 1) / PPW : F;
+  const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
+  if (wid >= (int64_t)B * H * chunks) return;       // wave-uniform
+  const int c = (int)(wid % chunks);
+  const int bh = (int)(wid / chunks);
+  const int h = bh % H, b = bh / H;
+  const float* base = qkv + (int64_t)b * N * ld + h * DH;
+
+  // my query
+  int qtok = -1, pl = 0, fq = 0;
+  if (MODE == 0) {
+    pl = lane / (NKEYS - 1); fq = lane % (NKEYS - 1);
+    const int p = c * PPW + pl;
+    if (pl < PPW && p < n) qtok = 1 + fq * n + p;
+    if (pl >= PPW) pl = 0;   // idle lanes must still address rows inside this wavefront's LDS slice
+  } else {
+    if (lane < n) qtok = 1 + c * n + lane;
+  }
+  const int row1 = MODE == 0 ? 1 + pl * (NKEYS - 1) : 1;   // LDS row of my key j = 1
+
+  auto stage = [&](int which) {   // which: 1 = K, 2 = V
+    for (int r0 = 0; r0 < ROWS; r0 += 4) {
+      const int r = r0 + (lane >> 4), c4 = lane & 15;
+      if (r < ROWS) {
+        int tok = 0;
+        if (r > 0) {
+          if (MODE == 0) {
+            const int pl2 = (r - 1) / (NKEYS - 1), f2 = (r - 1) % (NKEYS - 1);
+            const int p = c * PPW + pl2;
+            tok = p < n ? 1 + f2 * n + p : -1;
+          } else {
+            tok = 1 + c * n + (r - 1);
+          }
+        }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tok >= 0) v = *reinterpret_cast<const float4*>(base + (int64_t)tok * ld + which * inner + c4 * 4);
+        *reinterpret_cast<float4*>(kv + r * STRIDE + c4 * 4) = v;
+      }
+    }
+  };
+
+  stage(1);
+  float q[DH];
+  {
+    const float* qp = base + (int64_t)(qtok >= 0 ? qtok : 0) * ld;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(qp + i * 4);
+      q[4 * i] = v.x * scale; q[4 * i + 1] = v.y * scale; q[4 * i + 2] = v.z * scale; q[4 * i + 3] = v.w * scale;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  float mx = -FLT_MAX;
+#pragma unroll 2
+  for (int j = 0; j < NKEYS; ++j) {
+    const float* kr = kv + (j == 0 ? 0 : row1 + j - 1) * STRIDE;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < DH / 8; ++i) {
+      const float4 k0 = *reinterpret_cast<const float4*>(kr + i * 8);
+      const float4 k1 = *reinterpret_cast<const float4*>(kr + i * 8 + 4);
+      a0 = fmaf(q[8 * i], k0.x, a0); a0 = fmaf(q[8 * i + 1], k0.y, a0);
+      a0 = fmaf(q[8 * i + 2], k0.z, a0); a0 = fmaf(q[8 * i + 3], k0.w, a0);
+      a1 = fmaf(q[8 * i + 4], k1.x, a1); a1 = fmaf(q[8 * i + 5], k1.y, a1);
+      a1 = fmaf(q[8 * i + 6], k1.z, a1); a1 = fmaf(q[8 * i + 7], k1.w, a1);
+    }
+    float a = a0 + a1;
+    if (MODE == 0 && j > 0) {
+      const bool ok = mask[b * F + (j - 1)] && ident[(b * F + fq) * F + (j - 1)];
+      if (!ok) a = -FLT_MAX;                      // masked_fill_(~mask, -finfo.max)  (:82-85)
+    }
+    sc[j * 64] = a;
+    mx = fmaxf(mx, a);
+  }
+
+  __builtin_amdgcn_wave_barrier();
+  stage(2);
+  __builtin_amdgcn_wave_barrier();
+
+  float o[DH];
+#pragma unroll
+  for (int i = 0; i < DH; ++i) o[i] = 0.f;
+  float sum = 0.f;
+#pragma unroll 2
+  for (int j = 0; j < NKEYS; ++j) {
+    const float* vr = kv + (j == 0 ? 0 : row1 + j - 1) * STRIDE;
+    const float pj = expf(sc[j * 64] - mx);
+    sum += pj;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
+      const float4 vv = *reinterpret_cast<const float4*>(vr + i * 4);
+      o[4 * i] = fmaf(pj, vv.x, o[4 * i]); o[4 * i + 1] = fmaf(pj, vv.y, o[4 * i + 1]);
+      o[4 * i + 2] = fmaf(pj, vv.z, o[4 * i + 2]); o[4 * i + 3] = fmaf(pj, vv.w, o[4 * i + 3]);
+    }
+  }
+  if (qtok >= 0) {
+    const float inv = 1.0f / sum;
+    float* orow = out + ((int64_t)b * N + qtok) * inner + h * DH;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i)
+      *reinterpret_cast<float4*>(orow + i * 4) =
+          make_float4(o[4 * i] * inv, o[4 * i + 1] * inv, o[4 * i + 2] * inv, o[4 * i + 3] * inv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------- attention: cls query
+// one wavefront per (b,h): the (scaled) cls query attends to all N keys, padded frames masked (:120, :259-260)
+__global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                         float* __restrict__ att, const uint8_t* __restrict__ mask,
+                                                         int B, int H, int F, int n, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // N probabilities
+  const int lane = threadIdx.x;
+  const int bh = blockIdx.x, h = bh % H, b = bh / H;
+  const int N = 1 + F * n, inner = H * DH, ld = 3 * inner;
+  const float* base = qkv + (int64_t)b * N * ld + h * DH;
+  float q[DH];
+#pragma unroll
+  for (int i = 0; i < DH / 4; ++i) {
+    const float4 v = *reinterpret_cast<const float4*>(base + i * 4);
+    q[4 * i] = v.x * scale; q[4 * i + 1] = v.y * scale; q[4 * i + 2] = v.z * scale; q[4 * i + 3] = v.w * scale;
+  }
+  float mx = -FLT_MAX;
+  for (int j = lane; j < N; j += 64) {
+    const float* kr = base + (int64_t)j * ld + inner;
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
+      const float4 kk = *reinterpret_cast<const float4*>(kr + i * 4);
+      a = fmaf(q[4 * i], kk.x, a); a = fmaf(q[4 * i + 1], kk.y, a);
+      a = fmaf(q[4 * i + 2], kk.z, a); a = fmaf(q[4 * i + 3], kk.w, a);
+    }
+    if (j > 0 && mask && !mask[b * F + (j - 1) / n]) a = -FLT_MAX;
+    lds[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < N; j += 64) { const float e = expf(lds[j] - mx); lds[j] = e; sum += e; }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int j = lane; j < N; j += 64) {
+    const float pj = lds[j] * inv;
+    lds[j] = pj;
+    if (att) att[(int64_t)bh * N + j] = pj;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
+  // out[d] = sum_j p_j v_j[d], lane = d
+  const float* vb = base + 2 * inner + lane;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+  int j = 0;
+  for (; j + 4 <= N; j += 4) {
+    o0 = fmaf(lds[j], vb[(int64_t)j * ld], o0);
+    o1 = fmaf(lds[j + 1], vb[(int64_t)(j + 1) * ld], o1);
+    o2 = fmaf(lds[j + 2], vb[(int64_t)(j + 2) * ld], o2);
+    o3 = fmaf(lds[j + 3], vb[(int64_t)(j + 3) * ld], o3);
+  }
+  for (; j < N; ++j) o0 = fmaf(lds[j], vb[(int64_t)j * ld], o0);
+  out[(int64_t)b * N * inner + h * DH + lane] = (o0 + o1) + (o2 + o3);
+}
+
+// ---------------------------------------------------------------------------------------- classification head
+// logits[b, c] = LayerNorm(x[b,0,:]) . w[c,:] + bias[c]       one wavefront per clip
+__global__ __launch_bounds__(64) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ logits,
+                                                     int N, int D, int C, float eps) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* xr = x + (int64_t)b * N * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += xr[i];
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+  for (int i = lane; i < D; i += 64) { const float d = xr[i] - mean; ss += d * d; }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+  for (int c = 0; c < C; ++c) {
+    float a = 0.f;
+    for (int i = lane; i < D; i += 64) a += ((xr[i] - mean) * rstd * gamma[i] + beta[i]) * w[(int64_t)c * D + i];
+    a = wave_sum(a);
+    if (lane == 0) logits[b * C + c] = a + bias[c];
+  }
+}
+
+}  // namespace
+
+extern "C" int mt_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                                int rows, int dim, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y) return fail(MT_ERR_ARG, "mt_layernorm_fwd: null pointer");
+  if (dim <= 0 || (dim & 3) || dim > 1024) return fail(MT_ERR_ARG, "mt_layernorm_fwd: dim %d unsupported (need %%4==0, <=1024)", dim);
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, stats,
+                     rows, dim, eps);
+  return check_launch("mt_layernorm_fwd");
+}
+
+extern "C" int mt_embed_fwd(float* x, const float* cls, const float* pos_emb, const float* size_emb,
+                            const int64_t* positions, const int32_t* sizes, int B, int F, int n, int dim, void* stream) {
+  if (!x || !cls || !pos_emb) return fail(MT_ERR_ARG, "mt_embed_fwd: null pointer");
+  if (dim & 3) return fail(MT_ERR_ARG, "mt_embed_fwd: dim %% 4 != 0");
+  const int N = 1 + F * n;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((B * N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, cls, pos_emb, size_emb,
+                     positions, sizes, B, N, n, F, dim);
+  return check_launch("mt_embed_fwd");
+}
+
+namespace {
+template <int MODE, int NKEYS, int PPW, int STRIDE, int WPB>
+int launch_patch(const float* qkv, float* out, const uint8_t* mask, const uint8_t* ident, int B, int H, int F, int n,
+                 float scale, hipStream_t s) {
+  constexpr int ROWS = MODE == 0 ? 1 + PPW * (NKEYS - 1) : NKEYS;
+  const int chunks = MODE == 0 ? (n + PPW - 1) / PPW : F;
+  const int64_t waves = (int64_t)B * H * chunks;
+  const size_t lds = (size_t)WPB * (ROWS * STRIDE + NKEYS * 64) * sizeof(float);
+  auto k = attn_patch_fwd_kernel<MODE, NKEYS, PPW, STRIDE, WPB>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_attn_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, out, mask, ident, B, H, F, n, scale);
+  return check_launch("mt_attn_fwd(patch)");
+}
+}  // namespace
+
+extern "C" int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const uint8_t* mask, const uint8_t* ident,
+                           int B, int H, int F, int n, int mode, float scale, void* stream) {
+  if (!qkv || !out) return fail(MT_ERR_ARG, "mt_attn_fwd: null pointer");
+  if (mode == 0 && (!mask || !ident)) return fail(MT_ERR_ARG, "mt_attn_fwd: time attention needs mask and identities_mask");
+  if (n != 49) return fail(MT_ERR_UNSUPPORTED, "mt_attn_fwd: num-patches %d unsupported (49)", n);
+  hipStream_t s = (hipStream_t)stream;
+  const int N = 1 + F * n;
+  hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(64), N * sizeof(float), s, qkv, out, cls_att, mask, B, H, F, n, scale);
+  int rc = check_launch("mt_attn_fwd(cls)");
+  if (rc) return rc;
+  if (mode == 1) return launch_patch<1, 50, 1, 64, 2>(qkv, out, mask, ident, B, H, F, n, scale, s);
+  switch (F) {
+    case 8: return launch_patch<0, 9, 7, 68, 4>(qkv, out, mask, ident, B, H, F, n, scale, s);
+    case 16: return launch_patch<0, 17, 4, 68, 4>(qkv, out, mask, ident, B, H, F, n, scale, s);
+    case 32: return launch_patch<0, 33, 2, 68, 4>(qkv, out, mask, ident, B, H, F, n, scale, s);
+  }
+  return fail(MT_ERR_UNSUPPORTED, "mt_attn_fwd: num-frames %d unsupported (8/16/32, reference train.py:101)", F);
+}
+
+extern "C" int mt_head_fwd(const float* x, const float* gamma, const float* beta, const float* w, const float* bias,
+                           float* logits, int B, int N, int dim, int classes, float eps, void* stream) {
+  if (!x || !gamma || !beta || !w || !bias || !logits) return fail(MT_ERR_ARG, "mt_head_fwd: null pointer");
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, gamma, beta, w, bias, logits, N, dim,
+                     classes, eps);
+  return check_launch("mt_head_fwd");
+}

@@ -1,0 +1,128 @@
+"""ctypes binding of csrc/libmintime_hip.so (C ABI: include/mintime_hip.h).
+
+There is deliberately NO fallback: `get()` raises if the shared library is missing or a symbol the
+header declares is not exported, and every wrapper raises on a non-zero return code.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmintime_hip.so")
+
+_lib = None
+
+f32p = C.c_void_p
+i64 = C.c_int64
+
+
+class RowMap(C.Structure):
+    _fields_ = [("gin", C.c_int), ("gout", C.c_int), ("off", C.c_int)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("op", C.c_int), ("prologue", C.c_int), ("epilogue", C.c_int),
+                ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("lda", i64), ("ldb", i64), ("ldc", i64),
+                ("a_map", RowMap), ("b_map", RowMap), ("c_map", RowMap),
+                ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", i64),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("gate", C.c_void_p), ("hw", C.c_int),
+                ("C2", C.c_void_p), ("ldc2", i64), ("stats", C.c_void_p), ("stats_slots", C.c_int),
+                ("n_half", C.c_int), ("split_k", C.c_int)]
+
+
+OP_NT, OP_NN, OP_TN = 0, 1, 2
+PRO_NONE, PRO_BN_SWISH_GATE, PRO_BN_SWISH, PRO_AFFINE = 0, 1, 2, 3
+EPI_STORE, EPI_BIAS_RES, EPI_GEGLU, EPI_STATS, EPI_ATOMIC, EPI_GEGLU_BWD, EPI_ACCUM = 0, 1, 2, 3, 4, 5, 6
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES); mirrors include/mintime_hip.h
+PROTOTYPES = {
+    "mt_version": [],
+    "mt_last_error": [],
+    "mt_gemm": [C.POINTER(GemmDesc), C.c_void_p],
+    "mt_layernorm_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_void_p],
+    "mt_embed_fwd": [f32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_attn_fwd": [f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                    C.c_void_p],
+    "mt_head_fwd": [f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
+}
+_RESTYPES = {"mt_last_error": C.c_char_p}
+
+
+class MintimeHipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False):
+    """Compile every HIP source for gfx950 into csrc/libmintime_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(min(16, os.cpu_count() or 4))]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise MintimeHipError("building libmintime_hip.so failed:\n" + res.stdout[-4000:] + res.stderr[-8000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+def get():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MintimeHipError(
+            f"{LIB_PATH} is missing: the MINTIME hot path has no CPU/eager fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MintimeHipError(f"libmintime_hip.so does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    v = lib.mt_version()
+    if v != 100:
+        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 100; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = get().mt_last_error()
+        raise MintimeHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). Refuses CPU tensors: the library only takes device memory."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MintimeHipError("libmintime_hip takes device pointers only; got a CPU tensor (no CPU fallback exists)")
+    return C.c_void_p(t.data_ptr())
+
+
+def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI_STORE, bias=None, R=None, ldr=0,
+         scale=None, shift=None, gate=None, hw=1, C2=None, ldc2=0, stats=None, stats_slots=1, n_half=0, split_k=1,
+         a_map=(0, 0, 0), b_map=(0, 0, 0), c_map=(0, 0, 0)):
+    d = GemmDesc()
+    d.op, d.prologue, d.epilogue = op, prologue, epilogue
+    d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.a_map, d.b_map, d.c_map = RowMap(*a_map), RowMap(*b_map), RowMap(*c_map)
+    d.bias, d.R, d.ldr = ptr(bias), ptr(R), ldr
+    d.scale, d.shift, d.gate, d.hw = ptr(scale), ptr(shift), ptr(gate), hw
+    d.C2, d.ldc2, d.stats, d.stats_slots = ptr(C2), ldc2, ptr(stats), stats_slots
+    d.n_half, d.split_k = n_half, split_k
+    check(get().mt_gemm(C.byref(d), stream_ptr()), "mt_gemm")

@@ -1,0 +1,164 @@
+"""Launch sequences (forward and backward) of the Size-Invariant TimeSformer on libmintime_hip.
+
+Python here is plumbing only: it allocates device buffers through torch, passes raw pointers + the current
+HIP stream to the C ABI, and wires the result into autograd with ONE torch.autograd.Function for the whole
+transformer (inputs: token-major features + every parameter; the backward pass is our own reverse launch
+sequence, not torch autograd over torch ops).
+"""
+import ctypes as C
+
+import torch
+
+from . import arch
+from . import lib as L
+
+
+def _as_tokens(x):
+    """[B,F,C,h,w] (any strides) -> token-major [B*F*h*w, C] contiguous.  Zero-copy when x is the NHWC-strided
+    view our EfficientNet returns; otherwise one layout copy (the reference always pays it, :227)."""
+    b, f, c, h, w = x.shape
+    t = x.permute(0, 1, 3, 4, 2)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t.reshape(b * f * h * w, c)
+
+
+class _Aux:
+    """Device-side copies of the per-clip side inputs in the dtypes the kernels read."""
+
+    def __init__(self, model, x, mask, identities_mask, size_embedding, positions):
+        dev = x.device
+        b, f = x.shape[0], x.shape[1]
+        if mask is None:
+            mask = torch.ones(b, f, dtype=torch.bool, device=dev)
+        if identities_mask is None:
+            identities_mask = torch.ones(b, f, f, dtype=torch.bool, device=dev)
+        self.mask = mask.to(device=dev, dtype=torch.uint8).contiguous()
+        self.ident = identities_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        self.sizes = None
+        if model.enable_size_emb:
+            # arrives as a CPU int32 tensor in the reference call sites (train.py:355); moved here like :245
+            self.sizes = size_embedding.to(device=dev, dtype=torch.int32).contiguous()
+        self.positions = None
+        if model.enable_pos_emb:
+            self.positions = positions.to(device=dev, dtype=torch.int64).contiguous()
+
+
+def _new(dev, *shape):
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+
+def tsf_forward(model, feat, aux, params, B, F, n, save):
+    """Runs the forward launch sequence.  Returns (logits, space_att, time_att, saved-dict or None)."""
+    lib = L.get()
+    st = L.stream_ptr()
+    dev = feat.device
+    D, H, dh, C_in = model.dim, model.heads, model.dim_head, model.channels
+    inner = H * dh
+    N = 1 + F * n
+    M = B * N
+    eps = arch.LN_EPS
+    scale = float(dh) ** -0.5
+    it = iter(params)
+    w_pe, b_pe, cls, pos_w, size_w = next(it), next(it), next(it), next(it), next(it)
+
+    x = _new(dev, B, N, D)
+    L.gemm(L.OP_NT, feat, w_pe, x, B * F * n, D, C_in, C_in, C_in, D, bias=b_pe, c_map=(F * n, N, 1))
+    L.check(lib.mt_embed_fwd(L.ptr(x), L.ptr(cls), L.ptr(pos_w), L.ptr(size_w), L.ptr(aux.positions), L.ptr(aux.sizes),
+                             B, F, n, D, st), "mt_embed_fwd")
+
+    saved = {"layers": []} if save else None
+    want_att = model.require_attention
+    s_att = t_att = None
+    xn = _new(dev, M, D)
+    qkv = _new(dev, M, 3 * inner)
+    o = _new(dev, M, inner)
+    hbuf = _new(dev, M, 4 * D)
+    for li in range(model.depth):
+        last = li == model.depth - 1
+        rec = {}
+        for mode in (0, 1):   # 0 = time, 1 = space
+            g, b_, w_qkv, w_o, b_o = next(it), next(it), next(it), next(it), next(it)
+            if save:
+                xn, qkv, o = _new(dev, M, D), _new(dev, M, 3 * inner), _new(dev, M, inner)
+                stats = _new(dev, M, 2)
+            else:
+                stats = None
+            L.check(lib.mt_layernorm_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(xn), L.ptr(stats), M, D, eps, st), "mt_layernorm_fwd")
+            L.gemm(L.OP_NT, xn, w_qkv, qkv, M, 3 * inner, D, D, D, 3 * inner)
+            att = None
+            if want_att and last:
+                att = _new(dev, B * H, 1, N)
+                if mode == 0:
+                    t_att = att
+                else:
+                    s_att = att
+            L.check(lib.mt_attn_fwd(L.ptr(qkv), L.ptr(o), L.ptr(att), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
+                                    scale, st), "mt_attn_fwd")
+            x_new = _new(dev, B, N, D) if save else x
+            L.gemm(L.OP_NT, o, w_o, x_new, M, D, inner, inner, inner, D, epilogue=L.EPI_BIAS_RES, bias=b_o, R=x, ldr=D)
+            if save:
+                rec[mode] = dict(x=x, xn=xn, stats=stats, qkv=qkv, o=o)
+            x = x_new
+        g, b_, w1, b1, w2, b2 = next(it), next(it), next(it), next(it), next(it), next(it)
+        if save:
+            xn, hbuf, stats = _new(dev, M, D), _new(dev, M, 4 * D), _new(dev, M, 2)
+            u = _new(dev, M, 8 * D)
+        else:
+            stats, u = None, None
+        L.check(lib.mt_layernorm_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(xn), L.ptr(stats), M, D, eps, st), "mt_layernorm_fwd")
+        L.gemm(L.OP_NT, xn, w1, hbuf, M, 8 * D, D, D, D, 4 * D, epilogue=L.EPI_GEGLU, bias=b1, C2=u, ldc2=8 * D, n_half=4 * D)
+        x_new = _new(dev, B, N, D) if save else x
+        L.gemm(L.OP_NT, hbuf, w2, x_new, M, D, 4 * D, 4 * D, 4 * D, D, epilogue=L.EPI_BIAS_RES, bias=b2, R=x, ldr=D)
+        if save:
+            rec[2] = dict(x=x, xn=xn, stats=stats, u=u, h=hbuf)
+            saved["layers"].append(rec)
+        x = x_new
+    g, b_, w_h, b_h = next(it), next(it), next(it), next(it)
+    logits = _new(dev, B, model.num_classes)
+    L.check(lib.mt_head_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(w_h), L.ptr(b_h), L.ptr(logits), B, N, D, model.num_classes,
+                            eps, st), "mt_head_fwd")
+    if save:
+        saved["x_final"] = x
+    return logits, s_att, t_att, saved
+
+
+class _TSFFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, aux, dims, feat, *params):
+        B, F, n = dims
+        save = any(ctx.needs_input_grad)
+        logits, s_att, t_att, saved = tsf_forward(model, feat, aux, params, B, F, n, save)
+        ctx.model, ctx.aux, ctx.dims, ctx.saved = model, aux, dims, saved
+        ctx.feat, ctx.params = feat, params
+        outs = [logits]
+        if model.require_attention:
+            ctx.mark_non_differentiable(s_att, t_att)
+            outs += [s_att, t_att]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dlogits, *unused):
+        from .tsf_backward import tsf_backward
+        dfeat, dparams = tsf_backward(ctx.model, ctx.feat, ctx.aux, ctx.params, ctx.dims, ctx.saved,
+                                      dlogits.contiguous(), ctx.needs_input_grad[3], ctx.needs_input_grad[4:])
+        ctx.saved = None
+        return (None, None, None, dfeat) + tuple(dparams)
+
+
+def tsf_apply(model, x, mask, identities_mask, size_embedding, positions):
+    if not x.is_cuda:
+        raise L.MintimeHipError("SizeInvariantTimeSformer (MI355X build) needs device tensors; there is no CPU path")
+    b, f, c, h, w = x.shape
+    if c != model.channels:
+        raise ValueError(f"expected {model.channels} feature channels, got {c}")
+    if f != model.num_frames:
+        raise ValueError(f"expected num-frames={model.num_frames} face slots per clip, got {f}")
+    if h * w != model.num_patches:
+        raise ValueError(f"expected {model.num_patches} patches per slot, got {h * w}")
+    aux = _Aux(model, x, mask, identities_mask, size_embedding, positions)
+    feat = _as_tokens(x.float())
+    outs = _TSFFunction.apply(model, aux, (b, f, h * w), feat, *model._param_list())
+    if model.require_attention:
+        return outs[0], [outs[1], outs[2]]       # order [space, time] (reference :271)
+    return outs[0]

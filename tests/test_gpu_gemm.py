@@ -1,0 +1,109 @@
+"""GPU parity of the fp32-MFMA GEMM family (through the C ABI) against fp64 CPU matmuls."""
+import numpy as np
+import pytest
+import torch
+
+import mintime_amd
+from mintime_amd import lib as L
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5   # exact-fp32 MFMA vs fp64: rounding only
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 512), (1000, 1536, 512), (257, 96, 16), (4000, 16, 32), (777, 40, 144),
+                                   (513, 320, 1152), (130, 1280, 320), (64, 24, 96)])
+def test_nt_store_bias(M, N, K):
+    A, W, b = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3)
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    L.gemm(L.OP_NT, Ad, Wd, Cd, M, N, K, K, K, N, bias=bd)
+    ref = A.double() @ W.double().T + b.double()
+    assert_close(Cd, ref, TOL, f"NT {M}x{N}x{K}")
+
+
+def test_nt_bias_res_inplace_and_rowmap():
+    M, N, K = 2 * 392, 512, 1280
+    A, W, b = _rand(M, K, seed=1, scale=0.3), _rand(N, K, seed=2, scale=0.05), _rand(N, seed=3)
+    X = torch.zeros(2, 393, N)
+    Xd = X.cuda()
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), Xd, M, N, K, K, K, N, bias=b.cuda(), c_map=(392, 393, 1))
+    ref = (A.double() @ W.double().T + b.double()).reshape(2, 392, N)
+    assert_close(Xd[:, 1:], ref, TOL, "row-mapped store")
+    assert float(Xd[:, 0].abs().max()) == 0.0
+    # residual, in place
+    R = _rand(M, N, seed=5)
+    Rd = R.cuda()
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), Rd, M, N, K, K, K, N, epilogue=L.EPI_BIAS_RES, bias=b.cuda(), R=Rd, ldr=N)
+    assert_close(Rd, A.double() @ W.double().T + b.double() + R.double(), TOL, "bias+residual in place")
+
+
+@pytest.mark.parametrize("M", [393 * 2, 1000])
+def test_nt_geglu(M):
+    D = 512
+    A, W, b = _rand(M, D, seed=1), _rand(8 * D, D, seed=2, scale=0.05), _rand(8 * D, seed=3, scale=0.1)
+    h = torch.full((M, 4 * D), float("nan"), device="cuda")
+    u = torch.full((M, 8 * D), float("nan"), device="cuda")
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), h, M, 8 * D, D, D, D, 4 * D, epilogue=L.EPI_GEGLU, bias=b.cuda(), C2=u, ldc2=8 * D,
+           n_half=4 * D)
+    uref = A.double() @ W.double().T + b.double()
+    a, g = uref.chunk(2, dim=-1)
+    assert_close(u, uref, TOL, "GEGLU pre-activations")
+    assert_close(h, a * torch.nn.functional.gelu(g), TOL, "GEGLU output")
+
+
+def test_nt_stats_and_gate_prologue():
+    n_img, hw, K, N = 3, 49, 96, 24
+    M = n_img * hw
+    Z, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.2)
+    sc, sh, gate = _rand(K, seed=3).abs() + 0.5, _rand(K, seed=4, scale=0.2), torch.sigmoid(_rand(n_img, K, seed=5))
+    slots = 4
+    stats = torch.zeros(slots, 2, N, dtype=torch.float64, device="cuda")
+    Cd = torch.empty(M, N, device="cuda")
+    L.gemm(L.OP_NT, Z.cuda(), W.cuda(), Cd, M, N, K, K, K, N, prologue=L.PRO_BN_SWISH_GATE, epilogue=L.EPI_STATS,
+           scale=sc.cuda(), shift=sh.cuda(), gate=gate.cuda(), hw=hw, stats=stats, stats_slots=slots)
+    a = Z.double() * sc.double() + sh.double()
+    a = a * torch.sigmoid(a) * gate.double().repeat_interleave(hw, 0)
+    ref = a @ W.double().T
+    assert_close(Cd, ref, 5e-5, "gated project conv")
+    st = stats.sum(0).cpu()
+    assert_close(st[0], ref.sum(0), 5e-5, "column sums")
+    assert_close(st[1], (ref * ref).sum(0), 5e-5, "column sums of squares")
+
+
+@pytest.mark.parametrize("M,N,K", [(500, 512, 2048), (786, 1280, 512), (300, 16, 96)])
+def test_nn_dgrad(M, N, K):
+    dY, W = _rand(M, K, seed=1), _rand(K, N, seed=2, scale=0.1)
+    Cd = torch.empty(M, N, device="cuda")
+    L.gemm(L.OP_NN, dY.cuda(), W.cuda(), Cd, M, N, K, K, N, N)
+    assert_close(Cd, dY.double() @ W.double(), TOL, "NN")
+    acc = _rand(M, N, seed=3)
+    accd = acc.cuda()
+    L.gemm(L.OP_NN, dY.cuda(), W.cuda(), accd, M, N, K, K, N, N, epilogue=L.EPI_ACCUM)
+    assert_close(accd, acc.double() + dY.double() @ W.double(), TOL, "NN accumulate")
+
+
+def test_nn_geglu_bwd():
+    M, D = 700, 512
+    dy, W2 = _rand(M, D, seed=1), _rand(D, 4 * D, seed=2, scale=0.05)
+    u = _rand(M, 8 * D, seed=3)
+    du = torch.empty(M, 8 * D, device="cuda")
+    L.gemm(L.OP_NN, dy.cuda(), W2.cuda(), du, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=u.cuda(), ldc2=8 * D,
+           n_half=4 * D)
+    ud = u.double().requires_grad_(True)
+    a, g = ud.chunk(2, dim=-1)
+    (a * torch.nn.functional.gelu(g) * (dy.double() @ W2.double())).sum().backward()
+    assert_close(du, ud.grad, 5e-5, "GEGLU backward")
+
+
+@pytest.mark.parametrize("Mrows,N1,N2,split", [(2 * 393, 512, 1536, 1), (5000, 96, 16, 8), (1234, 2048, 512, 4)])
+def test_tn_wgrad(Mrows, N1, N2, split):
+    dY, X = _rand(Mrows, N1, seed=1), _rand(Mrows, N2, seed=2)
+    dW = torch.zeros(N1, N2, device="cuda")
+    L.gemm(L.OP_TN, dY.cuda(), X.cuda(), dW, N1, N2, Mrows, N1, N2, N2, epilogue=L.EPI_ATOMIC, split_k=split)
+    assert_close(dW, dY.double().T @ X.double(), 5e-5, "TN")

@@ -1,0 +1,77 @@
+"""GPU parity of the HIP SizeInvariantTimeSformer against the CPU oracle and the reference-generated fixtures."""
+import pytest
+import torch
+
+import mintime_amd
+from mintime_amd import arch, synth, SizeInvariantTimeSformer
+from oracle import mintime_oracle as O
+from tests.util import REL_TOL, assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(cfg, seed, require_attention=True):
+    model = SizeInvariantTimeSformer(config=cfg, require_attention=require_attention)
+    sd = synth.tsf_state(cfg, seed)
+    model.load_state_dict(sd, strict=True)
+    return model.cuda(), sd
+
+
+def _inputs(g):
+    B, Fr, C = int(g["batch"]), int(g["frames"]), int(g["channels"])
+    feats = synth.features(B, Fr, C, int(g["seed"]))
+    aux = synth.clip_inputs(B, Fr, int(g["identities"]), int(g["seed"]), ragged=bool(g["ragged"]), with_video=False)
+    return B, Fr, C, feats, aux
+
+
+@pytest.mark.parametrize("name", ["tsf_cfg1", "tsf_2id_ragged", "tsf_xs_3id"])
+def test_forward_matches_reference_fixture(name):
+    g = golden(name)
+    B, Fr, C, feats, aux = _inputs(g)
+    cfg = arch.default_tsf_config(C, Fr)
+    model, sd = _build(cfg, int(g["seed"]))
+    with torch.no_grad():
+        # size_embedding stays on the CPU like the reference call sites (train.py:355)
+        logits, (s_att, t_att) = model(feats.cuda(), mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(),
+                                       size_embedding=aux["size_embedding"], positions=aux["positions"].cuda())
+    assert logits.shape == (B, 1) and s_att.shape == (B * 8, 1, 1 + Fr * 49)
+    assert_close(logits, g["logits"], REL_TOL, "logits vs reference")
+    assert_close(s_att, g["space_att"], REL_TOL, "space cls attention vs reference")
+    assert_close(t_att, g["time_att"], REL_TOL, "time cls attention vs reference")
+    # elementwise gate on the logits: |d| <= 1e-3*|ref| + 1e-5
+    ref = torch.as_tensor(g["logits"])
+    assert bool(((logits.cpu() - ref).abs() <= 1e-3 * ref.abs() + 1e-5).all())
+    # and against the oracle run in this process
+    with torch.no_grad():
+        o_logits, (o_s, o_t) = O.tsf_forward(sd, cfg, feats, aux["mask"], aux["identities_mask"], aux["size_embedding"],
+                                             aux["positions"], require_attention=True)
+    assert_close(logits, o_logits, REL_TOL, "logits vs oracle")
+    assert_close(t_att, o_t, REL_TOL, "time att vs oracle")
+
+
+def test_masked_keys_get_exactly_zero_attention():
+    g = golden("tsf_2id_ragged")
+    B, Fr, C, feats, aux = _inputs(g)
+    cfg = arch.default_tsf_config(C, Fr)
+    model, _ = _build(cfg, int(g["seed"]))
+    with torch.no_grad():
+        _, (s_att, t_att) = model(feats.cuda(), mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(),
+                                  size_embedding=aux["size_embedding"], positions=aux["positions"].cuda())
+    m = aux["mask"]
+    cm = torch.cat([torch.ones(B, 1, dtype=torch.bool), m.repeat_interleave(49, 1)], 1)
+    cm = cm[:, None].expand(-1, 8, -1).reshape(-1, 1, cm.shape[-1])
+    assert float(t_att.cpu()[~cm].abs().max()) == 0.0
+    assert float(s_att.cpu()[~cm].abs().max()) == 0.0
+    assert_close(t_att.sum(-1), torch.ones(B * 8, 1), 1e-5, "probabilities sum to one")
+
+
+def test_nchw_contiguous_features_are_accepted():
+    """The drop-in contract: any [B,F,C,7,7] tensor works, not only our NHWC-strided view."""
+    g = golden("tsf_cfg1")
+    B, Fr, C, feats, aux = _inputs(g)
+    cfg = arch.default_tsf_config(C, Fr)
+    model, _ = _build(cfg, int(g["seed"]), require_attention=False)
+    with torch.no_grad():
+        out = model(feats.contiguous().cuda(), mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(),
+                    size_embedding=aux["size_embedding"], positions=aux["positions"].cuda())
+    assert_close(out, g["logits"], REL_TOL, "NCHW-contiguous input")
