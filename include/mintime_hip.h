@@ -82,6 +82,41 @@ int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const uint8_t* mas
 int mt_head_fwd(const float* x, const float* gamma, const float* beta, const float* w, const float* bias,
                 float* logits, int B, int N, int dim, int classes, float eps, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * EfficientNet-B0 forward, everything except the 1x1 convolutions (those are mt_gemm on NHWC rows).
+ * Activations are NHWC fp32.  Tensors between kernels hold the RAW conv output z; consumers apply
+ * swish(z*scale[c]+shift[c]) on load.  `stats` = [slots][2][C] fp64 accumulators (sum, sum of squares),
+ * zeroed by the caller; pass NULL when batch statistics are not needed (eval).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* _conv_stem: 3x3 stride-2 TF-SAME conv 3->32 (model.py:173,276; utils.py:248-276). x [N,H,W,3] -> z [N,H/2,W/2,32];
+ * w in torch layout [32,3,3,3]. */
+int mt_stem_conv_fwd(const float* x, const float* w, float* z, double* stats, int slots, int N, int H, int W, void* stream);
+
+/* _depthwise_conv (k 3|5, stride 1|2, TF-SAME) applied to swish(bn(zin)) (model.py:98-103). w torch layout [C,1,k,k]. */
+int mt_dwconv_fwd(const float* zin, const float* scale, const float* shift, const float* w, float* zout,
+                  double* stats, int slots, int N, int H, int W, int C, int k, int stride, void* stream);
+
+/* nn.BatchNorm2d bookkeeping (model.py:51-52,62,72,86,174,202): training!=0 -> batch statistics from `stats`
+ * (count = N*H*W), running-stat update with `momentum` (unbiased variance); else running statistics.
+ * Emits scale = gamma*invstd, shift = beta - mean*scale, and mean_invstd [2][C] (optional, for backward). */
+int mt_bn_finalize(const double* stats, int slots, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float* scale, float* shift, float* mean_invstd,
+                   int C, float eps, float momentum, int training, void* stream);
+
+/* squeeze: pooled[n,c] = mean_hw swish(bn(z)) (model.py:104-108). */
+int mt_se_pool_fwd(const float* z, const float* scale, const float* shift, float* pooled, int N, int HW, int C, void* stream);
+
+/* excite: gate = sigmoid(_se_expand(swish(_se_reduce(pooled)))) (model.py:109-112). w1 [CS,C], w2 [C,CS];
+ * hidden (optional) [N,CS] receives the pre-activation of the squeeze layer (kept for backward). */
+int mt_se_gate_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+                   float* gate, float* hidden, int N, int C, int CS, void* stream);
+
+/* y = act(z*scale+shift) * rowscale[row / rows_per_group] (+ res): _bn2 + drop_connect + identity skip
+ * (model.py:117-127, utils.py:129-154; act=0) and head _bn1+swish (model.py:286; act=1). rowscale may be NULL. */
+int mt_bn_act_fwd(const float* z, const float* scale, const float* shift, const float* res, float* y,
+                  int64_t rows, int C, int act, const float* rowscale, int rows_per_group, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

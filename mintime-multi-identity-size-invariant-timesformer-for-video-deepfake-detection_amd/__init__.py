@@ -6,6 +6,8 @@ There is no CPU or eager-PyTorch fallback: every op raises if the library is mis
 """
 from . import arch, synth, lib  # noqa: F401
 from . import timesformer, tsf_engine  # noqa: F401
+from . import efficientnet, effnet_engine  # noqa: F401
 from .timesformer import SizeInvariantTimeSformer  # noqa: F401
+from .efficientnet import EfficientNet  # noqa: F401
 
-__all__ = ["arch", "synth", "lib", "timesformer", "tsf_engine", "SizeInvariantTimeSformer"]
+__all__ = ["arch", "synth", "lib", "timesformer", "tsf_engine", "SizeInvariantTimeSformer", "efficientnet", "effnet_engine", "EfficientNet"]

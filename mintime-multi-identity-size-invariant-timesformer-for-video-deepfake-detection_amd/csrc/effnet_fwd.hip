@@ -1,0 +1,432 @@
+// EfficientNet-B0 forward kernels other than the 1x1 convolutions (those are mt_gemm), gfx950.
+//
+// Data layout decisions (MI355X-first):
+//   * activations are NHWC ([N*H*W, C] "pixel-major") everywhere -> a 1x1 conv is a plain GEMM, the extractor's last
+//     tensor is already the TimeSformer's token-major [B*F*49, C] operand, and channel vectors are float4-coalesced.
+//   * what lives in HBM between kernels is the RAW convolution output z (pre-BatchNorm).  Every consumer applies
+//     y = swish(z*scale[c] + shift[c]) while loading.  One code path serves eval mode (scale/shift from running
+//     stats) and train mode (from batch statistics, which only exist after the producing kernel has finished), and the
+//     backward pass needs z anyway (swish' and BN backward), so nothing is stored twice.
+//   * every producer accumulates per-channel sum / sum-of-squares of z in fp64 (block partials in fp32, one fp64
+//     atomic per block and channel into one of `slots` replicated accumulators) -> BatchNorm batch statistics cost no
+//     extra pass over the tensor.
+//
+// Reference ops replaced (models/efficientnet/efficientnet_pytorch):
+//   mt_stem_conv_fwd    _conv_stem (Conv2dStaticSamePadding k3 s2, utils.py:248-276; model.py:173,276)
+//   mt_dwconv_fwd       _bn0/_swish on load + _depthwise_conv (model.py:98-103)
+//   mt_bn_finalize      nn.BatchNorm2d statistics, running-stat update, affine folding (model.py:62,72,86,174,202)
+//   mt_se_pool_fwd      _bn1 + _swish + F.adaptive_avg_pool2d (model.py:104-108)
+//   mt_se_gate_fwd      _se_reduce + swish + _se_expand + sigmoid (model.py:109-112)
+//   mt_bn_act_fwd       _bn2 (+ residual, model.py:117-127) and the head's _bn1 + swish (model.py:286)
+#include "../../include/mintime_hip.h"
+#include "common.hpp"
+
+using namespace mt;
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+
+__device__ __forceinline__ float4 bn_swish4(float4 z, float4 sc, float4 sh) {
+  float4 a;
+  a.x = swishf_(fmaf(z.x, sc.x, sh.x)); a.y = swishf_(fmaf(z.y, sc.y, sh.y));
+  a.z = swishf_(fmaf(z.z, sc.z, sh.z)); a.w = swishf_(fmaf(z.w, sc.w, sh.w));
+  return a;
+}
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { atomicAdd(p, v); }
+
+// ------------------------------------------------------------------------------------------------ stem
+// x [N, H, W, 3] (raw 0..255) -> z [N, Ho, Wo, 32], 3x3 stride 2, TF-SAME pad (0,1,0,1) for H=224.
+// One thread per output pixel, all 32 output channels in registers; weights broadcast from LDS.
+constexpr int STEM_CO = 32;
+
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ z, double* __restrict__ stats, int slots,
+                                                        int N, int H, int W, int Ho, int Wo, int pad0) {
+  __shared__ float ws[27 * STEM_CO];            // [tap = (kh*3+kw)*3+ci][co]
+  __shared__ float red[4][2][STEM_CO];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 27 * STEM_CO; i += 256) {
+    // torch layout [co][ci][kh][kw] -> [kh][kw][ci][co]
+    const int co = i % STEM_CO, t = i / STEM_CO;
+    const int ci = t % 3, kk = t / 3, kw = kk % 3, kh = kk / 3;
+    ws[i] = w[((co * 3 + ci) * 3 + kh) * 3 + kw];
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)N * Ho * Wo;
+  const int64_t pix = (int64_t)blockIdx.x * 256 + tid;
+  float acc[STEM_CO];
+#pragma unroll
+  for (int c = 0; c < STEM_CO; ++c) acc[c] = 0.f;
+  const bool live = pix < total;
+  if (live) {
+    const int ow = (int)(pix % Wo);
+    const int64_t t = pix / Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh * 2 + kh - pad0;
+      if (ih < 0 || ih >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow * 2 + kw - pad0;
+        if (iw < 0 || iw >= W) continue;
+        const float* px = x + (((int64_t)n * H + ih) * W + iw) * 3;
+        const float v0 = px[0], v1 = px[1], v2 = px[2];
+        const float* wt = ws + ((kh * 3 + kw) * 3) * STEM_CO;
+#pragma unroll
+        for (int c = 0; c < STEM_CO; ++c)
+          acc[c] = fmaf(v2, wt[2 * STEM_CO + c], fmaf(v1, wt[STEM_CO + c], fmaf(v0, wt[c], acc[c])));
+      }
+    }
+    float4* zo = reinterpret_cast<float4*>(z + pix * STEM_CO);
+#pragma unroll
+    for (int c = 0; c < STEM_CO / 4; ++c) zo[c] = make_float4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
+  }
+  if (stats) {
+    // butterfly transpose-reduce: after 5 exchange steps lane l holds channel (l & 31)'s sum over its 32-lane half
+    const int lane = tid & 63, wave = tid >> 6;
+    float s1[STEM_CO], s2[STEM_CO];
+#pragma unroll
+    for (int c = 0; c < STEM_CO; ++c) { s1[c] = acc[c]; s2[c] = acc[c] * acc[c]; }
+#pragma unroll
+    for (int step = 0; step < 5; ++step) {
+      const int half = STEM_CO >> (step + 1);     // values kept after this step
+      const int bit = 16 >> step;                 // lane bit that selects which half I keep
+      const bool up = (lane & bit) != 0;
+#pragma unroll
+      for (int i = 0; i < half; ++i) {
+        const float send1 = up ? s1[i] : s1[i + half];
+        const float send2 = up ? s2[i] : s2[i + half];
+        const float r1 = __shfl_xor(send1, bit);
+        const float r2 = __shfl_xor(send2, bit);
+        s1[i] = (up ? s1[i + half] : s1[i]) + r1;
+        s2[i] = (up ? s2[i + half] : s2[i]) + r2;
+      }
+    }
+    // lane's channel: bits of lane (16,8,4,2,1) chose upper halves successively
+    float a = s1[0] + __shfl_xor(s1[0], 32);
+    float b = s2[0] + __shfl_xor(s2[0], 32);
+    if (lane < 32) {
+      const int ch = ((lane & 16) ? 16 : 0) + ((lane & 8) ? 8 : 0) + ((lane & 4) ? 4 : 0) + ((lane & 2) ? 2 : 0) + (lane & 1);
+      red[wave][0][ch] = a;
+      red[wave][1][ch] = b;
+    }
+    __syncthreads();
+    if (tid < 2 * STEM_CO) {
+      const int which = tid / STEM_CO, ch = tid % STEM_CO;
+      const float v = red[0][which][ch] + red[1][which][ch] + red[2][which][ch] + red[3][which][ch];
+      atomic_add_f64(stats + ((int64_t)(blockIdx.x % slots) * 2 + which) * STEM_CO + ch, (double)v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise
+// in  z_in [N,H,W,C] raw, activated on load: a = swish(z*scale+shift) (zero padding applies to a)
+// out z_out[N,Ho,Wo,C] raw + per-channel stats.  Thread = (channel quad, R consecutive output columns, RH rows).
+template <int K, int S, int R>
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ zin, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const float* __restrict__ w,
+                                                     float* __restrict__ zout, double* __restrict__ stats, int slots,
+                                                     int N, int H, int W, int C, int Ho, int Wo, int pad0,
+                                                     int CQB, int PB, int RH) {
+  extern __shared__ float red[];     // [PB][CQB*8]
+  constexpr int WIN = (R - 1) * S + K;
+  const int tid = threadIdx.x;
+  const int cql = tid % CQB, pl = tid / CQB;
+  const int CQ = C >> 2;
+  const int cq = blockIdx.y * CQB + cql;
+  const int wsegs = (Wo + R - 1) / R;
+  const int hsegs = (Ho + RH - 1) / RH;
+  const int64_t nseg = (int64_t)N * hsegs * wsegs;
+  const int64_t seg = (int64_t)blockIdx.x * PB + pl;
+  const bool live = pl < PB && cq < CQ && seg < nseg;
+
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (live) {
+    const int ws_ = (int)(seg % wsegs);
+    const int64_t t = seg / wsegs;
+    const int hs = (int)(t % hsegs);
+    const int n = (int)(t / hsegs);
+    const int c = cq * 4;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+    // weights: torch [C][1][K][K] -> per-lane 4 channels x K*K taps
+    float4 wt[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i)
+      wt[i] = make_float4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
+    const int ow0 = ws_ * R;
+    for (int r = 0; r < RH; ++r) {
+      const int oh = hs * RH + r;
+      if (oh >= Ho) break;
+      float4 acc[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        const int ih = oh * S + kh - pad0;
+        if (ih < 0 || ih >= H) continue;
+        const float* rowp = zin + (((int64_t)n * H + ih) * W) * C + c;
+        float4 a[WIN];
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+          const int iw = ow0 * S + i - pad0;
+          if (iw >= 0 && iw < W) a[i] = bn_swish4(*reinterpret_cast<const float4*>(rowp + (int64_t)iw * C), sc, sh);
+          else a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            const float4 v = a[j * S + kw];
+            const float4 ww = wt[kh * K + kw];
+            acc[j].x = fmaf(v.x, ww.x, acc[j].x); acc[j].y = fmaf(v.y, ww.y, acc[j].y);
+            acc[j].z = fmaf(v.z, ww.z, acc[j].z); acc[j].w = fmaf(v.w, ww.w, acc[j].w);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int ow = ow0 + j;
+        if (ow < Wo) {
+          *reinterpret_cast<float4*>(zout + (((int64_t)n * Ho + oh) * Wo + ow) * C + c) = acc[j];
+          s1.x += acc[j].x; s1.y += acc[j].y; s1.z += acc[j].z; s1.w += acc[j].w;
+          s2.x += acc[j].x * acc[j].x; s2.y += acc[j].y * acc[j].y; s2.z += acc[j].z * acc[j].z; s2.w += acc[j].w * acc[j].w;
+        }
+      }
+    }
+  }
+  if (stats) {
+    if (pl < PB) {
+      float* rr = red + (pl * CQB + cql) * 8;
+      rr[0] = s1.x; rr[1] = s1.y; rr[2] = s1.z; rr[3] = s1.w;
+      rr[4] = s2.x; rr[5] = s2.y; rr[6] = s2.z; rr[7] = s2.w;
+    }
+    __syncthreads();
+    // CQB*8 partial columns, each summed over PB rows
+    for (int i = tid; i < CQB * 8; i += blockDim.x) {
+      const int q = i >> 3, e = i & 7;
+      const int cqq = blockIdx.y * CQB + q;
+      if (cqq < CQ) {
+        float v = 0.f;
+        for (int p = 0; p < PB; ++p) v += red[(p * CQB + q) * 8 + e];
+        const int ch = cqq * 4 + (e & 3), which = e >> 2;
+        atomic_add_f64(stats + ((int64_t)(blockIdx.x % slots) * 2 + which) * C + ch, (double)v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm finalize
+// train: mean/var from the fp64 accumulators (biased var normalises, unbiased var updates running_var), momentum update
+// eval : running stats.  Either way emits scale = gamma*invstd, shift = beta - mean*scale, and (mean, invstd) for backward.
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int slots, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_invstd, int C, float eps, float momentum, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < slots; ++i) { s += stats[((int64_t)i * 2) * C + c]; q += stats[((int64_t)i * 2 + 1) * C + c]; }
+    const double m = s / count;
+    double v = q / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m; var = (float)v;
+    if (running_mean) {
+      const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  } else {
+    mean = running_mean[c]; var = running_var[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  if (mean_invstd) { mean_invstd[c] = mean; mean_invstd[C + c] = invstd; }
+}
+
+// ------------------------------------------------------------------------------------------------ SE: pooling
+// pooled[n, c] = mean over hw of swish(z[n,hw,c]*scale+shift).   grid (N, ceil(CQ/CQB)); block = CQB x PB
+__global__ __launch_bounds__(256) void se_pool_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, float* __restrict__ pooled,
+                                                      int HW, int C, int CQB, int PB) {
+  extern __shared__ float red[];   // [PB][CQB*4]
+  const int tid = threadIdx.x;
+  const int cql = tid % CQB, pl = tid / CQB;
+  const int cq = blockIdx.y * CQB + cql;
+  const int CQ = C >> 2;
+  const int n = blockIdx.x;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pl < PB && cq < CQ) {
+    const float4 sc = *reinterpret_cast<const float4*>(scale + cq * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + cq * 4);
+    const float* base = z + (int64_t)n * HW * C + cq * 4;
+    for (int p = pl; p < HW; p += PB) {
+      const float4 a = bn_swish4(*reinterpret_cast<const float4*>(base + (int64_t)p * C), sc, sh);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+  }
+  if (pl < PB) *reinterpret_cast<float4*>(red + (pl * CQB + cql) * 4) = s;
+  __syncthreads();
+  if (pl == 0 && cq < CQ) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < PB; ++p) {
+      const float4 v = *reinterpret_cast<const float4*>(red + (p * CQB + cql) * 4);
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    const float inv = 1.0f / (float)HW;
+    *reinterpret_cast<float4*>(pooled + (int64_t)n * C + cq * 4) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ SE: gate
+// gate[n,c] = sigmoid(W2[c,:] . swish(W1 . pooled[n,:] + b1) + b2[c]);  one block per image
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, float* __restrict__ gate,
+                                                      float* __restrict__ hidden, int C, int CS) {
+  extern __shared__ float sm[];    // pooled[C] + hid[CS]
+  float* pv = sm;
+  float* hid = sm + C;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < C; i += 256) pv[i] = pooled[(int64_t)n * C + i];
+  __syncthreads();
+  for (int j = wave; j < CS; j += 4) {
+    float a = 0.f;
+    for (int i = lane; i < C; i += 64) a = fmaf(w1[(int64_t)j * C + i], pv[i], a);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) {
+      const float pre = a + b1[j];
+      if (hidden) hidden[(int64_t)n * CS + j] = pre;
+      hid[j] = swishf_(pre);
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = b2[c];
+    for (int j = 0; j < CS; ++j) a = fmaf(w2[(int64_t)c * CS + j], hid[j], a);
+    gate[(int64_t)n * C + c] = sigmoidf_(a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BN apply (+swish) (+residual)
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const float* __restrict__ res,
+                                                     float* __restrict__ y, int64_t total4, int CQ, int act,
+                                                     const float* __restrict__ rowscale, int rows_per_group) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int cq = (int)(i % CQ);
+    const float4 v = reinterpret_cast<const float4*>(z)[i];
+    const float4 sc = reinterpret_cast<const float4*>(scale)[cq];
+    const float4 sh = reinterpret_cast<const float4*>(shift)[cq];
+    float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+    if (act) { o.x = swishf_(o.x); o.y = swishf_(o.y); o.z = swishf_(o.z); o.w = swishf_(o.w); }
+    if (rowscale) {   // per-sample drop-connect gate (utils.py:129-154)
+      const float g = rowscale[(i / CQ) / rows_per_group];
+      o.x *= g; o.y *= g; o.z *= g; o.w *= g;
+    }
+    if (res) { const float4 r = reinterpret_cast<const float4*>(res)[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
+int pick_cqb(int CQ) {
+  int best = 1;
+  for (int d = 1; d <= 64 && d <= CQ; ++d)
+    if (CQ % d == 0) best = d;
+  return best;
+}
+
+}  // namespace
+
+extern "C" int mt_stem_conv_fwd(const float* x, const float* w, float* z, double* stats, int slots, int N, int H, int W,
+                                void* stream) {
+  if (!x || !w || !z) return fail(MT_ERR_ARG, "mt_stem_conv_fwd: null pointer");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int padt = max((Ho - 1) * 2 + 3 - H, 0);
+  const int64_t total = (int64_t)N * Ho * Wo;
+  hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, z, stats,
+                     slots > 0 ? slots : 1, N, H, W, Ho, Wo, padt / 2);
+  return check_launch("mt_stem_conv_fwd");
+}
+
+namespace {
+template <int K, int S, int R>
+int launch_dw(const float* zin, const float* scale, const float* shift, const float* w, float* zout, double* stats, int slots,
+              int N, int H, int W, int C, hipStream_t s) {
+  const int Ho = (H + S - 1) / S, Wo = (W + S - 1) / S;
+  const int padt = max((Ho - 1) * S + K - H, 0);
+  const int CQ = C / 4;
+  const int CQB = pick_cqb(CQ);
+  const int PB = 256 / CQB;
+  const int RH = Ho >= 28 ? 4 : (Ho >= 14 ? 2 : 1);
+  const int wsegs = (Wo + R - 1) / R, hsegs = (Ho + RH - 1) / RH;
+  const int64_t nseg = (int64_t)N * hsegs * wsegs;
+  dim3 grid((unsigned)((nseg + PB - 1) / PB), CQ / CQB);
+  const size_t lds = (size_t)PB * CQB * 8 * sizeof(float);
+  hipLaunchKernelGGL((dwconv_kernel<K, S, R>), grid, dim3(CQB * PB), lds, s, zin, scale, shift, w, zout, stats,
+                     slots > 0 ? slots : 1, N, H, W, C, Ho, Wo, padt / 2, CQB, PB, RH);
+  return check_launch("mt_dwconv_fwd");
+}
+}  // namespace
+
+extern "C" int mt_dwconv_fwd(const float* zin, const float* scale, const float* shift, const float* w, float* zout,
+                             double* stats, int slots, int N, int H, int W, int C, int k, int stride, void* stream) {
+  if (!zin || !scale || !shift || !w || !zout) return fail(MT_ERR_ARG, "mt_dwconv_fwd: null pointer");
+  if (C & 3) return fail(MT_ERR_ARG, "mt_dwconv_fwd: C %% 4 != 0");
+  hipStream_t s = (hipStream_t)stream;
+  if (k == 3 && stride == 1) return launch_dw<3, 1, 4>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, s);
+  if (k == 3 && stride == 2) return launch_dw<3, 2, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, s);
+  if (k == 5 && stride == 1) return launch_dw<5, 1, 4>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, s);
+  if (k == 5 && stride == 2) return launch_dw<5, 2, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, s);
+  return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_fwd: k=%d stride=%d unsupported", k, stride);
+}
+
+extern "C" int mt_bn_finalize(const double* stats, int slots, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float* scale, float* shift, float* mean_invstd,
+                              int C, float eps, float momentum, int training, void* stream) {
+  if (!gamma || !beta || !scale || !shift) return fail(MT_ERR_ARG, "mt_bn_finalize: null pointer");
+  if (training && !stats) return fail(MT_ERR_ARG, "mt_bn_finalize: training needs stats");
+  if (!training && (!running_mean || !running_var)) return fail(MT_ERR_ARG, "mt_bn_finalize: eval needs running stats");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, slots, count, gamma,
+                     beta, running_mean, running_var, scale, shift, mean_invstd, C, eps, momentum, training);
+  return check_launch("mt_bn_finalize");
+}
+
+extern "C" int mt_se_pool_fwd(const float* z, const float* scale, const float* shift, float* pooled, int N, int HW, int C,
+                              void* stream) {
+  if (!z || !scale || !shift || !pooled) return fail(MT_ERR_ARG, "mt_se_pool_fwd: null pointer");
+  if (C & 3) return fail(MT_ERR_ARG, "mt_se_pool_fwd: C %% 4 != 0");
+  const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
+  hipLaunchKernelGGL(se_pool_kernel, dim3(N, CQ / CQB), dim3(CQB * PB), (size_t)PB * CQB * 4 * sizeof(float),
+                     (hipStream_t)stream, z, scale, shift, pooled, HW, C, CQB, PB);
+  return check_launch("mt_se_pool_fwd");
+}
+
+extern "C" int mt_se_gate_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+                              float* gate, float* hidden, int N, int C, int CS, void* stream) {
+  if (!pooled || !w1 || !b1 || !w2 || !b2 || !gate) return fail(MT_ERR_ARG, "mt_se_gate_fwd: null pointer");
+  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), (size_t)(C + CS) * sizeof(float), (hipStream_t)stream, pooled, w1, b1,
+                     w2, b2, gate, hidden, C, CS);
+  return check_launch("mt_se_gate_fwd");
+}
+
+extern "C" int mt_bn_act_fwd(const float* z, const float* scale, const float* shift, const float* res, float* y,
+                             int64_t rows, int C, int act, const float* rowscale, int rows_per_group, void* stream) {
+  if (!z || !scale || !shift || !y) return fail(MT_ERR_ARG, "mt_bn_act_fwd: null pointer");
+  if (C & 3) return fail(MT_ERR_ARG, "mt_bn_act_fwd: C %% 4 != 0");
+  const int64_t total4 = rows * (C / 4);
+  int64_t nb = (total4 + 255) / 256; if (nb > 4096) nb = 4096; const int blocks = (int)nb;
+  hipLaunchKernelGGL(bn_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, scale, shift, res, y, total4, C / 4, act,
+                     rowscale, rows_per_group > 0 ? rows_per_group : 1);
+  return check_launch("mt_bn_act_fwd");
+}

@@ -1,0 +1,197 @@
+"""Launch sequences (forward, backward) of EfficientNet-B0 on libmintime_hip.  Plumbing only: device buffers via
+torch, raw pointers + current stream into the C ABI, one torch.autograd.Function for the whole extractor."""
+import torch
+
+from . import arch
+from . import lib as L
+
+SLOTS = 32   # replicated fp64 BatchNorm accumulators (spreads atomic traffic)
+
+
+def _new(dev, *shape):
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+
+def param_list(model):
+    ps = [model._conv_stem.weight, model._bn0.weight, model._bn0.bias]
+    for blk in model._blocks:
+        if blk.spec.has_expand:
+            ps += [blk._expand_conv.weight, blk._bn0.weight, blk._bn0.bias]
+        ps += [blk._depthwise_conv.weight, blk._bn1.weight, blk._bn1.bias, blk._se_reduce.weight, blk._se_reduce.bias,
+               blk._se_expand.weight, blk._se_expand.bias, blk._project_conv.weight, blk._bn2.weight, blk._bn2.bias]
+    ps += [model._conv_head.weight, model._bn1.weight, model._bn1.bias]
+    return ps
+
+
+class _BNCtx:
+    """Per-BatchNorm scratch: accumulators + folded affine + saved statistics."""
+
+    def __init__(self, dev, C, training, stats_pool):
+        self.C = C
+        self.scale, self.shift = _new(dev, C), _new(dev, C)
+        self.mean_invstd = _new(dev, 2, C)
+        self.stats = stats_pool.take(C) if training else None
+        self.count = 0.0
+
+
+class _StatsPool:
+    """One zero-filled fp64 buffer per forward, carved into [SLOTS][2][C] accumulators."""
+
+    def __init__(self, dev, total_channels):
+        self.buf = torch.zeros(total_channels * 2 * SLOTS, dtype=torch.float64, device=dev)
+        self.off = 0
+
+    def take(self, C):
+        v = self.buf[self.off:self.off + 2 * SLOTS * C]
+        self.off += 2 * SLOTS * C
+        return v
+
+
+def _finalize(lib, st, bn_mod, ctx, count, training, gamma, beta):
+    ctx.count = float(count)
+    L.check(lib.mt_bn_finalize(L.ptr(ctx.stats), SLOTS, float(count), L.ptr(gamma), L.ptr(beta), L.ptr(bn_mod.running_mean),
+                               L.ptr(bn_mod.running_var), L.ptr(ctx.scale), L.ptr(ctx.shift), L.ptr(ctx.mean_invstd), ctx.C,
+                               bn_mod.eps, bn_mod.momentum, 1 if training else 0, st), "mt_bn_finalize")
+    if training:
+        bn_mod.num_batches_tracked += 1
+
+
+def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
+    """x_nhwc [N,H,W,3] contiguous fp32.  Returns (feat [N*Ho*Wo, 1280], saved or None, block outputs or None)."""
+    lib = L.get()
+    st = L.stream_ptr()
+    dev = x_nhwc.device
+    N, H, W, _ = x_nhwc.shape
+    blocks = model._blocks
+    total_c = arch.STEM_COUT + arch.HEAD_COUT + sum((b.spec.cexp if b.spec.has_expand else 0) + b.spec.cexp + b.spec.cout
+                                                    for b in blocks)
+    pool = _StatsPool(dev, total_c) if training else None
+    it = iter(params)
+    epi = L.EPI_STATS if training else L.EPI_STORE
+    saved = {"blocks": []} if save else None
+
+    # ---- stem
+    w_stem, g0, b0 = next(it), next(it), next(it)
+    Hc, Wc = (H + 1) // 2, (W + 1) // 2
+    bn = _BNCtx(dev, arch.STEM_COUT, training, pool)
+    z = _new(dev, N * Hc * Wc, arch.STEM_COUT)
+    L.check(lib.mt_stem_conv_fwd(L.ptr(x_nhwc), L.ptr(w_stem), L.ptr(z), L.ptr(bn.stats), SLOTS, N, H, W, st), "mt_stem_conv_fwd")
+    _finalize(lib, st, model._bn0, bn, N * Hc * Wc, training, g0, b0)
+    if save:
+        saved["stem"] = dict(x=x_nhwc, z=z, bn=bn)
+    cur_z, cur_bn = z, bn        # "virtual" activated tensor: swish(bn(z))
+    y = None                     # materialised block output (narrow tensor)
+    ys = [] if want_blocks else None
+
+    # per-sample drop-connect gates (utils.py:129-154), train mode only
+    for bi, blk in enumerate(blocks):
+        s = blk.spec
+        M_in = N * s.hin * s.hin
+        M_out = N * s.hout * s.hout
+        rec = {"spec": s}
+        if s.has_expand:
+            w_e, g, b = next(it), next(it), next(it)
+            bn_e = _BNCtx(dev, s.cexp, training, pool)
+            z_e = _new(dev, M_in, s.cexp)
+            L.gemm(L.OP_NT, y, w_e, z_e, M_in, s.cexp, s.cin, s.cin, s.cin, s.cexp, epilogue=epi, stats=bn_e.stats, stats_slots=SLOTS)
+            _finalize(lib, st, blk._bn0, bn_e, M_in, training, g, b)
+            rec.update(z_e=z_e, bn_e=bn_e)
+            dw_in, dw_bn = z_e, bn_e
+        else:
+            dw_in, dw_bn = cur_z, cur_bn
+        w_d, g, b = next(it), next(it), next(it)
+        bn_d = _BNCtx(dev, s.cexp, training, pool)
+        z_d = _new(dev, M_out, s.cexp)
+        L.check(lib.mt_dwconv_fwd(L.ptr(dw_in), L.ptr(dw_bn.scale), L.ptr(dw_bn.shift), L.ptr(w_d), L.ptr(z_d), L.ptr(bn_d.stats),
+                                  SLOTS, N, s.hin, s.hin, s.cexp, s.k, s.s, st), "mt_dwconv_fwd")
+        _finalize(lib, st, blk._bn1, bn_d, M_out, training, g, b)
+        w_r, b_r, w_x, b_x = next(it), next(it), next(it), next(it)
+        pooled, gate = _new(dev, N, s.cexp), _new(dev, N, s.cexp)
+        hidden = _new(dev, N, s.cse) if save else None
+        hw = s.hout * s.hout
+        L.check(lib.mt_se_pool_fwd(L.ptr(z_d), L.ptr(bn_d.scale), L.ptr(bn_d.shift), L.ptr(pooled), N, hw, s.cexp, st), "mt_se_pool_fwd")
+        L.check(lib.mt_se_gate_fwd(L.ptr(pooled), L.ptr(w_r), L.ptr(b_r), L.ptr(w_x), L.ptr(b_x), L.ptr(gate), L.ptr(hidden), N,
+                                   s.cexp, s.cse, st), "mt_se_gate_fwd")
+        w_p, g, b = next(it), next(it), next(it)
+        bn_p = _BNCtx(dev, s.cout, training, pool)
+        z_p = _new(dev, M_out, s.cout)
+        L.gemm(L.OP_NT, z_d, w_p, z_p, M_out, s.cout, s.cexp, s.cexp, s.cexp, s.cout, prologue=L.PRO_BN_SWISH_GATE, epilogue=epi,
+               scale=bn_d.scale, shift=bn_d.shift, gate=gate, hw=hw, stats=bn_p.stats, stats_slots=SLOTS)
+        _finalize(lib, st, blk._bn2, bn_p, M_out, training, g, b)
+        # block output: bn2(z_p) [* drop-connect gate] [+ block input]
+        dc = None
+        if s.skip and training and model.drop_connect_rate > 0:
+            rate = model.drop_connect_rate * float(bi) / len(blocks)          # model.py:280-282
+            if rate > 0:
+                keep = 1.0 - rate
+                dc = torch.floor(keep + torch.rand(N, device=dev, dtype=torch.float32)) / keep   # utils.py:148-153
+        y_new = _new(dev, M_out, s.cout)
+        L.check(lib.mt_bn_act_fwd(L.ptr(z_p), L.ptr(bn_p.scale), L.ptr(bn_p.shift), L.ptr(y if s.skip else None), L.ptr(y_new),
+                                  M_out, s.cout, 0, L.ptr(dc), hw, st), "mt_bn_act_fwd")
+        if save:
+            rec.update(y_in=y, dw_in=dw_in, dw_bn=dw_bn, z_d=z_d, bn_d=bn_d, pooled=pooled, hidden=hidden, gate=gate, z_p=z_p,
+                       bn_p=bn_p, dc=dc)
+            saved["blocks"].append(rec)
+        y = y_new
+        if want_blocks:
+            ys.append(y.view(N, s.hout, s.hout, s.cout).permute(0, 3, 1, 2))
+
+    # ---- head
+    w_h, g, b = next(it), next(it), next(it)
+    s = blocks[-1].spec
+    M = N * s.hout * s.hout
+    bn_h = _BNCtx(dev, arch.HEAD_COUT, training, pool)
+    z_h = _new(dev, M, arch.HEAD_COUT)
+    L.gemm(L.OP_NT, y, w_h, z_h, M, arch.HEAD_COUT, arch.HEAD_CIN, arch.HEAD_CIN, arch.HEAD_CIN, arch.HEAD_COUT, epilogue=epi,
+           stats=bn_h.stats, stats_slots=SLOTS)
+    _finalize(lib, st, model._bn1, bn_h, M, training, g, b)
+    feat = _new(dev, M, arch.HEAD_COUT)
+    L.check(lib.mt_bn_act_fwd(L.ptr(z_h), L.ptr(bn_h.scale), L.ptr(bn_h.shift), None, L.ptr(feat), M, arch.HEAD_COUT, 1, None, 1,
+                              st), "mt_bn_act_fwd")
+    if save:
+        saved["head"] = dict(y_in=y, z=z_h, bn=bn_h)
+    return feat, saved, ys
+
+
+class _EffNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, want_blocks, x_nhwc, *params):
+        save = any(ctx.needs_input_grad)
+        feat, saved, ys = effnet_forward(model, x_nhwc, params, model.training, save, want_blocks)
+        ctx.model, ctx.saved, ctx.params, ctx.training = model, saved, params, model.training
+        N, H, W, _ = x_nhwc.shape
+        ctx.shape = (N, H, W)
+        outs = [feat]
+        if want_blocks:
+            for t in ys:
+                ctx.mark_non_differentiable(t)
+            outs += ys
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dfeat, *unused):
+        from .effnet_backward import effnet_backward
+        dx, dparams = effnet_backward(ctx.model, ctx.params, ctx.saved, ctx.shape, ctx.training, dfeat.contiguous(),
+                                      ctx.needs_input_grad[2], ctx.needs_input_grad[3:])
+        ctx.saved = None
+        return (None, None, dx) + tuple(dparams)
+
+
+def effnet_apply(model, inputs, want_blocks=False):
+    if not inputs.is_cuda:
+        raise L.MintimeHipError("EfficientNet (MI355X build) needs device tensors; there is no CPU path")
+    if inputs.dim() != 4 or inputs.shape[1] != 3:
+        raise ValueError(f"expected [N,3,H,W] input, got {tuple(inputs.shape)}")
+    if inputs.shape[2] != model.image_size or inputs.shape[3] != model.image_size:
+        raise ValueError(f"static TF-SAME padding was built for {model.image_size}x{model.image_size} inputs "
+                         f"(utils.py:248-276); got {tuple(inputs.shape[2:])}")
+    # logical NCHW, physical NHWC: a view when the caller did `rearrange(videos, 'b f h w c -> (b f) c h w')` (train.py:341)
+    x_nhwc = inputs.float().permute(0, 2, 3, 1)
+    if not x_nhwc.is_contiguous():
+        x_nhwc = x_nhwc.contiguous()
+    outs = _EffNetFunction.apply(model, want_blocks, x_nhwc, *param_list(model))
+    feat = outs[0]
+    n = inputs.shape[0]
+    ho = model._blocks[-1].spec.hout
+    feat_nchw = feat.view(n, ho, ho, arch.HEAD_COUT).permute(0, 3, 1, 2)     # NHWC-strided [N,1280,7,7]
+    return feat_nchw, list(outs[1:])

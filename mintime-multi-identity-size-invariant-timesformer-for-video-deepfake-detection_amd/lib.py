@@ -49,6 +49,14 @@ PROTOTYPES = {
     "mt_attn_fwd": [f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                     C.c_void_p],
     "mt_head_fwd": [f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
+    "mt_stem_conv_fwd": [f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_dwconv_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                      C.c_void_p],
+    "mt_bn_finalize": [C.c_void_p, C.c_int, C.c_double, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_float,
+                       C.c_float, C.c_int, C.c_void_p],
+    "mt_se_pool_fwd": [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_se_gate_fwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_bn_act_fwd": [f32p, f32p, f32p, f32p, f32p, i64, C.c_int, C.c_int, f32p, C.c_int, C.c_void_p],
 }
 _RESTYPES = {"mt_last_error": C.c_char_p}
 

@@ -1,0 +1,70 @@
+"""GPU parity of the HIP EfficientNet-B0 against the CPU oracle and the reference-generated fixtures."""
+import pytest
+import torch
+
+import mintime_amd
+from mintime_amd import arch, synth, EfficientNet
+from oracle import mintime_oracle as O
+from tests.util import REL_TOL, assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(seed, training):
+    m = EfficientNet.from_name("efficientnet-b0", drop_connect_rate=0.0)
+    sd = synth.effnet_b0_state(seed)
+    m.load_state_dict(sd, strict=True)
+    m.train(training)
+    return m.cuda(), sd
+
+
+def _input(n, seed):
+    vid = synth.clip_inputs(1, n, 1, seed)["videos"]
+    return vid.reshape(n, 224, 224, 3).permute(0, 3, 1, 2)      # NHWC-strided NCHW view (train.py:341)
+
+
+@pytest.mark.parametrize("name", ["ef_eval", "ef_train"])
+def test_features_match_reference_fixture(name):
+    g = golden(name)
+    n, training, seed = int(g["n_img"]), bool(g["training"]), int(g["seed"])
+    model, sd = _model(seed, training)
+    x = _input(n, seed)
+    with torch.no_grad():
+        feats = model(x.cuda())
+    assert feats.shape == (n, 1280, 7, 7)
+    assert_close(feats, g["features"], REL_TOL, "features vs reference")
+    with torch.no_grad():
+        ends = model.extract_endpoints(x.cuda()) if not training else None
+    if ends is not None:
+        assert [tuple(v.shape[1:]) for v in ends.values()] == [(16, 112, 112), (24, 56, 56), (40, 28, 28), (112, 14, 14),
+                                                                (320, 7, 7), (1280, 7, 7)]
+    if training:
+        msd = model.state_dict()
+        for k in g.files:
+            if k.startswith("stat."):
+                assert_close(msd[k[5:]], g[k], REL_TOL, k)
+        assert int(msd["_bn0.num_batches_tracked"]) == int(g["nbt"])
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_block_outputs_match_oracle(training):
+    seed, n = 3, 3
+    model, sd = _model(seed, training)
+    x = _input(n, seed)
+    taps = {}
+    with torch.no_grad():
+        ref = O.effnet_b0_forward(sd, x, training=training, taps=taps)
+        from mintime_amd import effnet_engine
+        feat, ys = effnet_engine.effnet_apply(model, x.cuda(), want_blocks=True)
+    for i, y in enumerate(ys):
+        assert_close(y, taps[f"block{i}"], REL_TOL, f"block {i} output")
+    assert_close(feat, ref, REL_TOL, "features vs oracle")
+
+
+def test_nchw_contiguous_input_is_accepted():
+    g = golden("ef_eval")
+    model, _ = _model(int(g["seed"]), False)
+    x = _input(int(g["n_img"]), int(g["seed"])).contiguous()
+    with torch.no_grad():
+        feats = model(x.cuda())
+    assert_close(feats, g["features"], REL_TOL, "NCHW-contiguous input")
