@@ -117,6 +117,32 @@ int mt_se_gate_fwd(const float* pooled, const float* w1, const float* b1, const 
 int mt_bn_act_fwd(const float* z, const float* scale, const float* shift, const float* res, float* y,
                   int64_t rows, int C, int act, const float* rowscale, int rows_per_group, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Size-Invariant TimeSformer backward, non-GEMM pieces.  The reference derives these through torch autograd
+ * from the same source lines as the forward entry points; here they are explicit adjoint kernels.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* LayerNorm adjoint. dx (+)= LN'(dy) (accumulate!=0 adds into dx: the residual stream's gradient);
+ * dgamma/dbeta are accumulated atomically (caller zero-fills). stats = [rows,2] mean,rstd saved by the forward. */
+int mt_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
+                     float* dgamma, float* dbeta, int rows, int dim, int accumulate, void* stream);
+
+/* out[n] += sum_m A[map(m)*lda + n]   (bias gradients). */
+int mt_colsum(const float* A, int64_t lda, mt_rowmap map, int M, int N, float* out, void* stream);
+
+/* adjoint of mt_head_fwd; writes dx[:,0,:] (dx must be zero elsewhere), accumulates the four parameter grads. */
+int mt_head_bwd(const float* dlogits, const float* x, const float* gamma, const float* beta, const float* w,
+                float* dx, float* dgamma, float* dbeta, float* dw, float* dbias, int B, int N, int dim, int classes,
+                float eps, void* stream);
+
+/* adjoint of mt_embed_fwd: scatter-adds into dcls [dim], dpos_emb, dsize_emb (zero-filled by the caller). */
+int mt_embed_bwd(const float* dx, float* dcls, float* dpos_emb, float* dsize_emb, const int64_t* positions,
+                 const int32_t* sizes, int B, int F, int n, int dim, void* stream);
+
+/* adjoint of mt_attn_fwd: dout [B,N,H*64] -> dqkv [B,N,3*H*64] (fully written). Probabilities are recomputed from qkv. */
+int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, const uint8_t* mask, const uint8_t* ident,
+                int B, int H, int F, int n, int mode, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,575 @@
+// Size-Invariant TimeSformer backward kernels other than the dense contractions (gfx950).
+//
+// The reference has no hand-written backward: it is whatever torch autograd derives from
+// models/size_invariant_timesformer.py (:80-87 attn, :109-144 Attention.forward, :18-26 PreNorm, :231-248
+// embeddings, :270-276 head).  These kernels are the analytic adjoints of csrc/tsf_fwd.hip, on the same layouts:
+//   mt_head_bwd        LayerNorm + Linear on the cls row
+//   mt_layernorm_bwd   dx += LN'(dy), dgamma/dbeta accumulated
+//   mt_colsum          bias gradients (column sums with optional row map)
+//   mt_attn_bwd        divided attention core: recomputes the probabilities from q,k (nothing but qkv was saved)
+//   mt_embed_bwd       cls / pos_emb / size_emb scatter-adds
+#include "../../include/mintime_hip.h"
+#include "common.hpp"
+#include <float.h>
+
+using namespace mt;
+
+namespace {
+
+constexpr int DH = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------- LayerNorm backward
+// one wavefront per row, grid-strided so each wave keeps dgamma/dbeta partials in registers.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            float* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int rows, int D, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int nq = D >> 2;
+  float4 dg[4], db[4], g[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i];
+    const int q = lane + i * 64;
+    g[i] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int row = wave_global; row < rows; row += nwaves) {
+    const float mean = stats[2 * (int64_t)row], rstd = stats[2 * (int64_t)row + 1];
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+    const float4* dyr = reinterpret_cast<const float4*>(dy + (int64_t)row * D);
+    float4 xh[4], gy[4];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = lane + i * 64;
+      if (q < nq) {
+        const float4 xv = xr[q], d = dyr[q];
+        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        gy[i] = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
+        c1 += gy[i].x + gy[i].y + gy[i].z + gy[i].w;
+        c2 += gy[i].x * xh[i].x + gy[i].y * xh[i].y + gy[i].z * xh[i].z + gy[i].w * xh[i].w;
+        dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
+        db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+      }
+    }
+    c1 = wave_sum(c1) / (float)D;
+    c2 = wave_sum(c2) / (float)D;
+    float4* dxr = reinterpret_cast<float4*>(dx + (int64_t)row * D);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = lane + i * 64;
+      if (q < nq) {
+        float4 o;
+        o.x = rstd * (gy[i].x - c1 - xh[i].x * c2); o.y = rstd * (gy[i].y - c1 - xh[i].y * c2);
+        o.z = rstd * (gy[i].z - c1 - xh[i].z * c2); o.w = rstd * (gy[i].w - c1 - xh[i].w * c2);
+        if (accumulate) { const float4 p = dxr[q]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+        dxr[q] = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + i * 64;
+    if (q < nq) {
+      atomicAdd(dgamma + 4 * q, dg[i].x); atomicAdd(dgamma + 4 * q + 1, dg[i].y);
+      atomicAdd(dgamma + 4 * q + 2, dg[i].z); atomicAdd(dgamma + 4 * q + 3, dg[i].w);
+      atomicAdd(dbeta + 4 * q, db[i].x); atomicAdd(dbeta + 4 * q + 1, db[i].y);
+      atomicAdd(dbeta + 4 * q + 2, db[i].z); atomicAdd(dbeta + 4 * q + 3, db[i].w);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------- column sums (bias grads)
+// out[n] += sum_m A[map(m)*lda + n];  block = 64 columns x 4 row-lanes, grid (ceil(N/64), row chunks)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t lda, int gin, int gout, int off,
+                                                     int M, int N, float* __restrict__ out, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cl;
+  const int m0 = blockIdx.y * rows_per_block;
+  const int m1 = min(M, m0 + rows_per_block);
+  float s = 0.f;
+  if (n < N) {
+    for (int m = m0 + rl; m < m1; m += 4) {
+      int64_t r = m;
+      if (gin) { const int g = m / gin; r = (int64_t)g * gout + off + (m - g * gin); }
+      s += A[r * lda + n];
+    }
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && n < N) atomicAdd(out + n, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+// ---------------------------------------------------------------------------------------- head backward
+// one block (D threads) loops over clips; classes C small (1).
+__global__ void head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ x, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ w, float* __restrict__ dx,
+                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dw,
+                                float* __restrict__ dbias, int B, int N, int D, int C, float eps) {
+  __shared__ float red[2][16];
+  const int i = threadIdx.x;             // feature index, blockDim.x == D (<= 1024)
+  const int lane = i & 63, wv = i >> 6, nw = blockDim.x >> 6;
+  auto block_sum2 = [&](float a, float b, float& oa, float& ob) {
+    a = wave_sum(a); b = wave_sum(b);
+    __syncthreads();
+    if (lane == 0) { red[0][wv] = a; red[1][wv] = b; }
+    __syncthreads();
+    float sa = 0.f, sb = 0.f;
+    for (int k = 0; k < nw; ++k) { sa += red[0][k]; sb += red[1][k]; }
+    oa = sa; ob = sb;
+  };
+  float dg = 0.f, db = 0.f;
+  const float gi = gamma[i], bi = beta[i];
+  for (int b = 0; b < B; ++b) {
+    const float xv = x[(int64_t)b * N * D + i];
+    float s, dummy;
+    block_sum2(xv, 0.f, s, dummy);
+    const float mean = s / (float)D;
+    float ss;
+    block_sum2((xv - mean) * (xv - mean), 0.f, ss, dummy);
+    const float rstd = rsqrtf(ss / (float)D + eps);
+    const float xh = (xv - mean) * rstd;
+    const float xn = xh * gi + bi;
+    float dxn = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float dl = dlogits[b * C + c];
+      dxn += dl * w[(int64_t)c * D + i];
+      dw[(int64_t)c * D + i] += dl * xn;          // single block: plain accumulation
+    }
+    dg += dxn * xh; db += dxn;
+    const float gy = dxn * gi;
+    float c1, c2;
+    block_sum2(gy, gy * xh, c1, c2);
+    c1 /= (float)D; c2 /= (float)D;
+    dx[(int64_t)b * N * D + i] = rstd * (gy - c1 - xh * c2);
+  }
+  dgamma[i] += dg; dbeta[i] += db;
+  if (i < C) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogits[b * C + i];
+    dbias[i] += s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------- embeddings backward
+// dcls += sum_b dx[b,0]; dpos[positions[b,t]] += dx[b,t]; dsize[size idx] += dx[b,t]   (atomics; tables pre-zeroed)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dcls,
+                                                        float* __restrict__ dpos, float* __restrict__ dsize,
+                                                        const int64_t* __restrict__ positions, const int* __restrict__ sizes,
+                                                        int B, int N, int n, int F, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= B * N) return;
+  const int b = row / N, t = row - b * N;
+  const int64_t pi = positions ? positions[row] : (int64_t)t;
+  int si = 0;
+  if (t > 0 && sizes) si = sizes[b * F + (t - 1) / n];
+  const float* dr = dx + (int64_t)row * D;
+  for (int i = lane; i < D; i += 64) {
+    const float v = dr[i];
+    if (t == 0 && dcls) atomicAdd(dcls + i, v);
+    if (dpos) atomicAdd(dpos + pi * D + i, v);
+    if (dsize) atomicAdd(dsize + (int64_t)si * D + i, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------- attention backward: cls query
+// one wavefront per (b,h).  Writes dq (row 0) and INITIALISES dk, dv for every key row of this head with the cls
+// query's contribution; the patch kernel then accumulates on top.
+__global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                         float* __restrict__ dqkv, const uint8_t* __restrict__ mask,
+                                                         int B, int H, int F, int n, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // p[N], dS[N]
+  const int lane = threadIdx.x;
+  const int bh = blockIdx.x, h = bh % H, b = bh / H;
+  const int N = 1 + F * n, inner = H * DH, ld = 3 * inner;
+  float* pl_ = lds;
+  float* ds_ = lds + N;
+  const float* base = qkv + (int64_t)b * N * ld + h * DH;
+  float* dbase = dqkv + (int64_t)b * N * ld + h * DH;
+  const float* dob = dout + (int64_t)b * N * inner + h * DH;   // row 0
+  float q[DH], dO[DH];
+#pragma unroll
+  for (int i = 0; i < DH / 4; ++i) {
+    const float4 v = *reinterpret_cast<const float4*>(base + i * 4);
+    q[4 * i] = v.x * scale; q[4 * i + 1] = v.y * scale; q[4 * i + 2] = v.z * scale; q[4 * i + 3] = v.w * scale;
+    const float4 d = *reinterpret_cast<const float4*>(dob + i * 4);
+    dO[4 * i] = d.x; dO[4 * i + 1] = d.y; dO[4 * i + 2] = d.z; dO[4 * i + 3] = d.w;
+  }
+  float mx = -FLT_MAX;
+  for (int j = lane; j < N; j += 64) {
+    const float* kr = base + (int64_t)j * ld + inner;
+    const float* vr = base + (int64_t)j * ld + 2 * inner;
+    float a = 0.f, dp = 0.f;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
+      const float4 kk = *reinterpret_cast<const float4*>(kr + i * 4);
+      const float4 vv = *reinterpret_cast<const float4*>(vr + i * 4);
+      a = fmaf(q[4 * i], kk.x, a); a = fmaf(q[4 * i + 1], kk.y, a); a = fmaf(q[4 * i + 2], kk.z, a); a = fmaf(q[4 * i + 3], kk.w, a);
+      dp = fmaf(dO[4 * i], vv.x, dp); dp = fmaf(dO[4 * i + 1], vv.y, dp);
+      dp = fmaf(dO[4 * i + 2], vv.z, dp); dp = fmaf(dO[4 * i + 3], vv.w, dp);
+    }
+    if (j > 0 && mask && !mask[b * F + (j - 1) / n]) a = -FLT_MAX;
+    pl_[j] = a; ds_[j] = dp;
+    mx = fmaxf(mx, a);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < N; j += 64) { const float e = expf(pl_[j] - mx); pl_[j] = e; sum += e; }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  float delta = 0.f;
+  for (int j = lane; j < N; j += 64) { const float p = pl_[j] * inv; pl_[j] = p; delta += p * ds_[j]; }
+  delta = wave_sum(delta);
+  // per key: dS, write dk_j = dS*q_scaled, dv_j = p*dO
+  for (int j = lane; j < N; j += 64) {
+    const float p = pl_[j];
+    const float dS = p * (ds_[j] - delta);
+    ds_[j] = dS;
+    float* dk = dbase + (int64_t)j * ld + inner;
+    float* dv = dbase + (int64_t)j * ld + 2 * inner;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
+      *reinterpret_cast<float4*>(dk + i * 4) = make_float4(dS * q[4 * i], dS * q[4 * i + 1], dS * q[4 * i + 2], dS * q[4 * i + 3]);
+      *reinterpret_cast<float4*>(dv + i * 4) = make_float4(p * dO[4 * i], p * dO[4 * i + 1], p * dO[4 * i + 2], p * dO[4 * i + 3]);
+    }
+  }
+  __syncthreads();
+  // dq[d] = scale * sum_j dS_j k_j[d], lane = d
+  const float* kb = base + inner + lane;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int j = 0;
+  for (; j + 4 <= N; j += 4) {
+    a0 = fmaf(ds_[j], kb[(int64_t)j * ld], a0);
+    a1 = fmaf(ds_[j + 1], kb[(int64_t)(j + 1) * ld], a1);
+    a2 = fmaf(ds_[j + 2], kb[(int64_t)(j + 2) * ld], a2);
+    a3 = fmaf(ds_[j + 3], kb[(int64_t)(j + 3) * ld], a3);
+  }
+  for (; j < N; ++j) a0 = fmaf(ds_[j], kb[(int64_t)j * ld], a0);
+  dbase[lane] = scale * ((a0 + a1) + (a2 + a3));
+}
+
+// ---------------------------------------------------------------------------------------- attention backward: patch queries
+// Same decomposition as the forward kernel (one lane per query; MODE 0 time / 1 space).
+// pass 1 (lane = query i): s_ij, p_ij, dP_ij = dO_i.v_j, delta_i, dS_ij = p_ij(dP_ij - delta_i), dq_i = scale*sum_j dS_ij k_j
+// pass 2 (lane = key  j): dk_j = sum_i dS_ij (scale q_i),  dv_j = sum_i p_ij dO_i   -- roles transposed through LDS
+// Per-wavefront LDS: tile A [ROWS][STRIDE] (K, later Q.scale), tile B [ROWS][STRIDE] (V, later dO), P and dS [64][SP].
+template <int MODE, int NKEYS, int PPW, int STRIDE, int WPB>
+__global__ __launch_bounds__(WPB * 64) void attn_patch_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                 float* __restrict__ dqkv, const uint8_t* __restrict__ mask,
+                                                                 const uint8_t* __restrict__ ident, int B, int H, int F, int n,
+                                                                 float scale) {
+  constexpr int ROWS = MODE == 0 ? 1 + PPW * (NKEYS - 1) : NKEYS;
+  constexpr int QROWS = 64;                                  // pass-2 tiles hold one row per query lane
+  constexpr int TROWS = ROWS > QROWS ? ROWS : QROWS;
+  constexpr int SP = (NKEYS % 2 == 0) ? NKEYS + 1 : NKEYS;   // odd stride: conflict-free writer lanes
+  constexpr int WAVE_LDS = 2 * TROWS * STRIDE + 2 * 64 * SP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* tA = lds + wave * WAVE_LDS;
+  float* tB = tA + TROWS * STRIDE;
+  float* Pm = tB + TROWS * STRIDE;
+  float* Sm = Pm + 64 * SP;
+
+  const int N = 1 + F * n;
+  const int inner = H * DH;
+  const int ld = 3 * inner;
+  const int chunks = MODE == 0 ? (n + PPW - 1) / PPW : F;
+  const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
+  if (wid >= (int64_t)B * H * chunks) return;
+  const int c = (int)(wid % chunks);
+  const int bh = (int)(wid / chunks);
+  const int h = bh % H, b = bh / H;
+  const float* base = qkv + (int64_t)b * N * ld + h * DH;
+  float* dbase = dqkv + (int64_t)b * N * ld + h * DH;
+  const float* dob = dout + (int64_t)b * N * inner + h * DH;
+
+  int qtok = -1, pl = 0, fq = 0;
+  if (MODE == 0) {
+    pl = lane / (NKEYS - 1); fq = lane % (NKEYS - 1);
+    const int p = c * PPW + pl;
+    if (pl < PPW && p < n) qtok = 1 + fq * n + p;
+    if (pl >= PPW) pl = 0;
+  } else {
+    if (lane < n) qtok = 1 + c * n + lane;
+  }
+  const int row1 = MODE == 0 ? 1 + pl * (NKEYS - 1) : 1;
+
+  auto row_token = [&](int r) -> int {
+    if (r == 0) return 0;
+    if (MODE == 0) {
+      const int pl2 = (r - 1) / (NKEYS - 1), f2 = (r - 1) % (NKEYS - 1);
+      const int p = c * PPW + pl2;
+      return p < n ? 1 + f2 * n + p : -1;
+    }
+    return 1 + c * n + (r - 1);
+  };
+  auto stage = [&](float* tile, int which) {
+    for (int r0 = 0; r0 < ROWS; r0 += 4) {
+      const int r = r0 + (lane >> 4), c4 = lane & 15;
+      if (r < ROWS) {
+        const int tok = row_token(r);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tok >= 0) v = *reinterpret_cast<const float4*>(base + (int64_t)tok * ld + which * inner + c4 * 4);
+        *reinterpret_cast<float4*>(tile + r * STRIDE + c4 * 4) = v;
+      }
+    }
+  };
+
+  stage(tA, 1);
+  stage(tB, 2);
+  float q[DH];
+  {
+    const float* qp = base + (int64_t)(qtok >= 0 ? qtok : 0) * ld;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(qp + i * 4);
+      q[4 * i] = v.x * scale; q[4 * i + 1] = v.y * scale; q[4 * i + 2] = v.z * scale; q[4 * i + 3] = v.w * scale;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- pass 1a: scores -> Pm[lane][j]
+  float* myP = Pm + lane * SP;
+  float* myS = Sm + lane * SP;
+  float mx = -FLT_MAX;
+#pragma unroll 2
+  for (int j = 0; j < NKEYS; ++j) {
+    const float* kr = tA + (j == 0 ? 0 : row1 + j - 1) * STRIDE;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < DH / 8; ++i) {
+      const float4 k0 = *reinterpret_cast<const float4*>(kr + i * 8);
+      const float4 k1 = *reinterpret_cast<const float4*>(kr + i * 8 + 4);
+      a0 = fmaf(q[8 * i], k0.x, a0); a0 = fmaf(q[8 * i + 1], k0.y, a0);
+      a0 = fmaf(q[8 * i + 2], k0.z, a0); a0 = fmaf(q[8 * i + 3], k0.w, a0);
+      a1 = fmaf(q[8 * i + 4], k1.x, a1); a1 = fmaf(q[8 * i + 5], k1.y, a1);
+      a1 = fmaf(q[8 * i + 6], k1.z, a1); a1 = fmaf(q[8 * i + 7], k1.w, a1);
+    }
+    float a = a0 + a1;
+    if (MODE == 0 && j > 0) {
+      const bool ok = mask[b * F + (j - 1)] && ident[(b * F + fq) * F + (j - 1)];
+      if (!ok) a = -FLT_MAX;
+    }
+    myP[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  float sum = 0.f;
+  for (int j = 0; j < NKEYS; ++j) { const float e = expf(myP[j] - mx); myP[j] = e; sum += e; }
+  const float inv = qtok >= 0 ? 1.0f / sum : 0.f;            // idle lanes contribute nothing in pass 2
+
+  // ---- pass 1b: dP_j = dO . v_j ; delta
+  float dO[DH];
+  {
+    const float* dp = dob + (int64_t)(qtok >= 0 ? qtok : 0) * inner;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(dp + i * 4);
+      dO[4 * i] = v.x; dO[4 * i + 1] = v.y; dO[4 * i + 2] = v.z; dO[4 * i + 3] = v.w;
+    }
+  }
+  float delta = 0.f;
+#pragma unroll 2
+  for (int j = 0; j < NKEYS; ++j) {
+    const float* vr = tB + (j == 0 ? 0 : row1 + j - 1) * STRIDE;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < DH / 8; ++i) {
+      const float4 v0 = *reinterpret_cast<const float4*>(vr + i * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(vr + i * 8 + 4);
+      a0 = fmaf(dO[8 * i], v0.x, a0); a0 = fmaf(dO[8 * i + 1], v0.y, a0);
+      a0 = fmaf(dO[8 * i + 2], v0.z, a0); a0 = fmaf(dO[8 * i + 3], v0.w, a0);
+      a1 = fmaf(dO[8 * i + 4], v1.x, a1); a1 = fmaf(dO[8 * i + 5], v1.y, a1);
+      a1 = fmaf(dO[8 * i + 6], v1.z, a1); a1 = fmaf(dO[8 * i + 7], v1.w, a1);
+    }
+    const float dp = a0 + a1;
+    const float p = myP[j] * inv;
+    myP[j] = p;
+    myS[j] = dp;
+    delta += p * dp;
+  }
+  // ---- pass 1c: dS, dq
+  float dq[DH];
+#pragma unroll
+  for (int i = 0; i < DH; ++i) dq[i] = 0.f;
+#pragma unroll 2
+  for (int j = 0; j < NKEYS; ++j) {
+    const float* kr = tA + (j == 0 ? 0 : row1 + j - 1) * STRIDE;
+    const float dS = myP[j] * (myS[j] - delta);
+    myS[j] = dS;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
+      const float4 kk = *reinterpret_cast<const float4*>(kr + i * 4);
+      dq[4 * i] = fmaf(dS, kk.x, dq[4 * i]); dq[4 * i + 1] = fmaf(dS, kk.y, dq[4 * i + 1]);
+      dq[4 * i + 2] = fmaf(dS, kk.z, dq[4 * i + 2]); dq[4 * i + 3] = fmaf(dS, kk.w, dq[4 * i + 3]);
+    }
+  }
+  if (qtok >= 0) {
+    float* dqr = dbase + (int64_t)qtok * ld;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i)
+      *reinterpret_cast<float4*>(dqr + i * 4) =
+          make_float4(dq[4 * i] * scale, dq[4 * i + 1] * scale, dq[4 * i + 2] * scale, dq[4 * i + 3] * scale);
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- pass 2 set-up: tA[lane] = scaled q_lane, tB[lane] = dO_lane (rows indexed by QUERY lane now)
+  {
+    float* qa = tA + lane * STRIDE;
+    float* da = tB + lane * STRIDE;
+    const float live = qtok >= 0 ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
+      *reinterpret_cast<float4*>(qa + i * 4) = make_float4(q[4 * i] * live, q[4 * i + 1] * live, q[4 * i + 2] * live, q[4 * i + 3] * live);
+      *reinterpret_cast<float4*>(da + i * 4) = make_float4(dO[4 * i] * live, dO[4 * i + 1] * live, dO[4 * i + 2] * live, dO[4 * i + 3] * live);
+    }
+    if (qtok < 0) { for (int j = 0; j < NKEYS; ++j) { myP[j] = 0.f; myS[j] = 0.f; } }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- pass 2a: patch keys.  lane = key token (same lane->token map as the queries)
+  {
+    float dk[DH], dv[DH];
+#pragma unroll
+    for (int i = 0; i < DH; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
+    // queries that see my token as a key: time -> the F lanes of my patch group; space -> all n lanes
+    const int i0 = MODE == 0 ? pl * (NKEYS - 1) : 0;
+    const int cnt = MODE == 0 ? (NKEYS - 1) : n;
+    const int jme = MODE == 0 ? 1 + fq : 1 + lane;           // my key index inside those queries' score rows
+#pragma unroll 2
+    for (int t = 0; t < cnt; ++t) {
+      const int iq = i0 + t;
+      const float dS = Sm[iq * SP + jme];
+      const float p = Pm[iq * SP + jme];
+      const float* qr = tA + iq * STRIDE;
+      const float* dr = tB + iq * STRIDE;
+#pragma unroll
+      for (int i = 0; i < DH / 4; ++i) {
+        const float4 qq = *reinterpret_cast<const float4*>(qr + i * 4);
+        const float4 dd = *reinterpret_cast<const float4*>(dr + i * 4);
+        dk[4 * i] = fmaf(dS, qq.x, dk[4 * i]); dk[4 * i + 1] = fmaf(dS, qq.y, dk[4 * i + 1]);
+        dk[4 * i + 2] = fmaf(dS, qq.z, dk[4 * i + 2]); dk[4 * i + 3] = fmaf(dS, qq.w, dk[4 * i + 3]);
+        dv[4 * i] = fmaf(p, dd.x, dv[4 * i]); dv[4 * i + 1] = fmaf(p, dd.y, dv[4 * i + 1]);
+        dv[4 * i + 2] = fmaf(p, dd.z, dv[4 * i + 2]); dv[4 * i + 3] = fmaf(p, dd.w, dv[4 * i + 3]);
+      }
+    }
+    if (qtok >= 0) {   // exclusive owner of this token's k/v rows for this head: accumulate on the cls kernel's values
+      float* dkr = dbase + (int64_t)qtok * ld + inner;
+      float* dvr = dbase + (int64_t)qtok * ld + 2 * inner;
+#pragma unroll
+      for (int i = 0; i < DH / 4; ++i) {
+        float4 a = *reinterpret_cast<float4*>(dkr + i * 4);
+        a.x += dk[4 * i]; a.y += dk[4 * i + 1]; a.z += dk[4 * i + 2]; a.w += dk[4 * i + 3];
+        *reinterpret_cast<float4*>(dkr + i * 4) = a;
+        float4 v = *reinterpret_cast<float4*>(dvr + i * 4);
+        v.x += dv[4 * i]; v.y += dv[4 * i + 1]; v.z += dv[4 * i + 2]; v.w += dv[4 * i + 3];
+        *reinterpret_cast<float4*>(dvr + i * 4) = v;
+      }
+    }
+  }
+  // ---- pass 2b: the cls key (j = 0) is shared by every group of this head: lane = d, atomics into row 0
+  {
+    float ak = 0.f, av = 0.f;
+    for (int iq = 0; iq < 64; ++iq) {
+      ak = fmaf(Sm[iq * SP], tA[iq * STRIDE + lane], ak);
+      av = fmaf(Pm[iq * SP], tB[iq * STRIDE + lane], av);
+    }
+    atomicAdd(dbase + inner + lane, ak);
+    atomicAdd(dbase + 2 * inner + lane, av);
+  }
+}
+
+template <int MODE, int NKEYS, int PPW, int STRIDE, int WPB>
+int launch_patch_bwd(const float* qkv, const float* dout, float* dqkv, const uint8_t* mask, const uint8_t* ident, int B, int H,
+                     int F, int n, float scale, hipStream_t s) {
+  constexpr int ROWS = MODE == 0 ? 1 + PPW * (NKEYS - 1) : NKEYS;
+  constexpr int TROWS = ROWS > 64 ? ROWS : 64;
+  constexpr int SP = (NKEYS % 2 == 0) ? NKEYS + 1 : NKEYS;
+  const int chunks = MODE == 0 ? (n + PPW - 1) / PPW : F;
+  const int64_t waves = (int64_t)B * H * chunks;
+  const size_t lds = (size_t)WPB * (2 * TROWS * STRIDE + 2 * 64 * SP) * sizeof(float);
+  auto k = attn_patch_bwd_kernel<MODE, NKEYS, PPW, STRIDE, WPB>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_attn_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, dout, dqkv, mask, ident, B, H, F,
+                     n, scale);
+  return check_launch("mt_attn_bwd(patch)");
+}
+
+}  // namespace
+
+extern "C" int mt_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
+                                float* dgamma, float* dbeta, int rows, int dim, int accumulate, void* stream) {
+  if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta) return fail(MT_ERR_ARG, "mt_layernorm_bwd: null pointer");
+  if (dim <= 0 || (dim & 3) || dim > 1024) return fail(MT_ERR_ARG, "mt_layernorm_bwd: dim %d unsupported", dim);
+  if (rows <= 0) return 0;
+  int blocks = (rows + 3) / 4;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dgamma, dbeta,
+                     rows, dim, accumulate);
+  return check_launch("mt_layernorm_bwd");
+}
+
+extern "C" int mt_colsum(const float* A, int64_t lda, mt_rowmap map, int M, int N, float* out, void* stream) {
+  if (!A || !out) return fail(MT_ERR_ARG, "mt_colsum: null pointer");
+  const int rpb = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, A, lda, map.gin,
+                     map.gout, map.off, M, N, out, rpb);
+  return check_launch("mt_colsum");
+}
+
+extern "C" int mt_head_bwd(const float* dlogits, const float* x, const float* gamma, const float* beta, const float* w,
+                           float* dx, float* dgamma, float* dbeta, float* dw, float* dbias, int B, int N, int dim, int classes,
+                           float eps, void* stream) {
+  if (!dlogits || !x || !gamma || !beta || !w || !dx || !dgamma || !dbeta || !dw || !dbias)
+    return fail(MT_ERR_ARG, "mt_head_bwd: null pointer");
+  if (dim > 1024 || (dim & 63)) return fail(MT_ERR_ARG, "mt_head_bwd: dim %d unsupported (multiple of 64, <= 1024)", dim);
+  if (classes > dim) return fail(MT_ERR_ARG, "mt_head_bwd: classes > dim");
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(1), dim3(dim), 0, (hipStream_t)stream, dlogits, x, gamma, beta, w, dx, dgamma, dbeta, dw,
+                     dbias, B, N, dim, classes, eps);
+  return check_launch("mt_head_bwd");
+}
+
+extern "C" int mt_embed_bwd(const float* dx, float* dcls, float* dpos_emb, float* dsize_emb, const int64_t* positions,
+                            const int32_t* sizes, int B, int F, int n, int dim, void* stream) {
+  if (!dx) return fail(MT_ERR_ARG, "mt_embed_bwd: null pointer");
+  const int N = 1 + F * n;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((B * N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dx, dcls, dpos_emb, dsize_emb,
+                     positions, sizes, B, N, n, F, dim);
+  return check_launch("mt_embed_bwd");
+}
+
+extern "C" int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, const uint8_t* mask, const uint8_t* ident,
+                           int B, int H, int F, int n, int mode, float scale, void* stream) {
+  if (!qkv || !dout || !dqkv) return fail(MT_ERR_ARG, "mt_attn_bwd: null pointer");
+  if (mode == 0 && (!mask || !ident)) return fail(MT_ERR_ARG, "mt_attn_bwd: time attention needs mask and identities_mask");
+  if (n != 49) return fail(MT_ERR_UNSUPPORTED, "mt_attn_bwd: num-patches %d unsupported (49)", n);
+  hipStream_t s = (hipStream_t)stream;
+  const int N = 1 + F * n;
+  hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(64), 2 * N * sizeof(float), s, qkv, dout, dqkv, mask, B, H, F, n, scale);
+  int rc = check_launch("mt_attn_bwd(cls)");
+  if (rc) return rc;
+  if (mode == 1) return launch_patch_bwd<1, 50, 1, 64, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);
+  switch (F) {
+    case 8: return launch_patch_bwd<0, 9, 7, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);
+    case 16: return launch_patch_bwd<0, 17, 4, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);
+    case 32: return launch_patch_bwd<0, 33, 2, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);
+  }
+  return fail(MT_ERR_UNSUPPORTED, "mt_attn_bwd: num-frames %d unsupported (8/16/32)", F);
+}

@@ -1,0 +1,108 @@
+"""Reverse launch sequence of the Size-Invariant TimeSformer (analytic backward, not torch autograd over torch ops).
+
+Walks the layers last-to-first on the saved buffers of tsf_engine.tsf_forward:
+    dgemm (NN) for activations, wgrad (TN, split-K + fp32 atomics) for weights, column sums for biases,
+    the attention-core / LayerNorm / embedding / head adjoint kernels of csrc/tsf_bwd.hip.
+`dx` is the running gradient of the residual stream and is updated in place.
+"""
+import torch
+
+from . import arch
+from . import lib as L
+
+
+def _zeros_like_param(p):
+    return torch.zeros_like(p, dtype=torch.float32) if p is not None else None
+
+
+def _splits(M):
+    # enough K-splits to fill the chip for the skinny wgrad outputs, chunk kept >= 512 rows
+    return max(1, min(32, M // 512))
+
+
+def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, need_dparams):
+    lib = L.get()
+    st = L.stream_ptr()
+    dev = feat.device
+    B, F, n = dims
+    D, H, dh, C_in = model.dim, model.heads, model.dim_head, model.channels
+    inner = H * dh
+    N = 1 + F * n
+    M = B * N
+    eps = arch.LN_EPS
+    scale = float(dh) ** -0.5
+    sk = _splits(M)
+    grads = [_zeros_like_param(p) for p in params]
+    P = list(params)
+    idx = len(P)
+
+    def take(k):
+        nonlocal idx
+        idx -= k
+        return idx
+
+    def colsum(A, lda, rows, cols, out, amap=(0, 0, 0)):
+        L.check(lib.mt_colsum(L.ptr(A), lda, L.RowMap(*amap), rows, cols, L.ptr(out), st), "mt_colsum")
+
+    # ---- head
+    i0 = take(4)
+    g, b_, w_h, b_h = P[i0:i0 + 4]
+    dx = torch.zeros(B, N, D, dtype=torch.float32, device=dev)
+    L.check(lib.mt_head_bwd(L.ptr(dlogits), L.ptr(saved["x_final"]), L.ptr(g), L.ptr(b_), L.ptr(w_h), L.ptr(dx), L.ptr(grads[i0]),
+                            L.ptr(grads[i0 + 1]), L.ptr(grads[i0 + 2]), L.ptr(grads[i0 + 3]), B, N, D, model.num_classes, eps,
+                            st), "mt_head_bwd")
+    dx2 = dx.view(M, D)
+    dxn = torch.empty(M, D, dtype=torch.float32, device=dev)
+    du = torch.empty(M, 8 * D, dtype=torch.float32, device=dev)
+    do = torch.empty(M, inner, dtype=torch.float32, device=dev)
+    dqkv = torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)
+
+    for li in reversed(range(model.depth)):
+        rec = saved["layers"][li]
+        # ---- feed-forward: x_out = h W2^T + b2 + x ; h = a*gelu(g) ; [a|g] = LN(x) W1^T + b1
+        i0 = take(6)
+        g, b_, w1, b1, w2, b2 = P[i0:i0 + 6]
+        r = rec[2]
+        L.gemm(L.OP_TN, dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D, epilogue=L.EPI_ATOMIC, split_k=sk)
+        colsum(dx2, D, M, D, grads[i0 + 5])
+        L.gemm(L.OP_NN, dx2, w2, du, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D, n_half=4 * D)
+        L.gemm(L.OP_TN, du, r["xn"], grads[i0 + 2], 8 * D, D, M, 8 * D, D, D, epilogue=L.EPI_ATOMIC, split_k=sk)
+        colsum(du, 8 * D, M, 8 * D, grads[i0 + 3])
+        L.gemm(L.OP_NN, du, w1, dxn, M, D, 8 * D, 8 * D, D, D)
+        L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
+                                     L.ptr(grads[i0 + 1]), M, D, 1, st), "mt_layernorm_bwd")
+        r.clear()
+        # ---- attention blocks: x_out = o Wo^T + bo + x ; o = attn(qkv) ; qkv = LN(x) Wqkv^T
+        for mode in (1, 0):
+            i0 = take(5)
+            g, b_, w_qkv, w_o, b_o = P[i0:i0 + 5]
+            r = rec[mode]
+            L.gemm(L.OP_TN, dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner, epilogue=L.EPI_ATOMIC, split_k=sk)
+            colsum(dx2, D, M, D, grads[i0 + 4])
+            L.gemm(L.OP_NN, dx2, w_o, do, M, inner, D, D, inner, inner)
+            L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
+                                    scale, st), "mt_attn_bwd")
+            L.gemm(L.OP_TN, dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D, epilogue=L.EPI_ATOMIC, split_k=sk)
+            L.gemm(L.OP_NN, dqkv, w_qkv, dxn, M, D, 3 * inner, 3 * inner, D, D)
+            L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
+                                         L.ptr(grads[i0 + 1]), M, D, 1, st), "mt_layernorm_bwd")
+            r.clear()
+
+    # ---- embeddings + patch embedding
+    i0 = take(5)
+    w_pe, b_pe, cls, pos_w, size_w = P[i0:i0 + 5]
+    L.check(lib.mt_embed_bwd(L.ptr(dx), L.ptr(grads[i0 + 2]), L.ptr(grads[i0 + 3]), L.ptr(grads[i0 + 4]), L.ptr(aux.positions),
+                             L.ptr(aux.sizes), B, F, n, D, st), "mt_embed_bwd")
+    tok_map = (F * n, N, 1)      # token row r of the feature matrix lives at row (r/(F n))*N + 1 + r%(F n) of dx
+    Mt = B * F * n
+    L.gemm(L.OP_TN, dx2, feat, grads[i0], D, C_in, Mt, D, C_in, C_in, epilogue=L.EPI_ATOMIC, split_k=_splits(Mt), a_map=tok_map)
+    colsum(dx2, D, Mt, D, grads[i0 + 1], tok_map)
+    dfeat = None
+    if need_dfeat:
+        dfeat = torch.empty(Mt, C_in, dtype=torch.float32, device=dev)
+        L.gemm(L.OP_NN, dx2, w_pe, dfeat, Mt, C_in, D, D, C_in, C_in, a_map=tok_map)
+    assert idx == 0
+    out = []
+    for gneed, gr in zip(need_dparams, grads):
+        out.append(gr if gneed else None)
+    return dfeat, out

@@ -75,3 +75,52 @@ def test_nchw_contiguous_features_are_accepted():
         out = model(feats.contiguous().cuda(), mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(),
                     size_embedding=aux["size_embedding"], positions=aux["positions"].cuda())
     assert_close(out, g["logits"], REL_TOL, "NCHW-contiguous input")
+
+
+@pytest.mark.parametrize("name", ["tsf_cfg1", "tsf_2id_ragged"])
+def test_backward_matches_reference_fixture(name):
+    g = golden(name)
+    B, Fr, C, feats, aux = _inputs(g)
+    cfg = arch.default_tsf_config(C, Fr)
+    model, sd = _build(cfg, int(g["seed"]), require_attention=False)
+    x = feats.cuda().requires_grad_(True)
+    out = model(x, mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(),
+                size_embedding=aux["size_embedding"], positions=aux["positions"].cuda())
+    # loss on the CPU like the reference (train.py:367-368)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out.cpu(), aux["labels"].reshape(-1, 1))
+    loss.backward()
+    assert_close(loss, g["loss"], REL_TOL, "loss")
+    named = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith("gnorm."):
+            key = k[len("gnorm."):]
+            assert named[key].grad is not None, key
+            assert_close(named[key].grad.norm(), g[k], REL_TOL, k)
+            assert_close(named[key].grad.reshape(-1)[:256], g["gslice." + key], 2 * REL_TOL, "gslice." + key)
+    assert_close(named["pos_emb.weight"].grad[:8], g["gslice.pos_emb.rows"], REL_TOL, "pos_emb grad rows")
+    assert_close(named["size_emb.weight"].grad[:21], g["gslice.size_emb.rows"], REL_TOL, "size_emb grad rows")
+    assert float(named["pos_emb.weight"].grad[Fr * 49 + 1:].abs().max()) == 0.0
+    assert_close(x.grad.norm(), g["dfeats_norm"], REL_TOL, "dfeats norm")
+    assert_close(x.grad.permute(0, 1, 3, 4, 2).reshape(-1)[:512], g["dfeats_slice"], 2 * REL_TOL, "dfeats slice")
+
+
+def test_backward_all_parameters_vs_oracle():
+    """Every parameter gradient (not just the fixture's sample) against torch autograd over the CPU oracle."""
+    B, Fr, C, seed = 2, 8, 1280, 5
+    cfg = arch.default_tsf_config(C, Fr)
+    model, sd = _build(cfg, seed, require_attention=False)
+    feats = synth.features(B, Fr, C, seed)
+    aux = synth.clip_inputs(B, Fr, 2, seed, ragged=True, with_video=False)
+    out = model(feats.cuda(), mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(),
+                size_embedding=aux["size_embedding"], positions=aux["positions"].cuda())
+    w = torch.tensor([[1.0], [-0.7]])
+    (out.cpu() * w).sum().backward()
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oout = O.tsf_forward(osd, cfg, feats, aux["mask"], aux["identities_mask"], aux["size_embedding"], aux["positions"])
+    (oout * w).sum().backward()
+    for k, p in model.named_parameters():
+        ref = osd[k].grad
+        if float(ref.abs().max()) == 0.0:
+            assert float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert_close(p.grad, ref, REL_TOL, "grad " + k)
