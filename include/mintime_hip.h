@@ -38,7 +38,9 @@ enum { MT_OP_NT = 0,    /* C[M,N] = A[M,K] * B[N,K]^T      forward (torch weight
        MT_OP_NN = 1,    /* C[M,N] = A[M,K] * B[K,N]        dgrad                                      */
        MT_OP_TN = 2 };  /* C[M,N] = A[K,M]^T * B[K,N]      wgrad (split-K + fp32 atomics, C pre-zeroed) */
 
-enum { MT_PRO_NONE = 0, MT_PRO_BN_SWISH_GATE = 1, MT_PRO_BN_SWISH = 2, MT_PRO_AFFINE = 3 };
+enum { MT_PRO_NONE = 0, MT_PRO_BN_SWISH_GATE = 1, MT_PRO_BN_SWISH = 2, MT_PRO_AFFINE = 3,
+       MT_PRO_BN_BWD = 4 };  /* A := ka[c]*A + kb[c]*A2 + kc[c]  (BatchNorm backward folded into the load; ka,kb,kc = scale,shift,gate) */
+enum { MT_BPRO_NONE = 0, MT_BPRO_BN_SWISH_GATE = 1 };  /* TN only: B := swish(B*b_scale[n]+b_shift[n]) * b_gate[(k/b_hw)*N+n] */
 enum { MT_EPI_STORE = 0, MT_EPI_BIAS_RES = 1, MT_EPI_GEGLU = 2, MT_EPI_STATS = 3, MT_EPI_ATOMIC = 4,
        MT_EPI_GEGLU_BWD = 5, MT_EPI_ACCUM = 6 };
 
@@ -55,6 +57,8 @@ typedef struct {
   double* stats; int stats_slots;   /* STATS: [slots][2][N] fp64 accumulators (sum, sum of squares)      */
   int n_half;
   int split_k;                      /* TN: number of K splits (>=1)                                      */
+  const float* A2;                  /* BN_BWD prologue: second source, same layout as A                  */
+  int b_prologue; const float* b_scale; const float* b_shift; const float* b_gate; int b_hw;
 } mt_gemm_desc;
 
 int mt_gemm(const mt_gemm_desc* d, void* stream);
@@ -142,6 +146,40 @@ int mt_embed_bwd(const float* dx, float* dcls, float* dpos_emb, float* dsize_emb
 /* adjoint of mt_attn_fwd: dout [B,N,H*64] -> dqkv [B,N,3*H*64] (fully written). Probabilities are recomputed from qkv. */
 int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, const uint8_t* mask, const uint8_t* ident,
                 int B, int H, int F, int n, int mode, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * EfficientNet-B0 backward, everything except the 1x1-convolution dgrad/wgrad (mt_gemm with the BN_BWD prologue).
+ * BatchNorm backward is three steps: a producer accumulates sums[2][C] = (sum du, sum du*xhat) into fp64 slots;
+ * mt_bn_bwd_finalize turns them into kabc[3][C] so that dz = ka*du + kb*z + kc; consumers apply that on load.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* du = (din [*gate[n,c] + dpool[n,c]/hw] [*rowscale[n]]) * (act ? swish'(z*scale+shift) : 1), written to dout when
+ * non-NULL (in place allowed), plus the BN sums.  Adjoint of swish/_bn* + SE scaling + drop_connect (model.py:100-127). */
+int mt_bn_act_bwd(const float* din, const float* z, const float* scale, const float* shift,
+                  const float* mean_invstd, const float* gate, const float* dpool, const float* rowscale,
+                  float* dout, double* stats, int slots, int64_t rows, int C, int hw, int act, void* stream);
+
+/* training != 0: batch-statistics BN adjoint; else running-statistics (kb = kc = 0). dgamma/dbeta accumulate. */
+int mt_bn_bwd_finalize(const double* stats, int slots, double count, const float* gamma, const float* mean_invstd,
+                       float* kabc, float* dgamma, float* dbeta, int C, int training, void* stream);
+
+/* Squeeze-excite adjoint (model.py:104-113): from da = d(gated tensor) computes dgate, the two 1x1-conv weight/bias
+ * grads (accumulated) and dpooled [N,C] (the pooling path's contribution to d(activated tensor)). */
+int mt_se_bwd(const float* da, const float* z, const float* scale, const float* shift, const float* gate,
+              const float* hidden, const float* pooled, const float* w1, const float* w2, float* dgate,
+              float* dpre2, float* dhid, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, int N,
+              int HW, int C, int CS, void* stream);
+
+/* Depthwise-conv adjoint: dz = ka*du+kb*z+kc (virtual, output side).  Writes dw (accumulated, torch layout [C,1,k,k])
+ * and du_in = d(input pre-activation) = dgrad * swish'(bn_in(zin)), plus the input-side BN sums. */
+int mt_dwconv_bwd(const float* du, const float* z, const float* kabc, const float* w, const float* zin,
+                  const float* scale_in, const float* shift_in, const float* mean_invstd_in, float* du_in,
+                  double* stats_in, int slots, float* dw, int N, int H, int W, int C, int k, int stride,
+                  void* stream);
+
+/* _conv_stem weight gradient (accumulated, torch layout [32,3,3,3]); x [N,H,W,3]. */
+int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const float* x, float* dw, int N, int H,
+                       int W, void* stream);
 
 #ifdef __cplusplus
 }

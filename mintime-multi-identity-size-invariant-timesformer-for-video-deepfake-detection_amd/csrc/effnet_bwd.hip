@@ -1,0 +1,562 @@
+// EfficientNet-B0 backward kernels other than the 1x1-convolution dgrad/wgrad (those are mt_gemm), gfx950.
+//
+// The reference has no hand-written backward (torch autograd over model.py:89-128, 267-288 and the custom swish
+// backward utils.py:70-75).  Adjoint design, mirroring the forward's "raw z in HBM, activation on load" rule:
+//   * BatchNorm backward is split into (1) a reduction of sum(du) and sum(du*xhat) per channel -- fused into whichever
+//     kernel produces du --, (2) mt_bn_bwd_finalize, which turns them into three per-channel vectors so that
+//         dz = ka[c]*du + kb[c]*z + kc[c]
+//     and (3) consumers (GEMM operand loads, depthwise kernels) applying that affine while loading.  No dz tensor is
+//     ever written for the wide (expanded) activations.
+//   * swish'(u) = sig(u)*(1+u*(1-sig(u))) is recomputed from z (utils.py:70-75 saves only the input as well).
+#include "../../include/mintime_hip.h"
+#include "common.hpp"
+
+using namespace mt;
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float dswishf_(float u) { const float s = sigmoidf_(u); return s * (1.0f + u * (1.0f - s)); }
+
+__device__ __forceinline__ float4 f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+  return f4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return f4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return f4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// block-level reduction of per-thread (s1,s2) float4 partials over the PB row-lanes, then fp64 atomics
+__device__ __forceinline__ void reduce_stats(float* red, float4 s1, float4 s2, int cql, int pl, int CQB, int PB, int CQ,
+                                             int C, double* stats, int slots) {
+  if (pl < PB) {
+    float* rr = red + (pl * CQB + cql) * 8;
+    rr[0] = s1.x; rr[1] = s1.y; rr[2] = s1.z; rr[3] = s1.w;
+    rr[4] = s2.x; rr[5] = s2.y; rr[6] = s2.z; rr[7] = s2.w;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CQB * 8; i += blockDim.x) {
+    const int q = i >> 3, e = i & 7;
+    const int cqq = blockIdx.y * CQB + q;
+    if (cqq < CQ) {
+      float v = 0.f;
+      for (int p = 0; p < PB; ++p) v += red[(p * CQB + q) * 8 + e];
+      const int ch = cqq * 4 + (e & 3), which = e >> 2;
+      atomicAdd(stats + ((int64_t)(blockIdx.x % slots) * 2 + which) * C + ch, (double)v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ K1: activation/BN adjoint + sums
+// du = (d_in [*gate[n,c] + dpool[n,c]/hw] [*rowscale[n]]) * (act ? swish'(z*scale+shift) : 1)
+// sums: S1[c] += du, S2[c] += du * xhat,  xhat = (z-mean)*invstd
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict__ din, const float* __restrict__ z,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ mean_invstd, const float* __restrict__ gate,
+                                                         const float* __restrict__ dpool, const float* __restrict__ rowscale,
+                                                         float* __restrict__ dout, double* __restrict__ stats, int slots,
+                                                         int64_t rows, int C, int hw, int act, int CQB, int PB) {
+  extern __shared__ float red[];
+  const int tid = threadIdx.x;
+  const int cql = tid % CQB, pl = tid / CQB;
+  const int CQ = C >> 2;
+  const int cq = blockIdx.y * CQB + cql;
+  float4 s1 = f4(0, 0, 0, 0), s2 = s1;
+  if (pl < PB && cq < CQ) {
+    const int c = cq * 4;
+    const float4 sc = ld4(scale + c), sh = ld4(shift + c);
+    const float4 mean = ld4(mean_invstd + c), istd = ld4(mean_invstd + C + c);
+    const float inv_hw = 1.0f / (float)hw;
+    for (int64_t r = (int64_t)blockIdx.x * PB + pl; r < rows; r += (int64_t)gridDim.x * PB) {
+      const int n = (int)(r / hw);
+      float4 d = ld4(din + r * C + c);
+      const float4 zz = ld4(z + r * C + c);
+      if (gate) {
+        const float4 g = ld4(gate + (int64_t)n * C + c), dp = ld4(dpool + (int64_t)n * C + c);
+        d = f4(fmaf(d.x, g.x, dp.x * inv_hw), fmaf(d.y, g.y, dp.y * inv_hw), fmaf(d.z, g.z, dp.z * inv_hw), fmaf(d.w, g.w, dp.w * inv_hw));
+      }
+      if (rowscale) { const float rs = rowscale[n]; d = f4(d.x * rs, d.y * rs, d.z * rs, d.w * rs); }
+      if (act) {
+        const float4 u = fma4(zz, sc, sh);
+        d = f4(d.x * dswishf_(u.x), d.y * dswishf_(u.y), d.z * dswishf_(u.z), d.w * dswishf_(u.w));
+      }
+      if (dout) st4(dout + r * C + c, d);
+      const float4 xh = f4((zz.x - mean.x) * istd.x, (zz.y - mean.y) * istd.y, (zz.z - mean.z) * istd.z, (zz.w - mean.w) * istd.w);
+      s1 = add4(s1, d);
+      s2 = fma4(d, xh, s2);
+    }
+  }
+  reduce_stats(red, s1, s2, cql, pl, CQB, PB, CQ, C, stats, slots);
+}
+
+// ------------------------------------------------------------------------------------------------ K2: BN backward finalize
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, int slots, double count, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean_invstd, float* __restrict__ kabc, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int C, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < slots; ++i) { s1 += stats[((int64_t)i * 2) * C + c]; s2 += stats[((int64_t)i * 2 + 1) * C + c]; }
+  const float mean = mean_invstd[c], istd = mean_invstd[C + c];
+  const float ka = gamma[c] * istd;
+  float kb = 0.f, kc = 0.f;
+  if (training) {
+    const float c1 = (float)(s1 / count), c2 = (float)(s2 / count);
+    kb = -ka * c2 * istd;
+    kc = ka * c2 * istd * mean - ka * c1;
+  }
+  kabc[c] = ka; kabc[C + c] = kb; kabc[2 * C + c] = kc;
+  if (dgamma) dgamma[c] += (float)s2;
+  if (dbeta) dbeta[c] += (float)s1;
+}
+
+// ------------------------------------------------------------------------------------------------ K3: d(gate) reduction
+// dgate[n,c] = sum_hw da[n,hw,c] * swish(z*scale+shift)
+__global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ z,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            float* __restrict__ dgate, int HW, int C, int CQB, int PB) {
+  extern __shared__ float red[];
+  const int tid = threadIdx.x;
+  const int cql = tid % CQB, pl = tid / CQB;
+  const int cq = blockIdx.y * CQB + cql;
+  const int CQ = C >> 2;
+  const int n = blockIdx.x;
+  float4 s = f4(0, 0, 0, 0);
+  if (pl < PB && cq < CQ) {
+    const float4 sc = ld4(scale + cq * 4), sh = ld4(shift + cq * 4);
+    const int64_t base = (int64_t)n * HW * C + cq * 4;
+    for (int p = pl; p < HW; p += PB) {
+      const float4 u = fma4(ld4(z + base + (int64_t)p * C), sc, sh);
+      const float4 d = ld4(da + base + (int64_t)p * C);
+      s = f4(fmaf(d.x, swishf_(u.x), s.x), fmaf(d.y, swishf_(u.y), s.y), fmaf(d.z, swishf_(u.z), s.z), fmaf(d.w, swishf_(u.w), s.w));
+    }
+  }
+  if (pl < PB) st4(red + (pl * CQB + cql) * 4, s);
+  __syncthreads();
+  if (pl == 0 && cq < CQ) {
+    float4 t = f4(0, 0, 0, 0);
+    for (int p = 0; p < PB; ++p) t = add4(t, ld4(red + (p * CQB + cql) * 4));
+    st4(dgate + (int64_t)n * C + cq * 4, t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ K4: SE adjoint per image
+__global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                     const float* __restrict__ hidden, const float* __restrict__ w1,
+                                                     const float* __restrict__ w2, float* __restrict__ dpre2,
+                                                     float* __restrict__ dhid, float* __restrict__ dpooled, int C, int CS) {
+  extern __shared__ float sm[];     // dp2[C] + dh[CS]
+  float* dp2 = sm;
+  float* dh = sm + C;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < C; c += 256) {
+    const float g = gate[(int64_t)n * C + c];
+    const float v = dgate[(int64_t)n * C + c] * g * (1.0f - g);
+    dp2[c] = v;
+    dpre2[(int64_t)n * C + c] = v;
+  }
+  __syncthreads();
+  for (int j = wave; j < CS; j += 4) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a = fmaf(dp2[c], w2[(int64_t)c * CS + j], a);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) {
+      const float v = a * dswishf_(hidden[(int64_t)n * CS + j]);
+      dh[j] = v;
+      dhid[(int64_t)n * CS + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f;
+    for (int j = 0; j < CS; ++j) a = fmaf(dh[j], w1[(int64_t)j * C + c], a);
+    dpooled[(int64_t)n * C + c] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ K5: SE weight grads
+// thread per channel c: dW2[c,:] += sum_n dpre2[n,c]*swish(hidden[n,:]) ; db2[c] += sum_n dpre2[n,c]
+//                       dW1[:,c] += sum_n dhid[n,:]*pooled[n,c] ;         db1[j] += sum_n dhid[n,j] (block 0)
+constexpr int CS_MAX = 48;
+__global__ __launch_bounds__(128) void se_wgrad_kernel(const float* __restrict__ dpre2, const float* __restrict__ dhid,
+                                                       const float* __restrict__ hidden, const float* __restrict__ pooled,
+                                                       float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                       float* __restrict__ db2, int N, int C, int CS) {
+  __shared__ float s1[CS_MAX], dh[CS_MAX];
+  const int c = blockIdx.x * 128 + threadIdx.x;
+  float a2[CS_MAX], a1[CS_MAX];
+#pragma unroll
+  for (int j = 0; j < CS_MAX; ++j) { a2[j] = 0.f; a1[j] = 0.f; }
+  float b2 = 0.f, b1 = 0.f;
+  for (int n = 0; n < N; ++n) {
+    __syncthreads();
+    if (threadIdx.x < CS) {
+      s1[threadIdx.x] = swishf_(hidden[(int64_t)n * CS + threadIdx.x]);
+      dh[threadIdx.x] = dhid[(int64_t)n * CS + threadIdx.x];
+    }
+    __syncthreads();
+    if (c < C) {
+      const float d2 = dpre2[(int64_t)n * C + c], pc = pooled[(int64_t)n * C + c];
+      b2 += d2;
+#pragma unroll
+      for (int j = 0; j < CS_MAX; ++j)
+        if (j < CS) { a2[j] = fmaf(d2, s1[j], a2[j]); a1[j] = fmaf(dh[j], pc, a1[j]); }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < CS) b1 += dh[threadIdx.x];
+  }
+  if (c < C) {
+#pragma unroll
+    for (int j = 0; j < CS_MAX; ++j)
+      if (j < CS) { dw2[(int64_t)c * CS + j] += a2[j]; dw1[(int64_t)j * C + c] += a1[j]; }
+    db2[c] += b2;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < CS) db1[threadIdx.x] += b1;
+}
+
+// ------------------------------------------------------------------------------------------------ K6: depthwise dgrad
+// da_in[n,ih,iw,c] = sum_{kh,kw} w[c,kh,kw] * dz[n,(ih+P-kh)/S,(iw+P-kw)/S,c],  dz = ka*du + kb*z + kc  (virtual)
+// then du_in = da_in * swish'(zin*scale_in+shift_in) is written, with the BN sums of the INPUT-side BatchNorm.
+template <int K, int S, int R>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(
+    const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ w,
+    const float* __restrict__ zin, const float* __restrict__ scale_in, const float* __restrict__ shift_in,
+    const float* __restrict__ mi_in, float* __restrict__ du_in, double* __restrict__ stats, int slots, int N, int H, int W,
+    int C, int Ho, int Wo, int CQB, int PB, int RH) {
+  constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;        // TF-SAME pad-before for even H
+  // Output columns touched by R input columns, with compile-time indexing: with base = iw0 + P - (K-1) (iw0 is a
+  // multiple of R, R a multiple of S) the tap (j,kw) reads output column (base + t)/S, t = j + K-1-kw, when divisible.
+  // For S == 2 the parity of base is the compile-time constant ODD, so the window index (t+ODD)/S is static.
+  constexpr int ODD = (S == 2 && ((K - 1 - P) & 1)) ? 1 : 0;
+  constexpr int OW_SPAN = (R - 1 + K - 1 + ODD) / S + 1;
+  static_assert(R % S == 0, "R must be a multiple of the stride");
+  extern __shared__ float red[];
+  const int tid = threadIdx.x;
+  const int cql = tid % CQB, pl = tid / CQB;
+  const int CQ = C >> 2;
+  const int cq = blockIdx.y * CQB + cql;
+  const int wsegs = (W + R - 1) / R, hsegs = (H + RH - 1) / RH;
+  const int64_t nseg = (int64_t)N * hsegs * wsegs;
+  const int64_t seg = (int64_t)blockIdx.x * PB + pl;
+  const bool live = pl < PB && cq < CQ && seg < nseg;
+  float4 s1 = f4(0, 0, 0, 0), s2 = s1;
+  if (live) {
+    const int ws_ = (int)(seg % wsegs);
+    const int64_t t = seg / wsegs;
+    const int hs = (int)(t % hsegs);
+    const int n = (int)(t / hsegs);
+    const int c = cq * 4;
+    const float4 ka = ld4(kabc + c), kb = ld4(kabc + C + c), kc = ld4(kabc + 2 * C + c);
+    const float4 sc = ld4(scale_in + c), sh = ld4(shift_in + c);
+    const float4 mean = ld4(mi_in + c), istd = ld4(mi_in + C + c);
+    float4 wt[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i)
+      wt[i] = f4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
+    const int iw0 = ws_ * R;
+    const int ow_lo = (iw0 + P - (K - 1) - ODD) / S;             // exact division (numerator is a multiple of S)
+    for (int r = 0; r < RH; ++r) {
+      const int ih = hs * RH + r;
+      if (ih >= H) break;
+      float4 acc[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) acc[j] = f4(0, 0, 0, 0);
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        const int ohn = ih + P - kh;
+        if (ohn < 0 || (ohn % S) != 0) continue;
+        const int oh = ohn / S;
+        if (oh >= Ho) continue;
+        const int64_t rowb = (((int64_t)n * Ho + oh) * Wo) * C + c;
+        float4 dz[OW_SPAN];
+#pragma unroll
+        for (int i = 0; i < OW_SPAN; ++i) {
+          const int ow = ow_lo + i;
+          if (ow >= 0 && ow < Wo) {
+            const float4 a = ld4(du + rowb + (int64_t)ow * C), b = ld4(z + rowb + (int64_t)ow * C);
+            dz[i] = fma4(ka, a, fma4(kb, b, kc));
+          } else dz[i] = f4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            constexpr int dummy = 0; (void)dummy;
+            const int t2 = j + K - 1 - kw + ODD;          // compile-time after unrolling
+            if (t2 % S == 0) acc[j] = fma4(dz[t2 / S], wt[kh * K + kw], acc[j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int iw = iw0 + j;
+        if (iw < W) {
+          const int64_t off = (((int64_t)n * H + ih) * W + iw) * C + c;
+          const float4 zz = ld4(zin + off);
+          const float4 u = fma4(zz, sc, sh);
+          const float4 d = f4(acc[j].x * dswishf_(u.x), acc[j].y * dswishf_(u.y), acc[j].z * dswishf_(u.z), acc[j].w * dswishf_(u.w));
+          st4(du_in + off, d);
+          const float4 xh = f4((zz.x - mean.x) * istd.x, (zz.y - mean.y) * istd.y, (zz.z - mean.z) * istd.z, (zz.w - mean.w) * istd.w);
+          s1 = add4(s1, d);
+          s2 = fma4(d, xh, s2);
+        }
+      }
+    }
+  }
+  reduce_stats(red, s1, s2, cql, pl, CQB, PB, CQ, C, stats, slots);
+}
+
+// ------------------------------------------------------------------------------------------------ K7: depthwise wgrad
+// dw[c,kh,kw] += sum_{n,oh,ow} dz[n,oh,ow,c] * swish(bn(zin))[n, oh*S+kh-P, ow*S+kw-P, c]
+template <int K, int S, int R>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(
+    const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ zin,
+    const float* __restrict__ scale_in, const float* __restrict__ shift_in, float* __restrict__ dw, int N, int H, int W, int C,
+    int Ho, int Wo, int CQB, int PB, int RH) {
+  constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
+  constexpr int WIN = (R - 1) * S + K;
+  extern __shared__ float red[];      // [PB][CQB] float4
+  const int tid = threadIdx.x;
+  const int cql = tid % CQB, pl = tid / CQB;
+  const int CQ = C >> 2;
+  const int cq = blockIdx.y * CQB + cql;
+  const int wsegs = (Wo + R - 1) / R, hsegs = (Ho + RH - 1) / RH;
+  const int64_t nseg = (int64_t)N * hsegs * wsegs;
+  float4 wacc[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) wacc[i] = f4(0, 0, 0, 0);
+  if (pl < PB && cq < CQ) {
+    const int c = cq * 4;
+    const float4 ka = ld4(kabc + c), kb = ld4(kabc + C + c), kc = ld4(kabc + 2 * C + c);
+    const float4 sc = ld4(scale_in + c), sh = ld4(shift_in + c);
+    for (int64_t seg = (int64_t)blockIdx.x * PB + pl; seg < nseg; seg += (int64_t)gridDim.x * PB) {
+      const int ws_ = (int)(seg % wsegs);
+      const int64_t t = seg / wsegs;
+      const int hs = (int)(t % hsegs);
+      const int n = (int)(t / hsegs);
+      const int ow0 = ws_ * R;
+      for (int r = 0; r < RH; ++r) {
+        const int oh = hs * RH + r;
+        if (oh >= Ho) break;
+        float4 dz[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const int ow = ow0 + j;
+          if (ow < Wo) {
+            const int64_t off = (((int64_t)n * Ho + oh) * Wo + ow) * C + c;
+            dz[j] = fma4(ka, ld4(du + off), fma4(kb, ld4(z + off), kc));
+          } else dz[j] = f4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+          const int ih = oh * S + kh - P;
+          if (ih < 0 || ih >= H) continue;
+          const float* rowp = zin + (((int64_t)n * H + ih) * W) * C + c;
+          float4 a[WIN];
+#pragma unroll
+          for (int i = 0; i < WIN; ++i) {
+            const int iw = ow0 * S + i - P;
+            if (iw >= 0 && iw < W) {
+              const float4 u = fma4(ld4(rowp + (int64_t)iw * C), sc, sh);
+              a[i] = f4(swishf_(u.x), swishf_(u.y), swishf_(u.z), swishf_(u.w));
+            } else a[i] = f4(0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+            for (int j = 0; j < R; ++j) wacc[kh * K + kw] = fma4(dz[j], a[j * S + kw], wacc[kh * K + kw]);
+        }
+      }
+    }
+  }
+  // block reduction, one tap at a time (keeps LDS small), then one atomic per (channel, tap) per block
+#pragma unroll
+  for (int tp = 0; tp < K * K; ++tp) {
+    __syncthreads();
+    if (pl < PB) st4(red + (pl * CQB + cql) * 4, wacc[tp]);
+    __syncthreads();
+    if (pl == 0 && cq < CQ) {
+      float4 t = f4(0, 0, 0, 0);
+      for (int p = 0; p < PB; ++p) t = add4(t, ld4(red + (p * CQB + cql) * 4));
+      const int c = cq * 4;
+      atomicAdd(dw + (c + 0) * K * K + tp, t.x); atomicAdd(dw + (c + 1) * K * K + tp, t.y);
+      atomicAdd(dw + (c + 2) * K * K + tp, t.z); atomicAdd(dw + (c + 3) * K * K + tp, t.w);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ K8: stem wgrad
+// dW[co,ci,kh,kw] += sum_pix dz0[pix,co] * x[n, 2oh+kh-P, 2ow+kw-P, ci],  dz0 = ka*du+kb*z+kc
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ du, const float* __restrict__ z,
+                                                         const float* __restrict__ kabc, const float* __restrict__ x,
+                                                         float* __restrict__ dw, int N, int H, int W, int Ho, int Wo, int pad0) {
+  constexpr int CO = 32, TP = 64, TAPS = 27;
+  __shared__ float dzt[TP][CO + 1];
+  __shared__ float xt[TP][TAPS + 1];
+  const int tid = threadIdx.x;
+  const int co = tid & 31, g = tid >> 5;
+  const float ka = kabc[co], kb = kabc[CO + co], kc = kabc[2 * CO + co];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t total = (int64_t)N * Ho * Wo;
+  const int64_t ntiles = (total + TP - 1) / TP;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t p0 = tile * TP;
+    __syncthreads();
+    for (int i = tid; i < TP * CO; i += 256) {
+      const int p = i >> 5, c2 = i & 31;
+      const int64_t pix = p0 + p;
+      float v = 0.f;
+      if (pix < total) v = fmaf(kabc[c2], du[pix * CO + c2], fmaf(kabc[CO + c2], z[pix * CO + c2], kabc[2 * CO + c2]));
+      dzt[p][c2] = v;
+    }
+    for (int i = tid; i < TP * TAPS; i += 256) {
+      const int p = i / TAPS, tp = i - p * TAPS;
+      const int ci = tp % 3, kk = tp / 3, kw = kk % 3, kh = kk / 3;
+      const int64_t pix = p0 + p;
+      float v = 0.f;
+      if (pix < total) {
+        const int ow = (int)(pix % Wo);
+        const int64_t t = pix / Wo;
+        const int oh = (int)(t % Ho), n = (int)(t / Ho);
+        const int ih = oh * 2 + kh - pad0, iw = ow * 2 + kw - pad0;
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[(((int64_t)n * H + ih) * W + iw) * 3 + ci];
+      }
+      xt[p][tp] = v;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int p = 0; p < TP; ++p) {
+      const float d = dzt[p][co];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tp = g + 8 * i;
+        if (tp < TAPS) acc[i] = fmaf(d, xt[p][tp], acc[i]);
+      }
+    }
+  }
+  (void)ka; (void)kb; (void)kc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int tp = g + 8 * i;
+    if (tp < TAPS) {
+      const int ci = tp % 3, kk = tp / 3, kw = kk % 3, kh = kk / 3;
+      atomicAdd(dw + ((co * 3 + ci) * 3 + kh) * 3 + kw, acc[i]);
+    }
+  }
+}
+
+int pick_cqb(int CQ) {
+  int best = 1;
+  for (int d = 1; d <= 64 && d <= CQ; ++d)
+    if (CQ % d == 0) best = d;
+  return best;
+}
+
+template <int K, int S, int R>
+int launch_dw_bwd(const float* du, const float* z, const float* kabc, const float* w, const float* zin, const float* scale_in,
+                  const float* shift_in, const float* mi_in, float* du_in, double* stats, int slots, float* dw, int N, int H,
+                  int W, int C, hipStream_t s) {
+  const int Ho = (H + S - 1) / S, Wo = (W + S - 1) / S;
+  const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
+  // weight gradient: output-centric, grid-strided so each block issues one atomic per (channel, tap)
+  {
+    const int RH = Ho >= 28 ? 4 : (Ho >= 14 ? 2 : 1);
+    const int wsegs = (Wo + R - 1) / R, hsegs = (Ho + RH - 1) / RH;
+    const int64_t nseg = (int64_t)N * hsegs * wsegs;
+    int64_t nb = (nseg + PB - 1) / PB;
+    const int64_t cap = 2048 / (CQ / CQB) > 0 ? 2048 / (CQ / CQB) : 1;
+    if (nb > cap) nb = cap;
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, R>), dim3((unsigned)nb, CQ / CQB), dim3(CQB * PB),
+                       (size_t)PB * CQB * 4 * sizeof(float), s, du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo,
+                       CQB, PB, RH);
+    int rc = check_launch("mt_dwconv_bwd(weight)");
+    if (rc) return rc;
+  }
+  // data gradient: input-centric
+  {
+    constexpr int RI = 4;
+    const int RH = H >= 28 ? 4 : (H >= 14 ? 2 : 1);
+    const int wsegs = (W + RI - 1) / RI, hsegs = (H + RH - 1) / RH;
+    const int64_t nseg = (int64_t)N * hsegs * wsegs;
+    hipLaunchKernelGGL((dwconv_bwd_data_kernel<K, S, RI>), dim3((unsigned)((nseg + PB - 1) / PB), CQ / CQB), dim3(CQB * PB),
+                       (size_t)PB * CQB * 8 * sizeof(float), s, du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats,
+                       slots > 0 ? slots : 1, N, H, W, C, Ho, Wo, CQB, PB, RH);
+    return check_launch("mt_dwconv_bwd(data)");
+  }
+}
+
+}  // namespace
+
+extern "C" int mt_bn_act_bwd(const float* din, const float* z, const float* scale, const float* shift,
+                             const float* mean_invstd, const float* gate, const float* dpool, const float* rowscale,
+                             float* dout, double* stats, int slots, int64_t rows, int C, int hw, int act, void* stream) {
+  if (!din || !z || !scale || !shift || !mean_invstd || !stats) return fail(MT_ERR_ARG, "mt_bn_act_bwd: null pointer");
+  if ((gate == nullptr) != (dpool == nullptr)) return fail(MT_ERR_ARG, "mt_bn_act_bwd: gate and dpool go together");
+  if (C & 3) return fail(MT_ERR_ARG, "mt_bn_act_bwd: C %% 4 != 0");
+  const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
+  int64_t nb = (rows + PB - 1) / PB;
+  const int64_t cap = 4096 / (CQ / CQB) > 0 ? 4096 / (CQ / CQB) : 1;
+  if (nb > cap) nb = cap;
+  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((unsigned)nb, CQ / CQB), dim3(CQB * PB), (size_t)PB * CQB * 8 * sizeof(float),
+                     (hipStream_t)stream, din, z, scale, shift, mean_invstd, gate, dpool, rowscale, dout, stats,
+                     slots > 0 ? slots : 1, rows, C, hw > 0 ? hw : 1, act, CQB, PB);
+  return check_launch("mt_bn_act_bwd");
+}
+
+extern "C" int mt_bn_bwd_finalize(const double* stats, int slots, double count, const float* gamma, const float* mean_invstd,
+                                  float* kabc, float* dgamma, float* dbeta, int C, int training, void* stream) {
+  if (!stats || !gamma || !mean_invstd || !kabc) return fail(MT_ERR_ARG, "mt_bn_bwd_finalize: null pointer");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, slots, count, gamma,
+                     mean_invstd, kabc, dgamma, dbeta, C, training);
+  return check_launch("mt_bn_bwd_finalize");
+}
+
+extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, const float* shift, const float* gate,
+                         const float* hidden, const float* pooled, const float* w1, const float* w2, float* dgate,
+                         float* dpre2, float* dhid, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, int N,
+                         int HW, int C, int CS, void* stream) {
+  if (!da || !z || !scale || !shift || !gate || !hidden || !pooled || !w1 || !w2 || !dgate || !dpre2 || !dhid || !dpooled ||
+      !dw1 || !db1 || !dw2 || !db2)
+    return fail(MT_ERR_ARG, "mt_se_bwd: null pointer");
+  if (C & 3) return fail(MT_ERR_ARG, "mt_se_bwd: C %% 4 != 0");
+  if (CS > CS_MAX) return fail(MT_ERR_UNSUPPORTED, "mt_se_bwd: squeeze width %d > %d", CS, CS_MAX);
+  hipStream_t s = (hipStream_t)stream;
+  const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
+  hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(N, CQ / CQB), dim3(CQB * PB), (size_t)PB * CQB * 4 * sizeof(float), s, da, z, scale,
+                     shift, dgate, HW, C, CQB, PB);
+  int rc = check_launch("mt_se_bwd(reduce)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(se_bwd_kernel, dim3(N), dim3(256), (size_t)(C + CS) * sizeof(float), s, dgate, gate, hidden, w1, w2, dpre2, dhid,
+                     dpooled, C, CS);
+  rc = check_launch("mt_se_bwd(image)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 127) / 128), dim3(128), 0, s, dpre2, dhid, hidden, pooled, dw1, db1, dw2, db2, N, C, CS);
+  return check_launch("mt_se_bwd(wgrad)");
+}
+
+extern "C" int mt_dwconv_bwd(const float* du, const float* z, const float* kabc, const float* w, const float* zin,
+                             const float* scale_in, const float* shift_in, const float* mean_invstd_in, float* du_in,
+                             double* stats_in, int slots, float* dw, int N, int H, int W, int C, int k, int stride,
+                             void* stream) {
+  if (!du || !z || !kabc || !w || !zin || !scale_in || !shift_in || !mean_invstd_in || !du_in || !stats_in || !dw)
+    return fail(MT_ERR_ARG, "mt_dwconv_bwd: null pointer");
+  if (C & 3) return fail(MT_ERR_ARG, "mt_dwconv_bwd: C %% 4 != 0");
+  if (stride == 2 && ((H & 1) || (W & 1))) return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd: stride 2 needs even H, W");
+  hipStream_t s = (hipStream_t)stream;
+  if (k == 3 && stride == 1) return launch_dw_bwd<3, 1, 4>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, s);
+  if (k == 3 && stride == 2) return launch_dw_bwd<3, 2, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, s);
+  if (k == 5 && stride == 1) return launch_dw_bwd<5, 1, 4>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, s);
+  if (k == 5 && stride == 2) return launch_dw_bwd<5, 2, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, s);
+  return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd: k=%d stride=%d unsupported", k, stride);
+}
+
+extern "C" int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const float* x, float* dw, int N, int H,
+                                  int W, void* stream) {
+  if (!du || !z || !kabc || !x || !dw) return fail(MT_ERR_ARG, "mt_stem_conv_wgrad: null pointer");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int padt = max((Ho - 1) * 2 + 3 - H, 0);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, du, z, kabc, x, dw, N, H, W, Ho, Wo, padt / 2);
+  return check_launch("mt_stem_conv_wgrad");
+}

@@ -20,19 +20,19 @@ int pick_cfg(int N, int epilogue) {
   return pad_mid < pad_big ? CFG_MID : CFG_BIG;
 }
 
-template <int AL, int BL, int PRO, int EPI>
+template <int AL, int BL, int PRO, int EPI, int BPRO = BPRO_NONE>
 int launch(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
   switch (cfg) {
     case CFG_BIG:
-      hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, AL, BL, PRO, EPI>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, AL, BL, PRO, EPI, BPRO>), grid, dim3(256), 0, s, a);
       break;
     case CFG_MID:
       if constexpr (EPI == EPI_GEGLU) return fail(MT_ERR_UNSUPPORTED, "GEGLU needs the 128x128 tile");
-      else hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 1, AL, BL, PRO, EPI>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 1, AL, BL, PRO, EPI, BPRO>), grid, dim3(256), 0, s, a);
       break;
     case CFG_NARROW:
       if constexpr (EPI == EPI_GEGLU) return fail(MT_ERR_UNSUPPORTED, "GEGLU needs the 128x128 tile");
-      else hipLaunchKernelGGL((gemm_kernel<4, 1, 2, 1, AL, BL, PRO, EPI>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_kernel<4, 1, 2, 1, AL, BL, PRO, EPI, BPRO>), grid, dim3(256), 0, s, a);
       break;
   }
   return check_launch("mt_gemm");
@@ -58,6 +58,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   a.scale = d->scale; a.shift = d->shift; a.gate = d->gate; a.hw = d->hw > 0 ? d->hw : 1;
   a.C2 = d->C2; a.ldc2 = d->ldc2; a.stats = d->stats; a.stats_slots = d->stats_slots > 0 ? d->stats_slots : 1;
   a.n_half = d->n_half; a.k_chunk = 0;
+  a.A2 = d->A2; a.b_scale = d->b_scale; a.b_shift = d->b_shift; a.b_gate = d->b_gate; a.b_hw = d->b_hw > 0 ? d->b_hw : 1;
 
   // K-contiguous operands need K % 4 == 0 (float4 along K); k-major operands need M resp. N % 4 == 0
   if (d->op == MT_OP_NT && (d->K & 3)) return fail(MT_ERR_ARG, "mt_gemm NT: K %% 4 != 0");
@@ -69,6 +70,10 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   if (d->epilogue == MT_EPI_STATS && !d->stats) return fail(MT_ERR_ARG, "mt_gemm: STATS needs stats");
   if (d->epilogue == MT_EPI_GEGLU_BWD && !d->C2) return fail(MT_ERR_ARG, "mt_gemm: GEGLU_BWD needs C2 (pre-activations)");
   if (d->prologue != MT_PRO_NONE && (!d->scale || !d->shift)) return fail(MT_ERR_ARG, "mt_gemm: prologue needs scale/shift");
+  if (d->prologue == MT_PRO_BN_BWD && (!d->A2 || !d->gate)) return fail(MT_ERR_ARG, "mt_gemm: BN_BWD prologue needs A2 and kc");
+  if (d->prologue == MT_PRO_BN_BWD && ((uintptr_t)d->A2 & 15)) return fail(MT_ERR_ARG, "mt_gemm: A2 must be 16-byte aligned");
+  if (d->b_prologue != MT_BPRO_NONE && (d->op != MT_OP_TN || !d->b_scale || !d->b_shift || !d->b_gate))
+    return fail(MT_ERR_ARG, "mt_gemm: B prologue needs op TN and b_scale/b_shift/b_gate");
   if (d->prologue == MT_PRO_BN_SWISH_GATE && !d->gate) return fail(MT_ERR_ARG, "mt_gemm: gate prologue needs gate");
 
   const int cfg = pick_cfg(d->N, d->epilogue);
@@ -87,7 +92,13 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
     splits = (d->K + chunk - 1) / chunk;
     a.k_chunk = chunk;
     grid.y = splits;
+    if (d->b_prologue == MT_BPRO_BN_SWISH_GATE) {
+      if (d->prologue == MT_PRO_BN_BWD && d->epilogue == MT_EPI_ATOMIC)
+        return launch<LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_ATOMIC, BPRO_BN_SWISH_GATE>(cfg, a, grid, s);
+      return fail(MT_ERR_UNSUPPORTED, "mt_gemm TN: B prologue only with BN_BWD/ATOMIC");
+    }
     COMBO(MT_OP_TN, LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_NONE, EPI_ATOMIC)
+    COMBO(MT_OP_TN, LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_ATOMIC)
     return fail(MT_ERR_UNSUPPORTED, "mt_gemm TN: unsupported prologue/epilogue %d/%d", d->prologue, d->epilogue);
   }
   COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_NONE, EPI_STORE)
@@ -99,6 +110,8 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_STORE)
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_ACCUM)
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_GEGLU_BWD)
+  COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_STORE)
+  COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_BIAS_RES)
 #undef COMBO
   return fail(MT_ERR_UNSUPPORTED, "mt_gemm: unsupported op/prologue/epilogue %d/%d/%d", d->op, d->prologue, d->epilogue);
 }

@@ -33,7 +33,12 @@ enum : int {
   PRO_BN_SWISH_GATE = 1,   // a = swish(z*scale[k]+shift[k]) * gate[(m/hw)*K + k]      (MBConv project conv input)
   PRO_BN_SWISH = 2,        // a = swish(z*scale[k]+shift[k])
   PRO_AFFINE = 3,          // a = z*scale[k]+shift[k]
+  PRO_BN_BWD = 4,          // a = ka[c]*A[.] + kb[c]*A2[.] + kc[c]   (BatchNorm backward folded into the operand load:
+                           //     A = d(bn output), A2 = z (bn input); ka,kb,kc = scale, shift, gate vectors; c = channel)
 };
+
+// prologue applied to B elements (k-major B only): B = swish(z*b_scale[n]+b_shift[n]) * b_gate[(k/b_hw)*N + n]
+enum : int { BPRO_NONE = 0, BPRO_BN_SWISH_GATE = 1 };
 
 // epilogues
 enum : int {
@@ -72,6 +77,8 @@ struct GemmArgs {
   double* stats; int stats_slots;       // EPI_STATS: [slots][2][N] fp64
   int n_half;                           // GEGLU: N/2 of the weight (h width)
   int k_chunk;                          // split-K: contraction length per blockIdx.y (0 = whole K)
+  const float* A2;                      // PRO_BN_BWD second source (same layout / lda / row map as A)
+  const float* b_scale; const float* b_shift; const float* b_gate; int b_hw;   // B prologue
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -84,7 +91,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI, int BPRO = BPRO_NONE>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 void gemm_kernel(const GemmArgs p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -158,6 +165,14 @@ void gemm_kernel(const GemmArgs p) {
           const int m = m0 + row, k = k0 + kq * 4;
           if (m < p.M && k < k_end) {
             v = *reinterpret_cast<const float4*>(p.A + map_row(p.a_map, m) * p.lda + k);
+            if constexpr (PRO == PRO_BN_BWD) {
+              const float4 z2 = *reinterpret_cast<const float4*>(p.A2 + map_row(p.a_map, m) * p.lda + k);
+              const float4 ka = *reinterpret_cast<const float4*>(p.scale + k);
+              const float4 kb = *reinterpret_cast<const float4*>(p.shift + k);
+              const float4 kc = *reinterpret_cast<const float4*>(p.gate + k);
+              v.x = fmaf(ka.x, v.x, fmaf(kb.x, z2.x, kc.x)); v.y = fmaf(ka.y, v.y, fmaf(kb.y, z2.y, kc.y));
+              v.z = fmaf(ka.z, v.z, fmaf(kb.z, z2.z, kc.z)); v.w = fmaf(ka.w, v.w, fmaf(kb.w, z2.w, kc.w));
+            }
             if constexpr (PRO == PRO_BN_SWISH_GATE || PRO == PRO_BN_SWISH || PRO == PRO_AFFINE) {
               const float4 sc = *reinterpret_cast<const float4*>(p.scale + k);
               const float4 sh = *reinterpret_cast<const float4*>(p.shift + k);
@@ -175,8 +190,18 @@ void gemm_kernel(const GemmArgs p) {
           constexpr int QPR = BM / 4;
           const int kk = u / QPR, mq = u - kk * QPR;
           const int k = k0 + kk, m = m0 + mq * 4;
-          if (k < k_end && m < p.M)
-            v = *reinterpret_cast<const float4*>(p.A + map_row(p.a_map, k) * p.lda + m);
+          if (k < k_end && m < p.M) {
+            const int64_t off = map_row(p.a_map, k) * p.lda + m;
+            v = *reinterpret_cast<const float4*>(p.A + off);
+            if constexpr (PRO == PRO_BN_BWD) {      // channel index is the output row m here
+              const float4 z2 = *reinterpret_cast<const float4*>(p.A2 + off);
+              const float4 ka = *reinterpret_cast<const float4*>(p.scale + m);
+              const float4 kb = *reinterpret_cast<const float4*>(p.shift + m);
+              const float4 kc = *reinterpret_cast<const float4*>(p.gate + m);
+              v.x = fmaf(ka.x, v.x, fmaf(kb.x, z2.x, kc.x)); v.y = fmaf(ka.y, v.y, fmaf(kb.y, z2.y, kc.y));
+              v.z = fmaf(ka.z, v.z, fmaf(kb.z, z2.z, kc.z)); v.w = fmaf(ka.w, v.w, fmaf(kb.w, z2.w, kc.w));
+            }
+          }
         }
       }
       ra[i] = v;
@@ -194,7 +219,16 @@ void gemm_kernel(const GemmArgs p) {
           constexpr int QPR = BN / 4;
           const int kk = u / QPR, nq = u - kk * QPR;
           const int k = k0 + kk, n = n0 + nq * 4;
-          if (k < k_end && n < p.N) v = *reinterpret_cast<const float4*>(p.B + map_row(p.b_map, k) * p.ldb + n);
+          if (k < k_end && n < p.N) {
+            v = *reinterpret_cast<const float4*>(p.B + map_row(p.b_map, k) * p.ldb + n);
+            if constexpr (BPRO == BPRO_BN_SWISH_GATE) {
+              const float4 sc = *reinterpret_cast<const float4*>(p.b_scale + n);
+              const float4 sh = *reinterpret_cast<const float4*>(p.b_shift + n);
+              const float4 g = *reinterpret_cast<const float4*>(p.b_gate + (int64_t)(k / p.b_hw) * p.N + n);
+              v.x = swishf_(fmaf(v.x, sc.x, sh.x)) * g.x; v.y = swishf_(fmaf(v.y, sc.y, sh.y)) * g.y;
+              v.z = swishf_(fmaf(v.z, sc.z, sh.z)) * g.z; v.w = swishf_(fmaf(v.w, sc.w, sh.w)) * g.w;
+            }
+          }
         }
       }
       rb[i] = v;

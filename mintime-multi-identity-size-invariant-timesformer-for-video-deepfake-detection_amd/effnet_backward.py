@@ -1,0 +1,139 @@
+"""Reverse launch sequence of EfficientNet-B0 (analytic backward on libmintime_hip; see csrc/effnet_bwd.hip)."""
+import torch
+
+from . import arch
+from . import lib as L
+from .effnet_engine import SLOTS, _StatsPool
+
+
+def _new(dev, *shape):
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+
+def _splits(rows):
+    return max(1, min(64, rows // 1024))
+
+
+def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_dparams):
+    lib = L.get()
+    st = L.stream_ptr()
+    dev = dfeat.device
+    N, H, W = shape
+    blocks = model._blocks
+    P = list(params)
+    grads = [torch.zeros_like(p, dtype=torch.float32) for p in P]
+    # parameter index map (same order as effnet_engine.param_list)
+    pos = 3
+    bidx = []
+    for blk in blocks:
+        d = {}
+        if blk.spec.has_expand:
+            d["e"] = pos
+            pos += 3
+        d["d"] = pos
+        d["se"] = pos + 3
+        d["p"] = pos + 7
+        pos += 10
+        bidx.append(d)
+    ih = pos
+    total_c = arch.STEM_COUT + arch.HEAD_COUT + sum((b.spec.cexp if b.spec.has_expand else 0) + b.spec.cexp + b.spec.cout
+                                                    for b in blocks)
+    pool = _StatsPool(dev, total_c)
+    tr = 1 if training else 0
+
+    def bn_finalize(bnctx, sums, gidx_gamma):
+        kabc = _new(dev, 3, bnctx.C)
+        L.check(lib.mt_bn_bwd_finalize(L.ptr(sums), SLOTS, bnctx.count, L.ptr(P[gidx_gamma]), L.ptr(bnctx.mean_invstd), L.ptr(kabc),
+                                       L.ptr(grads[gidx_gamma]), L.ptr(grads[gidx_gamma + 1]), bnctx.C, tr, st), "mt_bn_bwd_finalize")
+        return kabc
+
+    def act_bwd(din, z, bnctx, dout, rows, hw, act, gate=None, dpool=None, rowscale=None):
+        sums = pool.take(bnctx.C)
+        L.check(lib.mt_bn_act_bwd(L.ptr(din), L.ptr(z), L.ptr(bnctx.scale), L.ptr(bnctx.shift), L.ptr(bnctx.mean_invstd), L.ptr(gate),
+                                  L.ptr(dpool), L.ptr(rowscale), L.ptr(dout), L.ptr(sums), SLOTS, rows, bnctx.C, hw, act, st),
+                "mt_bn_act_bwd")
+        return sums
+
+    def conv1x1_bwd(du, z, kabc, w, x_in, rows, cout, cin, gw_idx, need_dx_in, res=None, b_pro=None):
+        """z = x_in . w^T with dz = ka*du+kb*z+kc.  Returns dx_in [rows, cin] (+res) or None."""
+        kw = {}
+        if b_pro is not None:
+            kw = dict(b_prologue=L.BPRO_BN_SWISH_GATE, b_scale=b_pro[0], b_shift=b_pro[1], b_gate=b_pro[2], b_hw=b_pro[3])
+        L.gemm(L.OP_TN, du, x_in, grads[gw_idx], cout, cin, rows, cout, cin, cin, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC,
+               split_k=_splits(rows), A2=z, scale=kabc[0], shift=kabc[1], gate=kabc[2], **kw)
+        if not need_dx_in:
+            return None
+        dx_in = _new(dev, rows, cin)
+        if res is not None:
+            L.gemm(L.OP_NN, du, w, dx_in, rows, cin, cout, cout, cin, cin, prologue=L.PRO_BN_BWD, epilogue=L.EPI_BIAS_RES, A2=z,
+                   scale=kabc[0], shift=kabc[1], gate=kabc[2], R=res, ldr=cin)
+        else:
+            L.gemm(L.OP_NN, du, w, dx_in, rows, cin, cout, cout, cin, cin, prologue=L.PRO_BN_BWD, A2=z, scale=kabc[0], shift=kabc[1],
+                   gate=kabc[2])
+        return dx_in
+
+    # ---- head: feat = swish(bn1(z_h)), z_h = y . Wh^T
+    hd = saved["head"]
+    s_last = blocks[-1].spec
+    M = N * s_last.hout * s_last.hout
+    du_h = _new(dev, M, arch.HEAD_COUT)
+    sums = act_bwd(dfeat, hd["z"], hd["bn"], du_h, M, 1, 1)
+    kabc = bn_finalize(hd["bn"], sums, ih + 1)
+    dy = conv1x1_bwd(du_h, hd["z"], kabc, P[ih], hd["y_in"], M, arch.HEAD_COUT, arch.HEAD_CIN, ih, True)
+    del du_h
+
+    # ---- blocks, last to first
+    for bi in reversed(range(len(blocks))):
+        blk, rec, ix = blocks[bi], saved["blocks"][bi], bidx[bi]
+        s = rec["spec"]
+        M_in, M_out = N * s.hin * s.hin, N * s.hout * s.hout
+        hw = s.hout * s.hout
+        # (a) bn2 (+ drop-connect gate): y = bn2(z_p)*dc (+ y_in)
+        dc = rec["dc"]
+        dyb = _new(dev, M_out, s.cout) if dc is not None else None
+        sums = act_bwd(dy, rec["z_p"], rec["bn_p"], dyb, M_out, hw, 0, rowscale=dc)
+        kabc_p = bn_finalize(rec["bn_p"], sums, ix["p"] + 1)
+        dsrc = dyb if dc is not None else dy
+        # (b,c) project conv: z_p = (swish(bn1(z_d))*gate) . Wp^T
+        bn_d = rec["bn_d"]
+        da = conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], True,
+                         b_pro=(bn_d.scale, bn_d.shift, rec["gate"], hw))
+        # (d) squeeze-excite adjoint
+        dgate, dpre2, dpooled = _new(dev, N, s.cexp), _new(dev, N, s.cexp), _new(dev, N, s.cexp)
+        dhid = _new(dev, N, s.cse)
+        se = ix["se"]
+        L.check(lib.mt_se_bwd(L.ptr(da), L.ptr(rec["z_d"]), L.ptr(bn_d.scale), L.ptr(bn_d.shift), L.ptr(rec["gate"]), L.ptr(rec["hidden"]),
+                              L.ptr(rec["pooled"]), L.ptr(P[se]), L.ptr(P[se + 2]), L.ptr(dgate), L.ptr(dpre2), L.ptr(dhid), L.ptr(dpooled),
+                              L.ptr(grads[se]), L.ptr(grads[se + 1]), L.ptr(grads[se + 2]), L.ptr(grads[se + 3]), N, hw, s.cexp, s.cse,
+                              st), "mt_se_bwd")
+        # (e) through swish + bn1: du_d (in place over da)
+        sums = act_bwd(da, rec["z_d"], bn_d, da, M_out, hw, 1, gate=rec["gate"], dpool=dpooled)
+        kabc_d = bn_finalize(bn_d, sums, ix["d"] + 1)
+        # (f,g) depthwise conv adjoint -> du wrt the dw input's pre-activation (+ its BN sums)
+        in_bn = rec["dw_bn"]
+        du_in = _new(dev, M_in, s.cexp)
+        sums_in = pool.take(s.cexp)
+        L.check(lib.mt_dwconv_bwd(L.ptr(da), L.ptr(rec["z_d"]), L.ptr(kabc_d), L.ptr(P[ix["d"]]), L.ptr(rec["dw_in"]), L.ptr(in_bn.scale),
+                                  L.ptr(in_bn.shift), L.ptr(in_bn.mean_invstd), L.ptr(du_in), L.ptr(sums_in), SLOTS, L.ptr(grads[ix["d"]]),
+                                  N, s.hin, s.hin, s.cexp, s.k, s.s, st), "mt_dwconv_bwd")
+        del da
+        if s.has_expand:
+            # (h,i,j) bn0 + expand conv: z_e = y_in . We^T
+            kabc_e = bn_finalize(in_bn, sums_in, ix["e"] + 1)
+            dy = conv1x1_bwd(du_in, rec["z_e"], kabc_e, P[ix["e"]], rec["y_in"], M_in, s.cexp, s.cin, ix["e"], True,
+                             res=dy if s.skip else None)
+        else:
+            # block 0: the dw input is the stem's activated output
+            kabc0 = bn_finalize(in_bn, sums_in, 1)
+            stem = saved["stem"]
+            L.check(lib.mt_stem_conv_wgrad(L.ptr(du_in), L.ptr(stem["z"]), L.ptr(kabc0), L.ptr(stem["x"]), L.ptr(grads[0]), N, H, W, st),
+                    "mt_stem_conv_wgrad")
+            dy = None
+        del du_in
+        rec.clear()
+
+    if need_dx:
+        raise NotImplementedError("gradient w.r.t. the input crops is not part of the MINTIME training path "
+                                  "(train.py never sets requires_grad on videos)")
+    out = [g if need else None for need, g in zip(need_dparams, grads)]
+    return None, out

@@ -32,11 +32,14 @@ class GemmDesc(C.Structure):
                 ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", i64),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("gate", C.c_void_p), ("hw", C.c_int),
                 ("C2", C.c_void_p), ("ldc2", i64), ("stats", C.c_void_p), ("stats_slots", C.c_int),
-                ("n_half", C.c_int), ("split_k", C.c_int)]
+                ("n_half", C.c_int), ("split_k", C.c_int),
+                ("A2", C.c_void_p), ("b_prologue", C.c_int), ("b_scale", C.c_void_p), ("b_shift", C.c_void_p),
+                ("b_gate", C.c_void_p), ("b_hw", C.c_int)]
 
 
 OP_NT, OP_NN, OP_TN = 0, 1, 2
-PRO_NONE, PRO_BN_SWISH_GATE, PRO_BN_SWISH, PRO_AFFINE = 0, 1, 2, 3
+PRO_NONE, PRO_BN_SWISH_GATE, PRO_BN_SWISH, PRO_AFFINE, PRO_BN_BWD = 0, 1, 2, 3, 4
+BPRO_NONE, BPRO_BN_SWISH_GATE = 0, 1
 EPI_STORE, EPI_BIAS_RES, EPI_GEGLU, EPI_STATS, EPI_ATOMIC, EPI_GEGLU_BWD, EPI_ACCUM = 0, 1, 2, 3, 4, 5, 6
 
 # name -> argtypes (restype is always int unless listed in _RESTYPES); mirrors include/mintime_hip.h
@@ -64,6 +67,11 @@ PROTOTYPES = {
     "mt_embed_bwd": [f32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_attn_bwd": [f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                     C.c_void_p],
+    "mt_bn_act_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_bn_bwd_finalize": [C.c_void_p, C.c_int, C.c_double, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_void_p],
+    "mt_se_bwd": [f32p] * 17 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_dwconv_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_stem_conv_wgrad": [f32p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_void_p],
 }
 _RESTYPES = {"mt_last_error": C.c_char_p}
 
@@ -129,7 +137,8 @@ def ptr(t):
 
 def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI_STORE, bias=None, R=None, ldr=0,
          scale=None, shift=None, gate=None, hw=1, C2=None, ldc2=0, stats=None, stats_slots=1, n_half=0, split_k=1,
-         a_map=(0, 0, 0), b_map=(0, 0, 0), c_map=(0, 0, 0)):
+         a_map=(0, 0, 0), b_map=(0, 0, 0), c_map=(0, 0, 0), A2=None, b_prologue=BPRO_NONE, b_scale=None, b_shift=None,
+         b_gate=None, b_hw=1):
     d = GemmDesc()
     d.op, d.prologue, d.epilogue = op, prologue, epilogue
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
@@ -140,4 +149,5 @@ def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI
     d.scale, d.shift, d.gate, d.hw = ptr(scale), ptr(shift), ptr(gate), hw
     d.C2, d.ldc2, d.stats, d.stats_slots = ptr(C2), ldc2, ptr(stats), stats_slots
     d.n_half, d.split_k = n_half, split_k
+    d.A2, d.b_prologue, d.b_scale, d.b_shift, d.b_gate, d.b_hw = ptr(A2), b_prologue, ptr(b_scale), ptr(b_shift), ptr(b_gate), b_hw
     check(get().mt_gemm(C.byref(d), stream_ptr()), "mt_gemm")

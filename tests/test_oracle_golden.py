@@ -117,6 +117,21 @@ def test_end_to_end_step_matches_reference(name):
             assert_close(sd[key].grad.reshape(-1)[:256], g["gslice." + k[6:]], 5e-4, "gslice " + k)
 
 
+@pytest.mark.parametrize("name", ["e2e_cfg1_eval", "e2e_2id_train"])
+def test_end_to_end_step_fp64_matches_reference_fp64(name):
+    """The same restatement run in float64 reproduces the reference's float64 pass (the exact arithmetic)."""
+    g = golden(name)
+    B, Fr, seed = int(g["batch"]), int(g["frames"]), int(g["seed"])
+    cfg = arch.default_tsf_config(1280, Fr)
+    ef = O.to_dtype(synth.effnet_b0_state(seed), torch.float64)
+    ts = O.to_dtype(synth.tsf_state(cfg, seed), torch.float64)
+    inp = synth.clip_inputs(B, Fr, int(g["identities"]), seed, ragged=bool(g["ragged"]))
+    inp["videos"] = inp["videos"].double()
+    with torch.no_grad():
+        out = O.clip_forward(ef, ts, cfg, inp, training_extractor=bool(g["training"]))
+    assert_close(out, g["logits64"], 1e-9, "fp64 logits")
+
+
 def test_state_dict_manifest_matches_reference():
     with open(os.path.join(GOLDEN, "state_manifest.json")) as fh:
         man = json.load(fh)

@@ -31,7 +31,10 @@ def import_reference():
     # the reference's `models` package must win over this repo's drop-in `models/`
     for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
         del sys.modules[k]
-    sys.path.insert(0, REF)
+    # /root/reference/models has no __init__.py (namespace package), so this repo's regular `models` package would
+    # shadow it regardless of order: take the repo root off sys.path while the reference is imported.
+    saved_path = list(sys.path)
+    sys.path[:] = [REF] + [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -39,7 +42,8 @@ def import_reference():
         from models.efficientnet.efficientnet_pytorch import EfficientNet
     assert SizeInvariantTimeSformer.__module__ == "models.size_invariant_timesformer"
     import models
-    assert models.__path__[0].startswith(REF), models.__path__
+    assert list(models.__path__)[0].startswith(REF), models.__path__
+    sys.path[:] = saved_path
     return EfficientNet, SizeInvariantTimeSformer
 
 
@@ -158,32 +162,36 @@ def ef_case(EF, name, n_img, training, seed):
 
 
 def e2e_case(EF, TSF, name, batch, frames, identities, ragged, training, seed):
+    """Whole step.  Stored twice: the reference in fp32 (what a user would run) and in fp64 (its exact arithmetic;
+    the fp32 run of an ill-conditioned case -- train-mode BN over a batch with padded all-zero crops -- deviates from
+    it by several 1e-3, which bounds what "parity within 1e-3" can mean there)."""
     cfg = arch.default_tsf_config(channels=1280, num_frames=frames)
-    ef, _ = build_ef(EF, seed, training)
-    tsf, _ = build_tsf(TSF, cfg, seed, True)
     inp = synth.clip_inputs(batch, frames, identities, seed, ragged=ragged)
-    v = inp["videos"]
-    b, f, h, w, c = v.shape
-    vid = v.reshape(b * f, h, w, c).permute(0, 3, 1, 2)
-    ef.zero_grad(); tsf.zero_grad()
-    feats = ef(vid)
-    logits, (s_att, t_att) = tsf(feats.reshape(b, f, *feats.shape[1:]), mask=inp["mask"],
-                                 identities_mask=inp["identities_mask"], size_embedding=inp["size_embedding"],
-                                 positions=inp["positions"])
-    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, inp["labels"].reshape(-1, 1))
-    loss.backward()
-    grads = {}
-    for model, keys, tag in ((ef, GRAD_KEYS_EF, "ef."), (tsf, GRAD_KEYS_TSF, "tsf.")):
-        named = dict(model.named_parameters())
-        for key in keys:
-            g = named[key].grad
-            grads["gnorm." + tag + key] = g.norm()
-            grads["gslice." + tag + key] = g.reshape(-1)[:256].clone()
-    save(name, logits=logits, space_att=s_att, time_att=t_att, loss=loss.detach(),
-         feat_mean=feats.mean(dim=(0, 2, 3)), feat_absmax=feats.abs().amax(dim=(0, 2, 3)),
-         feat_slice=feats[:2, :, :2, :2].clone(), input_sum=checksum(v),
-         batch=batch, frames=frames, identities=identities, ragged=int(ragged), training=int(training), seed=seed,
-         **grads)
+    out = {}
+    for tag, dtype in (("", torch.float32), ("64", torch.float64)):
+        ef, _ = build_ef(EF, seed, training, dtype)
+        tsf, _ = build_tsf(TSF, cfg, seed, True, dtype)
+        v = inp["videos"].to(dtype)
+        b, f, h, w, c = v.shape
+        vid = v.reshape(b * f, h, w, c).permute(0, 3, 1, 2)
+        ef.zero_grad(); tsf.zero_grad()
+        feats = ef(vid)
+        logits, (s_att, t_att) = tsf(feats.reshape(b, f, *feats.shape[1:]), mask=inp["mask"],
+                                     identities_mask=inp["identities_mask"], size_embedding=inp["size_embedding"],
+                                     positions=inp["positions"])
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, inp["labels"].reshape(-1, 1).to(dtype))
+        loss.backward()
+        for model, keys, mtag in ((ef, GRAD_KEYS_EF, "ef."), (tsf, GRAD_KEYS_TSF, "tsf.")):
+            named = dict(model.named_parameters())
+            for key in keys:
+                g = named[key].grad
+                out[f"gnorm{tag}." + mtag + key] = g.norm()
+                out[f"gslice{tag}." + mtag + key] = g.reshape(-1)[:256].clone()
+        out.update({"logits" + tag: logits, "space_att" + tag: s_att, "time_att" + tag: t_att, "loss" + tag: loss.detach(),
+                    "feat_mean" + tag: feats.mean(dim=(0, 2, 3)), "feat_absmax" + tag: feats.abs().amax(dim=(0, 2, 3)),
+                    "feat_slice" + tag: feats[:2, :, :2, :2].clone()})
+    save(name, input_sum=checksum(inp["videos"]), batch=batch, frames=frames, identities=identities, ragged=int(ragged),
+         training=int(training), seed=seed, **out)
 
 
 def main():
