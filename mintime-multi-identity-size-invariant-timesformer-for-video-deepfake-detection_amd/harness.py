@@ -1,0 +1,72 @@
+"""The reference callers' step bodies (train.py:332-381, test.py:235-247) on the MI355X modules, for synthetic
+inputs.  train.py / test.py themselves import tensorflow, cv2, albumentations, timm ... and cannot run offline;
+this reproduces exactly what they do with the two models (same rearranges, same kwargs, same loss, same optimizer)."""
+import torch
+import torch.nn.functional as F
+
+from . import arch, synth
+from .efficientnet import EfficientNet
+from .timesformer import SizeInvariantTimeSformer
+
+
+def build_models(num_frames=8, seed=0, device="cuda", require_attention=False, drop_connect_rate=arch.DROP_CONNECT_RATE,
+                 train_extractor=True):
+    cfg = arch.default_tsf_config(1280, num_frames)
+    ef = EfficientNet.from_name("efficientnet-b0", drop_connect_rate=drop_connect_rate)
+    ef.load_state_dict(synth.effnet_b0_state(seed))
+    tsf = SizeInvariantTimeSformer(config=cfg, require_attention=require_attention)
+    tsf.load_state_dict(synth.tsf_state(cfg, seed))
+    ef.to(device).train(train_extractor)
+    tsf.to(device).train()
+    return cfg, ef, tsf
+
+
+def make_optimizer(cfg, ef, tsf):
+    """train.py:180-190: optimizer over chain(extractor, model) parameters; SGD(lr, weight_decay) from the YAML."""
+    t = cfg["training"]
+    params = list(ef.parameters()) + list(tsf.parameters())
+    return torch.optim.SGD(params, lr=t["lr"], weight_decay=t["weight-decay"])
+
+
+def device_batch(batch, num_frames=8, num_identities=2, seed=0, device="cuda", ragged=False):
+    """Synthetic clips resident on the device: videos are generated there (uint8-valued fp32, BGR 0..255)."""
+    aux = synth.clip_inputs(batch, num_frames, num_identities, seed, ragged=ragged, with_video=False)
+    g = torch.Generator(device=device).manual_seed(1000 + seed)
+    videos = torch.randint(0, 256, (batch, num_frames, 224, 224, 3), generator=g, device=device, dtype=torch.uint8).float()
+    if ragged:
+        videos = videos * aux["mask"].to(device)[:, :, None, None, None].float()
+    return dict(videos=videos, mask=aux["mask"].to(device), identities_mask=aux["identities_mask"].to(device),
+                size_embedding=aux["size_embedding"], positions=aux["positions"].to(device),
+                labels=aux["labels"].to(device))
+
+
+def forward(ef, tsf, batch):
+    videos = batch["videos"]
+    b, f, h, w, c = videos.shape
+    x = videos.reshape(b * f, h, w, c).permute(0, 3, 1, 2)                    # train.py:341 (a view)
+    features = ef(x)                                                           # train.py:348
+    features = features.reshape(b, f, *features.shape[1:])                    # train.py:354 (a view)
+    return tsf(features, mask=batch["mask"], size_embedding=batch["size_embedding"],
+               identities_mask=batch["identities_mask"], positions=batch["positions"])   # train.py:355
+
+
+def train_step(ef, tsf, optimizer, batch, reducer=None, pos_weight=None):
+    """One optimisation step (train.py:367-378).  The loss stays on the device (the reference moves the logits to the
+    CPU first, one D2H sync per step, train.py:367)."""
+    y_pred = forward(ef, tsf, batch)
+    if isinstance(y_pred, tuple):
+        y_pred = y_pred[0]
+    pw = None if pos_weight is None else torch.as_tensor([pos_weight], device=y_pred.device)
+    loss = F.binary_cross_entropy_with_logits(y_pred, batch["labels"].reshape(-1, 1), pos_weight=pw)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    if reducer is not None:
+        reducer.allreduce()
+    optimizer.step()
+    return loss
+
+
+@torch.no_grad()
+def eval_step(ef, tsf, batch):
+    """test.py:235-247 / predict.py:401-406: eval forward; returns logits (and attentions if the model was built with them)."""
+    return forward(ef, tsf, batch)

@@ -135,6 +135,11 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+# Optional live kernel timing (bench.py's roofline leg): {"match": fn(desc) -> bool, "events": [(start, end, flops)]}.
+# Events are recorded on the stream the kernel is launched on (torch's current stream).
+PROFILE = None
+
+
 def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI_STORE, bias=None, R=None, ldr=0,
          scale=None, shift=None, gate=None, hw=1, C2=None, ldc2=0, stats=None, stats_slots=1, n_half=0, split_k=1,
          a_map=(0, 0, 0), b_map=(0, 0, 0), c_map=(0, 0, 0), A2=None, b_prologue=BPRO_NONE, b_scale=None, b_shift=None,
@@ -150,4 +155,12 @@ def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI
     d.C2, d.ldc2, d.stats, d.stats_slots = ptr(C2), ldc2, ptr(stats), stats_slots
     d.n_half, d.split_k = n_half, split_k
     d.A2, d.b_prologue, d.b_scale, d.b_shift, d.b_gate, d.b_hw = ptr(A2), b_prologue, ptr(b_scale), ptr(b_shift), ptr(b_gate), b_hw
+    prof = PROFILE
+    if prof is not None and prof["match"](d):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(get().mt_gemm(C.byref(d), stream_ptr()), "mt_gemm")
+        e1.record()
+        prof["events"].append((e0, e1, 2.0 * M * N * K))
+        return
     check(get().mt_gemm(C.byref(d), stream_ptr()), "mt_gemm")
