@@ -56,7 +56,7 @@ typedef struct {
   float* C2; int64_t ldc2;          /* GEGLU: optional pre-activation store; GEGLU_BWD: pre-activations  */
   double* stats; int stats_slots;   /* STATS: [slots][2][N] fp64 accumulators (sum, sum of squares)      */
   int n_half;
-  int split_k;                      /* TN: number of K splits (>=1)                                      */
+  int split_k;                      /* TN: number of K splits; <= 0 picks one that fills the chip        */
   const float* A2;                  /* BN_BWD prologue: second source, same layout as A                  */
   int b_prologue; const float* b_scale; const float* b_shift; const float* b_gate; int b_hw;
 } mt_gemm_desc;

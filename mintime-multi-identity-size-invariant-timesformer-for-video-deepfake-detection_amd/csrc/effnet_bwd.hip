@@ -181,17 +181,20 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ d
 // thread per channel c: dW2[c,:] += sum_n dpre2[n,c]*swish(hidden[n,:]) ; db2[c] += sum_n dpre2[n,c]
 //                       dW1[:,c] += sum_n dhid[n,:]*pooled[n,c] ;         db1[j] += sum_n dhid[n,j] (block 0)
 constexpr int CS_MAX = 48;
+// grid (ceil(C/128), image chunks): each block reduces its chunk of images in registers, then fp32 atomics
 __global__ __launch_bounds__(128) void se_wgrad_kernel(const float* __restrict__ dpre2, const float* __restrict__ dhid,
                                                        const float* __restrict__ hidden, const float* __restrict__ pooled,
                                                        float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
-                                                       float* __restrict__ db2, int N, int C, int CS) {
+                                                       float* __restrict__ db2, int N, int C, int CS, int imgs_per_block) {
   __shared__ float s1[CS_MAX], dh[CS_MAX];
   const int c = blockIdx.x * 128 + threadIdx.x;
+  const int n0 = blockIdx.y * imgs_per_block;
+  const int n1 = min(N, n0 + imgs_per_block);
   float a2[CS_MAX], a1[CS_MAX];
 #pragma unroll
   for (int j = 0; j < CS_MAX; ++j) { a2[j] = 0.f; a1[j] = 0.f; }
   float b2 = 0.f, b1 = 0.f;
-  for (int n = 0; n < N; ++n) {
+  for (int n = n0; n < n1; ++n) {
     __syncthreads();
     if (threadIdx.x < CS) {
       s1[threadIdx.x] = swishf_(hidden[(int64_t)n * CS + threadIdx.x]);
@@ -210,10 +213,10 @@ __global__ __launch_bounds__(128) void se_wgrad_kernel(const float* __restrict__
   if (c < C) {
 #pragma unroll
     for (int j = 0; j < CS_MAX; ++j)
-      if (j < CS) { dw2[(int64_t)c * CS + j] += a2[j]; dw1[(int64_t)j * C + c] += a1[j]; }
-    db2[c] += b2;
+      if (j < CS) { atomicAdd(dw2 + (int64_t)c * CS + j, a2[j]); atomicAdd(dw1 + (int64_t)j * C + c, a1[j]); }
+    atomicAdd(db2 + c, b2);
   }
-  if (blockIdx.x == 0 && threadIdx.x < CS) db1[threadIdx.x] += b1;
+  if (blockIdx.x == 0 && threadIdx.x < CS) atomicAdd(db1 + threadIdx.x, b1);
 }
 
 // ------------------------------------------------------------------------------------------------ K6: depthwise dgrad
@@ -532,7 +535,9 @@ extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, co
                      dpooled, C, CS);
   rc = check_launch("mt_se_bwd(image)");
   if (rc) return rc;
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 127) / 128), dim3(128), 0, s, dpre2, dhid, hidden, pooled, dw1, db1, dw2, db2, N, C, CS);
+  const int ipb = 8;
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 127) / 128, (N + ipb - 1) / ipb), dim3(128), 0, s, dpre2, dhid, hidden, pooled, dw1,
+                     db1, dw2, db2, N, C, CS, ipb);
   return check_launch("mt_se_bwd(wgrad)");
 }
 

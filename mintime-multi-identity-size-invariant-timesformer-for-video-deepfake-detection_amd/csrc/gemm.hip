@@ -86,7 +86,16 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
     return launch<AL, BL, PRO, EPI>(cfg, a, grid, s);
 
   if (d->op == MT_OP_TN) {
-    int splits = d->split_k > 0 ? d->split_k : 1;
+    int splits = d->split_k;
+    if (splits <= 0) {
+      // auto: enough blocks to fill 256 CUs several times over (these outputs are skinny: a handful of tiles), but keep
+      // >= 256 contraction rows per block so the fp32 atomics of the epilogue stay a small fraction of the work
+      const int tiles = m_tiles * n_tiles;
+      splits = (2048 + tiles - 1) / tiles;
+      const int max_splits = d->K / 256 > 0 ? d->K / 256 : 1;
+      if (splits > max_splits) splits = max_splits;
+      if (splits < 1) splits = 1;
+    }
     int chunk = (d->K + splits - 1) / splits;
     chunk = (chunk + 15) / 16 * 16;
     splits = (d->K + chunk - 1) / chunk;

@@ -80,15 +80,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       }
     }
   }
+  // block reduction over the 4 wavefronts, then one atomic per column per block
+  __shared__ float red[2][4][1024];
+  const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = lane + i * 64;
     if (q < nq) {
-      atomicAdd(dgamma + 4 * q, dg[i].x); atomicAdd(dgamma + 4 * q + 1, dg[i].y);
-      atomicAdd(dgamma + 4 * q + 2, dg[i].z); atomicAdd(dgamma + 4 * q + 3, dg[i].w);
-      atomicAdd(dbeta + 4 * q, db[i].x); atomicAdd(dbeta + 4 * q + 1, db[i].y);
-      atomicAdd(dbeta + 4 * q + 2, db[i].z); atomicAdd(dbeta + 4 * q + 3, db[i].w);
+      *reinterpret_cast<float4*>(&red[0][wv][4 * q]) = dg[i];
+      *reinterpret_cast<float4*>(&red[1][wv][4 * q]) = db[i];
     }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
   }
 }
 
@@ -520,7 +526,7 @@ extern "C" int mt_layernorm_bwd(const float* dy, const float* x, const float* st
   if (dim <= 0 || (dim & 3) || dim > 1024) return fail(MT_ERR_ARG, "mt_layernorm_bwd: dim %d unsupported", dim);
   if (rows <= 0) return 0;
   int blocks = (rows + 3) / 4;
-  if (blocks > 512) blocks = 512;
+  if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dgamma, dbeta,
                      rows, dim, accumulate);
   return check_launch("mt_layernorm_bwd");

@@ -21,7 +21,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
     N, H, W = shape
     blocks = model._blocks
     P = list(params)
-    grads = [torch.zeros_like(p, dtype=torch.float32) for p in P]
+    grads = L.zero_grads(list(params))
     # parameter index map (same order as effnet_engine.param_list)
     pos = 3
     bidx = []
@@ -60,7 +60,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         if b_pro is not None:
             kw = dict(b_prologue=L.BPRO_BN_SWISH_GATE, b_scale=b_pro[0], b_shift=b_pro[1], b_gate=b_pro[2], b_hw=b_pro[3])
         L.gemm(L.OP_TN, du, x_in, grads[gw_idx], cout, cin, rows, cout, cin, cin, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC,
-               split_k=_splits(rows), A2=z, scale=kabc[0], shift=kabc[1], gate=kabc[2], **kw)
+               split_k=0, A2=z, scale=kabc[0], shift=kabc[1], gate=kabc[2], **kw)
         if not need_dx_in:
             return None
         dx_in = _new(dev, rows, cin)

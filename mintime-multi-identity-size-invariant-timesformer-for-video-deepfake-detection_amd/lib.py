@@ -164,3 +164,16 @@ def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI
         prof["events"].append((e0, e1, 2.0 * M * N * K))
         return
     check(get().mt_gemm(C.byref(d), stream_ptr()), "mt_gemm")
+
+
+def zero_grads(params):
+    """Zero-filled gradient tensors for `params` carved out of ONE flat buffer (one memset instead of hundreds);
+    every view starts on a 16-byte boundary.  Entries for None params are None."""
+    offs, total = [], 0
+    for p in params:
+        offs.append(total)
+        if p is not None:
+            total += (p.numel() + 3) // 4 * 4
+    dev = next(p for p in params if p is not None).device
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    return [None if p is None else flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)]

@@ -32,7 +32,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
     eps = arch.LN_EPS
     scale = float(dh) ** -0.5
     sk = _splits(M)
-    grads = [_zeros_like_param(p) for p in params]
+    grads = L.zero_grads(list(params))
     P = list(params)
     idx = len(P)
 
@@ -63,10 +63,10 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         i0 = take(6)
         g, b_, w1, b1, w2, b2 = P[i0:i0 + 6]
         r = rec[2]
-        L.gemm(L.OP_TN, dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D, epilogue=L.EPI_ATOMIC, split_k=sk)
+        L.gemm(L.OP_TN, dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D, epilogue=L.EPI_ATOMIC, split_k=0)
         colsum(dx2, D, M, D, grads[i0 + 5])
         L.gemm(L.OP_NN, dx2, w2, du, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D, n_half=4 * D)
-        L.gemm(L.OP_TN, du, r["xn"], grads[i0 + 2], 8 * D, D, M, 8 * D, D, D, epilogue=L.EPI_ATOMIC, split_k=sk)
+        L.gemm(L.OP_TN, du, r["xn"], grads[i0 + 2], 8 * D, D, M, 8 * D, D, D, epilogue=L.EPI_ATOMIC, split_k=0)
         colsum(du, 8 * D, M, 8 * D, grads[i0 + 3])
         L.gemm(L.OP_NN, du, w1, dxn, M, D, 8 * D, 8 * D, D, D)
         L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
@@ -77,12 +77,12 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             i0 = take(5)
             g, b_, w_qkv, w_o, b_o = P[i0:i0 + 5]
             r = rec[mode]
-            L.gemm(L.OP_TN, dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner, epilogue=L.EPI_ATOMIC, split_k=sk)
+            L.gemm(L.OP_TN, dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner, epilogue=L.EPI_ATOMIC, split_k=0)
             colsum(dx2, D, M, D, grads[i0 + 4])
             L.gemm(L.OP_NN, dx2, w_o, do, M, inner, D, D, inner, inner)
             L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
                                     scale, st), "mt_attn_bwd")
-            L.gemm(L.OP_TN, dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D, epilogue=L.EPI_ATOMIC, split_k=sk)
+            L.gemm(L.OP_TN, dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D, epilogue=L.EPI_ATOMIC, split_k=0)
             L.gemm(L.OP_NN, dqkv, w_qkv, dxn, M, D, 3 * inner, 3 * inner, D, D)
             L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
                                          L.ptr(grads[i0 + 1]), M, D, 1, st), "mt_layernorm_bwd")
@@ -95,7 +95,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
                              L.ptr(aux.sizes), B, F, n, D, st), "mt_embed_bwd")
     tok_map = (F * n, N, 1)      # token row r of the feature matrix lives at row (r/(F n))*N + 1 + r%(F n) of dx
     Mt = B * F * n
-    L.gemm(L.OP_TN, dx2, feat, grads[i0], D, C_in, Mt, D, C_in, C_in, epilogue=L.EPI_ATOMIC, split_k=_splits(Mt), a_map=tok_map)
+    L.gemm(L.OP_TN, dx2, feat, grads[i0], D, C_in, Mt, D, C_in, C_in, epilogue=L.EPI_ATOMIC, split_k=0, a_map=tok_map)
     colsum(dx2, D, Mt, D, grads[i0 + 1], tok_map)
     dfeat = None
     if need_dfeat:
