@@ -1,0 +1,156 @@
+"""CPU-only tests: host logic, state-dict compatibility, C-ABI surface (no compute calls without a GPU)."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+import mintime_amd
+from mintime_amd import arch, synth, lib, ddp, EfficientNet, SizeInvariantTimeSformer
+from tests.util import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function include/mintime_hip.h declares is exported by the built .so and bound in lib.PROTOTYPES."""
+    hdr = open(os.path.join(ROOT, "include", "mintime_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(mt_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 20
+    if not os.path.exists(lib.LIB_PATH):
+        lib.build()
+    handle = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in the header but not exported"
+    assert declared == set(lib.PROTOTYPES), declared ^ set(lib.PROTOTYPES)
+    assert lib.get().mt_version() == 100
+
+
+def test_errors_are_reported_not_swallowed():
+    h = lib.get()
+    d = lib.GemmDesc()          # all-null descriptor
+    rc = h.mt_gemm(ctypes.byref(d), None)
+    assert rc < 0 and b"null pointer" in h.mt_last_error()
+    with pytest.raises(lib.MintimeHipError):
+        lib.ptr(torch.zeros(4))                       # CPU tensors are refused: no CPU fallback exists
+
+
+def test_modules_refuse_cpu_tensors():
+    cfg = arch.default_tsf_config(1280, 8)
+    tsf = SizeInvariantTimeSformer(config=cfg)
+    with pytest.raises(lib.MintimeHipError):
+        tsf(torch.zeros(1, 8, 1280, 7, 7), mask=torch.ones(1, 8, dtype=torch.bool),
+            identities_mask=torch.ones(1, 8, 8, dtype=torch.bool), size_embedding=torch.ones(1, 8, dtype=torch.int32),
+            positions=torch.zeros(1, 393, dtype=torch.long))
+    ef = EfficientNet.from_name("efficientnet-b0")
+    with pytest.raises(lib.MintimeHipError):
+        ef(torch.zeros(1, 3, 224, 224))
+
+
+def test_state_dicts_match_reference_manifest():
+    with open(os.path.join(GOLDEN, "state_manifest.json")) as fh:
+        man = json.load(fh)
+    ef = EfficientNet.from_name("efficientnet-b0")
+    assert [[k, list(v.shape), str(v.dtype)] for k, v in ef.state_dict().items()] == man["efficientnet-b0"]
+    for (c, f) in ((1280, 8), (2048, 16)):
+        m = SizeInvariantTimeSformer(config=arch.default_tsf_config(c, f))
+        ours = {k: [list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()}
+        ref = {k: [s, d] for k, s, d in man[f"tsf_c{c}_f{f}"]}
+        assert ours == ref
+        assert sorted(m.no_weight_decay()) == man[f"tsf_c{c}_f{f}_no_weight_decay"]
+    # train.py:159-167 parses parameter names as "_blocks.<i>.<sub>"
+    for name, _ in ef.named_parameters():
+        if "blocks" in name:
+            assert 0 <= int(name.split(".")[1]) < 16
+
+
+def test_drop_in_import_paths():
+    """The reference's import lines (train.py:27-28) resolve to the HIP-backed classes."""
+    from models.efficientnet.efficientnet_pytorch import EfficientNet as E2
+    from models.size_invariant_timesformer import SizeInvariantTimeSformer as T2
+    assert E2 is EfficientNet and T2 is SizeInvariantTimeSformer
+
+
+def test_reference_config_yaml_schema_is_accepted():
+    import yaml
+    text = """
+model: {image-size: 224, patch-size: 1, num-classes: 1, num-patches: 49, num-frames: 16, max-identities: 2, dim: 512,
+        depth: 9, dim-head: 64, channels: 2048, heads: 8, attn-dropout: 0., ff-dropout: 0., shift-tokens: False,
+        enable-size-emb: True, enable-pos-emb: True, enable-identity-attention: True}
+"""
+    m = SizeInvariantTimeSformer(config=yaml.safe_load(text))
+    assert m.pos_emb.weight.shape == (16 * 2048 + 1, 512)
+    bad = yaml.safe_load(text)
+    bad["model"]["shift-tokens"] = True
+    with pytest.raises(NotImplementedError):
+        SizeInvariantTimeSformer(config=bad)
+
+
+def test_load_matching_state_dict_semantics():
+    ef = EfficientNet.from_name("efficientnet-b0")
+    sd = synth.effnet_b0_state(3)
+    prefixed = {"efficient_net." + k: v for k, v in sd.items()}
+    prefixed["not.a.key"] = torch.zeros(3)
+    ef.load_matching_state_dict(prefixed)
+    assert torch.equal(ef.state_dict()["_blocks.3._bn1.running_var"], sd["_blocks.3._bn1.running_var"])
+
+
+def test_b0_block_table():
+    b = arch.effnet_b0_blocks()
+    assert len(b) == 16
+    assert [(x.k, x.s, x.cin, x.cout, x.hin, x.hout, x.pad0, x.pad1, x.skip) for x in (b[0], b[1], b[3], b[11], b[15])] == [
+        (3, 1, 32, 16, 112, 112, 1, 1, False), (3, 2, 16, 24, 112, 56, 0, 1, False), (5, 2, 24, 40, 56, 28, 1, 2, False),
+        (5, 2, 112, 192, 14, 7, 1, 2, False), (3, 1, 192, 320, 7, 7, 1, 1, False)]
+    assert [x.idx for x in b if x.skip] == [2, 4, 6, 7, 9, 10, 12, 13, 14]
+    assert [x.cse for x in b[:4]] == [8, 4, 6, 6]
+    assert arch.same_pad(224, 3, 2) == (0, 1)
+
+
+def test_synthetic_inputs_follow_the_dataset_contract():
+    inp = synth.clip_inputs(2, 8, 2, seed=0, ragged=True, with_video=False)
+    assert inp["identities_mask"][0].int().tolist() == [[1] * 4 + [0] * 4] * 4 + [[0] * 4 + [1] * 4] * 4
+    assert inp["mask"][0].tolist() == [True, True, True, False] * 2
+    pos = inp["positions"][0]
+    assert pos[0] == 0 and pos[1] == 1 and pos[49] == 49 and pos[50] == 50
+    assert pos[1 + 3 * 49] == 2 * 49 + 1            # padded slot re-uses the previous temporal rank
+    assert pos[1 + 4 * 49] == 1                     # second identity restarts at rank 1
+    assert synth.identity_split(16, 3) == [7, 5, 4]
+    a, b = synth.effnet_b0_state(5), synth.effnet_b0_state(5)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_shard_range():
+    assert [ddp.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert ddp.shard_range(256, 7, 8) == (224, 256)
+
+
+def _gloo_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ps = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2))]
+    ps[0].grad = torch.full((5, 3), float(rank + 1))
+    ps[1].grad = torch.arange(7.0) * (rank + 1)
+    # ps[2] gets no gradient on any rank (like EfficientNet._fc): skipped deterministically
+    red = ddp.GradAllReducer(ps)
+    n = red.allreduce()
+    red.allreduce()                                   # second step re-uses the flat buffer
+    out[rank] = (n, ps[0].grad.clone(), ps[1].grad.clone(), ps[2].grad)
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker, args=(2, port, out), nprocs=2, join=True)
+    for rank in (0, 1):
+        n, g0, g1, g2 = out[rank]
+        assert n == 22
+        assert torch.allclose(g0, torch.full((5, 3), 1.5))
+        assert torch.allclose(g1, torch.arange(7.0) * 1.5)
+        assert g2 is None
