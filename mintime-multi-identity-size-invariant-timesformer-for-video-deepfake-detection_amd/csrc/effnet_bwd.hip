@@ -390,6 +390,121 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------ K7b: depthwise wgrad, LDS-tiled
+// One block = one 16-channel chunk, grid-strided over T x T output tiles of all images.  The activated input tile (with halo)
+// and the dz tile are built ONCE per tile in LDS (swish / BN-backward affine evaluated once per element instead of once per
+// tap); thread (cq, kh, ps) then accumulates the K taps of kernel row kh for channel quad cq over its share of the pixels.
+// Accumulators persist across the block's tiles -> one atomic per (channel, tap) per block.
+template <int K, int S, int T>
+__global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
+    const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ zin,
+    const float* __restrict__ scale_in, const float* __restrict__ shift_in, float* __restrict__ dw, int N, int H, int W, int C,
+    int Ho, int Wo) {
+  constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
+  constexpr int CC = 16;
+  constexpr int IH = (T - 1) * S + K;
+  constexpr int IWP = IH | 1;                    // odd row pitch (in pixels) spreads kernel rows over LDS banks
+  constexpr int PS = 64 / K;                     // pixel-split groups
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* a_t = lds;                              // [IH][IWP][CC]
+  float* dz_t = lds + IH * IWP * CC;             // [T][T][CC]
+  const int tid = threadIdx.x;
+  const int cq = tid & 3, r = tid >> 2;
+  const int kh = r % K, ps = r / K;
+  const bool worker = ps < PS;
+  const int c0 = blockIdx.y * CC;
+  const int ty_n = (Ho + T - 1) / T, tx_n = (Wo + T - 1) / T;
+  const int64_t ntiles = (int64_t)N * ty_n * tx_n;
+
+  // per-thread BN vectors for the loader role (channel quad = tid & 3)
+  const float4 ka = ld4(kabc + c0 + cq * 4), kb = ld4(kabc + C + c0 + cq * 4), kc = ld4(kabc + 2 * C + c0 + cq * 4);
+  const float4 sc = ld4(scale_in + c0 + cq * 4), sh = ld4(shift_in + c0 + cq * 4);
+
+  float4 acc[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) acc[i] = f4(0, 0, 0, 0);
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = (int)(tile % tx_n);
+    const int64_t t2 = tile / tx_n;
+    const int ty = (int)(t2 % ty_n);
+    const int n = (int)(t2 / ty_n);
+    const int oh0 = ty * T, ow0 = tx * T;
+    __syncthreads();                              // previous tile fully consumed
+    for (int idx = tid; idx < IH * IH * 4; idx += 256) {
+      const int q = idx & 3, pix = idx >> 2;
+      const int iy = pix / IH, ix = pix - iy * IH;
+      const int ih = oh0 * S - P + iy, iw = ow0 * S - P + ix;
+      float4 v = f4(0, 0, 0, 0);
+      if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+        const float4 u = fma4(ld4(zin + (((int64_t)n * H + ih) * W + iw) * C + c0 + q * 4), sc, sh);
+        v = f4(swishf_(u.x), swishf_(u.y), swishf_(u.z), swishf_(u.w));
+      }
+      st4(a_t + (iy * IWP + ix) * CC + q * 4, v);
+    }
+    for (int idx = tid; idx < T * T * 4; idx += 256) {
+      const int q = idx & 3, pix = idx >> 2;
+      const int oy = pix / T, ox = pix - oy * T;
+      const int oh = oh0 + oy, ow = ow0 + ox;
+      float4 v = f4(0, 0, 0, 0);
+      if (oh < Ho && ow < Wo) {
+        const int64_t off = (((int64_t)n * Ho + oh) * Wo + ow) * C + c0 + q * 4;
+        v = fma4(ka, ld4(du + off), fma4(kb, ld4(z + off), kc));
+      }
+      st4(dz_t + pix * CC + q * 4, v);
+    }
+    __syncthreads();
+    if (worker) {
+      for (int p = ps; p < T * T; p += PS) {
+        const int oy = p / T, ox = p - oy * T;
+        const float4 d = ld4(dz_t + p * CC + cq * 4);
+        const float* arow = a_t + ((oy * S + kh) * IWP + ox * S) * CC + cq * 4;
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) acc[kw] = fma4(d, ld4(arow + kw * CC), acc[kw]);
+      }
+    }
+  }
+  // reduce over the PS pixel-split groups through LDS, then atomics
+  __syncthreads();
+  float* red = lds;                               // [PS][K(kh)][4(cq)][K(kw)] float4
+  if (worker) {
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) st4(red + (((ps * K + kh) * 4 + cq) * K + kw) * 4, acc[kw]);
+  }
+  __syncthreads();
+  if (tid < K * 4 * K) {                          // (kh, cq, kw)
+    const int kw = tid % K, q = (tid / K) & 3, khh = tid / (4 * K);
+    float4 t = f4(0, 0, 0, 0);
+    for (int g = 0; g < PS; ++g) t = add4(t, ld4(red + (((g * K + khh) * 4 + q) * K + kw) * 4));
+    const int c = c0 + q * 4, tp = khh * K + kw;
+    atomicAdd(dw + (c + 0) * K * K + tp, t.x); atomicAdd(dw + (c + 1) * K * K + tp, t.y);
+    atomicAdd(dw + (c + 2) * K * K + tp, t.z); atomicAdd(dw + (c + 3) * K * K + tp, t.w);
+  }
+}
+
+template <int K, int S, int T>
+int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, const float* zin, const float* scale_in,
+                          const float* shift_in, float* dw, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+  constexpr int IH = (T - 1) * S + K;
+  constexpr int IWP = IH | 1;
+  constexpr int PS = 64 / K;
+  size_t lds = (size_t)(IH * IWP * 16 + T * T * 16) * sizeof(float);
+  const size_t red = (size_t)PS * K * 4 * K * 4 * sizeof(float);
+  if (red > lds) lds = red;
+  const int chunks = C / 16;
+  const int64_t ntiles = (int64_t)N * ((Ho + T - 1) / T) * ((Wo + T - 1) / T);
+  int64_t bx = 4096 / chunks;
+  if (bx < 1) bx = 1;
+  if (bx > ntiles) bx = ntiles;
+  auto k = dwconv_wgrad_tiled_kernel<K, S, T>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)bx, chunks), dim3(256), lds, s, du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo);
+  return check_launch("mt_dwconv_bwd(weight, tiled)");
+}
+
 // ------------------------------------------------------------------------------------------------ K8: stem wgrad
 // dW[co,ci,kh,kw] += sum_pix dz0[pix,co] * x[n, 2oh+kh-P, 2ow+kw-P, ci],  dz0 = ka*du+kb*z+kc
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ du, const float* __restrict__ z,
@@ -463,8 +578,14 @@ int launch_dw_bwd(const float* du, const float* z, const float* kabc, const floa
                   int W, int C, hipStream_t s) {
   const int Ho = (H + S - 1) / S, Wo = (W + S - 1) / S;
   const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
-  // weight gradient: output-centric, grid-strided so each block issues one atomic per (channel, tap)
-  {
+  // weight gradient: LDS-tiled kernel when the channel count is a multiple of 16 (always, for EfficientNet-B0);
+  // otherwise the register-blocked fallback
+  if (C % 16 == 0) {
+    int rc;
+    if (Ho % 14 == 0 && Wo % 14 == 0) rc = launch_dw_wgrad_tiled<K, S, 14>(du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s);
+    else rc = launch_dw_wgrad_tiled<K, S, 7>(du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s);
+    if (rc) return rc;
+  } else {
     const int RH = Ho >= 28 ? 4 : (Ho >= 14 ? 2 : 1);
     const int wsegs = (Wo + R - 1) / R, hsegs = (Ho + RH - 1) / RH;
     const int64_t nseg = (int64_t)N * hsegs * wsegs;
