@@ -170,12 +170,13 @@ int mt_se_bwd(const float* da, const float* z, const float* scale, const float* 
               float* dpre2, float* dhid, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, int N,
               int HW, int C, int CS, void* stream);
 
-/* Depthwise-conv adjoint: dz = ka*du+kb*z+kc (virtual, output side).  Writes dw (accumulated, torch layout [C,1,k,k])
- * and du_in = d(input pre-activation) = dgrad * swish'(bn_in(zin)), plus the input-side BN sums. */
+/* Depthwise-conv adjoint: dz = ka*du+kb*z+kc (virtual, output side).  parts&1: dw (accumulated, torch layout
+ * [C,1,k,k]); parts&2: du_in = d(input pre-activation) = dgrad * swish'(bn_in(zin)), plus the input-side BN sums.
+ * The two parts are independent kernels (the host runs the weight part on a second stream). */
 int mt_dwconv_bwd(const float* du, const float* z, const float* kabc, const float* w, const float* zin,
                   const float* scale_in, const float* shift_in, const float* mean_invstd_in, float* du_in,
                   double* stats_in, int slots, float* dw, int N, int H, int W, int C, int k, int stride,
-                  void* stream);
+                  int parts, void* stream);
 
 /* _conv_stem weight gradient (accumulated, torch layout [32,3,3,3]); x [N,H,W,3]. */
 int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const float* x, float* dw, int N, int H,

@@ -575,12 +575,13 @@ int pick_cqb(int CQ) {
 template <int K, int S, int R>
 int launch_dw_bwd(const float* du, const float* z, const float* kabc, const float* w, const float* zin, const float* scale_in,
                   const float* shift_in, const float* mi_in, float* du_in, double* stats, int slots, float* dw, int N, int H,
-                  int W, int C, hipStream_t s) {
+                  int W, int C, int parts, hipStream_t s) {
   const int Ho = (H + S - 1) / S, Wo = (W + S - 1) / S;
   const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
   // weight gradient: LDS-tiled kernel when the channel count is a multiple of 16 (always, for EfficientNet-B0);
   // otherwise the register-blocked fallback
-  if (C % 16 == 0) {
+  if (!(parts & 1)) {
+  } else if (C % 16 == 0) {
     int rc;
     if (Ho % 14 == 0 && Wo % 14 == 0) rc = launch_dw_wgrad_tiled<K, S, 14>(du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s);
     else rc = launch_dw_wgrad_tiled<K, S, 7>(du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s);
@@ -599,6 +600,7 @@ int launch_dw_bwd(const float* du, const float* z, const float* kabc, const floa
     if (rc) return rc;
   }
   // data gradient: input-centric
+  if (!(parts & 2)) return 0;
   {
     constexpr int RI = 4;
     const int RH = H >= 28 ? 4 : (H >= 14 ? 2 : 1);
@@ -665,16 +667,17 @@ extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, co
 extern "C" int mt_dwconv_bwd(const float* du, const float* z, const float* kabc, const float* w, const float* zin,
                              const float* scale_in, const float* shift_in, const float* mean_invstd_in, float* du_in,
                              double* stats_in, int slots, float* dw, int N, int H, int W, int C, int k, int stride,
-                             void* stream) {
-  if (!du || !z || !kabc || !w || !zin || !scale_in || !shift_in || !mean_invstd_in || !du_in || !stats_in || !dw)
-    return fail(MT_ERR_ARG, "mt_dwconv_bwd: null pointer");
+                             int parts, void* stream) {
+  if (!du || !z || !kabc || !zin || !scale_in || !shift_in) return fail(MT_ERR_ARG, "mt_dwconv_bwd: null pointer");
+  if ((parts & 1) && !dw) return fail(MT_ERR_ARG, "mt_dwconv_bwd: weight part needs dw");
+  if ((parts & 2) && (!w || !mean_invstd_in || !du_in || !stats_in)) return fail(MT_ERR_ARG, "mt_dwconv_bwd: data part needs w, mean_invstd_in, du_in, stats_in");
   if (C & 3) return fail(MT_ERR_ARG, "mt_dwconv_bwd: C %% 4 != 0");
   if (stride == 2 && ((H & 1) || (W & 1))) return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd: stride 2 needs even H, W");
   hipStream_t s = (hipStream_t)stream;
-  if (k == 3 && stride == 1) return launch_dw_bwd<3, 1, 4>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, s);
-  if (k == 3 && stride == 2) return launch_dw_bwd<3, 2, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, s);
-  if (k == 5 && stride == 1) return launch_dw_bwd<5, 1, 4>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, s);
-  if (k == 5 && stride == 2) return launch_dw_bwd<5, 2, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, s);
+  if (k == 3 && stride == 1) return launch_dw_bwd<3, 1, 4>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, s);
+  if (k == 3 && stride == 2) return launch_dw_bwd<3, 2, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, s);
+  if (k == 5 && stride == 1) return launch_dw_bwd<5, 1, 4>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, s);
+  if (k == 5 && stride == 2) return launch_dw_bwd<5, 2, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, s);
   return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd: k=%d stride=%d unsupported", k, stride);
 }
 

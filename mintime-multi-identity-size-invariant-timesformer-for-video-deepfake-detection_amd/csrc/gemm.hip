@@ -2,18 +2,20 @@
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
 #include "gemm_core.hpp"
+#include <stdlib.h>
 
 using namespace mt;
 
 namespace {
 
-enum { CFG_BIG = 0, CFG_MID = 1, CFG_NARROW = 2 };
+enum { CFG_BIG = 0, CFG_MID = 1, CFG_NARROW = 2, CFG_SMALL = 3 };
 
 struct Cfg { int bm, bn, threads; };
-constexpr Cfg kCfg[3] = {{128, 128, 256}, {128, 64, 256}, {256, 32, 256}};
+constexpr Cfg kCfg[4] = {{128, 128, 256}, {128, 64, 256}, {256, 32, 256}, {64, 64, 256}};
 
 int pick_cfg(int N, int epilogue) {
   if (epilogue == MT_EPI_GEGLU) return CFG_BIG;
+  if (const char* f = getenv("MT_FORCE_CFG")) return atoi(f);   // tuning experiments only
   if (N <= 32) return CFG_NARROW;
   const int pad_big = (N + 127) / 128 * 128;
   const int pad_mid = (N + 63) / 64 * 64;
@@ -33,6 +35,10 @@ int launch(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
     case CFG_NARROW:
       if constexpr (EPI == EPI_GEGLU) return fail(MT_ERR_UNSUPPORTED, "GEGLU needs the 128x128 tile");
       else hipLaunchKernelGGL((gemm_kernel<4, 1, 2, 1, AL, BL, PRO, EPI, BPRO>), grid, dim3(256), 0, s, a);
+      break;
+    case CFG_SMALL:
+      if constexpr (EPI == EPI_GEGLU) return fail(MT_ERR_UNSUPPORTED, "GEGLU needs the 128x128 tile");
+      else hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, AL, BL, PRO, EPI, BPRO>), grid, dim3(256), 0, s, a);
       break;
   }
   return check_launch("mt_gemm");
@@ -97,7 +103,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
       if (splits < 1) splits = 1;
     }
     int chunk = (d->K + splits - 1) / splits;
-    chunk = (chunk + 15) / 16 * 16;
+    chunk = (chunk + MT_BK - 1) / MT_BK * MT_BK;
     splits = (d->K + chunk - 1) / chunk;
     a.k_chunk = chunk;
     grid.y = splits;

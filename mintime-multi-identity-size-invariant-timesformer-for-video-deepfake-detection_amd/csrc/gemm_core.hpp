@@ -21,6 +21,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef MT_BK
+#define MT_BK 16
+#endif
+#ifndef MT_MIN_WAVES
+#define MT_MIN_WAVES 1
+#endif
+#ifndef MT_ROWMAJOR_LDS
+#define MT_ROWMAJOR_LDS 0
+#endif
+
 namespace mt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -92,22 +102,32 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI, int BPRO = BPRO_NONE>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MT_MIN_WAVES)
 void gemm_kernel(const GemmArgs p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
-  constexpr int BK = 16;
-  constexpr int LDA_S = BM + 4;
-  constexpr int LDB_S = BN + 4;
+  constexpr int BK = MT_BK;
+  constexpr int KQ = BK / 4;                    // float4 units per k-contiguous row
+  // LDS tile per operand follows its GLOBAL layout so the global->LDS path is a straight float4 copy:
+  //   k-contiguous operand -> [rows][BK+4]  (fragment = one ds_read_b128: 4 consecutive k for 4 MFMA steps; the +4 pad makes
+  //                                           the 16-lane b128 service groups hit 16 distinct 16-byte slots)
+  //   k-major operand      -> [BK][rows+4]  (fragment = ds_read_b32 of 32 consecutive rows, conflict-free)
+  // Both use the same k order inside a tile: MFMA step (g,t), lane half kh consumes k = 8g + 4kh + t.
+  constexpr bool A_ROWS = MT_ROWMAJOR_LDS && AL == LAYOUT_KCONTIG;   // LDS tile stored [rows][BK+4] (else [BK][rows+4])
+  constexpr bool B_ROWS = MT_ROWMAJOR_LDS && BL == LAYOUT_KCONTIG;
+  constexpr int LDA_S = A_ROWS ? BK + 4 : BM + 4;
+  constexpr int LDB_S = B_ROWS ? BK + 4 : BN + 4;
+  constexpr int A_TILE = A_ROWS ? BM * LDA_S : BK * LDA_S;
+  constexpr int B_TILE = B_ROWS ? BN * LDB_S : BK * LDB_S;
   constexpr int A_UNITS = (BM * BK / 4 + NT - 1) / NT;   // float4 units per thread
   constexpr int B_UNITS = (BN * BK / 4 + NT - 1) / NT;
   constexpr bool A_EXACT = (BM * BK / 4) % NT == 0;
   constexpr bool B_EXACT = (BN * BK / 4) % NT == 0;
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA_S + LDB_S)];
-  float* As = smem;                       // [2][BK][LDA_S]
-  float* Bs = smem + 2 * BK * LDA_S;      // [2][BK][LDB_S]
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+  float* As = smem;                       // [2][A_TILE]
+  float* Bs = smem + 2 * A_TILE;          // [2][B_TILE]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -161,7 +181,7 @@ void gemm_kernel(const GemmArgs p) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (A_EXACT || u < BM * BK / 4) {
         if constexpr (AL == LAYOUT_KCONTIG) {
-          const int row = u >> 2, kq = u & 3;
+          const int row = u / KQ, kq = u % KQ;
           const int m = m0 + row, k = k0 + kq * 4;
           if (m < p.M && k < k_end) {
             v = *reinterpret_cast<const float4*>(p.A + map_row(p.a_map, m) * p.lda + k);
@@ -212,7 +232,7 @@ void gemm_kernel(const GemmArgs p) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (B_EXACT || u < BN * BK / 4) {
         if constexpr (BL == LAYOUT_KCONTIG) {
-          const int row = u >> 2, kq = u & 3;
+          const int row = u / KQ, kq = u % KQ;
           const int n = b_row(row), k = k0 + kq * 4;
           if (n >= 0 && k < k_end) v = *reinterpret_cast<const float4*>(p.B + (int64_t)n * p.ldb + k);
         } else {
@@ -236,18 +256,20 @@ void gemm_kernel(const GemmArgs p) {
   };
 
   auto store_tiles = [&](int buf) {
-    float* as = As + buf * BK * LDA_S;
-    float* bs = Bs + buf * BK * LDB_S;
+    float* as = As + buf * A_TILE;
+    float* bs = Bs + buf * B_TILE;
 #pragma unroll
     for (int i = 0; i < A_UNITS; ++i) {
       const int u = tid + i * NT;
       if (A_EXACT || u < BM * BK / 4) {
         if constexpr (AL == LAYOUT_KCONTIG) {
-          const int row = u >> 2, kq = u & 3;
-          as[(kq * 4 + 0) * LDA_S + row] = ra[i].x;
-          as[(kq * 4 + 1) * LDA_S + row] = ra[i].y;
-          as[(kq * 4 + 2) * LDA_S + row] = ra[i].z;
-          as[(kq * 4 + 3) * LDA_S + row] = ra[i].w;
+          const int row = u / KQ, kq = u % KQ;
+          if constexpr (A_ROWS) {
+            *reinterpret_cast<float4*>(as + row * LDA_S + kq * 4) = ra[i];
+          } else {
+            as[(kq * 4 + 0) * LDA_S + row] = ra[i].x; as[(kq * 4 + 1) * LDA_S + row] = ra[i].y;
+            as[(kq * 4 + 2) * LDA_S + row] = ra[i].z; as[(kq * 4 + 3) * LDA_S + row] = ra[i].w;
+          }
         } else {
           constexpr int QPR = BM / 4;
           const int kk = u / QPR, mq = u - kk * QPR;
@@ -260,11 +282,13 @@ void gemm_kernel(const GemmArgs p) {
       const int u = tid + i * NT;
       if (B_EXACT || u < BN * BK / 4) {
         if constexpr (BL == LAYOUT_KCONTIG) {
-          const int row = u >> 2, kq = u & 3;
-          bs[(kq * 4 + 0) * LDB_S + row] = rb[i].x;
-          bs[(kq * 4 + 1) * LDB_S + row] = rb[i].y;
-          bs[(kq * 4 + 2) * LDB_S + row] = rb[i].z;
-          bs[(kq * 4 + 3) * LDB_S + row] = rb[i].w;
+          const int row = u / KQ, kq = u % KQ;
+          if constexpr (B_ROWS) {
+            *reinterpret_cast<float4*>(bs + row * LDB_S + kq * 4) = rb[i];
+          } else {
+            bs[(kq * 4 + 0) * LDB_S + row] = rb[i].x; bs[(kq * 4 + 1) * LDB_S + row] = rb[i].y;
+            bs[(kq * 4 + 2) * LDB_S + row] = rb[i].z; bs[(kq * 4 + 3) * LDB_S + row] = rb[i].w;
+          }
         } else {
           constexpr int QPR = BN / 4;
           const int kk = u / QPR, nq = u - kk * QPR;
@@ -286,27 +310,45 @@ void gemm_kernel(const GemmArgs p) {
   store_tiles(0);
   __syncthreads();
 
-  const int a_off = wm * TM * 32 + (lane & 31);
-  const int b_off = wn * TN * 32 + (lane & 31);
+  const int a_row = wm * TM * 32 + (lane & 31);
+  const int b_frag = wn * TN * 32 + (lane & 31);
   const int khalf = lane >> 5;
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tiles(kt + 1);
-    const float* as = As + buf * BK * LDA_S + khalf * LDA_S + a_off;
-    const float* bs = Bs + buf * BK * LDB_S + khalf * LDB_S + b_off;
+    const float* as = As + buf * A_TILE;
+    const float* bs = Bs + buf * B_TILE;
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      float af[TM], bf[TN];
+    for (int g = 0; g < BK / 8; ++g) {
+      float af[TM][4], bf[TN][4];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = as[ks * 2 * LDA_S + i * 32];
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (A_ROWS) {
+          const float4 v = *reinterpret_cast<const float4*>(as + (a_row + i * 32) * LDA_S + g * 8 + khalf * 4);
+          af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+        } else {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = bs[ks * 2 * LDB_S + j * 32];
+          for (int t = 0; t < 4; ++t) af[i][t] = as[(g * 8 + khalf * 4 + t) * LDA_S + a_row + i * 32];
+        }
+      }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (B_ROWS) {
+          const float4 v = *reinterpret_cast<const float4*>(bs + (b_frag + j * 32) * LDB_S + g * 8 + khalf * 4);
+          bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int t = 0; t < 4; ++t) bf[j][t] = bs[(g * 8 + khalf * 4 + t) * LDB_S + b_frag + j * 32];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();

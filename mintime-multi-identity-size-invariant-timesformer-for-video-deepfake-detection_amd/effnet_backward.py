@@ -40,6 +40,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                                                     for b in blocks)
     pool = _StatsPool(dev, total_c)
     tr = 1 if training else 0
+    side = L.SideStream(dev)
 
     def bn_finalize(bnctx, sums, gidx_gamma):
         kabc = _new(dev, 3, bnctx.C)
@@ -59,8 +60,9 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         kw = {}
         if b_pro is not None:
             kw = dict(b_prologue=L.BPRO_BN_SWISH_GATE, b_scale=b_pro[0], b_shift=b_pro[1], b_gate=b_pro[2], b_hw=b_pro[3])
-        L.gemm(L.OP_TN, du, x_in, grads[gw_idx], cout, cin, rows, cout, cin, cin, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC,
-               split_k=0, A2=z, scale=kabc[0], shift=kabc[1], gate=kabc[2], **kw)
+        side.launch(lambda: L.gemm(L.OP_TN, du, x_in, grads[gw_idx], cout, cin, rows, cout, cin, cin, prologue=L.PRO_BN_BWD,
+                                   epilogue=L.EPI_ATOMIC, split_k=0, A2=z, scale=kabc[0], shift=kabc[1], gate=kabc[2], **kw),
+                    reads=(du, z, x_in, kabc) + (tuple(b_pro[:3]) if b_pro is not None else ()))
         if not need_dx_in:
             return None
         dx_in = _new(dev, rows, cin)
@@ -113,9 +115,13 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         in_bn = rec["dw_bn"]
         du_in = _new(dev, M_in, s.cexp)
         sums_in = pool.take(s.cexp)
-        L.check(lib.mt_dwconv_bwd(L.ptr(da), L.ptr(rec["z_d"]), L.ptr(kabc_d), L.ptr(P[ix["d"]]), L.ptr(rec["dw_in"]), L.ptr(in_bn.scale),
-                                  L.ptr(in_bn.shift), L.ptr(in_bn.mean_invstd), L.ptr(du_in), L.ptr(sums_in), SLOTS, L.ptr(grads[ix["d"]]),
-                                  N, s.hin, s.hin, s.cexp, s.k, s.s, st), "mt_dwconv_bwd")
+        def dw_part(parts, _da=da, _rec=rec, _kabc=kabc_d, _bn=in_bn, _du_in=du_in, _sums=sums_in, _s=s, _ix=ix):
+            L.check(lib.mt_dwconv_bwd(L.ptr(_da), L.ptr(_rec["z_d"]), L.ptr(_kabc), L.ptr(P[_ix["d"]]), L.ptr(_rec["dw_in"]),
+                                      L.ptr(_bn.scale), L.ptr(_bn.shift), L.ptr(_bn.mean_invstd), L.ptr(_du_in), L.ptr(_sums), SLOTS,
+                                      L.ptr(grads[_ix["d"]]), N, _s.hin, _s.hin, _s.cexp, _s.k, _s.s, parts, L.stream_ptr()),
+                    "mt_dwconv_bwd")
+        side.launch(lambda: dw_part(1), reads=(da, rec["z_d"], kabc_d, rec["dw_in"], in_bn.scale, in_bn.shift))
+        dw_part(2)
         del da
         if s.has_expand:
             # (h,i,j) bn0 + expand conv: z_e = y_in . We^T
@@ -132,6 +138,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         del du_in
         rec.clear()
 
+    side.wait()
     if need_dx:
         raise NotImplementedError("gradient w.r.t. the input crops is not part of the MINTIME training path "
                                   "(train.py never sets requires_grad on videos)")

@@ -70,7 +70,8 @@ PROTOTYPES = {
     "mt_bn_act_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_bn_bwd_finalize": [C.c_void_p, C.c_int, C.c_double, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_void_p],
     "mt_se_bwd": [f32p] * 17 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
-    "mt_dwconv_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_dwconv_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                      C.c_void_p],
     "mt_stem_conv_wgrad": [f32p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_void_p],
 }
 _RESTYPES = {"mt_last_error": C.c_char_p}
@@ -177,3 +178,53 @@ def zero_grads(params):
     dev = next(p for p in params if p is not None).device
     flat = torch.zeros(total, dtype=torch.float32, device=dev)
     return [None if p is None else flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)]
+
+
+class SideStream:
+    """Second HIP stream for work that is independent of the critical path (weight-gradient GEMMs, bias sums): their
+    blocks fill the CUs a skinny dgrad leaves idle (396 tiles on 256 CUs = 23 % idle slots).  Every launch is fenced by
+    events both ways; tensors read on the side stream are pinned with record_stream so the caching allocator cannot
+    hand their memory to a later main-stream allocation while the side kernel is still reading it."""
+
+    _streams = {}
+
+    def __init__(self, device, enabled=True):
+        self.enabled = enabled and os.environ.get("MT_SIDE_STREAM", "1") != "0"
+        self.device = device
+        if self.enabled:
+            key = str(device)
+            if key not in SideStream._streams:
+                SideStream._streams[key] = torch.cuda.Stream(device=device)
+            self.stream = SideStream._streams[key]
+        self.pending = []
+
+    def launch(self, fn, reads=()):
+        """Run fn() on the side stream once everything enqueued so far on the current stream is done."""
+        if not self.enabled:
+            fn()
+            return None
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self.stream.wait_event(ready)
+        for t in reads:
+            if t is not None:
+                t.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            fn()
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        self.pending.append(done)
+        return done
+
+    def wait(self, event=None):
+        """Make the current (main) stream wait for one side launch, or for all of them."""
+        if not self.enabled:
+            return
+        main = torch.cuda.current_stream(self.device)
+        if event is not None:
+            main.wait_event(event)
+            return
+        for e in self.pending:
+            main.wait_event(e)
+        self.pending = []

@@ -41,8 +41,18 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         idx -= k
         return idx
 
+    side = L.SideStream(dev)
+
     def colsum(A, lda, rows, cols, out, amap=(0, 0, 0)):
-        L.check(lib.mt_colsum(L.ptr(A), lda, L.RowMap(*amap), rows, cols, L.ptr(out), st), "mt_colsum")
+        L.check(lib.mt_colsum(L.ptr(A), lda, L.RowMap(*amap), rows, cols, L.ptr(out), L.stream_ptr()), "mt_colsum")
+
+    def wgrad(A, Bm, out, M_, N_, K_, lda, ldb, ldc, bias_out=None, **kw):
+        """dW (+ db) on the side stream: reads A [K_,M_] and Bm [K_,N_], accumulates into zero-filled grads."""
+        def run():
+            L.gemm(L.OP_TN, A, Bm, out, M_, N_, K_, lda, ldb, ldc, epilogue=L.EPI_ATOMIC, split_k=0, **kw)
+            if bias_out is not None:
+                colsum(A, lda, K_, M_, bias_out, kw.get("a_map", (0, 0, 0)))
+        return side.launch(run, reads=(A, Bm))
 
     # ---- head
     i0 = take(4)
@@ -63,12 +73,12 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         i0 = take(6)
         g, b_, w1, b1, w2, b2 = P[i0:i0 + 6]
         r = rec[2]
-        L.gemm(L.OP_TN, dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D, epilogue=L.EPI_ATOMIC, split_k=0)
-        colsum(dx2, D, M, D, grads[i0 + 5])
+        side.wait()                                   # du / dx2 readers of the previous sub-block are done
+        e_dx = wgrad(dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D, bias_out=grads[i0 + 5])
         L.gemm(L.OP_NN, dx2, w2, du, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D, n_half=4 * D)
-        L.gemm(L.OP_TN, du, r["xn"], grads[i0 + 2], 8 * D, D, M, 8 * D, D, D, epilogue=L.EPI_ATOMIC, split_k=0)
-        colsum(du, 8 * D, M, 8 * D, grads[i0 + 3])
+        wgrad(du, r["xn"], grads[i0 + 2], 8 * D, D, M, 8 * D, D, D, bias_out=grads[i0 + 3])
         L.gemm(L.OP_NN, du, w1, dxn, M, D, 8 * D, 8 * D, D, D)
+        side.wait(e_dx)                               # LayerNorm backward updates dx2 in place
         L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
                                      L.ptr(grads[i0 + 1]), M, D, 1, st), "mt_layernorm_bwd")
         r.clear()
@@ -77,13 +87,14 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             i0 = take(5)
             g, b_, w_qkv, w_o, b_o = P[i0:i0 + 5]
             r = rec[mode]
-            L.gemm(L.OP_TN, dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner, epilogue=L.EPI_ATOMIC, split_k=0)
-            colsum(dx2, D, M, D, grads[i0 + 4])
+            side.wait()                               # dqkv / dx2 readers of the previous sub-block are done
+            e_dx = wgrad(dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner, bias_out=grads[i0 + 4])
             L.gemm(L.OP_NN, dx2, w_o, do, M, inner, D, D, inner, inner)
             L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
                                     scale, st), "mt_attn_bwd")
-            L.gemm(L.OP_TN, dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D, epilogue=L.EPI_ATOMIC, split_k=0)
+            wgrad(dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
             L.gemm(L.OP_NN, dqkv, w_qkv, dxn, M, D, 3 * inner, 3 * inner, D, D)
+            side.wait(e_dx)
             L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
                                          L.ptr(grads[i0 + 1]), M, D, 1, st), "mt_layernorm_bwd")
             r.clear()
@@ -95,12 +106,13 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
                              L.ptr(aux.sizes), B, F, n, D, st), "mt_embed_bwd")
     tok_map = (F * n, N, 1)      # token row r of the feature matrix lives at row (r/(F n))*N + 1 + r%(F n) of dx
     Mt = B * F * n
-    L.gemm(L.OP_TN, dx2, feat, grads[i0], D, C_in, Mt, D, C_in, C_in, epilogue=L.EPI_ATOMIC, split_k=0, a_map=tok_map)
-    colsum(dx2, D, Mt, D, grads[i0 + 1], tok_map)
+    side.wait()
+    wgrad(dx2, feat, grads[i0], D, C_in, Mt, D, C_in, C_in, bias_out=grads[i0 + 1], a_map=tok_map)
     dfeat = None
     if need_dfeat:
         dfeat = torch.empty(Mt, C_in, dtype=torch.float32, device=dev)
         L.gemm(L.OP_NN, dx2, w_pe, dfeat, Mt, C_in, D, D, C_in, C_in, a_map=tok_map)
+    side.wait()
     assert idx == 0
     out = []
     for gneed, gr in zip(need_dparams, grads):
