@@ -10,6 +10,7 @@
 //   * swish'(u) = sig(u)*(1+u*(1-sig(u))) is recomputed from z (utils.py:70-75 saves only the input as well).
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
+#include <stdlib.h>
 
 using namespace mt;
 
@@ -505,6 +506,119 @@ int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, co
   return check_launch("mt_dwconv_bwd(weight, tiled)");
 }
 
+// ------------------------------------------------------------------------------------------------ K6b: depthwise dgrad, LDS-tiled
+// One block = one 16-channel chunk, grid-strided over T x T INPUT tiles.  dz = ka*du+kb*z+kc over the output positions
+// the tile's taps can reach is built once in LDS; thread (cq, slot) then gathers its input pixels' taps from LDS,
+// applies swish' of the input-side BatchNorm and accumulates that BatchNorm's backward sums in registers.
+template <int K, int S, int T>
+__global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
+    const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ w,
+    const float* __restrict__ zin, const float* __restrict__ scale_in, const float* __restrict__ shift_in,
+    const float* __restrict__ mi_in, float* __restrict__ du_in, double* __restrict__ stats, int slots, int N, int H, int W,
+    int C, int Ho, int Wo) {
+  constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
+  constexpr int CC = 16;
+  constexpr int OT = (T - 1 + K - 1) / S + 2;       // output rows/cols a T-wide input tile can touch (upper bound)
+  constexpr int OTP = OT | 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // dz_t [OT][OTP][CC]; later the stats reduction buffer
+  const int tid = threadIdx.x;
+  const int cq = tid & 3, slot = tid >> 2;
+  const int c0 = blockIdx.y * CC;
+  const int ty_n = (H + T - 1) / T, tx_n = (W + T - 1) / T;
+  const int64_t ntiles = (int64_t)N * ty_n * tx_n;
+  const int c = c0 + cq * 4;
+  const float4 sc = ld4(scale_in + c), sh = ld4(shift_in + c);
+  const float4 mean = ld4(mi_in + c), istd = ld4(mi_in + C + c);
+  float4 wt[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i)
+    wt[i] = f4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
+  float4 s1 = f4(0, 0, 0, 0), s2 = s1;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = (int)(tile % tx_n);
+    const int64_t t2 = tile / tx_n;
+    const int ty = (int)(t2 % ty_n);
+    const int n = (int)(t2 / ty_n);
+    const int ih0 = ty * T, iw0 = tx * T;
+    // first output row/col reachable from this tile: ceil((ih0 + P - (K-1)) / S), possibly negative
+    const int nh = ih0 + P - (K - 1), nw = iw0 + P - (K - 1);
+    const int oh_lo = nh >= 0 ? (nh + S - 1) / S : -((-nh) / S);
+    const int ow_lo = nw >= 0 ? (nw + S - 1) / S : -((-nw) / S);
+    __syncthreads();
+    for (int idx = tid; idx < OT * OT * 4; idx += 256) {
+      const int q = idx & 3, pix = idx >> 2;
+      const int oy = pix / OT, ox = pix - oy * OT;
+      const int oh = oh_lo + oy, ow = ow_lo + ox;
+      float4 v = f4(0, 0, 0, 0);
+      if (oh >= 0 && oh < Ho && ow >= 0 && ow < Wo) {
+        const int64_t off = (((int64_t)n * Ho + oh) * Wo + ow) * C + c0 + q * 4;
+        v = fma4(ld4(kabc + c0 + q * 4), ld4(du + off), fma4(ld4(kabc + C + c0 + q * 4), ld4(z + off), ld4(kabc + 2 * C + c0 + q * 4)));
+      }
+      st4(lds + (oy * OTP + ox) * CC + q * 4, v);
+    }
+    __syncthreads();
+    for (int p = slot; p < T * T; p += 64) {
+      const int iy = p / T, ix = p - iy * T;
+      const int ih = ih0 + iy, iw = iw0 + ix;
+      if (ih < H && iw < W) {
+        float4 acc = f4(0, 0, 0, 0);
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+          const int ohn = ih + P - kh;
+          if (S == 2 && (ohn & 1)) continue;
+          const int oy = ohn / S - oh_lo;          // ohn may be negative only when the row is out of range -> zero row in LDS
+          if (ohn < 0) continue;
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            const int own = iw + P - kw;
+            if (S == 2 && (own & 1)) continue;
+            if (own < 0) continue;
+            const int ox = own / S - ow_lo;
+            acc = fma4(ld4(lds + (oy * OTP + ox) * CC + cq * 4), wt[kh * K + kw], acc);
+          }
+        }
+        const int64_t off = (((int64_t)n * H + ih) * W + iw) * C + c;
+        const float4 zz = ld4(zin + off);
+        const float4 u = fma4(zz, sc, sh);
+        const float4 d = f4(acc.x * dswishf_(u.x), acc.y * dswishf_(u.y), acc.z * dswishf_(u.z), acc.w * dswishf_(u.w));
+        st4(du_in + off, d);
+        const float4 xh = f4((zz.x - mean.x) * istd.x, (zz.y - mean.y) * istd.y, (zz.z - mean.z) * istd.z, (zz.w - mean.w) * istd.w);
+        s1 = add4(s1, d);
+        s2 = fma4(d, xh, s2);
+      }
+    }
+  }
+  __syncthreads();
+  float* rr = lds + tid * 8;
+  rr[0] = s1.x; rr[1] = s1.y; rr[2] = s1.z; rr[3] = s1.w; rr[4] = s2.x; rr[5] = s2.y; rr[6] = s2.z; rr[7] = s2.w;
+  __syncthreads();
+  if (tid < 32) {
+    const int q = tid >> 3, e = tid & 7;
+    float v = 0.f;
+    for (int sl = 0; sl < 64; ++sl) v += lds[(sl * 4 + q) * 8 + e];
+    const int ch = c0 + q * 4 + (e & 3), which = e >> 2;
+    atomicAdd(stats + ((int64_t)(blockIdx.x % slots) * 2 + which) * C + ch, (double)v);
+  }
+}
+
+template <int K, int S, int T>
+int launch_dw_dgrad_tiled(const float* du, const float* z, const float* kabc, const float* w, const float* zin,
+                          const float* scale_in, const float* shift_in, const float* mi_in, float* du_in, double* stats, int slots,
+                          int N, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+  constexpr int OT = (T - 1 + K - 1) / S + 2;
+  constexpr int OTP = OT | 1;
+  size_t lds = (size_t)OT * OTP * 16 * sizeof(float);
+  if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);
+  const int chunks = C / 16;
+  const int64_t ntiles = (int64_t)N * ((H + T - 1) / T) * ((W + T - 1) / T);
+  int64_t bx = 8192 / chunks;
+  if (bx < 1) bx = 1;
+  if (bx > ntiles) bx = ntiles;
+  hipLaunchKernelGGL((dwconv_dgrad_tiled_kernel<K, S, T>), dim3((unsigned)bx, chunks), dim3(256), lds, s, du, z, kabc, w, zin,
+                     scale_in, shift_in, mi_in, du_in, stats, slots > 0 ? slots : 1, N, H, W, C, Ho, Wo);
+  return check_launch("mt_dwconv_bwd(data, tiled)");
+}
+
 // ------------------------------------------------------------------------------------------------ K8: stem wgrad
 // dW[co,ci,kh,kw] += sum_pix dz0[pix,co] * x[n, 2oh+kh-P, 2ow+kw-P, ci],  dz0 = ka*du+kb*z+kc
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ du, const float* __restrict__ z,
@@ -599,8 +713,12 @@ int launch_dw_bwd(const float* du, const float* z, const float* kabc, const floa
     int rc = check_launch("mt_dwconv_bwd(weight)");
     if (rc) return rc;
   }
-  // data gradient: input-centric
+  // data gradient: input-centric (LDS-tiled when the channel count allows)
   if (!(parts & 2)) return 0;
+  if (C % 16 == 0 && !getenv("MT_DW_UNTILED")) {
+    if (H % 14 == 0 && W % 14 == 0) return launch_dw_dgrad_tiled<K, S, 14>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, s);
+    return launch_dw_dgrad_tiled<K, S, 7>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, s);
+  }
   {
     constexpr int RI = 4;
     const int RH = H >= 28 ? 4 : (H >= 14 ? 2 : 1);

@@ -20,6 +20,7 @@
 //   mt_bn_act_fwd       _bn2 (+ residual, model.py:117-127) and the head's _bn1 + swish (model.py:286)
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
+#include <stdlib.h>
 
 using namespace mt;
 
@@ -221,6 +222,112 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ z
   }
 }
 
+// ------------------------------------------------------------------------------------------------ depthwise, LDS-tiled
+// One block = one 16-channel chunk, grid-strided over T x T output tiles.  The activated input tile (with halo) is built
+// once in LDS (swish evaluated once per element, not once per tap); thread (cq = tid&3, slot = tid>>2) then produces the
+// outputs slot, slot+64, ... of the tile for its channel quad with its K*K weights held in registers.  BatchNorm sums
+// stay in registers across the block's tiles -> one fp64 atomic per channel per block.
+template <int K, int S, int T>
+__global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restrict__ zin, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ w,
+                                                           float* __restrict__ zout, double* __restrict__ stats, int slots,
+                                                           int N, int H, int W, int C, int Ho, int Wo, int pad0) {
+  constexpr int CC = 16;
+  constexpr int IH = (T - 1) * S + K;
+  constexpr int IWP = IH | 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // a_t [IH][IWP][CC]; later the stats reduction buffer
+  const int tid = threadIdx.x;
+  const int cq = tid & 3, slot = tid >> 2;
+  const int c0 = blockIdx.y * CC;
+  const int ty_n = (Ho + T - 1) / T, tx_n = (Wo + T - 1) / T;
+  const int64_t ntiles = (int64_t)N * ty_n * tx_n;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + c0 + cq * 4);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + c0 + cq * 4);
+  float4 wt[K * K];
+  {
+    const int c = c0 + cq * 4;
+#pragma unroll
+    for (int i = 0; i < K * K; ++i)
+      wt[i] = make_float4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
+  }
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = (int)(tile % tx_n);
+    const int64_t t2 = tile / tx_n;
+    const int ty = (int)(t2 % ty_n);
+    const int n = (int)(t2 / ty_n);
+    const int oh0 = ty * T, ow0 = tx * T;
+    __syncthreads();
+    for (int idx = tid; idx < IH * IH * 4; idx += 256) {
+      const int q = idx & 3, pix = idx >> 2;
+      const int iy = pix / IH, ix = pix - iy * IH;
+      const int ih = oh0 * S - pad0 + iy, iw = ow0 * S - pad0 + ix;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+        v = bn_swish4(*reinterpret_cast<const float4*>(zin + (((int64_t)n * H + ih) * W + iw) * C + c0 + q * 4),
+                      *reinterpret_cast<const float4*>(scale + c0 + q * 4), *reinterpret_cast<const float4*>(shift + c0 + q * 4));
+      *reinterpret_cast<float4*>(lds + (iy * IWP + ix) * CC + q * 4) = v;
+    }
+    __syncthreads();
+    for (int p = slot; p < T * T; p += 64) {
+      const int oy = p / T, ox = p - oy * T;
+      const int oh = oh0 + oy, ow = ow0 + ox;
+      if (oh < Ho && ow < Wo) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* base = lds + ((oy * S) * IWP + ox * S) * CC + cq * 4;
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            const float4 a = *reinterpret_cast<const float4*>(base + (kh * IWP + kw) * CC);
+            const float4 ww = wt[kh * K + kw];
+            acc.x = fmaf(a.x, ww.x, acc.x); acc.y = fmaf(a.y, ww.y, acc.y);
+            acc.z = fmaf(a.z, ww.z, acc.z); acc.w = fmaf(a.w, ww.w, acc.w);
+          }
+        *reinterpret_cast<float4*>(zout + (((int64_t)n * Ho + oh) * Wo + ow) * C + c0 + cq * 4) = acc;
+        s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+        s2.x += acc.x * acc.x; s2.y += acc.y * acc.y; s2.z += acc.z * acc.z; s2.w += acc.w * acc.w;
+      }
+    }
+  }
+  (void)sc; (void)sh;
+  if (stats) {
+    __syncthreads();
+    float* rr = lds + tid * 8;          // [256][8]
+    rr[0] = s1.x; rr[1] = s1.y; rr[2] = s1.z; rr[3] = s1.w; rr[4] = s2.x; rr[5] = s2.y; rr[6] = s2.z; rr[7] = s2.w;
+    __syncthreads();
+    if (tid < 32) {                     // (cq, e): 4 quads x 8 entries
+      const int q = tid >> 3, e = tid & 7;
+      float v = 0.f;
+      for (int sl = 0; sl < 64; ++sl) v += lds[(sl * 4 + q) * 8 + e];
+      const int ch = c0 + q * 4 + (e & 3), which = e >> 2;
+      atomic_add_f64(stats + ((int64_t)(blockIdx.x % slots) * 2 + which) * C + ch, (double)v);
+    }
+  }
+}
+
+template <int K, int S, int T>
+int launch_dw_tiled(const float* zin, const float* scale, const float* shift, const float* w, float* zout, double* stats, int slots,
+                    int N, int H, int W, int C, int Ho, int Wo, int pad0, hipStream_t s) {
+  constexpr int IH = (T - 1) * S + K;
+  constexpr int IWP = IH | 1;
+  size_t lds = (size_t)IH * IWP * 16 * sizeof(float);
+  if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);
+  const int chunks = C / 16;
+  const int64_t ntiles = (int64_t)N * ((Ho + T - 1) / T) * ((Wo + T - 1) / T);
+  int64_t bx = 8192 / chunks;
+  if (bx < 1) bx = 1;
+  if (bx > ntiles) bx = ntiles;
+  auto k = dwconv_tiled_kernel<K, S, T>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)bx, chunks), dim3(256), lds, s, zin, scale, shift, w, zout, stats, slots > 0 ? slots : 1, N, H,
+                     W, C, Ho, Wo, pad0);
+  return check_launch("mt_dwconv_fwd(tiled)");
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm finalize
 // train: mean/var from the fp64 accumulators (biased var normalises, unbiased var updates running_var), momentum update
 // eval : running stats.  Either way emits scale = gamma*invstd, shift = beta - mean*scale, and (mean, invstd) for backward.
@@ -365,6 +472,10 @@ int launch_dw(const float* zin, const float* scale, const float* shift, const fl
               int N, int H, int W, int C, hipStream_t s) {
   const int Ho = (H + S - 1) / S, Wo = (W + S - 1) / S;
   const int padt = max((Ho - 1) * S + K - H, 0);
+  if (C % 16 == 0 && !getenv("MT_DW_UNTILED")) {
+    if (Ho % 14 == 0 && Wo % 14 == 0) return launch_dw_tiled<K, S, 14>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, padt / 2, s);
+    return launch_dw_tiled<K, S, 7>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, padt / 2, s);
+  }
   const int CQ = C / 4;
   const int CQB = pick_cqb(CQ);
   const int PB = 256 / CQB;
