@@ -39,8 +39,10 @@ enum { MT_OP_NT = 0,    /* C[M,N] = A[M,K] * B[N,K]^T      forward (torch weight
        MT_OP_TN = 2 };  /* C[M,N] = A[K,M]^T * B[K,N]      wgrad (split-K + fp32 atomics, C pre-zeroed) */
 
 enum { MT_PRO_NONE = 0, MT_PRO_BN_SWISH_GATE = 1, MT_PRO_BN_SWISH = 2, MT_PRO_AFFINE = 3,
-       MT_PRO_BN_BWD = 4 };  /* A := ka[c]*A + kb[c]*A2 + kc[c]  (BatchNorm backward folded into the load; ka,kb,kc = scale,shift,gate) */
-enum { MT_BPRO_NONE = 0, MT_BPRO_BN_SWISH_GATE = 1 };  /* TN only: B := swish(B*b_scale[n]+b_shift[n]) * b_gate[(k/b_hw)*N+n] */
+       MT_PRO_BN_BWD = 4,
+       MT_PRO_IM2COL = 5 };  /* A := act(affine(x[n, oh*s+kh-p, ow*s+kw-p, ci])) gathered from an NHWC image (conv_* fields):
+                                dense k x k / strided 1x1 convolution as a GEMM with M = N*Ho*Wo, K = k*k*C (padded to %4) */  /* A := ka[c]*A + kb[c]*A2 + kc[c]  (BatchNorm backward folded into the load; ka,kb,kc = scale,shift,gate) */
+enum { MT_BPRO_NONE = 0, MT_BPRO_BN_SWISH_GATE = 1, MT_BPRO_IM2COL = 2 };  /* TN only: B := swish(B*b_scale[n]+b_shift[n]) * b_gate[(k/b_hw)*N+n] */
 enum { MT_EPI_STORE = 0, MT_EPI_BIAS_RES = 1, MT_EPI_GEGLU = 2, MT_EPI_STATS = 3, MT_EPI_ATOMIC = 4,
        MT_EPI_GEGLU_BWD = 5, MT_EPI_ACCUM = 6 };
 
@@ -59,6 +61,7 @@ typedef struct {
   int split_k;                      /* TN: number of K splits; <= 0 picks one that fills the chip        */
   const float* A2;                  /* BN_BWD prologue: second source, same layout as A                  */
   int b_prologue; const float* b_scale; const float* b_shift; const float* b_gate; int b_hw;
+  int conv_H, conv_W, conv_C, conv_Ho, conv_Wo, conv_k, conv_stride, conv_pad, conv_act;   /* im2col prologues */
 } mt_gemm_desc;
 
 int mt_gemm(const mt_gemm_desc* d, void* stream);
@@ -97,9 +100,11 @@ int mt_head_fwd(const float* x, const float* gamma, const float* beta, const flo
  * w in torch layout [32,3,3,3]. */
 int mt_stem_conv_fwd(const float* x, const float* w, float* z, double* stats, int slots, int N, int H, int W, void* stream);
 
-/* _depthwise_conv (k 3|5, stride 1|2, TF-SAME) applied to swish(bn(zin)) (model.py:98-103). w torch layout [C,1,k,k]. */
+/* Depthwise conv (k 3|5, stride 1|2, TF-SAME padding; for k3 s1 that is pad 1) applied to act(zin*scale+shift);
+ * act 1 = swish: EfficientNet _depthwise_conv on swish(bn(z)) (model.py:98-103);
+ * act 2 = relu / 0 = none: Xception SeparableConv2d.conv1 (xception.py:21,25).  w torch layout [C,1,k,k]. */
 int mt_dwconv_fwd(const float* zin, const float* scale, const float* shift, const float* w, float* zout,
-                  double* stats, int slots, int N, int H, int W, int C, int k, int stride, void* stream);
+                  double* stats, int slots, int N, int H, int W, int C, int k, int stride, int act, void* stream);
 
 /* nn.BatchNorm2d bookkeeping (model.py:51-52,62,72,86,174,202): training!=0 -> batch statistics from `stats`
  * (count = N*H*W), running-stat update with `momentum` (unbiased variance); else running statistics.
@@ -176,11 +181,33 @@ int mt_se_bwd(const float* da, const float* z, const float* scale, const float* 
 int mt_dwconv_bwd(const float* du, const float* z, const float* kabc, const float* w, const float* zin,
                   const float* scale_in, const float* shift_in, const float* mean_invstd_in, float* du_in,
                   double* stats_in, int slots, float* dw, int N, int H, int W, int C, int k, int stride,
-                  int parts, void* stream);
+                  int parts, int act, const float* res_pre, const float* res_post, void* stream);
+/* act as in mt_dwconv_fwd; stats_in/mean_invstd_in may both be NULL.  du_in = (dgrad + res_pre) * act'(.) + res_post: gradients of
+ * other consumers of the activated (res_pre) or raw (res_post) input tensor (Xception skip paths), either may be NULL. */
 
 /* _conv_stem weight gradient (accumulated, torch layout [32,3,3,3]); x [N,H,W,3]. */
 int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const float* x, float* dw, int N, int H,
                        int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Xception (config 5 extractor, reference models/xception.py).  Dense convolutions are mt_gemm with the IM2COL
+ * prologue; separable convolutions are mt_dwconv_* (act 0/2) + mt_gemm; the rest:
+ * ------------------------------------------------------------------------------------------------ */
+
+/* torch conv weight [Co,Ci,k,k] -> GEMM operand out[r][(kh,kw,c)] with row pitch ld (zero padded, ld %% 4 == 0).
+ * transpose 0: rows = Co (forward / wgrad layout); 1: rows = Ci with the kernel flipped (data-gradient convolution). */
+int mt_conv_weight_pack(const float* w, float* out, int Co, int Ci, int k, int ld, int transpose, void* stream);
+/* dw[co][ci][kh][kw] += dwp[co][(kh,kw,ci)] */
+int mt_conv_weight_unpack_grad(const float* dwp, float* dw, int Co, int Ci, int k, int ld, void* stream);
+
+/* Block tail (xception.py:64-79): y = MaxPool2d(3,2,1)(z*scale+shift) + (zs*scale_s+shift_s); z [N,H,W,C], zs,y [N,Ho,Wo,C]. */
+int mt_maxpool_add_fwd(const float* z, const float* scale, const float* shift, const float* zs, const float* scale_s,
+                       const float* shift_s, float* y, int N, int H, int W, int C, void* stream);
+/* du (pre-zeroed, [N,H,W,C]) += dy routed to each window's arg-max of z*scale+shift. */
+int mt_maxpool_bwd(const float* dy, const float* z, const float* scale, const float* shift, float* du, int N, int H,
+                   int W, int C, void* stream);
+/* dz = ka*du + kb*z + kc materialised (dense conv2's data gradient is itself an im2col GEMM over dz). */
+int mt_bn_bwd_apply(const float* du, const float* z, const float* kabc, float* dz, int64_t rows, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,5 +10,7 @@ from . import efficientnet, effnet_engine, effnet_backward  # noqa: F401
 from . import ddp, harness  # noqa: F401
 from .timesformer import SizeInvariantTimeSformer  # noqa: F401
 from .efficientnet import EfficientNet  # noqa: F401
+from . import xception as xception_module, xception_engine  # noqa: F401
+from .xception import xception, Xception  # noqa: F401
 
 __all__ = ["arch", "synth", "lib", "timesformer", "tsf_engine", "SizeInvariantTimeSformer", "efficientnet", "effnet_engine", "EfficientNet"]

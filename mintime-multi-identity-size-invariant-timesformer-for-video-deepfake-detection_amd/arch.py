@@ -172,3 +172,69 @@ def tsf_state_spec(cfg):
     spec.append(("to_out.1.weight", (m["num-classes"], dim), "lin_w"))
     spec.append(("to_out.1.bias", (m["num-classes"],), "lin_b"))
     return spec
+
+
+# ---------------------------------------------------------------------------------------------
+# Xception (config 5 extractor; reference models/xception.py:82-217)
+# ---------------------------------------------------------------------------------------------
+BN_EPS_XCEPTION = 1e-5        # nn.BatchNorm2d default (xception.py:97)
+BN_MOMENTUM_XCEPTION = 0.1
+
+XCEPTION_BLOCKS = [  # (name, cin, cout, reps, stride, start_with_relu, grow_first)   xception.py:113-129
+    ("block1", 64, 128, 2, 2, False, True), ("block2", 128, 256, 2, 2, True, True), ("block3", 256, 728, 2, 2, True, True),
+    *[(f"block{i}", 728, 728, 3, 1, True, True) for i in range(4, 12)],
+    ("block12", 728, 1024, 2, 2, True, False)]
+
+
+def xception_block_units(cin, cout, reps, grow_first):
+    """(cin, cout) of a Block's separable convs in order (xception.py:44-58)."""
+    units, filters = [], cin
+    if grow_first:
+        units.append((cin, cout))
+        filters = cout
+    units += [(filters, filters)] * (reps - 1)
+    if not grow_first:
+        units.append((cin, cout))
+    return units
+
+
+def xception_unit_keys(name, start_with_relu, n_units):
+    """(separable-conv prefix, bn prefix) per unit: nn.Sequential indices of Block.rep (xception.py:44-66)."""
+    out, idx = [], 0
+    for u in range(n_units):
+        if u > 0 or start_with_relu:
+            idx += 1
+        out.append((f"{name}.rep.{idx}", f"{name}.rep.{idx + 1}"))
+        idx += 2
+    return out
+
+
+def xception_state_spec(num_classes: int = 1):
+    """Ordered (key, shape, kind) matching the reference Xception state_dict (276 entries)."""
+    spec = []
+
+    def bn(prefix, c):
+        spec.extend([(prefix + ".weight", (c,), "bn_w"), (prefix + ".bias", (c,), "bn_b"),
+                     (prefix + ".running_mean", (c,), "bn_rm"), (prefix + ".running_var", (c,), "bn_rv"),
+                     (prefix + ".num_batches_tracked", (), "bn_nbt")])
+
+    spec.append(("conv1.weight", (32, 3, 3, 3), "conv_first"))
+    bn("bn1", 32)
+    spec.append(("conv2.weight", (64, 32, 3, 3), "conv"))
+    bn("bn2", 64)
+    for (name, cin, cout, reps, stride, srelu, grow) in XCEPTION_BLOCKS:
+        if cout != cin or stride != 1:
+            spec.append((name + ".skip.weight", (cout, cin, 1, 1), "pw"))
+            bn(name + ".skipbn", cout)
+        units = xception_block_units(cin, cout, reps, grow)
+        for (sep, bnp), (ci, co) in zip(xception_unit_keys(name, srelu, len(units)), units):
+            spec.append((sep + ".conv1.weight", (ci, 1, 3, 3), "dw"))
+            spec.append((sep + ".pointwise.weight", (co, ci, 1, 1), "pw"))
+            bn(bnp, co)
+    for (sep, bnp, ci, co) in (("conv3", "bn3", 1024, 1536), ("conv4", "bn4", 1536, 2048)):
+        spec.append((sep + ".conv1.weight", (ci, 1, 3, 3), "dw"))
+        spec.append((sep + ".pointwise.weight", (co, ci, 1, 1), "pw"))
+        bn(bnp, co)
+    spec.append(("fc.weight", (num_classes, 2048), "fc_w"))
+    spec.append(("fc.bias", (num_classes,), "fc_b"))
+    return spec

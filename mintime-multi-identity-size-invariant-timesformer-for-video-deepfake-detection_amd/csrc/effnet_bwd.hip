@@ -29,6 +29,19 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return f4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return f4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+template <int ACT>
+__device__ __forceinline__ float4 act4(float4 u) {
+  if (ACT == 1) return f4(swishf_(u.x), swishf_(u.y), swishf_(u.z), swishf_(u.w));
+  if (ACT == 2) return f4(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f), fmaxf(u.w, 0.f));
+  return u;
+}
+template <int ACT>
+__device__ __forceinline__ float4 dact4(float4 u) {     // derivative of the activation at pre-activation u
+  if (ACT == 1) return f4(dswishf_(u.x), dswishf_(u.y), dswishf_(u.z), dswishf_(u.w));
+  if (ACT == 2) return f4(u.x > 0.f ? 1.f : 0.f, u.y > 0.f ? 1.f : 0.f, u.z > 0.f ? 1.f : 0.f, u.w > 0.f ? 1.f : 0.f);
+  return f4(1.f, 1.f, 1.f, 1.f);
+}
+
 // block-level reduction of per-thread (s1,s2) float4 partials over the PB row-lanes, then fp64 atomics
 __device__ __forceinline__ void reduce_stats(float* red, float4 s1, float4 s2, int cql, int pl, int CQB, int PB, int CQ,
                                              int C, double* stats, int slots) {
@@ -79,9 +92,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
         d = f4(fmaf(d.x, g.x, dp.x * inv_hw), fmaf(d.y, g.y, dp.y * inv_hw), fmaf(d.z, g.z, dp.z * inv_hw), fmaf(d.w, g.w, dp.w * inv_hw));
       }
       if (rowscale) { const float rs = rowscale[n]; d = f4(d.x * rs, d.y * rs, d.z * rs, d.w * rs); }
-      if (act) {
+      if (act == 1) {
         const float4 u = fma4(zz, sc, sh);
         d = f4(d.x * dswishf_(u.x), d.y * dswishf_(u.y), d.z * dswishf_(u.z), d.w * dswishf_(u.w));
+      } else if (act == 2) {
+        const float4 u = fma4(zz, sc, sh);
+        d = f4(u.x > 0.f ? d.x : 0.f, u.y > 0.f ? d.y : 0.f, u.z > 0.f ? d.z : 0.f, u.w > 0.f ? d.w : 0.f);
       }
       if (dout) st4(dout + r * C + c, d);
       const float4 xh = f4((zz.x - mean.x) * istd.x, (zz.y - mean.y) * istd.y, (zz.z - mean.z) * istd.z, (zz.w - mean.w) * istd.w);
@@ -396,21 +412,21 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(
 // and the dz tile are built ONCE per tile in LDS (swish / BN-backward affine evaluated once per element instead of once per
 // tap); thread (cq, kh, ps) then accumulates the K taps of kernel row kh for channel quad cq over its share of the pixels.
 // Accumulators persist across the block's tiles -> one atomic per (channel, tap) per block.
-template <int K, int S, int T>
+template <int K, int S, int T, int ACT, int CC>
 __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
     const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ zin,
     const float* __restrict__ scale_in, const float* __restrict__ shift_in, float* __restrict__ dw, int N, int H, int W, int C,
     int Ho, int Wo) {
   constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
-  constexpr int CC = 16;
+  constexpr int CQN = CC / 4;
   constexpr int IH = (T - 1) * S + K;
   constexpr int IWP = IH | 1;                    // odd row pitch (in pixels) spreads kernel rows over LDS banks
-  constexpr int PS = 64 / K;                     // pixel-split groups
+  constexpr int PS = (256 / CQN) / K;            // pixel-split groups
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* a_t = lds;                              // [IH][IWP][CC]
   float* dz_t = lds + IH * IWP * CC;             // [T][T][CC]
   const int tid = threadIdx.x;
-  const int cq = tid & 3, r = tid >> 2;
+  const int cq = tid % CQN, r = tid / CQN;
   const int kh = r % K, ps = r / K;
   const bool worker = ps < PS;
   const int c0 = blockIdx.y * CC;
@@ -432,25 +448,24 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
     const int n = (int)(t2 / ty_n);
     const int oh0 = ty * T, ow0 = tx * T;
     __syncthreads();                              // previous tile fully consumed
-    for (int idx = tid; idx < IH * IH * 4; idx += 256) {
-      const int q = idx & 3, pix = idx >> 2;
+    for (int idx = tid; idx < IH * IH * CQN; idx += 256) {
+      const int q = idx % CQN, pix = idx / CQN;
       const int iy = pix / IH, ix = pix - iy * IH;
       const int ih = oh0 * S - P + iy, iw = ow0 * S - P + ix;
       float4 v = f4(0, 0, 0, 0);
       if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
-        const float4 u = fma4(ld4(zin + (((int64_t)n * H + ih) * W + iw) * C + c0 + q * 4), sc, sh);
-        v = f4(swishf_(u.x), swishf_(u.y), swishf_(u.z), swishf_(u.w));
+        v = act4<ACT>(fma4(ld4(zin + (((int64_t)n * H + ih) * W + iw) * C + c0 + q * 4), ld4(scale_in + c0 + q * 4), ld4(shift_in + c0 + q * 4)));
       }
       st4(a_t + (iy * IWP + ix) * CC + q * 4, v);
     }
-    for (int idx = tid; idx < T * T * 4; idx += 256) {
-      const int q = idx & 3, pix = idx >> 2;
+    for (int idx = tid; idx < T * T * CQN; idx += 256) {
+      const int q = idx % CQN, pix = idx / CQN;
       const int oy = pix / T, ox = pix - oy * T;
       const int oh = oh0 + oy, ow = ow0 + ox;
       float4 v = f4(0, 0, 0, 0);
       if (oh < Ho && ow < Wo) {
         const int64_t off = (((int64_t)n * Ho + oh) * Wo + ow) * C + c0 + q * 4;
-        v = fma4(ka, ld4(du + off), fma4(kb, ld4(z + off), kc));
+        v = fma4(ld4(kabc + c0 + q * 4), ld4(du + off), fma4(ld4(kabc + C + c0 + q * 4), ld4(z + off), ld4(kabc + 2 * C + c0 + q * 4)));
       }
       st4(dz_t + pix * CC + q * 4, v);
     }
@@ -467,37 +482,38 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
   }
   // reduce over the PS pixel-split groups through LDS, then atomics
   __syncthreads();
-  float* red = lds;                               // [PS][K(kh)][4(cq)][K(kw)] float4
+  float* red = lds;                               // [PS][K(kh)][CQN(cq)][K(kw)] float4
   if (worker) {
 #pragma unroll
-    for (int kw = 0; kw < K; ++kw) st4(red + (((ps * K + kh) * 4 + cq) * K + kw) * 4, acc[kw]);
+    for (int kw = 0; kw < K; ++kw) st4(red + (((ps * K + kh) * CQN + cq) * K + kw) * 4, acc[kw]);
   }
   __syncthreads();
-  if (tid < K * 4 * K) {                          // (kh, cq, kw)
-    const int kw = tid % K, q = (tid / K) & 3, khh = tid / (4 * K);
+  if (tid < K * CQN * K) {                        // (kh, cq, kw)
+    const int kw = tid % K, q = (tid / K) % CQN, khh = tid / (CQN * K);
     float4 t = f4(0, 0, 0, 0);
-    for (int g = 0; g < PS; ++g) t = add4(t, ld4(red + (((g * K + khh) * 4 + q) * K + kw) * 4));
+    for (int g = 0; g < PS; ++g) t = add4(t, ld4(red + (((g * K + khh) * CQN + q) * K + kw) * 4));
     const int c = c0 + q * 4, tp = khh * K + kw;
     atomicAdd(dw + (c + 0) * K * K + tp, t.x); atomicAdd(dw + (c + 1) * K * K + tp, t.y);
     atomicAdd(dw + (c + 2) * K * K + tp, t.z); atomicAdd(dw + (c + 3) * K * K + tp, t.w);
   }
 }
 
-template <int K, int S, int T>
+template <int K, int S, int T, int ACT, int CC>
 int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, const float* zin, const float* scale_in,
                           const float* shift_in, float* dw, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
   constexpr int IH = (T - 1) * S + K;
   constexpr int IWP = IH | 1;
-  constexpr int PS = 64 / K;
-  size_t lds = (size_t)(IH * IWP * 16 + T * T * 16) * sizeof(float);
-  const size_t red = (size_t)PS * K * 4 * K * 4 * sizeof(float);
+  constexpr int CQN = CC / 4;
+  constexpr int PS = (256 / CQN) / K;
+  size_t lds = (size_t)(IH * IWP * CC + T * T * CC) * sizeof(float);
+  const size_t red = (size_t)PS * K * CQN * K * 4 * sizeof(float);
   if (red > lds) lds = red;
-  const int chunks = C / 16;
+  const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((Ho + T - 1) / T) * ((Wo + T - 1) / T);
   int64_t bx = 4096 / chunks;
   if (bx < 1) bx = 1;
   if (bx > ntiles) bx = ntiles;
-  auto k = dwconv_wgrad_tiled_kernel<K, S, T>;
+  auto k = dwconv_wgrad_tiled_kernel<K, S, T, ACT, CC>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
@@ -510,25 +526,25 @@ int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, co
 // One block = one 16-channel chunk, grid-strided over T x T INPUT tiles.  dz = ka*du+kb*z+kc over the output positions
 // the tile's taps can reach is built once in LDS; thread (cq, slot) then gathers its input pixels' taps from LDS,
 // applies swish' of the input-side BatchNorm and accumulates that BatchNorm's backward sums in registers.
-template <int K, int S, int T>
+template <int K, int S, int T, int ACT, int CC>
 __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
     const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ w,
     const float* __restrict__ zin, const float* __restrict__ scale_in, const float* __restrict__ shift_in,
     const float* __restrict__ mi_in, float* __restrict__ du_in, double* __restrict__ stats, int slots, int N, int H, int W,
-    int C, int Ho, int Wo) {
+    int C, int Ho, int Wo, const float* __restrict__ res_pre, const float* __restrict__ res_post) {
   constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
-  constexpr int CC = 16;
+  constexpr int CQN = CC / 4, NSLOT = 256 / CQN;
   constexpr int OT = (T - 1 + K - 1) / S + 2;       // output rows/cols a T-wide input tile can touch (upper bound)
   constexpr int OTP = OT | 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];   // dz_t [OT][OTP][CC]; later the stats reduction buffer
   const int tid = threadIdx.x;
-  const int cq = tid & 3, slot = tid >> 2;
+  const int cq = tid % CQN, slot = tid / CQN;
   const int c0 = blockIdx.y * CC;
   const int ty_n = (H + T - 1) / T, tx_n = (W + T - 1) / T;
   const int64_t ntiles = (int64_t)N * ty_n * tx_n;
   const int c = c0 + cq * 4;
   const float4 sc = ld4(scale_in + c), sh = ld4(shift_in + c);
-  const float4 mean = ld4(mi_in + c), istd = ld4(mi_in + C + c);
+  const float4 mean = mi_in ? ld4(mi_in + c) : f4(0, 0, 0, 0), istd = mi_in ? ld4(mi_in + C + c) : f4(0, 0, 0, 0);
   float4 wt[K * K];
 #pragma unroll
   for (int i = 0; i < K * K; ++i)
@@ -545,8 +561,8 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
     const int oh_lo = nh >= 0 ? (nh + S - 1) / S : -((-nh) / S);
     const int ow_lo = nw >= 0 ? (nw + S - 1) / S : -((-nw) / S);
     __syncthreads();
-    for (int idx = tid; idx < OT * OT * 4; idx += 256) {
-      const int q = idx & 3, pix = idx >> 2;
+    for (int idx = tid; idx < OT * OT * CQN; idx += 256) {
+      const int q = idx % CQN, pix = idx / CQN;
       const int oy = pix / OT, ox = pix - oy * OT;
       const int oh = oh_lo + oy, ow = ow_lo + ox;
       float4 v = f4(0, 0, 0, 0);
@@ -557,7 +573,7 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
       st4(lds + (oy * OTP + ox) * CC + q * 4, v);
     }
     __syncthreads();
-    for (int p = slot; p < T * T; p += 64) {
+    for (int p = slot; p < T * T; p += NSLOT) {
       const int iy = p / T, ix = p - iy * T;
       const int ih = ih0 + iy, iw = iw0 + ix;
       if (ih < H && iw < W) {
@@ -580,7 +596,9 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
         const int64_t off = (((int64_t)n * H + ih) * W + iw) * C + c;
         const float4 zz = ld4(zin + off);
         const float4 u = fma4(zz, sc, sh);
-        const float4 d = f4(acc.x * dswishf_(u.x), acc.y * dswishf_(u.y), acc.z * dswishf_(u.z), acc.w * dswishf_(u.w));
+        if (res_pre) acc = add4(acc, ld4(res_pre + off));       // another consumer of the same activated tensor
+        float4 d = mul4(acc, dact4<ACT>(u));
+        if (res_post) d = add4(d, ld4(res_post + off));         // a consumer of the raw (pre-activation) tensor
         st4(du_in + off, d);
         const float4 xh = f4((zz.x - mean.x) * istd.x, (zz.y - mean.y) * istd.y, (zz.z - mean.z) * istd.z, (zz.w - mean.w) * istd.w);
         s1 = add4(s1, d);
@@ -588,35 +606,58 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
       }
     }
   }
+  if (!stats) return;
   __syncthreads();
   float* rr = lds + tid * 8;
   rr[0] = s1.x; rr[1] = s1.y; rr[2] = s1.z; rr[3] = s1.w; rr[4] = s2.x; rr[5] = s2.y; rr[6] = s2.z; rr[7] = s2.w;
   __syncthreads();
-  if (tid < 32) {
+  if (tid < CQN * 8) {
     const int q = tid >> 3, e = tid & 7;
     float v = 0.f;
-    for (int sl = 0; sl < 64; ++sl) v += lds[(sl * 4 + q) * 8 + e];
+    for (int sl = 0; sl < NSLOT; ++sl) v += lds[(sl * CQN + q) * 8 + e];
     const int ch = c0 + q * 4 + (e & 3), which = e >> 2;
     atomicAdd(stats + ((int64_t)(blockIdx.x % slots) * 2 + which) * C + ch, (double)v);
   }
 }
 
-template <int K, int S, int T>
+template <int K, int S, int T, int ACT, int CC>
 int launch_dw_dgrad_tiled(const float* du, const float* z, const float* kabc, const float* w, const float* zin,
                           const float* scale_in, const float* shift_in, const float* mi_in, float* du_in, double* stats, int slots,
-                          int N, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+                          int N, int H, int W, int C, int Ho, int Wo, const float* res_pre, const float* res_post, hipStream_t s) {
   constexpr int OT = (T - 1 + K - 1) / S + 2;
   constexpr int OTP = OT | 1;
-  size_t lds = (size_t)OT * OTP * 16 * sizeof(float);
+  size_t lds = (size_t)OT * OTP * CC * sizeof(float);
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);
-  const int chunks = C / 16;
+  const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((H + T - 1) / T) * ((W + T - 1) / T);
   int64_t bx = 8192 / chunks;
   if (bx < 1) bx = 1;
   if (bx > ntiles) bx = ntiles;
-  hipLaunchKernelGGL((dwconv_dgrad_tiled_kernel<K, S, T>), dim3((unsigned)bx, chunks), dim3(256), lds, s, du, z, kabc, w, zin,
-                     scale_in, shift_in, mi_in, du_in, stats, slots > 0 ? slots : 1, N, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL((dwconv_dgrad_tiled_kernel<K, S, T, ACT, CC>), dim3((unsigned)bx, chunks), dim3(256), lds, s, du, z, kabc, w, zin,
+                     scale_in, shift_in, mi_in, du_in, stats, slots > 0 ? slots : 1, N, H, W, C, Ho, Wo, res_pre, res_post);
   return check_launch("mt_dwconv_bwd(data, tiled)");
+}
+
+template <int K, int S, int ACT>
+int launch_dw_bwd_tiled_any(const float* du, const float* z, const float* kabc, const float* w, const float* zin, const float* scale_in,
+                            const float* shift_in, const float* mi_in, float* du_in, double* stats, int slots, float* dw, int N, int H,
+                            int W, int C, int Ho, int Wo, int parts, const float* res_pre, const float* res_post, hipStream_t s) {
+  int rc = 0;
+  const bool t14o = Ho >= 14, t14i = H >= 14;
+  if (parts & 1) {
+    if (C % 16 == 0) rc = t14o ? launch_dw_wgrad_tiled<K, S, 14, ACT, 16>(du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s)
+                               : launch_dw_wgrad_tiled<K, S, 7, ACT, 16>(du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s);
+    else rc = t14o ? launch_dw_wgrad_tiled<K, S, 14, ACT, 8>(du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s)
+                   : launch_dw_wgrad_tiled<K, S, 7, ACT, 8>(du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s);
+    if (rc) return rc;
+  }
+  if (parts & 2) {
+    if (C % 16 == 0) rc = t14i ? launch_dw_dgrad_tiled<K, S, 14, ACT, 16>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, res_pre, res_post, s)
+                               : launch_dw_dgrad_tiled<K, S, 7, ACT, 16>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, res_pre, res_post, s);
+    else rc = t14i ? launch_dw_dgrad_tiled<K, S, 14, ACT, 8>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, res_pre, res_post, s)
+                   : launch_dw_dgrad_tiled<K, S, 7, ACT, 8>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, res_pre, res_post, s);
+  }
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ K8: stem wgrad
@@ -689,46 +730,12 @@ int pick_cqb(int CQ) {
 template <int K, int S, int R>
 int launch_dw_bwd(const float* du, const float* z, const float* kabc, const float* w, const float* zin, const float* scale_in,
                   const float* shift_in, const float* mi_in, float* du_in, double* stats, int slots, float* dw, int N, int H,
-                  int W, int C, int parts, hipStream_t s) {
+                  int W, int C, int parts, int act, const float* res_pre, const float* res_post, hipStream_t s) {
   const int Ho = (H + S - 1) / S, Wo = (W + S - 1) / S;
-  const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
-  // weight gradient: LDS-tiled kernel when the channel count is a multiple of 16 (always, for EfficientNet-B0);
-  // otherwise the register-blocked fallback
-  if (!(parts & 1)) {
-  } else if (C % 16 == 0) {
-    int rc;
-    if (Ho % 14 == 0 && Wo % 14 == 0) rc = launch_dw_wgrad_tiled<K, S, 14>(du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s);
-    else rc = launch_dw_wgrad_tiled<K, S, 7>(du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s);
-    if (rc) return rc;
-  } else {
-    const int RH = Ho >= 28 ? 4 : (Ho >= 14 ? 2 : 1);
-    const int wsegs = (Wo + R - 1) / R, hsegs = (Ho + RH - 1) / RH;
-    const int64_t nseg = (int64_t)N * hsegs * wsegs;
-    int64_t nb = (nseg + PB - 1) / PB;
-    const int64_t cap = 2048 / (CQ / CQB) > 0 ? 2048 / (CQ / CQB) : 1;
-    if (nb > cap) nb = cap;
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S, R>), dim3((unsigned)nb, CQ / CQB), dim3(CQB * PB),
-                       (size_t)PB * CQB * 4 * sizeof(float), s, du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo,
-                       CQB, PB, RH);
-    int rc = check_launch("mt_dwconv_bwd(weight)");
-    if (rc) return rc;
-  }
-  // data gradient: input-centric (LDS-tiled when the channel count allows)
-  if (!(parts & 2)) return 0;
-  if (C % 16 == 0 && !getenv("MT_DW_UNTILED")) {
-    if (H % 14 == 0 && W % 14 == 0) return launch_dw_dgrad_tiled<K, S, 14>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, s);
-    return launch_dw_dgrad_tiled<K, S, 7>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, s);
-  }
-  {
-    constexpr int RI = 4;
-    const int RH = H >= 28 ? 4 : (H >= 14 ? 2 : 1);
-    const int wsegs = (W + RI - 1) / RI, hsegs = (H + RH - 1) / RH;
-    const int64_t nseg = (int64_t)N * hsegs * wsegs;
-    hipLaunchKernelGGL((dwconv_bwd_data_kernel<K, S, RI>), dim3((unsigned)((nseg + PB - 1) / PB), CQ / CQB), dim3(CQB * PB),
-                       (size_t)PB * CQB * 8 * sizeof(float), s, du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats,
-                       slots > 0 ? slots : 1, N, H, W, C, Ho, Wo, CQB, PB, RH);
-    return check_launch("mt_dwconv_bwd(data)");
-  }
+  if (C % 8 != 0) return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd: channel count %d is not a multiple of 8", C);
+  if (act == 1) return launch_dw_bwd_tiled_any<K, S, 1>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, dw, N, H, W, C, Ho, Wo, parts, res_pre, res_post, s);
+  if (act == 2) return launch_dw_bwd_tiled_any<K, S, 2>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, dw, N, H, W, C, Ho, Wo, parts, res_pre, res_post, s);
+  return launch_dw_bwd_tiled_any<K, S, 0>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, dw, N, H, W, C, Ho, Wo, parts, res_pre, res_post, s);
 }
 
 }  // namespace
@@ -785,17 +792,18 @@ extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, co
 extern "C" int mt_dwconv_bwd(const float* du, const float* z, const float* kabc, const float* w, const float* zin,
                              const float* scale_in, const float* shift_in, const float* mean_invstd_in, float* du_in,
                              double* stats_in, int slots, float* dw, int N, int H, int W, int C, int k, int stride,
-                             int parts, void* stream) {
+                             int parts, int act, const float* res_pre, const float* res_post, void* stream) {
   if (!du || !z || !kabc || !zin || !scale_in || !shift_in) return fail(MT_ERR_ARG, "mt_dwconv_bwd: null pointer");
   if ((parts & 1) && !dw) return fail(MT_ERR_ARG, "mt_dwconv_bwd: weight part needs dw");
-  if ((parts & 2) && (!w || !mean_invstd_in || !du_in || !stats_in)) return fail(MT_ERR_ARG, "mt_dwconv_bwd: data part needs w, mean_invstd_in, du_in, stats_in");
+  if ((parts & 2) && (!w || !du_in)) return fail(MT_ERR_ARG, "mt_dwconv_bwd: data part needs w and du_in");
+  if ((parts & 2) && ((stats_in == nullptr) != (mean_invstd_in == nullptr))) return fail(MT_ERR_ARG, "mt_dwconv_bwd: stats_in and mean_invstd_in go together");
   if (C & 3) return fail(MT_ERR_ARG, "mt_dwconv_bwd: C %% 4 != 0");
   if (stride == 2 && ((H & 1) || (W & 1))) return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd: stride 2 needs even H, W");
   hipStream_t s = (hipStream_t)stream;
-  if (k == 3 && stride == 1) return launch_dw_bwd<3, 1, 4>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, s);
-  if (k == 3 && stride == 2) return launch_dw_bwd<3, 2, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, s);
-  if (k == 5 && stride == 1) return launch_dw_bwd<5, 1, 4>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, s);
-  if (k == 5 && stride == 2) return launch_dw_bwd<5, 2, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, s);
+  if (k == 3 && stride == 1) return launch_dw_bwd<3, 1, 4>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
+  if (k == 3 && stride == 2) return launch_dw_bwd<3, 2, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
+  if (k == 5 && stride == 1) return launch_dw_bwd<5, 1, 4>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
+  if (k == 5 && stride == 2) return launch_dw_bwd<5, 2, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
   return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd: k=%d stride=%d unsupported", k, stride);
 }
 

@@ -227,22 +227,30 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ z
 // once in LDS (swish evaluated once per element, not once per tap); thread (cq = tid&3, slot = tid>>2) then produces the
 // outputs slot, slot+64, ... of the tile for its channel quad with its K*K weights held in registers.  BatchNorm sums
 // stay in registers across the block's tiles -> one fp64 atomic per channel per block.
-template <int K, int S, int T>
+template <int ACT>
+__device__ __forceinline__ float4 act_affine4(float4 z, float4 sc, float4 sh) {
+  float4 a = make_float4(fmaf(z.x, sc.x, sh.x), fmaf(z.y, sc.y, sh.y), fmaf(z.z, sc.z, sh.z), fmaf(z.w, sc.w, sh.w));
+  if (ACT == 1) { a.x = swishf_(a.x); a.y = swishf_(a.y); a.z = swishf_(a.z); a.w = swishf_(a.w); }
+  if (ACT == 2) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+  return a;
+}
+
+// ACT: input activation applied after the per-channel affine (0 none, 1 swish [EfficientNet], 2 relu [Xception]).
+// CC : channels per block (16, or 8 for channel counts like Xception's 728 that are not multiples of 16).
+template <int K, int S, int T, int ACT, int CC>
 __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restrict__ zin, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ w,
                                                            float* __restrict__ zout, double* __restrict__ stats, int slots,
                                                            int N, int H, int W, int C, int Ho, int Wo, int pad0) {
-  constexpr int CC = 16;
+  constexpr int CQN = CC / 4, NSLOT = 256 / CQN;
   constexpr int IH = (T - 1) * S + K;
   constexpr int IWP = IH | 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];   // a_t [IH][IWP][CC]; later the stats reduction buffer
   const int tid = threadIdx.x;
-  const int cq = tid & 3, slot = tid >> 2;
+  const int cq = tid % CQN, slot = tid / CQN;
   const int c0 = blockIdx.y * CC;
   const int ty_n = (Ho + T - 1) / T, tx_n = (Wo + T - 1) / T;
   const int64_t ntiles = (int64_t)N * ty_n * tx_n;
-  const float4 sc = *reinterpret_cast<const float4*>(scale + c0 + cq * 4);
-  const float4 sh = *reinterpret_cast<const float4*>(shift + c0 + cq * 4);
   float4 wt[K * K];
   {
     const int c = c0 + cq * 4;
@@ -258,18 +266,18 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
     const int n = (int)(t2 / ty_n);
     const int oh0 = ty * T, ow0 = tx * T;
     __syncthreads();
-    for (int idx = tid; idx < IH * IH * 4; idx += 256) {
-      const int q = idx & 3, pix = idx >> 2;
+    for (int idx = tid; idx < IH * IH * CQN; idx += 256) {
+      const int q = idx % CQN, pix = idx / CQN;
       const int iy = pix / IH, ix = pix - iy * IH;
       const int ih = oh0 * S - pad0 + iy, iw = ow0 * S - pad0 + ix;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ih >= 0 && ih < H && iw >= 0 && iw < W)
-        v = bn_swish4(*reinterpret_cast<const float4*>(zin + (((int64_t)n * H + ih) * W + iw) * C + c0 + q * 4),
-                      *reinterpret_cast<const float4*>(scale + c0 + q * 4), *reinterpret_cast<const float4*>(shift + c0 + q * 4));
+        v = act_affine4<ACT>(*reinterpret_cast<const float4*>(zin + (((int64_t)n * H + ih) * W + iw) * C + c0 + q * 4),
+                             *reinterpret_cast<const float4*>(scale + c0 + q * 4), *reinterpret_cast<const float4*>(shift + c0 + q * 4));
       *reinterpret_cast<float4*>(lds + (iy * IWP + ix) * CC + q * 4) = v;
     }
     __syncthreads();
-    for (int p = slot; p < T * T; p += 64) {
+    for (int p = slot; p < T * T; p += NSLOT) {
       const int oy = p / T, ox = p - oy * T;
       const int oh = oh0 + oy, ow = ow0 + ox;
       if (oh < Ho && ow < Wo) {
@@ -290,35 +298,34 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
       }
     }
   }
-  (void)sc; (void)sh;
   if (stats) {
     __syncthreads();
     float* rr = lds + tid * 8;          // [256][8]
     rr[0] = s1.x; rr[1] = s1.y; rr[2] = s1.z; rr[3] = s1.w; rr[4] = s2.x; rr[5] = s2.y; rr[6] = s2.z; rr[7] = s2.w;
     __syncthreads();
-    if (tid < 32) {                     // (cq, e): 4 quads x 8 entries
+    if (tid < CQN * 8) {                // (cq, e)
       const int q = tid >> 3, e = tid & 7;
       float v = 0.f;
-      for (int sl = 0; sl < 64; ++sl) v += lds[(sl * 4 + q) * 8 + e];
+      for (int sl = 0; sl < NSLOT; ++sl) v += lds[(sl * CQN + q) * 8 + e];
       const int ch = c0 + q * 4 + (e & 3), which = e >> 2;
       atomic_add_f64(stats + ((int64_t)(blockIdx.x % slots) * 2 + which) * C + ch, (double)v);
     }
   }
 }
 
-template <int K, int S, int T>
+template <int K, int S, int T, int ACT, int CC>
 int launch_dw_tiled(const float* zin, const float* scale, const float* shift, const float* w, float* zout, double* stats, int slots,
                     int N, int H, int W, int C, int Ho, int Wo, int pad0, hipStream_t s) {
   constexpr int IH = (T - 1) * S + K;
   constexpr int IWP = IH | 1;
-  size_t lds = (size_t)IH * IWP * 16 * sizeof(float);
+  size_t lds = (size_t)IH * IWP * CC * sizeof(float);
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);
-  const int chunks = C / 16;
+  const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((Ho + T - 1) / T) * ((Wo + T - 1) / T);
   int64_t bx = 8192 / chunks;
   if (bx < 1) bx = 1;
   if (bx > ntiles) bx = ntiles;
-  auto k = dwconv_tiled_kernel<K, S, T>;
+  auto k = dwconv_tiled_kernel<K, S, T, ACT, CC>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
@@ -326,6 +333,18 @@ int launch_dw_tiled(const float* zin, const float* scale, const float* shift, co
   hipLaunchKernelGGL(k, dim3((unsigned)bx, chunks), dim3(256), lds, s, zin, scale, shift, w, zout, stats, slots > 0 ? slots : 1, N, H,
                      W, C, Ho, Wo, pad0);
   return check_launch("mt_dwconv_fwd(tiled)");
+}
+
+template <int K, int S, int ACT>
+int launch_dw_tiled_any(const float* zin, const float* scale, const float* shift, const float* w, float* zout, double* stats,
+                        int slots, int N, int H, int W, int C, int Ho, int Wo, int pad0, hipStream_t s) {
+  const bool t14 = Ho >= 14;
+  if (C % 16 == 0) {
+    if (t14) return launch_dw_tiled<K, S, 14, ACT, 16>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s);
+    return launch_dw_tiled<K, S, 7, ACT, 16>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s);
+  }
+  if (t14) return launch_dw_tiled<K, S, 14, ACT, 8>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s);
+  return launch_dw_tiled<K, S, 7, ACT, 8>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s);
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm finalize
@@ -436,7 +455,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ z
     const float4 sc = reinterpret_cast<const float4*>(scale)[cq];
     const float4 sh = reinterpret_cast<const float4*>(shift)[cq];
     float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
-    if (act) { o.x = swishf_(o.x); o.y = swishf_(o.y); o.z = swishf_(o.z); o.w = swishf_(o.w); }
+    if (act == 1) { o.x = swishf_(o.x); o.y = swishf_(o.y); o.z = swishf_(o.z); o.w = swishf_(o.w); }
+    if (act == 2) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     if (rowscale) {   // per-sample drop-connect gate (utils.py:129-154)
       const float g = rowscale[(i / CQ) / rows_per_group];
       o.x *= g; o.y *= g; o.z *= g; o.w *= g;
@@ -469,13 +489,16 @@ extern "C" int mt_stem_conv_fwd(const float* x, const float* w, float* z, double
 namespace {
 template <int K, int S, int R>
 int launch_dw(const float* zin, const float* scale, const float* shift, const float* w, float* zout, double* stats, int slots,
-              int N, int H, int W, int C, hipStream_t s) {
+              int N, int H, int W, int C, int act, hipStream_t s) {
   const int Ho = (H + S - 1) / S, Wo = (W + S - 1) / S;
   const int padt = max((Ho - 1) * S + K - H, 0);
-  if (C % 16 == 0 && !getenv("MT_DW_UNTILED")) {
-    if (Ho % 14 == 0 && Wo % 14 == 0) return launch_dw_tiled<K, S, 14>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, padt / 2, s);
-    return launch_dw_tiled<K, S, 7>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, padt / 2, s);
+  const int pad = padt / 2;
+  if (C % 8 == 0 && !getenv("MT_DW_UNTILED")) {
+    if (act == 1) return launch_dw_tiled_any<K, S, 1>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s);
+    if (act == 2) return launch_dw_tiled_any<K, S, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s);
+    return launch_dw_tiled_any<K, S, 0>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s);
   }
+  if (act != 1) return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_fwd: the untiled fallback only implements the swish prologue");
   const int CQ = C / 4;
   const int CQB = pick_cqb(CQ);
   const int PB = 256 / CQB;
@@ -491,14 +514,14 @@ int launch_dw(const float* zin, const float* scale, const float* shift, const fl
 }  // namespace
 
 extern "C" int mt_dwconv_fwd(const float* zin, const float* scale, const float* shift, const float* w, float* zout,
-                             double* stats, int slots, int N, int H, int W, int C, int k, int stride, void* stream) {
+                             double* stats, int slots, int N, int H, int W, int C, int k, int stride, int act, void* stream) {
   if (!zin || !scale || !shift || !w || !zout) return fail(MT_ERR_ARG, "mt_dwconv_fwd: null pointer");
   if (C & 3) return fail(MT_ERR_ARG, "mt_dwconv_fwd: C %% 4 != 0");
   hipStream_t s = (hipStream_t)stream;
-  if (k == 3 && stride == 1) return launch_dw<3, 1, 4>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, s);
-  if (k == 3 && stride == 2) return launch_dw<3, 2, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, s);
-  if (k == 5 && stride == 1) return launch_dw<5, 1, 4>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, s);
-  if (k == 5 && stride == 2) return launch_dw<5, 2, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, s);
+  if (k == 3 && stride == 1) return launch_dw<3, 1, 4>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
+  if (k == 3 && stride == 2) return launch_dw<3, 2, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
+  if (k == 5 && stride == 1) return launch_dw<5, 1, 4>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
+  if (k == 5 && stride == 2) return launch_dw<5, 2, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
   return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_fwd: k=%d stride=%d unsupported", k, stride);
 }
 

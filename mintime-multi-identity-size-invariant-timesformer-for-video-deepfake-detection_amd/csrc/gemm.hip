@@ -64,6 +64,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   a.scale = d->scale; a.shift = d->shift; a.gate = d->gate; a.hw = d->hw > 0 ? d->hw : 1;
   a.C2 = d->C2; a.ldc2 = d->ldc2; a.stats = d->stats; a.stats_slots = d->stats_slots > 0 ? d->stats_slots : 1;
   a.n_half = d->n_half; a.k_chunk = 0;
+  a.conv = {d->conv_H, d->conv_W, d->conv_C, d->conv_Ho, d->conv_Wo, d->conv_k, d->conv_stride, d->conv_pad, d->conv_act};
   a.A2 = d->A2; a.b_scale = d->b_scale; a.b_shift = d->b_shift; a.b_gate = d->b_gate; a.b_hw = d->b_hw > 0 ? d->b_hw : 1;
 
   // K-contiguous operands need K % 4 == 0 (float4 along K); k-major operands need M resp. N % 4 == 0
@@ -75,11 +76,19 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   if (d->epilogue == MT_EPI_BIAS_RES && !d->R) return fail(MT_ERR_ARG, "mt_gemm: BIAS_RES needs R");
   if (d->epilogue == MT_EPI_STATS && !d->stats) return fail(MT_ERR_ARG, "mt_gemm: STATS needs stats");
   if (d->epilogue == MT_EPI_GEGLU_BWD && !d->C2) return fail(MT_ERR_ARG, "mt_gemm: GEGLU_BWD needs C2 (pre-activations)");
-  if (d->prologue != MT_PRO_NONE && (!d->scale || !d->shift)) return fail(MT_ERR_ARG, "mt_gemm: prologue needs scale/shift");
+  if (d->prologue != MT_PRO_NONE && d->prologue != MT_PRO_IM2COL && (!d->scale || !d->shift))
+    return fail(MT_ERR_ARG, "mt_gemm: prologue needs scale/shift");
+  if (d->prologue == MT_PRO_IM2COL || d->b_prologue == MT_BPRO_IM2COL) {
+    if (d->conv_k <= 0 || d->conv_stride <= 0 || d->conv_C <= 0 || d->conv_Ho <= 0 || d->conv_Wo <= 0)
+      return fail(MT_ERR_ARG, "mt_gemm: im2col prologue needs the conv_* geometry");
+    if ((d->scale == nullptr) != (d->shift == nullptr) || (d->b_scale == nullptr) != (d->b_shift == nullptr))
+      return fail(MT_ERR_ARG, "mt_gemm: im2col affine needs both scale and shift");
+  }
   if (d->prologue == MT_PRO_BN_BWD && (!d->A2 || !d->gate)) return fail(MT_ERR_ARG, "mt_gemm: BN_BWD prologue needs A2 and kc");
   if (d->prologue == MT_PRO_BN_BWD && ((uintptr_t)d->A2 & 15)) return fail(MT_ERR_ARG, "mt_gemm: A2 must be 16-byte aligned");
-  if (d->b_prologue != MT_BPRO_NONE && (d->op != MT_OP_TN || !d->b_scale || !d->b_shift || !d->b_gate))
+  if (d->b_prologue == MT_BPRO_BN_SWISH_GATE && (d->op != MT_OP_TN || !d->b_scale || !d->b_shift || !d->b_gate))
     return fail(MT_ERR_ARG, "mt_gemm: B prologue needs op TN and b_scale/b_shift/b_gate");
+  if (d->b_prologue == MT_BPRO_IM2COL && d->op != MT_OP_TN) return fail(MT_ERR_ARG, "mt_gemm: im2col B prologue needs op TN");
   if (d->prologue == MT_PRO_BN_SWISH_GATE && !d->gate) return fail(MT_ERR_ARG, "mt_gemm: gate prologue needs gate");
 
   const int cfg = pick_cfg(d->N, d->epilogue);
@@ -112,6 +121,11 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
         return launch<LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_ATOMIC, BPRO_BN_SWISH_GATE>(cfg, a, grid, s);
       return fail(MT_ERR_UNSUPPORTED, "mt_gemm TN: B prologue only with BN_BWD/ATOMIC");
     }
+    if (d->b_prologue == MT_BPRO_IM2COL) {
+      if (d->prologue == MT_PRO_BN_BWD && d->epilogue == MT_EPI_ATOMIC)
+        return launch<LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_ATOMIC, BPRO_IM2COL>(cfg, a, grid, s);
+      return fail(MT_ERR_UNSUPPORTED, "mt_gemm TN: im2col B prologue only with BN_BWD/ATOMIC");
+    }
     COMBO(MT_OP_TN, LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_NONE, EPI_ATOMIC)
     COMBO(MT_OP_TN, LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_ATOMIC)
     return fail(MT_ERR_UNSUPPORTED, "mt_gemm TN: unsupported prologue/epilogue %d/%d", d->prologue, d->epilogue);
@@ -122,6 +136,8 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_NONE, EPI_STATS)
   COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_BN_SWISH_GATE, EPI_STATS)
   COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_BN_SWISH_GATE, EPI_STORE)
+  COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_IM2COL, EPI_STORE)
+  COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_IM2COL, EPI_STATS)
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_STORE)
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_ACCUM)
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_GEGLU_BWD)

@@ -43,12 +43,14 @@ enum : int {
   PRO_BN_SWISH_GATE = 1,   // a = swish(z*scale[k]+shift[k]) * gate[(m/hw)*K + k]      (MBConv project conv input)
   PRO_BN_SWISH = 2,        // a = swish(z*scale[k]+shift[k])
   PRO_AFFINE = 3,          // a = z*scale[k]+shift[k]
+  PRO_IM2COL = 5,          // a = act(x[n, oh*s+kh-p, ow*s+kw-p, ci]*scale[ci]+shift[ci]) gathered on the fly from an NHWC image
+                           //     (dense k x k convolution / strided 1x1 as a GEMM; m = (n,oh,ow), k = (kh,kw,ci); no im2col buffer)
   PRO_BN_BWD = 4,          // a = ka[c]*A[.] + kb[c]*A2[.] + kc[c]   (BatchNorm backward folded into the operand load:
                            //     A = d(bn output), A2 = z (bn input); ka,kb,kc = scale, shift, gate vectors; c = channel)
 };
 
 // prologue applied to B elements (k-major B only): B = swish(z*b_scale[n]+b_shift[n]) * b_gate[(k/b_hw)*N + n]
-enum : int { BPRO_NONE = 0, BPRO_BN_SWISH_GATE = 1 };
+enum : int { BPRO_NONE = 0, BPRO_BN_SWISH_GATE = 1, BPRO_IM2COL = 2 };   // BPRO_IM2COL: B[k=(n,oh,ow)][n=(kh,kw,ci)] gathered (conv wgrad)
 
 // epilogues
 enum : int {
@@ -71,6 +73,55 @@ __device__ __forceinline__ int64_t map_row(const RowMap& rm, int r) {
   return (int64_t)g * rm.gout + rm.off + (r - g * rm.gin);
 }
 
+struct ConvDesc {   // geometry of an im2col prologue
+  int H, W, C, Ho, Wo, k, stride, pad, act;   // act: 0 none, 2 relu (applied after the optional per-channel affine)
+};
+
+__device__ __forceinline__ float conv_act(float v, int act) { return act == 2 ? fmaxf(v, 0.f) : v; }
+
+// value of the virtual im2col matrix at (pixel row m, column kk) for 4 consecutive kk (kk % 4 == 0)
+__device__ __forceinline__ float4 im2col_gather4(const float* __restrict__ x, const ConvDesc& cd, const float* __restrict__ scale,
+                                                 const float* __restrict__ shift, int m, int kk) {
+  const int ow = m % cd.Wo;
+  const int t = m / cd.Wo;
+  const int oh = t % cd.Ho;
+  const int n = t / cd.Ho;
+  const int kt = cd.k * cd.k * cd.C;
+  float out[4];
+  if ((cd.C & 3) == 0) {
+    const int tap = kk / cd.C, ci = kk - tap * cd.C;
+    const int kh = tap / cd.k, kw = tap - kh * cd.k;
+    const int ih = oh * cd.stride + kh - cd.pad, iw = ow * cd.stride + kw - cd.pad;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kk < kt && ih >= 0 && ih < cd.H && iw >= 0 && iw < cd.W) {
+      v = *reinterpret_cast<const float4*>(x + (((int64_t)n * cd.H + ih) * cd.W + iw) * cd.C + ci);
+      if (scale) {
+        const float4 sc = *reinterpret_cast<const float4*>(scale + ci), sh = *reinterpret_cast<const float4*>(shift + ci);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+      }
+      v.x = conv_act(v.x, cd.act); v.y = conv_act(v.y, cd.act); v.z = conv_act(v.z, cd.act); v.w = conv_act(v.w, cd.act);
+    }
+    return v;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k1 = kk + e;
+    float v = 0.f;
+    if (k1 < kt) {
+      const int tap = k1 / cd.C, ci = k1 - tap * cd.C;
+      const int kh = tap / cd.k, kw = tap - kh * cd.k;
+      const int ih = oh * cd.stride + kh - cd.pad, iw = ow * cd.stride + kw - cd.pad;
+      if (ih >= 0 && ih < cd.H && iw >= 0 && iw < cd.W) {
+        v = x[(((int64_t)n * cd.H + ih) * cd.W + iw) * cd.C + ci];
+        if (scale) v = fmaf(v, scale[ci], shift[ci]);
+        v = conv_act(v, cd.act);
+      }
+    }
+    out[e] = v;
+  }
+  return make_float4(out[0], out[1], out[2], out[3]);
+}
+
 struct GemmArgs {
   const float* A; const float* B; float* C;
   int M, N, K;
@@ -89,6 +140,7 @@ struct GemmArgs {
   int k_chunk;                          // split-K: contraction length per blockIdx.y (0 = whole K)
   const float* A2;                      // PRO_BN_BWD second source (same layout / lda / row map as A)
   const float* b_scale; const float* b_shift; const float* b_gate; int b_hw;   // B prologue
+  ConvDesc conv;                        // PRO_IM2COL / BPRO_IM2COL geometry
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -183,7 +235,9 @@ void gemm_kernel(const GemmArgs p) {
         if constexpr (AL == LAYOUT_KCONTIG) {
           const int row = u / KQ, kq = u % KQ;
           const int m = m0 + row, k = k0 + kq * 4;
-          if (m < p.M && k < k_end) {
+          if constexpr (PRO == PRO_IM2COL) {
+            if (m < p.M && k < k_end) v = im2col_gather4(p.A, p.conv, p.scale, p.shift, m, k);
+          } else if (m < p.M && k < k_end) {
             v = *reinterpret_cast<const float4*>(p.A + map_row(p.a_map, m) * p.lda + k);
             if constexpr (PRO == PRO_BN_BWD) {
               const float4 z2 = *reinterpret_cast<const float4*>(p.A2 + map_row(p.a_map, m) * p.lda + k);
@@ -239,7 +293,9 @@ void gemm_kernel(const GemmArgs p) {
           constexpr int QPR = BN / 4;
           const int kk = u / QPR, nq = u - kk * QPR;
           const int k = k0 + kk, n = n0 + nq * 4;
-          if (k < k_end && n < p.N) {
+          if constexpr (BPRO == BPRO_IM2COL) {
+            if (k < k_end && n < p.N) v = im2col_gather4(p.B, p.conv, p.b_scale, p.b_shift, k, n);
+          } else if (k < k_end && n < p.N) {
             v = *reinterpret_cast<const float4*>(p.B + map_row(p.b_map, k) * p.ldb + n);
             if constexpr (BPRO == BPRO_BN_SWISH_GATE) {
               const float4 sc = *reinterpret_cast<const float4*>(p.b_scale + n);

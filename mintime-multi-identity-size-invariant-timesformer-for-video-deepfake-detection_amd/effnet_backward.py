@@ -118,7 +118,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         def dw_part(parts, _da=da, _rec=rec, _kabc=kabc_d, _bn=in_bn, _du_in=du_in, _sums=sums_in, _s=s, _ix=ix):
             L.check(lib.mt_dwconv_bwd(L.ptr(_da), L.ptr(_rec["z_d"]), L.ptr(_kabc), L.ptr(P[_ix["d"]]), L.ptr(_rec["dw_in"]),
                                       L.ptr(_bn.scale), L.ptr(_bn.shift), L.ptr(_bn.mean_invstd), L.ptr(_du_in), L.ptr(_sums), SLOTS,
-                                      L.ptr(grads[_ix["d"]]), N, _s.hin, _s.hin, _s.cexp, _s.k, _s.s, parts, L.stream_ptr()),
+                                      L.ptr(grads[_ix["d"]]), N, _s.hin, _s.hin, _s.cexp, _s.k, _s.s, parts, 1, None, None, L.stream_ptr()),
                     "mt_dwconv_bwd")
         side.launch(lambda: dw_part(1), reads=(da, rec["z_d"], kabc_d, rec["dw_in"], in_bn.scale, in_bn.shift))
         dw_part(2)

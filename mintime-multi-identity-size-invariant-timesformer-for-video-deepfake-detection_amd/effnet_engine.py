@@ -103,7 +103,7 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
         bn_d = _BNCtx(dev, s.cexp, training, pool)
         z_d = _new(dev, M_out, s.cexp)
         L.check(lib.mt_dwconv_fwd(L.ptr(dw_in), L.ptr(dw_bn.scale), L.ptr(dw_bn.shift), L.ptr(w_d), L.ptr(z_d), L.ptr(bn_d.stats),
-                                  SLOTS, N, s.hin, s.hin, s.cexp, s.k, s.s, st), "mt_dwconv_fwd")
+                                  SLOTS, N, s.hin, s.hin, s.cexp, s.k, s.s, 1, st), "mt_dwconv_fwd")
         _finalize(lib, st, blk._bn1, bn_d, M_out, training, g, b)
         w_r, b_r, w_x, b_x = next(it), next(it), next(it), next(it)
         pooled, gate = _new(dev, N, s.cexp), _new(dev, N, s.cexp)

@@ -34,12 +34,14 @@ class GemmDesc(C.Structure):
                 ("C2", C.c_void_p), ("ldc2", i64), ("stats", C.c_void_p), ("stats_slots", C.c_int),
                 ("n_half", C.c_int), ("split_k", C.c_int),
                 ("A2", C.c_void_p), ("b_prologue", C.c_int), ("b_scale", C.c_void_p), ("b_shift", C.c_void_p),
-                ("b_gate", C.c_void_p), ("b_hw", C.c_int)]
+                ("b_gate", C.c_void_p), ("b_hw", C.c_int),
+                ("conv_H", C.c_int), ("conv_W", C.c_int), ("conv_C", C.c_int), ("conv_Ho", C.c_int), ("conv_Wo", C.c_int),
+                ("conv_k", C.c_int), ("conv_stride", C.c_int), ("conv_pad", C.c_int), ("conv_act", C.c_int)]
 
 
 OP_NT, OP_NN, OP_TN = 0, 1, 2
-PRO_NONE, PRO_BN_SWISH_GATE, PRO_BN_SWISH, PRO_AFFINE, PRO_BN_BWD = 0, 1, 2, 3, 4
-BPRO_NONE, BPRO_BN_SWISH_GATE = 0, 1
+PRO_NONE, PRO_BN_SWISH_GATE, PRO_BN_SWISH, PRO_AFFINE, PRO_BN_BWD, PRO_IM2COL = 0, 1, 2, 3, 4, 5
+BPRO_NONE, BPRO_BN_SWISH_GATE, BPRO_IM2COL = 0, 1, 2
 EPI_STORE, EPI_BIAS_RES, EPI_GEGLU, EPI_STATS, EPI_ATOMIC, EPI_GEGLU_BWD, EPI_ACCUM = 0, 1, 2, 3, 4, 5, 6
 
 # name -> argtypes (restype is always int unless listed in _RESTYPES); mirrors include/mintime_hip.h
@@ -54,7 +56,7 @@ PROTOTYPES = {
     "mt_head_fwd": [f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "mt_stem_conv_fwd": [f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_dwconv_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                      C.c_void_p],
+                      C.c_int, C.c_void_p],
     "mt_bn_finalize": [C.c_void_p, C.c_int, C.c_double, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_float,
                        C.c_float, C.c_int, C.c_void_p],
     "mt_se_pool_fwd": [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
@@ -71,7 +73,12 @@ PROTOTYPES = {
     "mt_bn_bwd_finalize": [C.c_void_p, C.c_int, C.c_double, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_void_p],
     "mt_se_bwd": [f32p] * 17 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_dwconv_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                      C.c_void_p],
+                      C.c_int, f32p, f32p, C.c_void_p],
+    "mt_conv_weight_pack": [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_conv_weight_unpack_grad": [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_maxpool_add_fwd": [f32p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_maxpool_bwd": [f32p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_bn_bwd_apply": [f32p, f32p, f32p, f32p, i64, C.c_int, C.c_void_p],
     "mt_stem_conv_wgrad": [f32p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_void_p],
 }
 _RESTYPES = {"mt_last_error": C.c_char_p}
@@ -144,7 +151,7 @@ PROFILE = None
 def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI_STORE, bias=None, R=None, ldr=0,
          scale=None, shift=None, gate=None, hw=1, C2=None, ldc2=0, stats=None, stats_slots=1, n_half=0, split_k=1,
          a_map=(0, 0, 0), b_map=(0, 0, 0), c_map=(0, 0, 0), A2=None, b_prologue=BPRO_NONE, b_scale=None, b_shift=None,
-         b_gate=None, b_hw=1):
+         b_gate=None, b_hw=1, conv=None):
     d = GemmDesc()
     d.op, d.prologue, d.epilogue = op, prologue, epilogue
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
@@ -156,6 +163,8 @@ def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI
     d.C2, d.ldc2, d.stats, d.stats_slots = ptr(C2), ldc2, ptr(stats), stats_slots
     d.n_half, d.split_k = n_half, split_k
     d.A2, d.b_prologue, d.b_scale, d.b_shift, d.b_gate, d.b_hw = ptr(A2), b_prologue, ptr(b_scale), ptr(b_shift), ptr(b_gate), b_hw
+    if conv is not None:   # (H, W, C, Ho, Wo, k, stride, pad, act)
+        (d.conv_H, d.conv_W, d.conv_C, d.conv_Ho, d.conv_Wo, d.conv_k, d.conv_stride, d.conv_pad, d.conv_act) = conv
     prof = PROFILE
     if prof is not None and prof["match"](d):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

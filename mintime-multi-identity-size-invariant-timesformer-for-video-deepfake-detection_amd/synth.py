@@ -116,6 +116,85 @@ def _calibrate_bn(sd, seed):
     bn(F.conv2d(x, d["_conv_head.weight"]), "_bn1")
 
 
+def xception_state(seed: int = 0, num_classes: int = 1, calibrate: bool = True):
+    """Seeded state-dict with the reference Xception keys/shapes (276 entries); BN buffers calibrated like effnet_b0_state."""
+    sd = {}
+    for i, (key, shape, kind) in enumerate(arch.xception_state_spec(num_classes)):
+        g = _rng(seed, 20000 + i)
+        if kind == "conv_first":
+            w = g.standard_normal(shape) / (np.sqrt(27.0) * 74.0)
+        elif kind == "conv":
+            w = g.standard_normal(shape) * (1.4 / np.sqrt(shape[1] * 9))
+        elif kind == "dw":
+            w = g.standard_normal(shape) * (1.4 / 3.0)
+        elif kind == "pw":
+            w = g.standard_normal(shape) * (1.0 / np.sqrt(shape[1]))
+        elif kind == "bn_w":
+            w = g.uniform(0.5, 1.5, shape)
+        elif kind == "bn_b":
+            w = g.standard_normal(shape) * 0.1
+        elif kind == "bn_rm":
+            w = g.standard_normal(shape) * 0.1
+        elif kind == "bn_rv":
+            w = g.uniform(0.5, 1.5, shape)
+        elif kind == "bn_nbt":
+            sd[key] = torch.tensor(0, dtype=torch.int64)
+            continue
+        elif kind == "fc_w":
+            w = g.standard_normal(shape) * 0.01
+        elif kind == "fc_b":
+            w = np.zeros(shape)
+        else:
+            raise KeyError(kind)
+        sd[key] = _t(w)
+    if calibrate:
+        _calibrate_xception_bn(sd, seed)
+    return sd
+
+
+def _calibrate_xception_bn(sd, seed):
+    """Weight-synthesis helper (NOT a forward path of the product): one fp64 host walk of the Xception graph."""
+    import torch.nn.functional as F
+    g = _rng(seed, 78)
+    x = torch.from_numpy(g.integers(0, 256, size=(2, 3, arch.IMAGE_SIZE, arch.IMAGE_SIZE)).astype(np.float64))
+    d = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    layer = [0]
+
+    def bn(z, prefix):
+        c = z.shape[1]
+        gg = _rng(seed, 300 + layer[0])
+        layer[0] += 1
+        mu, var = z.mean(dim=(0, 2, 3)), z.var(dim=(0, 2, 3), unbiased=False)
+        rm = (mu + var.sqrt() * torch.from_numpy(gg.standard_normal(c) * 0.1)).float()
+        rv = (var * torch.from_numpy(gg.uniform(0.8, 1.25, c))).float()
+        sd[prefix + ".running_mean"], sd[prefix + ".running_var"] = rm, rv
+        sh = (1, c, 1, 1)
+        return (z - rm.double().view(sh)) / torch.sqrt(rv.double().view(sh) + arch.BN_EPS_XCEPTION) * d[prefix + ".weight"].view(sh) \
+            + d[prefix + ".bias"].view(sh)
+
+    def sep(t, prefix):
+        t = F.conv2d(t, d[prefix + ".conv1.weight"], None, 1, 1, 1, t.shape[1])
+        return F.conv2d(t, d[prefix + ".pointwise.weight"])
+
+    x = F.relu(bn(F.conv2d(x, d["conv1.weight"], None, 2, 0), "bn1"))
+    x = F.relu(bn(F.conv2d(x, d["conv2.weight"], None, 1, 0), "bn2"))
+    for (name, cin, cout, reps, stride, srelu, grow) in arch.XCEPTION_BLOCKS:
+        inp = x
+        units = arch.xception_block_units(cin, cout, reps, grow)
+        for u, (sp, bnp) in enumerate(arch.xception_unit_keys(name, srelu, len(units))):
+            if u > 0 or srelu:
+                x = F.relu(x)
+            x = bn(sep(x, sp), bnp)
+        if stride != 1:
+            x = F.max_pool2d(x, 3, stride, 1)
+        if cout != cin or stride != 1:
+            x = x + bn(F.conv2d(inp, d[name + ".skip.weight"], None, stride), name + ".skipbn")
+        else:
+            x = x + inp
+    x = F.relu(bn(sep(x, "conv3"), "bn3"))
+    bn(sep(x, "conv4"), "bn4")
+
+
 def tsf_state(cfg, seed: int = 0):
     """Seeded state-dict with the reference SizeInvariantTimeSformer keys/shapes."""
     sd = {}

@@ -1,0 +1,356 @@
+"""Launch sequences (forward and backward) of Xception on libmintime_hip (reference models/xception.py:161-217).
+
+Same rules as the EfficientNet engine: NHWC rows, raw conv outputs in HBM with BatchNorm(+ReLU) applied by the consumer on
+load, BatchNorm statistics accumulated by the producer, BatchNorm backward folded into GEMM operand loads.
+A `_Src` describes how a consumer obtains a tensor's value: stored data + pending per-channel affine + pending activation.
+"""
+import torch
+
+from . import arch
+from . import lib as L
+from .effnet_engine import SLOTS, _StatsPool, _BNCtx
+
+RELU, NONE = 2, 0
+
+
+def _new(dev, *shape):
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+
+class _Src:
+    def __init__(self, t, C, H, scale=None, shift=None, act=NONE, bn=None):
+        self.t, self.C, self.H, self.scale, self.shift, self.act, self.bn = t, C, H, scale, shift, act, bn
+
+
+class _Consts:
+    """ones / zeros vectors for tensors that carry no pending affine (the depthwise kernels always take scale/shift)."""
+
+    def __init__(self, dev):
+        self.dev, self.cache = dev, {}
+
+    def ident(self, C):
+        if C not in self.cache:
+            self.cache[C] = (torch.ones(C, device=self.dev), torch.zeros(C, device=self.dev))
+        return self.cache[C]
+
+    def kabc_ident(self, C):
+        key = ("k", C)
+        if key not in self.cache:
+            k = torch.zeros(3, C, device=self.dev)
+            k[0] = 1.0
+            self.cache[key] = k
+        return self.cache[key]
+
+
+def param_list(model):
+    ps = [model.conv1.weight, model.bn1.weight, model.bn1.bias, model.conv2.weight, model.bn2.weight, model.bn2.bias]
+    for blk in model.blocks():
+        if blk.skip is not None:
+            ps += [blk.skip.weight, blk.skipbn.weight, blk.skipbn.bias]
+        for (i_sep, i_bn, ci, co) in blk.unit_index:
+            sep, bn = getattr(blk.rep, str(i_sep)), getattr(blk.rep, str(i_bn))
+            ps += [sep.conv1.weight, sep.pointwise.weight, bn.weight, bn.bias]
+    for sep, bn in ((model.conv3, model.bn3), (model.conv4, model.bn4)):
+        ps += [sep.conv1.weight, sep.pointwise.weight, bn.weight, bn.bias]
+    return ps
+
+
+def _total_channels(model):
+    c = 32 + 64 + 1536 + 2048
+    for blk in model.blocks():
+        if blk.skip is not None:
+            c += blk.cfg[2]
+        c += sum(co for (_, _, _, co) in blk.unit_index)
+    return c
+
+
+def _finalize(lib, bn_mod, ctx, count, training, gamma, beta):
+    ctx.count = float(count)
+    L.check(lib.mt_bn_finalize(L.ptr(ctx.stats), SLOTS, float(count), L.ptr(gamma), L.ptr(beta), L.ptr(bn_mod.running_mean),
+                               L.ptr(bn_mod.running_var), L.ptr(ctx.scale), L.ptr(ctx.shift), L.ptr(ctx.mean_invstd), ctx.C,
+                               bn_mod.eps, bn_mod.momentum, 1 if training else 0, L.stream_ptr()), "mt_bn_finalize")
+    if training:
+        bn_mod.num_batches_tracked += 1
+
+
+def xception_forward(model, x, params, training, save):
+    lib = L.get()
+    dev = x.device
+    N, H, W, _ = x.shape
+    pool = _StatsPool(dev, _total_channels(model)) if training else None
+    consts = _Consts(dev)
+    epi = L.EPI_STATS if training else L.EPI_STORE
+    it = iter(params)
+    saved = {"x": x, "blocks": [], "consts": consts} if save else None
+
+    def pack(w, Co, Ci, k, ld, transpose=0):
+        out = _new(dev, Ci if transpose else Co, ld)
+        L.check(lib.mt_conv_weight_pack(L.ptr(w), L.ptr(out), Co, Ci, k, ld, transpose, L.stream_ptr()), "mt_conv_weight_pack")
+        return out
+
+    def conv_im2col(src, wp, Cout, K, geom, bn_mod, gamma, beta):
+        """z = im2col(act(affine(src))) . wp^T  (+ BatchNorm statistics)."""
+        Hh, Ww, Cc, Ho, Wo, k, s_, p_ = geom
+        M = N * Ho * Wo
+        ctx = _BNCtx(dev, Cout, training, pool)
+        z = _new(dev, M, Cout)
+        L.gemm(L.OP_NT, src.t, wp, z, M, Cout, K, K, K, Cout, prologue=L.PRO_IM2COL, epilogue=epi, scale=src.scale, shift=src.shift,
+               stats=ctx.stats, stats_slots=SLOTS, conv=(Hh, Ww, Cc, Ho, Wo, k, s_, p_, src.act))
+        _finalize(lib, bn_mod, ctx, M, training, gamma, beta)
+        return z, ctx
+
+    def sep_unit(src, act, w_dw, w_pw, co, bn_mod, gamma, beta):
+        """[act] -> depthwise 3x3 pad 1 -> pointwise 1x1 -> BatchNorm (xception.py:17-27, 44-58)."""
+        Hh, ci = src.H, src.C
+        M = N * Hh * Hh
+        sc, sh = (src.scale, src.shift) if src.scale is not None else consts.ident(ci)
+        eff = RELU if (act == RELU or src.act == RELU) else NONE
+        d = _new(dev, M, ci)
+        L.check(lib.mt_dwconv_fwd(L.ptr(src.t), L.ptr(sc), L.ptr(sh), L.ptr(w_dw), L.ptr(d), None, SLOTS, N, Hh, Hh, ci, 3, 1, eff,
+                                  L.stream_ptr()), "mt_dwconv_fwd")
+        ctx = _BNCtx(dev, co, training, pool)
+        z = _new(dev, M, co)
+        L.gemm(L.OP_NT, d, w_pw, z, M, co, ci, ci, ci, co, epilogue=epi, stats=ctx.stats, stats_slots=SLOTS)
+        _finalize(lib, bn_mod, ctx, M, training, gamma, beta)
+        rec = dict(src=src, eff=eff, sc=sc, sh=sh, d=d, z=z, bn=ctx, ci=ci, co=co, H=Hh) if save else None
+        return _Src(z, co, Hh, ctx.scale, ctx.shift, NONE, ctx), rec
+
+    # ---- conv1 (3x3 s2 p0, 3 -> 32) and conv2 (3x3 s1 p0, 32 -> 64) as im2col GEMMs
+    w1, g1, b1, w2, g2, b2 = next(it), next(it), next(it), next(it), next(it), next(it)
+    H1 = (H - 3) // 2 + 1
+    wp1 = pack(w1, 32, 3, 3, 28)
+    z1, bn1 = conv_im2col(_Src(x, 3, H), wp1, 32, 28, (H, W, 3, H1, H1, 3, 2, 0), model.bn1, g1, b1)
+    s1 = _Src(z1, 32, H1, bn1.scale, bn1.shift, RELU, bn1)
+    H2 = H1 - 2
+    wp2 = pack(w2, 64, 32, 3, 288)
+    z2, bn2 = conv_im2col(s1, wp2, 64, 288, (H1, H1, 32, H2, H2, 3, 1, 0), model.bn2, g2, b2)
+    cur = _Src(z2, 64, H2, bn2.scale, bn2.shift, RELU, bn2)
+    if save:
+        saved.update(z1=z1, bn1=bn1, s1=s1, z2=z2, bn2=bn2, H1=H1, H2=H2)
+
+    # ---- blocks
+    for blk in model.blocks():
+        name, cin, cout, reps, stride, srelu, grow = blk.cfg
+        inp = cur
+        brec = {"inp": inp, "units": [], "stride": stride}
+        if blk.skip is not None:
+            w_s, g_s, b_s = next(it), next(it), next(it)
+        src = cur
+        for u, (i_sep, i_bn, ci, co) in enumerate(blk.unit_index):
+            w_dw, w_pw, g, b = next(it), next(it), next(it), next(it)
+            act = RELU if (u > 0 or srelu) else NONE
+            src, rec = sep_unit(src, act, w_dw, w_pw, co, getattr(blk.rep, str(i_bn)), g, b)
+            brec["units"].append(rec)
+        Hin = inp.H
+        if stride != 1:
+            Ho = (Hin - 1) // 2 + 1
+            z_s, bn_s = conv_im2col(inp, w_s.view(cout, cin), cout, cin, (Hin, Hin, cin, Ho, Ho, 1, 2, 0), blk.skipbn, g_s, b_s)
+            y = _new(dev, N * Ho * Ho, cout)
+            L.check(lib.mt_maxpool_add_fwd(L.ptr(src.t), L.ptr(src.scale), L.ptr(src.shift), L.ptr(z_s), L.ptr(bn_s.scale),
+                                           L.ptr(bn_s.shift), L.ptr(y), N, Hin, Hin, cout, L.stream_ptr()), "mt_maxpool_add_fwd")
+            brec.update(z_s=z_s, bn_s=bn_s, Ho=Ho)
+            cur = _Src(y, cout, Ho)
+        else:
+            y = _new(dev, N * Hin * Hin, cout)
+            L.check(lib.mt_bn_act_fwd(L.ptr(src.t), L.ptr(src.scale), L.ptr(src.shift), L.ptr(inp.t), L.ptr(y), N * Hin * Hin, cout, 0,
+                                      None, 1, L.stream_ptr()), "mt_bn_act_fwd")
+            cur = _Src(y, cout, Hin)
+        if save:
+            saved["blocks"].append(brec)
+
+    # ---- conv3 / conv4 tail
+    tail = []
+    for k_, (sep_mod, bn_mod, co, act) in enumerate(((model.conv3, model.bn3, 1536, NONE), (model.conv4, model.bn4, 2048, RELU))):
+        w_dw, w_pw, g, b = next(it), next(it), next(it), next(it)
+        cur, rec = sep_unit(cur, act, w_dw, w_pw, co, bn_mod, g, b)
+        tail.append(rec)
+    M = N * cur.H * cur.H
+    feat = _new(dev, M, 2048)
+    L.check(lib.mt_bn_act_fwd(L.ptr(cur.t), L.ptr(cur.scale), L.ptr(cur.shift), None, L.ptr(feat), M, 2048, 0, None, 1, L.stream_ptr()),
+            "mt_bn_act_fwd")
+    if save:
+        saved["tail"] = tail
+    return feat, saved, cur.H
+
+
+def xception_backward(model, params, saved, shape, training, dfeat, need_dparams):
+    lib = L.get()
+    dev = dfeat.device
+    N, H, W = shape
+    P = list(params)
+    grads = L.zero_grads(P)
+    consts = saved["consts"]
+    pool = _StatsPool(dev, 2 * _total_channels(model) + 4096)
+    tr = 1 if training else 0
+    side = L.SideStream(dev)
+    # parameter index map
+    pos = 6
+    bmap = []
+    for blk in model.blocks():
+        d = {}
+        if blk.skip is not None:
+            d["skip"] = pos
+            pos += 3
+        d["units"] = []
+        for _ in blk.unit_index:
+            d["units"].append(pos)
+            pos += 4
+        bmap.append(d)
+    tail_idx = [pos, pos + 4]
+
+    def bn_sums(g, z, ctx, rows, act=0, dout=None):
+        sums = pool.take(ctx.C)
+        L.check(lib.mt_bn_act_bwd(L.ptr(g), L.ptr(z), L.ptr(ctx.scale), L.ptr(ctx.shift), L.ptr(ctx.mean_invstd), None, None, None,
+                                  L.ptr(dout), L.ptr(sums), SLOTS, rows, ctx.C, 1, act, L.stream_ptr()), "mt_bn_act_bwd")
+        return sums
+
+    def bn_kabc(ctx, sums, gi):
+        kabc = _new(dev, 3, ctx.C)
+        L.check(lib.mt_bn_bwd_finalize(L.ptr(sums), SLOTS, ctx.count, L.ptr(P[gi]), L.ptr(ctx.mean_invstd), L.ptr(kabc), L.ptr(grads[gi]),
+                                       L.ptr(grads[gi + 1]), ctx.C, tr, L.stream_ptr()), "mt_bn_bwd_finalize")
+        return kabc
+
+    def unit_backward(rec, pi, g, sums, res_pre=None, res_post=None):
+        """g = gradient w.r.t. this unit's BatchNorm output (sums already accumulated when `sums` is given).
+        Returns (gradient w.r.t. the source's affine output [activation derivative applied], its BN sums or None)."""
+        ci, co, Hh = rec["ci"], rec["co"], rec["H"]
+        M = N * Hh * Hh
+        if sums is None:
+            sums = bn_sums(g, rec["z"], rec["bn"], M)
+        kabc = bn_kabc(rec["bn"], sums, pi + 2)
+        w_dw, w_pw = P[pi], P[pi + 1]
+        # pointwise: z = d . Wpw^T
+        side.launch(lambda: L.gemm(L.OP_TN, g, rec["d"], grads[pi + 1], co, ci, M, co, ci, ci, prologue=L.PRO_BN_BWD,
+                                   epilogue=L.EPI_ATOMIC, split_k=0, A2=rec["z"], scale=kabc[0], shift=kabc[1], gate=kabc[2]),
+                    reads=(g, rec["d"], rec["z"], kabc))
+        dd = _new(dev, M, ci)
+        L.gemm(L.OP_NN, g, w_pw, dd, M, ci, co, co, ci, ci, prologue=L.PRO_BN_BWD, A2=rec["z"], scale=kabc[0], shift=kabc[1], gate=kabc[2])
+        # depthwise: d = dw(act(affine(src)))
+        src = rec["src"]
+        kid = consts.kabc_ident(ci)
+        has_bn = src.bn is not None
+        sums_in = pool.take(ci) if has_bn else None
+        du_in = _new(dev, M, ci)
+
+        def dw_part(parts):
+            L.check(lib.mt_dwconv_bwd(L.ptr(dd), L.ptr(dd), L.ptr(kid), L.ptr(w_dw), L.ptr(src.t), L.ptr(rec["sc"]), L.ptr(rec["sh"]),
+                                      L.ptr(src.bn.mean_invstd) if has_bn else None, L.ptr(du_in), L.ptr(sums_in), SLOTS,
+                                      L.ptr(grads[pi]), N, Hh, Hh, ci, 3, 1, parts, rec["eff"], L.ptr(res_pre), L.ptr(res_post),
+                                      L.stream_ptr()), "mt_dwconv_bwd")
+        side.launch(lambda: dw_part(1), reads=(dd, kid, src.t, rec["sc"], rec["sh"]))
+        dw_part(2)
+        return du_in, sums_in
+
+    # ---- tail: feat = bn4(z4); conv4 consumes relu(bn3(z3)); conv3 consumes y12 (no relu)
+    t3, t4 = saved["tail"]
+    g, sums = unit_backward(t4, tail_idx[1], dfeat, None)            # -> grad wrt bn3 output (+ bn3 sums)
+    dy, _ = unit_backward(t3, tail_idx[0], g, sums)                  # -> grad wrt y12
+
+    # ---- blocks, last to first
+    blocks = model.blocks()
+    for bi in reversed(range(len(blocks))):
+        blk, brec, bm = blocks[bi], saved["blocks"][bi], bmap[bi]
+        name, cin, cout, reps, stride, srelu, grow = blk.cfg
+        inp = brec["inp"]
+        units = brec["units"]
+        last = units[-1]
+        Hin = inp.H
+        res_pre = res_post = None
+        if stride != 1:
+            Ho = brec["Ho"]
+            Mo = N * Ho * Ho
+            # skip path: y += skipbn(z_s), z_s = conv1x1_s2(value of inp)
+            ks = bn_kabc(brec["bn_s"], bn_sums(dy, brec["z_s"], brec["bn_s"], Mo), bm["skip"] + 1)
+            geom = (Hin, Hin, cin, Ho, Ho, 1, 2, 0, inp.act)
+            side.launch(lambda dy=dy, ks=ks, brec=brec, geom=geom, inp=inp, gi=bm["skip"]:
+                        L.gemm(L.OP_TN, dy, inp.t, grads[gi].view(cout, cin), cout, cin, Mo, cout, cin, cin, prologue=L.PRO_BN_BWD,
+                               epilogue=L.EPI_ATOMIC, split_k=0, A2=brec["z_s"], scale=ks[0], shift=ks[1], gate=ks[2],
+                               b_prologue=L.BPRO_IM2COL, b_scale=inp.scale, b_shift=inp.shift, conv=geom),
+                        reads=(dy, inp.t, brec["z_s"], ks))
+            d_small = _new(dev, Mo, cin)
+            L.gemm(L.OP_NN, dy, P[bm["skip"]].view(cout, cin), d_small, Mo, cin, cout, cout, cin, cin, prologue=L.PRO_BN_BWD,
+                   A2=brec["z_s"], scale=ks[0], shift=ks[1], gate=ks[2])
+            # scatter to the strided positions (2oh, 2ow) of an input-sized zero tensor
+            d_skip = torch.zeros(N, Hin, Hin, cin, dtype=torch.float32, device=dev)
+            d_skip[:, ::2, ::2, :] = d_small.view(N, Ho, Ho, cin)
+            d_skip = d_skip.view(N * Hin * Hin, cin)
+            if inp.bn is not None or inp.act == RELU:
+                res_pre = d_skip          # the skip conv consumed the same activated tensor as the first unit
+            else:
+                res_post = d_skip         # the skip conv consumed the raw block input, the first unit relu(input)
+            # main path: y += maxpool(bn(z_last))
+            du_last = torch.zeros(N * Hin * Hin, cout, dtype=torch.float32, device=dev)
+            L.check(lib.mt_maxpool_bwd(L.ptr(dy), L.ptr(last["z"]), L.ptr(last["bn"].scale), L.ptr(last["bn"].shift), L.ptr(du_last), N,
+                                       Hin, Hin, cout, L.stream_ptr()), "mt_maxpool_bwd")
+            g, sums = du_last, None
+        else:
+            g, sums = dy, None
+            res_post = dy                 # identity skip: y = bn(z_last) + inp
+        for u in reversed(range(len(units))):
+            first = u == 0
+            g, sums = unit_backward(units[u], bm["units"][u], g, sums, res_pre if first else None, res_post if first else None)
+        # for block1 the result is the gradient w.r.t. bn2's output (sums accumulated); otherwise w.r.t. the previous block's y
+        dy = g
+        bn2_sums = sums
+        brec.clear()
+
+    # ---- conv2 / conv1
+    z1, z2, bn1, bn2, s1 = saved["z1"], saved["z2"], saved["bn1"], saved["bn2"], saved["s1"]
+    H1, H2 = saved["H1"], saved["H2"]
+    M1, M2 = N * H1 * H1, N * H2 * H2
+    k2 = bn_kabc(bn2, bn2_sums, 4)
+    dwp2 = torch.zeros(64, 288, dtype=torch.float32, device=dev)
+    geom2 = (H1, H1, 32, H2, H2, 3, 1, 0, RELU)
+    L.gemm(L.OP_TN, dy, z1, dwp2, 64, 288, M2, 64, 288, 288, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC, split_k=0, A2=z2, scale=k2[0],
+           shift=k2[1], gate=k2[2], b_prologue=L.BPRO_IM2COL, b_scale=bn1.scale, b_shift=bn1.shift, conv=geom2)
+    L.check(lib.mt_conv_weight_unpack_grad(L.ptr(dwp2), L.ptr(grads[3]), 64, 32, 3, 288, L.stream_ptr()), "mt_conv_weight_unpack_grad")
+    dz2 = _new(dev, M2, 64)
+    L.check(lib.mt_bn_bwd_apply(L.ptr(dy), L.ptr(z2), L.ptr(k2), L.ptr(dz2), M2, 64, L.stream_ptr()), "mt_bn_bwd_apply")
+    # data gradient of conv2 = "full" correlation of dz2 with the flipped kernel: im2col(dz2, pad 2) . W2flip^T
+    wp2t = _new(dev, 32, 576)
+    L.check(lib.mt_conv_weight_pack(L.ptr(P[3]), L.ptr(wp2t), 64, 32, 3, 576, 1, L.stream_ptr()), "mt_conv_weight_pack")
+    da1 = _new(dev, M1, 32)
+    L.gemm(L.OP_NT, dz2, wp2t, da1, M1, 32, 576, 576, 576, 32, prologue=L.PRO_IM2COL, conv=(H2, H2, 64, H1, H1, 3, 1, 2, NONE))
+    du1 = _new(dev, M1, 32)
+    k1 = bn_kabc(bn1, bn_sums(da1, z1, bn1, M1, act=RELU, dout=du1), 1)
+    dwp1 = torch.zeros(32, 28, dtype=torch.float32, device=dev)
+    L.gemm(L.OP_TN, du1, saved["x"], dwp1, 32, 28, M1, 32, 28, 28, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC, split_k=0, A2=z1,
+           scale=k1[0], shift=k1[1], gate=k1[2], b_prologue=L.BPRO_IM2COL, conv=(H, W, 3, H1, H1, 3, 2, 0, NONE))
+    L.check(lib.mt_conv_weight_unpack_grad(L.ptr(dwp1), L.ptr(grads[0]), 32, 3, 3, 28, L.stream_ptr()), "mt_conv_weight_unpack_grad")
+    side.wait()
+    return [g_ if need else None for need, g_ in zip(need_dparams, grads)]
+
+
+class _XceptionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x_nhwc, *params):
+        save = any(ctx.needs_input_grad)
+        feat, saved, ho = xception_forward(model, x_nhwc, params, model.training, save)
+        ctx.model, ctx.saved, ctx.params, ctx.training = model, saved, params, model.training
+        N, H, W, _ = x_nhwc.shape
+        ctx.shape = (N, H, W)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("gradient w.r.t. the input crops is not part of the MINTIME training path")
+        dparams = xception_backward(ctx.model, ctx.params, ctx.saved, ctx.shape, ctx.training, dfeat.contiguous(),
+                                    ctx.needs_input_grad[2:])
+        ctx.saved = None
+        return (None, None) + tuple(dparams)
+
+
+def xception_apply(model, inputs):
+    if not inputs.is_cuda:
+        raise L.MintimeHipError("Xception (MI355X build) needs device tensors; there is no CPU path")
+    if inputs.dim() != 4 or inputs.shape[1] != 3:
+        raise ValueError(f"expected [N,3,H,W] input, got {tuple(inputs.shape)}")
+    x = inputs.float().permute(0, 2, 3, 1)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    feat = _XceptionFunction.apply(model, x, *param_list(model))
+    n = inputs.shape[0]
+    ho = feat.shape[0] // n
+    side = int(round(ho ** 0.5))
+    return feat.view(n, side, side, 2048).permute(0, 3, 1, 2)

@@ -116,6 +116,81 @@ def effnet_b0_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bo
 
 
 # --------------------------------------------------------------------------------------------
+# Xception (config 5 extractor)
+# --------------------------------------------------------------------------------------------
+_XC_BLOCKS = [  # (name, cin, cout, reps, stride, start_with_relu, grow_first)    models/xception.py:113-129
+    ("block1", 64, 128, 2, 2, False, True), ("block2", 128, 256, 2, 2, True, True), ("block3", 256, 728, 2, 2, True, True),
+    *[(f"block{i}", 728, 728, 3, 1, True, True) for i in range(4, 12)],
+    ("block12", 728, 1024, 2, 2, True, False)]
+_XC_BN_EPS, _XC_BN_MOM = 1e-5, 0.1   # nn.BatchNorm2d defaults (xception.py:97)
+
+
+def _xc_bn(x, sd, prefix, training, bn_state):
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    if not training:
+        return F.batch_norm(x, rm, rv, w, b, False, _XC_BN_MOM, _XC_BN_EPS)
+    rm2, rv2 = rm.detach().clone(), rv.detach().clone()
+    y = F.batch_norm(x, rm2, rv2, w, b, True, _XC_BN_MOM, _XC_BN_EPS)
+    if bn_state is not None:
+        bn_state.updates[prefix + ".running_mean"] = rm2
+        bn_state.updates[prefix + ".running_var"] = rv2
+    return y
+
+
+def _xc_sep(x, sd, prefix):
+    """SeparableConv2d (xception.py:17-27): depthwise 3x3 pad 1, then pointwise 1x1; no norm/activation in between."""
+    x = F.conv2d(x, sd[prefix + ".conv1.weight"], None, 1, 1, 1, x.shape[1])
+    return F.conv2d(x, sd[prefix + ".pointwise.weight"])
+
+
+def xception_block_units(cin, cout, reps, grow_first):
+    """Channel plan of a Block's separable convs (xception.py:44-58)."""
+    units = []
+    filters = cin
+    if grow_first:
+        units.append((cin, cout))
+        filters = cout
+    for _ in range(reps - 1):
+        units.append((filters, filters))
+    if not grow_first:
+        units.append((cin, cout))
+    return units
+
+
+def xception_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool = False,
+                     bn_state: Optional[BNState] = None, taps: Optional[dict] = None):
+    """x [N,3,224,224] -> bn4 output [N,2048,7,7] WITHOUT the final ReLU (xception.py:161-203, 215-217)."""
+    x = F.relu(_xc_bn(F.conv2d(x, sd["conv1.weight"], None, 2, 0), sd, "bn1", training, bn_state))
+    x = F.relu(_xc_bn(F.conv2d(x, sd["conv2.weight"], None, 1, 0), sd, "bn2", training, bn_state))
+    for (name, cin, cout, reps, stride, start_relu, grow_first) in _XC_BLOCKS:
+        inp = x
+        units = xception_block_units(cin, cout, reps, grow_first)
+        # rep = [ReLU, Sep, BN] per unit (first ReLU dropped when not start_with_relu), then MaxPool(3, stride, 1) if stride != 1.
+        # Sequential indices: with start_with_relu units sit at rep.1, rep.4, rep.7 (BN at +1); without, at rep.0, rep.3.
+        idx = 0
+        for u in range(len(units)):
+            if u > 0 or start_relu:
+                x = F.relu(x)
+                idx += 1
+            x = _xc_sep(x, sd, f"{name}.rep.{idx}")
+            x = _xc_bn(x, sd, f"{name}.rep.{idx + 1}", training, bn_state)
+            idx += 2
+        if stride != 1:
+            x = F.max_pool2d(x, 3, stride, 1)
+        if cout != cin or stride != 1:
+            skip = _xc_bn(F.conv2d(inp, sd[f"{name}.skip.weight"], None, stride), sd, f"{name}.skipbn", training, bn_state)
+        else:
+            skip = inp
+        x = x + skip
+        if taps is not None:
+            taps[name] = x
+    x = F.relu(_xc_bn(_xc_sep(x, sd, "conv3"), sd, "bn3", training, bn_state))
+    x = _xc_bn(_xc_sep(x, sd, "conv4"), sd, "bn4", training, bn_state)
+    return x
+
+
+# --------------------------------------------------------------------------------------------
 # Size-Invariant TimeSformer
 # --------------------------------------------------------------------------------------------
 

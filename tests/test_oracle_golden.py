@@ -141,3 +141,35 @@ def test_state_dict_manifest_matches_reference():
         spec = arch.tsf_state_spec(arch.default_tsf_config(c, f))
         ref = man[f"tsf_c{c}_f{f}"]
         assert sorted([k, list(s)] for k, s, _ in spec) == sorted([k, s] for k, s, _ in ref)
+
+
+@pytest.mark.parametrize("name", ["xc_eval", "xc_train"])
+def test_xception_matches_reference(name):
+    g = golden(name)
+    n, training, seed = int(g["n_img"]), bool(g["training"]), int(g["seed"])
+    sd = synth.xception_state(seed)
+    x = synth.clip_inputs(1, n, 1, seed)["videos"].reshape(n, 224, 224, 3).permute(0, 3, 1, 2)
+    assert abs(checksum(x) - float(g["input_sum"])) < 1e-9 * abs(float(g["input_sum"]))
+    taps, st = {}, O.BNState()
+    with torch.no_grad():
+        feats = O.xception_forward(sd, x, training=training, bn_state=st, taps=taps)
+    assert_close(feats, g["features"], 1e-4, "xception features")
+    for i in (1, 3, 7, 12):
+        assert_close(taps[f"block{i}"].mean(dim=(0, 2, 3)), g[f"block{i}_mean"], 1e-4, f"block{i} mean")
+        assert_close(taps[f"block{i}"][0, :, :3, :3], g[f"block{i}_slice"], 1e-4, f"block{i} slice")
+    if training:
+        for k in g.files:
+            if k.startswith("stat."):
+                assert_close(st.updates[k[5:]], g[k], 1e-5, k)
+    # gradients in float64 against the reference's float64 pass
+    sd64 = {k: (v.double().requires_grad_("running_" not in k and not k.startswith("fc")) if v.is_floating_point() else v)
+            for k, v in sd.items()}
+    gw = torch.from_numpy(np.random.Generator(np.random.Philox(key=[seed, 4242])).standard_normal((n, 2048, 7, 7)) * 0.1)
+    out = O.xception_forward(sd64, x.double(), training=training)
+    assert_close(out[:, :256], g["feat64_slice"], 1e-9, "fp64 features")
+    (out * gw).sum().backward()
+    for k in g.files:
+        if k.startswith("gnorm64."):
+            key = k[len("gnorm64."):]
+            assert_close(sd64[key].grad.norm(), g[k], 1e-8, k)
+            assert_close(sd64[key].grad.reshape(-1)[:256], g["gslice64." + key], 1e-8, "gslice64." + key)

@@ -194,6 +194,58 @@ def e2e_case(EF, TSF, name, batch, frames, identities, ragged, training, seed):
          training=int(training), seed=seed, **out)
 
 
+def xc_case(name, n_img, training, seed):
+    from models.xception import xception as ref_xception      # resolved from /root/reference by import_reference()
+    import contextlib, io
+    model = ref_xception(num_classes=1, pretrain_path=None)
+    sd = synth.xception_state(seed)
+    model.load_state_dict(sd, strict=True)
+    model.train(training)
+    vid = synth.clip_inputs(1, n_img, 1, seed)["videos"]
+    x = vid.reshape(n_img, 224, 224, 3).permute(0, 3, 1, 2)
+    taps = {}
+    hooks = [getattr(model, f"block{i}").register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(i, o.detach().clone()))
+             for i in (1, 3, 7, 12)]
+    with torch.no_grad():
+        feats = model(x)
+    for h in hooks:
+        h.remove()
+    extra = {}
+    if training:
+        msd = model.state_dict()
+        for k in ("bn1.running_mean", "bn2.running_var", "block1.skipbn.running_var", "block5.rep.5.running_mean", "bn4.running_var"):
+            extra["stat." + k] = msd[k].clone()
+    m64 = ref_xception(num_classes=1, pretrain_path=None)
+    m64.load_state_dict(sd, strict=True)
+    m64.train(training).double()
+    with torch.no_grad():
+        feats64 = m64(x.double())
+    # backward sample: d(sum(feats * w)) for a few parameters (fp64 pass = the exact arithmetic)
+    model.train(training)
+    for prm in m64.parameters():
+        prm.grad = None
+    gw = torch.from_numpy(np.random.Generator(np.random.Philox(key=[seed, 4242])).standard_normal((n_img, 2048, 7, 7)) * 0.1)
+    m64.load_state_dict(sd, strict=True)   # reset running stats the first pass updated
+    out = m64(x.double())
+    (out * gw).sum().backward()
+    named = dict(m64.named_parameters())
+    grads = {}
+    for key in GRAD_KEYS_XC:
+        gg = named[key].grad
+        grads["gnorm64." + key] = gg.norm()
+        grads["gslice64." + key] = gg.reshape(-1)[:256].clone()
+    save(name, features=feats, feat64_mean=feats64.mean(dim=(0, 2, 3)), feat64_slice=feats64[:, :256].clone(), input_sum=checksum(x),
+         **{f"block{i}_mean": taps[i].mean(dim=(0, 2, 3)) for i in taps},
+         **{f"block{i}_slice": taps[i][0, :, :3, :3].clone() for i in taps},
+         n_img=n_img, training=int(training), seed=seed, **extra, **grads)
+
+
+GRAD_KEYS_XC = ["conv1.weight", "bn1.weight", "conv2.weight", "bn2.bias", "block1.skip.weight", "block1.skipbn.weight",
+                "block1.rep.0.conv1.weight", "block1.rep.0.pointwise.weight", "block1.rep.4.weight", "block3.rep.4.conv1.weight",
+                "block6.rep.4.pointwise.weight", "block6.rep.8.bias", "block12.rep.4.pointwise.weight", "block12.skip.weight",
+                "conv3.conv1.weight", "bn3.weight", "conv4.pointwise.weight", "bn4.weight", "bn4.bias"]
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
@@ -209,6 +261,15 @@ def main():
         json.dump(man, fh)
     print("wrote state_manifest.json")
 
+    from models.xception import xception as _xc
+    man["xception"] = [[k, list(v.shape), str(v.dtype)] for k, v in _xc(num_classes=1).state_dict().items()]
+    with open(os.path.join(OUT, "state_manifest.json"), "w") as fh:
+        json.dump(man, fh)
+    if os.environ.get("GOLDEN_ONLY", "") in ("", "xc"):
+        xc_case("xc_eval", n_img=2, training=False, seed=0)
+        xc_case("xc_train", n_img=3, training=True, seed=1)
+    if os.environ.get("GOLDEN_ONLY", "") == "xc":
+        return
     tsf_case(TSF, "tsf_cfg1", batch=2, frames=8, channels=1280, identities=1, ragged=False, seed=0)
     tsf_case(TSF, "tsf_2id_ragged", batch=2, frames=8, channels=1280, identities=2, ragged=True, seed=1)
     tsf_case(TSF, "tsf_xs_3id", batch=1, frames=16, channels=2048, identities=3, ragged=True, seed=2)
