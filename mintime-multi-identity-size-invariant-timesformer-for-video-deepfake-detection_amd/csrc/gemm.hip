@@ -130,6 +130,18 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
     COMBO(MT_OP_TN, LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_ATOMIC)
     return fail(MT_ERR_UNSUPPORTED, "mt_gemm TN: unsupported prologue/epilogue %d/%d", d->prologue, d->epilogue);
   }
+  if (d->epilogue == MT_EPI_ATOMIC && (d->op == MT_OP_NT || d->op == MT_OP_NN)) {
+    // split-K with fp32 atomics into a caller-initialised C: evens out the tail of skinny problems (e.g. 396 tiles on 256 CUs)
+    int splits = d->split_k > 0 ? d->split_k : 1;
+    int chunk = (d->K + splits - 1) / splits;
+    chunk = (chunk + MT_BK - 1) / MT_BK * MT_BK;
+    splits = (d->K + chunk - 1) / chunk;
+    a.k_chunk = chunk;
+    grid.y = splits;
+    COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_NONE, EPI_ATOMIC)
+    COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_ATOMIC)
+    return fail(MT_ERR_UNSUPPORTED, "mt_gemm: split-K atomic epilogue only without prologue");
+  }
   COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_NONE, EPI_STORE)
   COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_NONE, EPI_BIAS_RES)
   COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_NONE, EPI_GEGLU)

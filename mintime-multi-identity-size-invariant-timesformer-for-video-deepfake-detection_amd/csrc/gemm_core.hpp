@@ -25,7 +25,7 @@
 #define MT_BK 16
 #endif
 #ifndef MT_MIN_WAVES
-#define MT_MIN_WAVES 1
+#define MT_MIN_WAVES 3
 #endif
 #ifndef MT_ROWMAJOR_LDS
 #define MT_ROWMAJOR_LDS 0
@@ -58,7 +58,7 @@ enum : int {
   EPI_BIAS_RES = 1,     // C = acc + bias[n] + R[m,n]
   EPI_GEGLU = 2,        // h[m,j] = (acc_a+ba[j]) * gelu(acc_g+bg[j]);  optional u store (pre-activations)
   EPI_STATS = 3,        // C = acc ; per-column sum / sum-of-squares accumulated in fp64 (BatchNorm batch statistics)
-  EPI_ATOMIC = 4,       // C += acc via fp32 atomics (split-K wgrad); C must be pre-zeroed or hold a partial
+  EPI_ATOMIC = 4,       // C += acc (+bias on the first K-slice) via fp32 atomics (split-K); C pre-zeroed or holding the residual
   EPI_GEGLU_BWD = 5,    // acc = dh[m,j]; du[m,j] = dh*gelu(g), du[m,Nh+j] = dh*a*gelu'(g)   (a,g from u)
   EPI_ACCUM = 6,        // C = C + acc (+bias)  -- gradient accumulation into an existing tensor
 };
@@ -446,6 +446,8 @@ void gemm_kernel(const GemmArgs p) {
       float bias = 0.f;
       if constexpr (EPI == EPI_STORE || EPI == EPI_BIAS_RES || EPI == EPI_ACCUM)
         bias = (nok && p.bias) ? p.bias[n] : 0.f;
+      if constexpr (EPI == EPI_ATOMIC)      // split-K: the bias rides on the first K-slice only
+        bias = (nok && p.bias && blockIdx.y == 0) ? p.bias[n] : 0.f;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -465,7 +467,7 @@ void gemm_kernel(const GemmArgs p) {
               p.C[crow * p.ldc + n] = v;
               s1 += v; s2 += v * v;
             } else if constexpr (EPI == EPI_ATOMIC) {
-              atomicAdd(p.C + crow * p.ldc + n, v);
+              atomicAdd(p.C + crow * p.ldc + n, v + bias);
             } else if constexpr (EPI == EPI_GEGLU_BWD) {
               // n indexes h columns [0, n_half); u = [a | g] pre-activations
               const float a = p.C2[(int64_t)m * p.ldc2 + n];

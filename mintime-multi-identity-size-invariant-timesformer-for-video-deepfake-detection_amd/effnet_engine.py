@@ -75,7 +75,12 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
     Hc, Wc = (H + 1) // 2, (W + 1) // 2
     bn = _BNCtx(dev, arch.STEM_COUT, training, pool)
     z = _new(dev, N * Hc * Wc, arch.STEM_COUT)
-    L.check(lib.mt_stem_conv_fwd(L.ptr(x_nhwc), L.ptr(w_stem), L.ptr(z), L.ptr(bn.stats), SLOTS, N, H, W, st), "mt_stem_conv_fwd")
+    # stem = dense 3x3 s2 conv as an im2col GEMM on the fp32 MFMA path (K = 27 taps padded to 28); TF-SAME pad (0,1) is the
+    # gather's bounds check.  (mt_stem_conv_fwd, the direct kernel, is kept in the ABI but is LDS-read bound: 1.15 ms vs 0.2.)
+    wp = _new(dev, arch.STEM_COUT, 28)
+    L.check(lib.mt_conv_weight_pack(L.ptr(w_stem), L.ptr(wp), arch.STEM_COUT, 3, 3, 28, 0, st), "mt_conv_weight_pack")
+    L.gemm(L.OP_NT, x_nhwc, wp, z, N * Hc * Wc, arch.STEM_COUT, 28, 28, 28, arch.STEM_COUT, prologue=L.PRO_IM2COL, epilogue=epi,
+           stats=bn.stats, stats_slots=SLOTS, conv=(H, W, 3, Hc, Wc, 3, 2, 0, 0))
     _finalize(lib, st, model._bn0, bn, N * Hc * Wc, training, g0, b0)
     if save:
         saved["stem"] = dict(x=x_nhwc, z=z, bn=bn)

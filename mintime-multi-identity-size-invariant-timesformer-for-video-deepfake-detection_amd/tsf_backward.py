@@ -46,6 +46,14 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
     def colsum(A, lda, rows, cols, out, amap=(0, 0, 0)):
         L.check(lib.mt_colsum(L.ptr(A), lda, L.RowMap(*amap), rows, cols, L.ptr(out), L.stream_ptr()), "mt_colsum")
 
+    def dgrad_skinny(dY, Wm, out, K_):
+        """out[M,D] = dY[M,K_] . Wm[K_,D]: only 396 output tiles -> K-slices + fp32 atomics onto a zeroed output when K is long."""
+        if M >= 4096 and K_ >= 1024:
+            out.zero_()
+            L.gemm(L.OP_NN, dY, Wm, out, M, D, K_, K_, D, D, epilogue=L.EPI_ATOMIC, split_k=5 if K_ >= 2048 else 3)
+        else:
+            L.gemm(L.OP_NN, dY, Wm, out, M, D, K_, K_, D, D)
+
     def wgrad(A, Bm, out, M_, N_, K_, lda, ldb, ldc, bias_out=None, **kw):
         """dW (+ db) on the side stream: reads A [K_,M_] and Bm [K_,N_], accumulates into zero-filled grads."""
         def run():
@@ -77,7 +85,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         e_dx = wgrad(dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D, bias_out=grads[i0 + 5])
         L.gemm(L.OP_NN, dx2, w2, du, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D, n_half=4 * D)
         wgrad(du, r["xn"], grads[i0 + 2], 8 * D, D, M, 8 * D, D, D, bias_out=grads[i0 + 3])
-        L.gemm(L.OP_NN, du, w1, dxn, M, D, 8 * D, 8 * D, D, D)
+        dgrad_skinny(du, w1, dxn, 8 * D)
         side.wait(e_dx)                               # LayerNorm backward updates dx2 in place
         L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
                                      L.ptr(grads[i0 + 1]), M, D, 1, st), "mt_layernorm_bwd")
@@ -93,7 +101,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
                                     scale, st), "mt_attn_bwd")
             wgrad(dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
-            L.gemm(L.OP_NN, dqkv, w_qkv, dxn, M, D, 3 * inner, 3 * inner, D, D)
+            dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner)
             side.wait(e_dx)
             L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
                                          L.ptr(grads[i0 + 1]), M, D, 1, st), "mt_layernorm_bwd")

@@ -107,3 +107,45 @@ def test_tn_wgrad(Mrows, N1, N2, split):
     dW = torch.zeros(N1, N2, device="cuda")
     L.gemm(L.OP_TN, dY.cuda(), X.cuda(), dW, N1, N2, Mrows, N1, N2, N2, epilogue=L.EPI_ATOMIC, split_k=split)
     assert_close(dW, dY.double().T @ X.double(), 5e-5, "TN")
+
+
+@pytest.mark.parametrize("op", ["NT", "NN"])
+def test_split_k_atomic_onto_initialised_output(op):
+    """The skinny-GEMM path of the engines: K-slices accumulated with fp32 atomics onto a residual (bias on slice 0)."""
+    M, N, K = 1500, 512, 2048
+    A, b, R = _rand(M, K, seed=1), _rand(N, seed=3), _rand(M, N, seed=4)
+    if op == "NT":
+        W = _rand(N, K, seed=2, scale=0.05)
+        Cd = R.cuda().clone()
+        L.gemm(L.OP_NT, A.cuda(), W.cuda(), Cd, M, N, K, K, K, N, epilogue=L.EPI_ATOMIC, bias=b.cuda(), split_k=5)
+        ref = R.double() + b.double() + A.double() @ W.double().T
+    else:
+        W = _rand(K, N, seed=2, scale=0.05)
+        Cd = torch.zeros(M, N, device="cuda")
+        L.gemm(L.OP_NN, A.cuda(), W.cuda(), Cd, M, N, K, K, N, N, epilogue=L.EPI_ATOMIC, split_k=3)
+        ref = A.double() @ W.double()
+    assert_close(Cd, ref, TOL, "split-K " + op)
+
+
+def test_im2col_conv_matches_torch_conv():
+    """Dense convolution as a GEMM with the im2col prologue (Xception conv1/conv2, EfficientNet stem, strided 1x1 skip)."""
+    import torch.nn.functional as F
+    lib = L.get()
+    for (Cin, Cout, k, s, p, H, relu) in ((3, 32, 3, 2, 0, 37, False), (32, 64, 3, 1, 0, 21, True), (64, 128, 1, 2, 0, 19, False),
+                                          (64, 32, 3, 1, 2, 11, False)):
+        n = 2
+        x = _rand(n, H, H, Cin, seed=1)
+        w = _rand(Cout, Cin, k, k, seed=2, scale=0.2)
+        sc, sh = _rand(Cin, seed=3).abs() + 0.5, _rand(Cin, seed=4, scale=0.3)
+        Ho = (H + 2 * p - k) // s + 1
+        K = (k * k * Cin + 3) // 4 * 4
+        wp = torch.empty(Cout, K, device="cuda")
+        L.check(lib.mt_conv_weight_pack(L.ptr(w.cuda()), L.ptr(wp), Cout, Cin, k, K, 0, L.stream_ptr()), "pack")
+        out = torch.empty(n * Ho * Ho, Cout, device="cuda")
+        L.gemm(L.OP_NT, x.cuda(), wp, out, n * Ho * Ho, Cout, K, K, K, Cout, prologue=L.PRO_IM2COL, scale=sc.cuda(), shift=sh.cuda(),
+               conv=(H, H, Cin, Ho, Ho, k, s, p, 2 if relu else 0))
+        a = x.double() * sc.double() + sh.double()
+        if relu:
+            a = a.clamp_min(0)
+        ref = F.conv2d(a.permute(0, 3, 1, 2), w.double(), None, s, p).permute(0, 2, 3, 1).reshape(n * Ho * Ho, Cout)
+        assert_close(out, ref, 5e-5, f"im2col conv {Cin}->{Cout} k{k} s{s} p{p}")

@@ -104,16 +104,18 @@ def test_backward_matches_reference_fixture(name):
     assert_close(x.grad.permute(0, 1, 3, 4, 2).reshape(-1)[:512], g["dfeats_slice"], 2 * REL_TOL, "dfeats slice")
 
 
-def test_backward_all_parameters_vs_oracle():
-    """Every parameter gradient (not just the fixture's sample) against torch autograd over the CPU oracle."""
-    B, Fr, C, seed = 2, 8, 1280, 5
+@pytest.mark.parametrize("B,Fr,C,ids", [(2, 8, 1280, 2), (1, 16, 2048, 3)])
+def test_backward_all_parameters_vs_oracle(B, Fr, C, ids):
+    """Every parameter gradient (not just the fixture's sample) against torch autograd over the CPU oracle;
+    the second case is the XS configuration (Xception features, 16 frames, 3 identities [7,5,4])."""
+    seed = 5
     cfg = arch.default_tsf_config(C, Fr)
     model, sd = _build(cfg, seed, require_attention=False)
     feats = synth.features(B, Fr, C, seed)
-    aux = synth.clip_inputs(B, Fr, 2, seed, ragged=True, with_video=False)
+    aux = synth.clip_inputs(B, Fr, ids, seed, ragged=True, with_video=False)
     out = model(feats.cuda(), mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(),
                 size_embedding=aux["size_embedding"], positions=aux["positions"].cuda())
-    w = torch.tensor([[1.0], [-0.7]])
+    w = torch.tensor([[1.0], [-0.7]])[:B]
     (out.cpu() * w).sum().backward()
     osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     oout = O.tsf_forward(osd, cfg, feats, aux["mask"], aux["identities_mask"], aux["size_embedding"], aux["positions"])
