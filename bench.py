@@ -80,6 +80,44 @@ def cpu_baseline(num_frames, seed, budget_s=20.0):
             "sample": f"{n} fwd+bwd steps of {B} clips (8-frame, 2-identity, 224x224), train-mode BN, fp32 torch CPU ops"}
 
 
+def attention_modules_leg(dev, B, F=8, reps=3):
+    """north_star sub-metric: forward of the divided space-time attention MODULES (QKV GEMM + attention core + out-proj GEMM,
+    time and space, 9 layers = 18 modules) at batch B, as a fraction of the fp32 MFMA peak.  Timed with HIP events."""
+    from mintime_amd import lib
+    h = lib.get()
+    D, H, n = 512, 8, 49
+    N = 1 + F * n
+    M = B * N
+    g = torch.Generator(device=dev).manual_seed(7)
+    xn = torch.randn(M, D, device=dev, generator=g)
+    wqkv = torch.randn(3 * D, D, device=dev, generator=g) * 0.08
+    wo, bo = torch.randn(D, D, device=dev, generator=g) * 0.03, torch.randn(D, device=dev, generator=g) * 0.02
+    qkv, o, x = torch.empty(M, 3 * D, device=dev), torch.empty(M, D, device=dev), torch.randn(M, D, device=dev, generator=g)
+    mask = torch.ones(B, F, dtype=torch.uint8, device=dev)
+    ident = torch.block_diag(torch.ones(F // 2, F // 2), torch.ones(F - F // 2, F - F // 2)).to(torch.uint8).to(dev).repeat(B, 1, 1).contiguous()
+
+    def modules():
+        for layer in range(9):
+            for mode in (0, 1):
+                lib.gemm(lib.OP_NT, xn, wqkv, qkv, M, 3 * D, D, D, D, 3 * D)
+                lib.check(h.mt_attn_fwd(lib.ptr(qkv), lib.ptr(o), None, lib.ptr(mask), lib.ptr(ident), B, H, F, n, mode, 0.125,
+                                        lib.stream_ptr()), "mt_attn_fwd")
+                lib.gemm(lib.OP_NT, o, wo, x, M, D, D, D, D, D, epilogue=lib.EPI_BIAS_RES, bias=bo, R=x, ldr=D)
+
+    modules()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        modules()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = B * 2 * 7638018048            # BASELINE.md: attention-module MACs per clip (QKV + core + out-proj, x18)
+    return {"batch": B, "fwd_ms": round(ms, 3), "tflops": round(flops / ms / 1e9, 2),
+            "mfma_frac": round(flops / (ms * 1e-3) / PEAK_FP32_MFMA, 4), "target_frac": 0.40}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,6 +204,8 @@ def main():
                          "launches_timed": len(durs), "avg_launch_us": round(avg * 1e6, 1),
                          "flops_per_launch": flops},
         }
+        if world == 1:
+            out["attention_modules"] = attention_modules_leg(dev, B, a.frames)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(a.frames)
         print(json.dumps(out))

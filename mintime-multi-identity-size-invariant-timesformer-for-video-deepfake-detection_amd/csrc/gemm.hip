@@ -95,6 +95,17 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   const int m_tiles = (d->M + kCfg[cfg].bm - 1) / kCfg[cfg].bm;
   const int n_tiles = (d->N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
   dim3 grid(m_tiles * n_tiles, 1, 1);
+  a.group_n = 0;
+  if (m_tiles >= 32 && n_tiles >= 2 && !getenv("MT_NO_L2_BLOCKING")) {
+    // size a column group so its B panels take ~2 MB of the XCD's 4 MB L2
+    const int64_t panel = (int64_t)kCfg[cfg].bn * d->K * 4;
+    int gn = (int)((2 << 20) / (panel > 0 ? panel : 1));
+    if (gn < 1) gn = 1;
+    if (gn > n_tiles) gn = n_tiles;
+    a.group_n = gn;
+    const int max_rows = (m_tiles + 7) / 8;
+    grid.x = 8 * max_rows * n_tiles;
+  }
 
 #define COMBO(OP, AL, BL, PRO, EPI)                                                        \
   if (d->op == OP && d->prologue == PRO && d->epilogue == EPI)                             \

@@ -141,6 +141,7 @@ struct GemmArgs {
   const float* A2;                      // PRO_BN_BWD second source (same layout / lda / row map as A)
   const float* b_scale; const float* b_shift; const float* b_gate; int b_hw;   // B prologue
   ConvDesc conv;                        // PRO_IM2COL / BPRO_IM2COL geometry
+  int group_n;                          // > 0: L2-blocked tile order with this many tile columns per group
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -187,18 +188,40 @@ void gemm_kernel(const GemmArgs p) {
   const int wm = wave / WAVES_N;
   const int wn = wave % WAVES_N;
 
-  // ---- XCD-aware block order: consecutive logical tiles (sharing an A row-panel) land on one XCD's L2
+  // ---- XCD-aware tile order.  Block b runs on XCD b % 8 (observed dispatch; used for speed only, never for correctness).
   const int n_tiles = (p.N + BN - 1) / BN;     // for GEGLU p.N is the full GEMM width (2*n_half)
   const int m_tiles = (p.M + BM - 1) / BM;
-  const int nblk = n_tiles * m_tiles;
-  int bid = blockIdx.x;
-  {
+  int mt_, nt_;
+  if (p.group_n > 0) {
+    // L2-blocked order for tall problems: every XCD owns a contiguous band of tile ROWS and sweeps it one group of
+    // `group_n` tile columns at a time, so the group's B panels (group_n x BN x K floats, sized to ~2 MB) stay in that XCD's
+    // 4 MB L2 while the A row-panels stream past once per group.  Without it an 8 MB weight matrix is re-fetched from
+    // the Infinity Cache for every 128-row panel (FETCH_SIZE 20x the algorithmic read on the FF1 GEMM).
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int q = m_tiles >> 3, r = m_tiles & 7;
+    const int row0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int rows = q + (xcd < r ? 1 : 0);
+    if (rows == 0) return;
+    const int per_group = rows * p.group_n;
+    const int groups = (n_tiles + p.group_n - 1) / p.group_n;
+    int g = idx / per_group;
+    if (g > groups - 1) g = groups - 1;
+    const int rem = idx - g * per_group;
+    const int gw = (g == groups - 1) ? n_tiles - g * p.group_n : p.group_n;
+    const int ml = rem / gw;
+    if (ml >= rows) return;                     // padding block (bands differ by one row)
+    mt_ = row0 + ml;
+    nt_ = g * p.group_n + (rem - ml * gw);
+  } else {
+    // default: consecutive logical tiles (sharing an A row-panel) land on one XCD's L2
+    const int nblk = n_tiles * m_tiles;
+    int bid = blockIdx.x;
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    mt_ = bid / n_tiles;
+    nt_ = bid - mt_ * n_tiles;
   }
-  const int mt_ = bid / n_tiles;
-  const int nt_ = bid - mt_ * n_tiles;
   const int m0 = mt_ * BM;
   const int n0 = nt_ * BN;
 
