@@ -142,6 +142,7 @@ struct GemmArgs {
   const float* b_scale; const float* b_shift; const float* b_gate; int b_hw;   // B prologue
   ConvDesc conv;                        // PRO_IM2COL / BPRO_IM2COL geometry
   int group_n;                          // > 0: L2-blocked tile order with this many tile columns per group
+  int stagger;                          // s_sleep(127) units (8128 cycles) of start skew per residency class, 0 = off
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -385,6 +386,14 @@ void gemm_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // De-phase the co-resident workgroups.  All blocks of the first dispatch round start together, compete for the SIMD's
+  // matrix pipe, finish together and are replaced together: their load/epilogue phases stay ALIGNED and are never covered by
+  // another block's MFMAs (measured: 2 -> 4 waves/SIMD changed nothing).  Delaying the 2nd/3rd block of each CU by 1/3 and 2/3
+  // of a tile once, at kernel start, staggers every later round as well (blocks are replaced as they finish).
+  if (p.stagger > 0 && blockIdx.x < 768 && blockIdx.y == 0) {
+    const int cls = (blockIdx.x >> 8) % 3;
+    for (int i = 0; i < cls * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   load_tiles(0);
   store_tiles(0);
   __syncthreads();
@@ -393,43 +402,61 @@ void gemm_kernel(const GemmArgs p) {
   const int b_frag = wn * TN * 32 + (lane & 31);
   const int khalf = lane >> 5;
 
+  // Main loop, software-pipelined at the source level (hipcc keeps this order):
+  //   * fragments for MFMA group g+1 are read from LDS BEFORE group g's MFMAs are issued -> ds_read latency sits under
+  //     256+ cycles of matrix work instead of in front of it;
+  //   * the next tile's global loads are issued at the top and their LDS stores placed MID-tile (other buffer), so the
+  //     store phase is covered by this wave's remaining MFMAs rather than serialised in front of the barrier.
+  auto load_frags = [&](const float* as, const float* bs, int g, float (&af)[TM][4], float (&bf)[TN][4]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if constexpr (A_ROWS) {
+        const float4 v = *reinterpret_cast<const float4*>(as + (a_row + i * 32) * LDA_S + g * 8 + khalf * 4);
+        af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[i][t] = as[(g * 8 + khalf * 4 + t) * LDA_S + a_row + i * 32];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (B_ROWS) {
+        const float4 v = *reinterpret_cast<const float4*>(bs + (b_frag + j * 32) * LDB_S + g * 8 + khalf * 4);
+        bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bf[j][t] = bs[(g * 8 + khalf * 4 + t) * LDB_S + b_frag + j * 32];
+      }
+    }
+  };
+  auto mma_group = [&](const float (&af)[TM][4], const float (&bf)[TN][4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+  };
+  constexpr int NG = BK / 8;
+  static_assert(NG == 2 || NG == 4, "BK must be 16 or 32");
+
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
+    const bool more = kt + 1 < nk;
+    if (more) load_tiles(kt + 1);
     const float* as = As + buf * A_TILE;
     const float* bs = Bs + buf * B_TILE;
+    float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
+    load_frags(as, bs, 0, fa0, fb0);
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      float af[TM][4], bf[TN][4];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if constexpr (A_ROWS) {
-          const float4 v = *reinterpret_cast<const float4*>(as + (a_row + i * 32) * LDA_S + g * 8 + khalf * 4);
-          af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) af[i][t] = as[(g * 8 + khalf * 4 + t) * LDA_S + a_row + i * 32];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if constexpr (B_ROWS) {
-          const float4 v = *reinterpret_cast<const float4*>(bs + (b_frag + j * 32) * LDB_S + g * 8 + khalf * 4);
-          bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) bf[j][t] = bs[(g * 8 + khalf * 4 + t) * LDB_S + b_frag + j * 32];
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    for (int g = 0; g < NG; g += 2) {
+      load_frags(as, bs, g + 1, fa1, fb1);
+      mma_group(fa0, fb0);
+      if (g + 2 < NG) load_frags(as, bs, g + 2, fa0, fb0);
+      if (g == NG - 2 && more) store_tiles(buf ^ 1);      // before the last MFMA group of the tile
+      mma_group(fa1, fb1);
     }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
   }
 
