@@ -126,6 +126,12 @@ int mt_se_gate_fwd(const float* pooled, const float* w1, const float* b1, const 
 int mt_bn_act_fwd(const float* z, const float* scale, const float* shift, const float* res, float* y,
                   int64_t rows, int C, int act, const float* rowscale, int rows_per_group, void* stream);
 
+/* Attention explainability post-process (utils.py:68-96 aggregate_attentions): out [3][F] = softmax over frame chunks of
+ * scale_factor * mean over the chunk's tokens of max over (batch*heads) of the cls attention; rows space / time / combined.
+ * space_att, time_att: [(B*H), N] as returned by mt_attn_fwd's cls_att. */
+int mt_attn_aggregate(const float* space_att, const float* time_att, float* out, int BH, int N, int F,
+                      float scale_factor, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Size-Invariant TimeSformer backward, non-GEMM pieces.  The reference derives these through torch autograd
  * from the same source lines as the forward entry points; here they are explicit adjoint kernels.

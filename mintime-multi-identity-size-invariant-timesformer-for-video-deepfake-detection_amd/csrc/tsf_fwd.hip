@@ -381,3 +381,50 @@ extern "C" int mt_head_fwd(const float* x, const float* gamma, const float* beta
                      classes, eps);
   return check_launch("mt_head_fwd");
 }
+
+// ---------------------------------------------------------------------------------------- attention explainability (next-row f3)
+// Reference utils.py:68-96 aggregate_attentions: per token, max over (batch*heads) of the cls attention; tokens split into
+// num_frames chunks like numpy.array_split (the first N % F chunks get one extra token; the cls token sits in chunk 0);
+// per chunk mean * scale_factor, softmax over the chunks.  Rows: 0 = space, 1 = time, 2 = combined (sum of the two maxima).
+namespace {
+__global__ __launch_bounds__(256) void attn_aggregate_kernel(const float* __restrict__ space, const float* __restrict__ time_,
+                                                            float* __restrict__ out, int BH, int N, int F, float scale_factor) {
+  extern __shared__ float sm[];        // tok[3][N] then chunk[3][F]
+  float* tok = sm;
+  float* chunk = sm + 3 * N;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < N; t += 256) {
+    float ms = -FLT_MAX, mt = -FLT_MAX;
+    for (int r = 0; r < BH; ++r) {
+      ms = fmaxf(ms, space[(int64_t)r * N + t]);
+      mt = fmaxf(mt, time_[(int64_t)r * N + t]);
+    }
+    tok[t] = ms; tok[N + t] = mt; tok[2 * N + t] = ms + mt;
+  }
+  __syncthreads();
+  const int base = N / F, extra = N % F;
+  for (int i = tid; i < 3 * F; i += 256) {
+    const int row = i / F, c = i % F;
+    const int start = c * base + min(c, extra), len = base + (c < extra ? 1 : 0);
+    float s = 0.f;
+    for (int k = 0; k < len; ++k) s += tok[row * N + start + k];
+    chunk[i] = s / (float)len * scale_factor;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    float mx = -FLT_MAX, sum = 0.f;
+    for (int c = 0; c < F; ++c) mx = fmaxf(mx, chunk[tid * F + c]);
+    for (int c = 0; c < F; ++c) sum += expf(chunk[tid * F + c] - mx);
+    for (int c = 0; c < F; ++c) out[tid * F + c] = expf(chunk[tid * F + c] - mx) / sum;
+  }
+}
+}  // namespace
+
+extern "C" int mt_attn_aggregate(const float* space_att, const float* time_att, float* out, int BH, int N, int F,
+                                 float scale_factor, void* stream) {
+  if (!space_att || !time_att || !out) return fail(MT_ERR_ARG, "mt_attn_aggregate: null pointer");
+  if (F <= 0 || N < F) return fail(MT_ERR_ARG, "mt_attn_aggregate: bad sizes");
+  hipLaunchKernelGGL(attn_aggregate_kernel, dim3(1), dim3(256), (size_t)(3 * N + 3 * F) * sizeof(float), (hipStream_t)stream,
+                     space_att, time_att, out, BH, N, F, scale_factor);
+  return check_launch("mt_attn_aggregate");
+}

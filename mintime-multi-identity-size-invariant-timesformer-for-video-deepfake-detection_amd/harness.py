@@ -70,3 +70,24 @@ def train_step(ef, tsf, optimizer, batch, reducer=None, pos_weight=None):
 def eval_step(ef, tsf, batch):
     """test.py:235-247 / predict.py:401-406: eval forward; returns logits (and attentions if the model was built with them)."""
     return forward(ef, tsf, batch)
+
+
+def aggregate_attentions(attentions, heads, num_frames, frames_per_identity, scale_factor=50000):
+    """Reference utils.py:68-96 on the device: attentions = [space, time] as returned by the model with
+    require_attention=True.  Returns (aggregated [space, time, combined] lists of num_frames floats, per-identity sums) with the
+    reference's own slicing rule for the identity sums (utils.py:87-94)."""
+    from . import lib as L
+    space, time_ = attentions
+    bh, _, n = space.shape
+    out = torch.empty(3, num_frames, dtype=torch.float32, device=space.device)
+    L.check(L.get().mt_attn_aggregate(L.ptr(space.contiguous()), L.ptr(time_.contiguous()), L.ptr(out), bh, n, num_frames,
+                                      float(scale_factor), L.stream_ptr()), "mt_attn_aggregate")
+    agg = out.cpu().tolist()
+    comb = agg[-1]
+    identity = []
+    for index, frames in enumerate(frames_per_identity):
+        if index == 0:
+            identity.append(sum(comb[:frames - 1]))
+        else:
+            identity.append(sum(comb[frames_per_identity[index - 1] - 1:frames - 1]))
+    return agg, identity

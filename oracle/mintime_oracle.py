@@ -318,3 +318,27 @@ def bce_with_logits(logits, labels, pos_weight=None):
 
 def to_dtype(sd, dtype):
     return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def aggregate_attentions(attentions, heads, num_frames, frames_per_identity, scale_factor=50000):
+    """Restatement of reference utils.py:68-96 (numpy): max over batch*heads per token, np.array_split into frames,
+    mean*scale, softmax; identity sums with the reference's slicing."""
+    import numpy as np
+    agg = []
+    for att in attentions:
+        a = att.squeeze(1).reshape(-1, heads, att.shape[-1])
+        agg.append([float(a[:, :, i].max()) for i in range(a.shape[2])])
+    agg.append(list(np.sum(np.asarray(agg), axis=0)))
+    out = []
+    for row in agg:
+        chunks = np.array_split(np.asarray(row, dtype=np.float64), num_frames)
+        v = np.array([c.mean() * scale_factor for c in chunks])
+        e = np.exp(v - v.max())
+        out.append(list(e / e.sum()))
+    ident = []
+    for index, frames in enumerate(frames_per_identity):
+        if index == 0:
+            ident.append(sum(out[-1][:frames - 1]))
+        else:
+            ident.append(sum(out[-1][frames_per_identity[index - 1] - 1:frames - 1]))
+    return out, ident

@@ -126,3 +126,14 @@ def test_backward_all_parameters_vs_oracle(B, Fr, C, ids):
             assert float(p.grad.abs().max()) == 0.0, k
         else:
             assert_close(p.grad, ref, REL_TOL, "grad " + k)
+
+
+def test_attention_aggregation_matches_reference_rule():
+    """Next-row f3: utils.py:68-96 aggregate_attentions on the device vs its numpy restatement."""
+    from mintime_amd import harness
+    g = golden("tsf_2id_ragged")
+    s_att, t_att = torch.as_tensor(g["space_att"]), torch.as_tensor(g["time_att"])
+    ref, ref_id = O.aggregate_attentions([s_att, t_att], 8, 8, [4, 8], scale_factor=50000)
+    got, got_id = harness.aggregate_attentions([s_att.cuda(), t_att.cuda()], 8, 8, [4, 8], scale_factor=50000)
+    assert_close(torch.tensor(got), torch.tensor(ref), 1e-4, "aggregated attentions")
+    assert_close(torch.tensor(got_id), torch.tensor(ref_id), 1e-4, "identity attentions")
