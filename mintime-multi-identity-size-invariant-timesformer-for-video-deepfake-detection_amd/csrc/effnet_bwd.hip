@@ -236,178 +236,7 @@ __global__ __launch_bounds__(128) void se_wgrad_kernel(const float* __restrict__
   if (blockIdx.x == 0 && threadIdx.x < CS) atomicAdd(db1 + threadIdx.x, b1);
 }
 
-// ------------------------------------------------------------------------------------------------ K6: depthwise dgrad
-// da_in[n,ih,iw,c] = sum_{kh,kw} w[c,kh,kw] * dz[n,(ih+P-kh)/S,(iw+P-kw)/S,c],  dz = ka*du + kb*z + kc  (virtual)
-// then du_in = da_in * swish'(zin*scale_in+shift_in) is written, with the BN sums of the INPUT-side BatchNorm.
-template <int K, int S, int R>
-__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(
-    const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ w,
-    const float* __restrict__ zin, const float* __restrict__ scale_in, const float* __restrict__ shift_in,
-    const float* __restrict__ mi_in, float* __restrict__ du_in, double* __restrict__ stats, int slots, int N, int H, int W,
-    int C, int Ho, int Wo, int CQB, int PB, int RH) {
-  constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;        // TF-SAME pad-before for even H
-  // Output columns touched by R input columns, with compile-time indexing: with base = iw0 + P - (K-1) (iw0 is a
-  // multiple of R, R a multiple of S) the tap (j,kw) reads output column (base + t)/S, t = j + K-1-kw, when divisible.
-  // For S == 2 the parity of base is the compile-time constant ODD, so the window index (t+ODD)/S is static.
-  constexpr int ODD = (S == 2 && ((K - 1 - P) & 1)) ? 1 : 0;
-  constexpr int OW_SPAN = (R - 1 + K - 1 + ODD) / S + 1;
-  static_assert(R % S == 0, "R must be a multiple of the stride");
-  extern __shared__ float red[];
-  const int tid = threadIdx.x;
-  const int cql = tid % CQB, pl = tid / CQB;
-  const int CQ = C >> 2;
-  const int cq = blockIdx.y * CQB + cql;
-  const int wsegs = (W + R - 1) / R, hsegs = (H + RH - 1) / RH;
-  const int64_t nseg = (int64_t)N * hsegs * wsegs;
-  const int64_t seg = (int64_t)blockIdx.x * PB + pl;
-  const bool live = pl < PB && cq < CQ && seg < nseg;
-  float4 s1 = f4(0, 0, 0, 0), s2 = s1;
-  if (live) {
-    const int ws_ = (int)(seg % wsegs);
-    const int64_t t = seg / wsegs;
-    const int hs = (int)(t % hsegs);
-    const int n = (int)(t / hsegs);
-    const int c = cq * 4;
-    const float4 ka = ld4(kabc + c), kb = ld4(kabc + C + c), kc = ld4(kabc + 2 * C + c);
-    const float4 sc = ld4(scale_in + c), sh = ld4(shift_in + c);
-    const float4 mean = ld4(mi_in + c), istd = ld4(mi_in + C + c);
-    float4 wt[K * K];
-#pragma unroll
-    for (int i = 0; i < K * K; ++i)
-      wt[i] = f4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
-    const int iw0 = ws_ * R;
-    const int ow_lo = (iw0 + P - (K - 1) - ODD) / S;             // exact division (numerator is a multiple of S)
-    for (int r = 0; r < RH; ++r) {
-      const int ih = hs * RH + r;
-      if (ih >= H) break;
-      float4 acc[R];
-#pragma unroll
-      for (int j = 0; j < R; ++j) acc[j] = f4(0, 0, 0, 0);
-#pragma unroll
-      for (int kh = 0; kh < K; ++kh) {
-        const int ohn = ih + P - kh;
-        if (ohn < 0 || (ohn % S) != 0) continue;
-        const int oh = ohn / S;
-        if (oh >= Ho) continue;
-        const int64_t rowb = (((int64_t)n * Ho + oh) * Wo) * C + c;
-        float4 dz[OW_SPAN];
-#pragma unroll
-        for (int i = 0; i < OW_SPAN; ++i) {
-          const int ow = ow_lo + i;
-          if (ow >= 0 && ow < Wo) {
-            const float4 a = ld4(du + rowb + (int64_t)ow * C), b = ld4(z + rowb + (int64_t)ow * C);
-            dz[i] = fma4(ka, a, fma4(kb, b, kc));
-          } else dz[i] = f4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-#pragma unroll
-          for (int kw = 0; kw < K; ++kw) {
-            constexpr int dummy = 0; (void)dummy;
-            const int t2 = j + K - 1 - kw + ODD;          // compile-time after unrolling
-            if (t2 % S == 0) acc[j] = fma4(dz[t2 / S], wt[kh * K + kw], acc[j]);
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const int iw = iw0 + j;
-        if (iw < W) {
-          const int64_t off = (((int64_t)n * H + ih) * W + iw) * C + c;
-          const float4 zz = ld4(zin + off);
-          const float4 u = fma4(zz, sc, sh);
-          const float4 d = f4(acc[j].x * dswishf_(u.x), acc[j].y * dswishf_(u.y), acc[j].z * dswishf_(u.z), acc[j].w * dswishf_(u.w));
-          st4(du_in + off, d);
-          const float4 xh = f4((zz.x - mean.x) * istd.x, (zz.y - mean.y) * istd.y, (zz.z - mean.z) * istd.z, (zz.w - mean.w) * istd.w);
-          s1 = add4(s1, d);
-          s2 = fma4(d, xh, s2);
-        }
-      }
-    }
-  }
-  reduce_stats(red, s1, s2, cql, pl, CQB, PB, CQ, C, stats, slots);
-}
-
-// ------------------------------------------------------------------------------------------------ K7: depthwise wgrad
-// dw[c,kh,kw] += sum_{n,oh,ow} dz[n,oh,ow,c] * swish(bn(zin))[n, oh*S+kh-P, ow*S+kw-P, c]
-template <int K, int S, int R>
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(
-    const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ zin,
-    const float* __restrict__ scale_in, const float* __restrict__ shift_in, float* __restrict__ dw, int N, int H, int W, int C,
-    int Ho, int Wo, int CQB, int PB, int RH) {
-  constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
-  constexpr int WIN = (R - 1) * S + K;
-  extern __shared__ float red[];      // [PB][CQB] float4
-  const int tid = threadIdx.x;
-  const int cql = tid % CQB, pl = tid / CQB;
-  const int CQ = C >> 2;
-  const int cq = blockIdx.y * CQB + cql;
-  const int wsegs = (Wo + R - 1) / R, hsegs = (Ho + RH - 1) / RH;
-  const int64_t nseg = (int64_t)N * hsegs * wsegs;
-  float4 wacc[K * K];
-#pragma unroll
-  for (int i = 0; i < K * K; ++i) wacc[i] = f4(0, 0, 0, 0);
-  if (pl < PB && cq < CQ) {
-    const int c = cq * 4;
-    const float4 ka = ld4(kabc + c), kb = ld4(kabc + C + c), kc = ld4(kabc + 2 * C + c);
-    const float4 sc = ld4(scale_in + c), sh = ld4(shift_in + c);
-    for (int64_t seg = (int64_t)blockIdx.x * PB + pl; seg < nseg; seg += (int64_t)gridDim.x * PB) {
-      const int ws_ = (int)(seg % wsegs);
-      const int64_t t = seg / wsegs;
-      const int hs = (int)(t % hsegs);
-      const int n = (int)(t / hsegs);
-      const int ow0 = ws_ * R;
-      for (int r = 0; r < RH; ++r) {
-        const int oh = hs * RH + r;
-        if (oh >= Ho) break;
-        float4 dz[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-          const int ow = ow0 + j;
-          if (ow < Wo) {
-            const int64_t off = (((int64_t)n * Ho + oh) * Wo + ow) * C + c;
-            dz[j] = fma4(ka, ld4(du + off), fma4(kb, ld4(z + off), kc));
-          } else dz[j] = f4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int kh = 0; kh < K; ++kh) {
-          const int ih = oh * S + kh - P;
-          if (ih < 0 || ih >= H) continue;
-          const float* rowp = zin + (((int64_t)n * H + ih) * W) * C + c;
-          float4 a[WIN];
-#pragma unroll
-          for (int i = 0; i < WIN; ++i) {
-            const int iw = ow0 * S + i - P;
-            if (iw >= 0 && iw < W) {
-              const float4 u = fma4(ld4(rowp + (int64_t)iw * C), sc, sh);
-              a[i] = f4(swishf_(u.x), swishf_(u.y), swishf_(u.z), swishf_(u.w));
-            } else a[i] = f4(0, 0, 0, 0);
-          }
-#pragma unroll
-          for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-            for (int j = 0; j < R; ++j) wacc[kh * K + kw] = fma4(dz[j], a[j * S + kw], wacc[kh * K + kw]);
-        }
-      }
-    }
-  }
-  // block reduction, one tap at a time (keeps LDS small), then one atomic per (channel, tap) per block
-#pragma unroll
-  for (int tp = 0; tp < K * K; ++tp) {
-    __syncthreads();
-    if (pl < PB) st4(red + (pl * CQB + cql) * 4, wacc[tp]);
-    __syncthreads();
-    if (pl == 0 && cq < CQ) {
-      float4 t = f4(0, 0, 0, 0);
-      for (int p = 0; p < PB; ++p) t = add4(t, ld4(red + (p * CQB + cql) * 4));
-      const int c = cq * 4;
-      atomicAdd(dw + (c + 0) * K * K + tp, t.x); atomicAdd(dw + (c + 1) * K * K + tp, t.y);
-      atomicAdd(dw + (c + 2) * K * K + tp, t.z); atomicAdd(dw + (c + 3) * K * K + tp, t.w);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ K7b: depthwise wgrad, LDS-tiled
+// ------------------------------------------------------------------------------------------------ K6: depthwise wgrad, LDS-tiled
 // One block = one 16-channel chunk, grid-strided over T x T output tiles of all images.  The activated input tile (with halo)
 // and the dz tile are built ONCE per tile in LDS (swish / BN-backward affine evaluated once per element instead of once per
 // tap); thread (cq, kh, ps) then accumulates the K taps of kernel row kh for channel quad cq over its share of the pixels.
@@ -522,7 +351,7 @@ int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, co
   return check_launch("mt_dwconv_bwd(weight, tiled)");
 }
 
-// ------------------------------------------------------------------------------------------------ K6b: depthwise dgrad, LDS-tiled
+// ------------------------------------------------------------------------------------------------ K7: depthwise dgrad, LDS-tiled
 // One block = one 16-channel chunk, grid-strided over T x T INPUT tiles.  dz = ka*du+kb*z+kc over the output positions
 // the tile's taps can reach is built once in LDS; thread (cq, slot) then gathers its input pixels' taps from LDS,
 // applies swish' of the input-side BatchNorm and accumulates that BatchNorm's backward sums in registers.
@@ -727,7 +556,7 @@ int pick_cqb(int CQ) {
   return best;
 }
 
-template <int K, int S, int R>
+template <int K, int S>
 int launch_dw_bwd(const float* du, const float* z, const float* kabc, const float* w, const float* zin, const float* scale_in,
                   const float* shift_in, const float* mi_in, float* du_in, double* stats, int slots, float* dw, int N, int H,
                   int W, int C, int parts, int act, const float* res_pre, const float* res_post, hipStream_t s) {
@@ -797,13 +626,12 @@ extern "C" int mt_dwconv_bwd(const float* du, const float* z, const float* kabc,
   if ((parts & 1) && !dw) return fail(MT_ERR_ARG, "mt_dwconv_bwd: weight part needs dw");
   if ((parts & 2) && (!w || !du_in)) return fail(MT_ERR_ARG, "mt_dwconv_bwd: data part needs w and du_in");
   if ((parts & 2) && ((stats_in == nullptr) != (mean_invstd_in == nullptr))) return fail(MT_ERR_ARG, "mt_dwconv_bwd: stats_in and mean_invstd_in go together");
-  if (C & 3) return fail(MT_ERR_ARG, "mt_dwconv_bwd: C %% 4 != 0");
   if (stride == 2 && ((H & 1) || (W & 1))) return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd: stride 2 needs even H, W");
   hipStream_t s = (hipStream_t)stream;
-  if (k == 3 && stride == 1) return launch_dw_bwd<3, 1, 4>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
-  if (k == 3 && stride == 2) return launch_dw_bwd<3, 2, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
-  if (k == 5 && stride == 1) return launch_dw_bwd<5, 1, 4>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
-  if (k == 5 && stride == 2) return launch_dw_bwd<5, 2, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
+  if (k == 3 && stride == 1) return launch_dw_bwd<3, 1>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
+  if (k == 3 && stride == 2) return launch_dw_bwd<3, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
+  if (k == 5 && stride == 1) return launch_dw_bwd<5, 1>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
+  if (k == 5 && stride == 2) return launch_dw_bwd<5, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
   return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd: k=%d stride=%d unsupported", k, stride);
 }
 

@@ -125,103 +125,6 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   }
 }
 
-// ------------------------------------------------------------------------------------------------ depthwise
-// in  z_in [N,H,W,C] raw, activated on load: a = swish(z*scale+shift) (zero padding applies to a)
-// out z_out[N,Ho,Wo,C] raw + per-channel stats.  Thread = (channel quad, R consecutive output columns, RH rows).
-template <int K, int S, int R>
-__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ zin, const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, const float* __restrict__ w,
-                                                     float* __restrict__ zout, double* __restrict__ stats, int slots,
-                                                     int N, int H, int W, int C, int Ho, int Wo, int pad0,
-                                                     int CQB, int PB, int RH) {
-  extern __shared__ float red[];     // [PB][CQB*8]
-  constexpr int WIN = (R - 1) * S + K;
-  const int tid = threadIdx.x;
-  const int cql = tid % CQB, pl = tid / CQB;
-  const int CQ = C >> 2;
-  const int cq = blockIdx.y * CQB + cql;
-  const int wsegs = (Wo + R - 1) / R;
-  const int hsegs = (Ho + RH - 1) / RH;
-  const int64_t nseg = (int64_t)N * hsegs * wsegs;
-  const int64_t seg = (int64_t)blockIdx.x * PB + pl;
-  const bool live = pl < PB && cq < CQ && seg < nseg;
-
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-  if (live) {
-    const int ws_ = (int)(seg % wsegs);
-    const int64_t t = seg / wsegs;
-    const int hs = (int)(t % hsegs);
-    const int n = (int)(t / hsegs);
-    const int c = cq * 4;
-    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
-    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
-    // weights: torch [C][1][K][K] -> per-lane 4 channels x K*K taps
-    float4 wt[K * K];
-#pragma unroll
-    for (int i = 0; i < K * K; ++i)
-      wt[i] = make_float4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
-    const int ow0 = ws_ * R;
-    for (int r = 0; r < RH; ++r) {
-      const int oh = hs * RH + r;
-      if (oh >= Ho) break;
-      float4 acc[R];
-#pragma unroll
-      for (int j = 0; j < R; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int kh = 0; kh < K; ++kh) {
-        const int ih = oh * S + kh - pad0;
-        if (ih < 0 || ih >= H) continue;
-        const float* rowp = zin + (((int64_t)n * H + ih) * W) * C + c;
-        float4 a[WIN];
-#pragma unroll
-        for (int i = 0; i < WIN; ++i) {
-          const int iw = ow0 * S + i - pad0;
-          if (iw >= 0 && iw < W) a[i] = bn_swish4(*reinterpret_cast<const float4*>(rowp + (int64_t)iw * C), sc, sh);
-          else a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-#pragma unroll
-          for (int kw = 0; kw < K; ++kw) {
-            const float4 v = a[j * S + kw];
-            const float4 ww = wt[kh * K + kw];
-            acc[j].x = fmaf(v.x, ww.x, acc[j].x); acc[j].y = fmaf(v.y, ww.y, acc[j].y);
-            acc[j].z = fmaf(v.z, ww.z, acc[j].z); acc[j].w = fmaf(v.w, ww.w, acc[j].w);
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const int ow = ow0 + j;
-        if (ow < Wo) {
-          *reinterpret_cast<float4*>(zout + (((int64_t)n * Ho + oh) * Wo + ow) * C + c) = acc[j];
-          s1.x += acc[j].x; s1.y += acc[j].y; s1.z += acc[j].z; s1.w += acc[j].w;
-          s2.x += acc[j].x * acc[j].x; s2.y += acc[j].y * acc[j].y; s2.z += acc[j].z * acc[j].z; s2.w += acc[j].w * acc[j].w;
-        }
-      }
-    }
-  }
-  if (stats) {
-    if (pl < PB) {
-      float* rr = red + (pl * CQB + cql) * 8;
-      rr[0] = s1.x; rr[1] = s1.y; rr[2] = s1.z; rr[3] = s1.w;
-      rr[4] = s2.x; rr[5] = s2.y; rr[6] = s2.z; rr[7] = s2.w;
-    }
-    __syncthreads();
-    // CQB*8 partial columns, each summed over PB rows
-    for (int i = tid; i < CQB * 8; i += blockDim.x) {
-      const int q = i >> 3, e = i & 7;
-      const int cqq = blockIdx.y * CQB + q;
-      if (cqq < CQ) {
-        float v = 0.f;
-        for (int p = 0; p < PB; ++p) v += red[(p * CQB + q) * 8 + e];
-        const int ch = cqq * 4 + (e & 3), which = e >> 2;
-        atomic_add_f64(stats + ((int64_t)(blockIdx.x % slots) * 2 + which) * C + ch, (double)v);
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ depthwise, LDS-tiled
 // One block = one 16-channel chunk, grid-strided over T x T output tiles.  The activated input tile (with halo) is built
 // once in LDS (swish evaluated once per element, not once per tap); thread (cq = tid&3, slot = tid>>2) then produces the
@@ -487,41 +390,27 @@ extern "C" int mt_stem_conv_fwd(const float* x, const float* w, float* z, double
 }
 
 namespace {
-template <int K, int S, int R>
+template <int K, int S>
 int launch_dw(const float* zin, const float* scale, const float* shift, const float* w, float* zout, double* stats, int slots,
               int N, int H, int W, int C, int act, hipStream_t s) {
   const int Ho = (H + S - 1) / S, Wo = (W + S - 1) / S;
-  const int padt = max((Ho - 1) * S + K - H, 0);
-  const int pad = padt / 2;
-  if (C % 8 == 0 && !getenv("MT_DW_UNTILED")) {
-    if (act == 1) return launch_dw_tiled_any<K, S, 1>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s);
-    if (act == 2) return launch_dw_tiled_any<K, S, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s);
-    return launch_dw_tiled_any<K, S, 0>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s);
-  }
-  if (act != 1) return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_fwd: the untiled fallback only implements the swish prologue");
-  const int CQ = C / 4;
-  const int CQB = pick_cqb(CQ);
-  const int PB = 256 / CQB;
-  const int RH = Ho >= 28 ? 4 : (Ho >= 14 ? 2 : 1);
-  const int wsegs = (Wo + R - 1) / R, hsegs = (Ho + RH - 1) / RH;
-  const int64_t nseg = (int64_t)N * hsegs * wsegs;
-  dim3 grid((unsigned)((nseg + PB - 1) / PB), CQ / CQB);
-  const size_t lds = (size_t)PB * CQB * 8 * sizeof(float);
-  hipLaunchKernelGGL((dwconv_kernel<K, S, R>), grid, dim3(CQB * PB), lds, s, zin, scale, shift, w, zout, stats,
-                     slots > 0 ? slots : 1, N, H, W, C, Ho, Wo, padt / 2, CQB, PB, RH);
-  return check_launch("mt_dwconv_fwd");
+  const int pad = max((Ho - 1) * S + K - H, 0) / 2;              // TF-SAME pad-before
+  if (act == 1) return launch_dw_tiled_any<K, S, 1>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s);
+  if (act == 2) return launch_dw_tiled_any<K, S, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s);
+  return launch_dw_tiled_any<K, S, 0>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s);
 }
 }  // namespace
 
 extern "C" int mt_dwconv_fwd(const float* zin, const float* scale, const float* shift, const float* w, float* zout,
                              double* stats, int slots, int N, int H, int W, int C, int k, int stride, int act, void* stream) {
   if (!zin || !scale || !shift || !w || !zout) return fail(MT_ERR_ARG, "mt_dwconv_fwd: null pointer");
-  if (C & 3) return fail(MT_ERR_ARG, "mt_dwconv_fwd: C %% 4 != 0");
+  if (C & 7) return fail(MT_ERR_ARG, "mt_dwconv_fwd: C must be a multiple of 8 (got %d)", C);
+  if (act < 0 || act > 2) return fail(MT_ERR_ARG, "mt_dwconv_fwd: act must be 0, 1 or 2");
   hipStream_t s = (hipStream_t)stream;
-  if (k == 3 && stride == 1) return launch_dw<3, 1, 4>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
-  if (k == 3 && stride == 2) return launch_dw<3, 2, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
-  if (k == 5 && stride == 1) return launch_dw<5, 1, 4>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
-  if (k == 5 && stride == 2) return launch_dw<5, 2, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
+  if (k == 3 && stride == 1) return launch_dw<3, 1>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
+  if (k == 3 && stride == 2) return launch_dw<3, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
+  if (k == 5 && stride == 1) return launch_dw<5, 1>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
+  if (k == 5 && stride == 2) return launch_dw<5, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
   return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_fwd: k=%d stride=%d unsupported", k, stride);
 }
 

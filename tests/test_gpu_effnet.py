@@ -68,3 +68,26 @@ def test_nchw_contiguous_input_is_accepted():
     with torch.no_grad():
         feats = model(x.cuda())
     assert_close(feats, g["features"], REL_TOL, "NCHW-contiguous input")
+
+
+def test_direct_stem_kernel_agrees_with_the_im2col_gemm_path():
+    """mt_stem_conv_fwd (direct kernel, kept in the ABI) and the im2col-prologue GEMM the engine uses compute the same stem."""
+    from mintime_amd import lib as L
+    lib = L.get()
+    n, H = 2, 224
+    x = torch.randint(0, 256, (n, H, H, 3)).float().cuda()
+    w = (torch.randn(32, 3, 3, 3) * 0.01).cuda()
+    z_direct = torch.empty(n * 112 * 112, 32, device="cuda")
+    st_direct = torch.zeros(4, 2, 32, dtype=torch.float64, device="cuda")
+    L.check(lib.mt_stem_conv_fwd(L.ptr(x), L.ptr(w), L.ptr(z_direct), L.ptr(st_direct), 4, n, H, H, L.stream_ptr()), "stem")
+    wp = torch.empty(32, 28, device="cuda")
+    L.check(lib.mt_conv_weight_pack(L.ptr(w), L.ptr(wp), 32, 3, 3, 28, 0, L.stream_ptr()), "pack")
+    z_gemm = torch.empty_like(z_direct)
+    st_gemm = torch.zeros(4, 2, 32, dtype=torch.float64, device="cuda")
+    L.gemm(L.OP_NT, x, wp, z_gemm, n * 112 * 112, 32, 28, 28, 28, 32, prologue=L.PRO_IM2COL, epilogue=L.EPI_STATS, stats=st_gemm,
+           stats_slots=4, conv=(H, H, 3, 112, 112, 3, 2, 0, 0))
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x.cpu().permute(0, 3, 1, 2).double(), [0, 1, 0, 1]), w.cpu().double(),
+                                     None, 2).permute(0, 2, 3, 1).reshape(-1, 32)
+    assert_close(z_direct, ref, 2e-5, "direct stem")
+    assert_close(z_gemm, ref, 2e-5, "im2col GEMM stem")
+    assert_close(st_direct.sum(0), st_gemm.sum(0), 1e-6, "BatchNorm sums")
