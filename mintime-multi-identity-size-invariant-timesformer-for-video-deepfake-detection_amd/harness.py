@@ -91,3 +91,32 @@ def aggregate_attentions(attentions, heads, num_frames, frames_per_identity, sca
         else:
             identity.append(sum(comb[frames_per_identity[index - 1] - 1:frames - 1]))
     return agg, identity
+
+
+class GraphedEval:
+    """Eval forward captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed: the ~440 kernel launches of
+    EfficientNet-B0 + TimeSformer become one graph launch, which removes the per-launch host cost that dominates small-batch
+    inference (test.py runs bs = 1).  Inputs are copied into static buffers; outputs are static tensors overwritten by replay."""
+
+    def __init__(self, ef, tsf, example_batch):
+        assert not ef.training and not tsf.training, "capture the eval() forward"
+        self.ef, self.tsf = ef, tsf
+        dev = next(tsf.parameters()).device
+        # every input lives in a static device buffer (an H2D copy of the reference's host-side size_embedding is not capturable)
+        self.static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(2):                      # warm-up: loads kernels, sets LDS attributes, fills the allocator
+                forward(ef, tsf, self.static)
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = forward(ef, tsf, self.static)
+
+    def __call__(self, batch):
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        return self.out

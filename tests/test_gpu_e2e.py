@@ -95,3 +95,23 @@ def test_effnet_backward_all_parameters_vs_oracle(training):
             continue
         worst = max(worst, assert_close(p.grad, ref, 3 * REL_TOL, "grad " + k))
     print("worst relative gradient error", worst)
+
+
+def test_hip_graph_replay_matches_eager_eval():
+    """The whole eval forward captured in a HIP graph: replays bit-identically and on new inputs."""
+    from mintime_amd import harness
+    cfg, ef, tsf, _, _ = _models(0, 8, False, require_attention=False)
+    ef.eval(); tsf.eval()
+    inp = synth.clip_inputs(2, 8, 2, 0, ragged=True)
+    b0 = {k: (v.cuda() if k != "size_embedding" else v) for k, v in inp.items()}
+    with torch.no_grad():
+        eager0 = harness.forward(ef, tsf, b0).clone()
+    graphed = harness.GraphedEval(ef, tsf, b0)
+    assert torch.equal(graphed(b0), eager0)
+    inp1 = synth.clip_inputs(2, 8, 2, 0, ragged=True)
+    inp1["videos"] = synth.clip_inputs(2, 8, 2, 5, ragged=True)["videos"]
+    b1 = {k: (v.cuda() if k != "size_embedding" else v) for k, v in inp1.items()}
+    with torch.no_grad():
+        eager1 = harness.forward(ef, tsf, b1).clone()
+    assert not torch.equal(eager1, eager0)
+    assert torch.equal(graphed(b1), eager1)
