@@ -62,6 +62,7 @@ typedef struct {
   const float* A2;                  /* BN_BWD prologue: second source, same layout as A                  */
   int b_prologue; const float* b_scale; const float* b_shift; const float* b_gate; int b_hw;
   int conv_H, conv_W, conv_C, conv_Ho, conv_Wo, conv_k, conv_stride, conv_pad, conv_act;   /* im2col prologues */
+  int conv_src_u8;                  /* im2col source image is uint8 (raw crops, 3 channels) instead of fp32      */
 } mt_gemm_desc;
 
 int mt_gemm(const mt_gemm_desc* d, void* stream);
@@ -192,8 +193,8 @@ int mt_dwconv_bwd(const float* du, const float* z, const float* kabc, const floa
  * other consumers of the activated (res_pre) or raw (res_post) input tensor (Xception skip paths), either may be NULL. */
 
 /* _conv_stem weight gradient (accumulated, torch layout [32,3,3,3]); x [N,H,W,3]. */
-int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const float* x, float* dw, int N, int H,
-                       int W, void* stream);
+int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N,
+                       int H, int W, void* stream);   /* x fp32 or (x_is_u8) uint8 */
 
 /* ------------------------------------------------------------------------------------------------
  * Xception (config 5 extractor, reference models/xception.py).  Dense convolutions are mt_gemm with the IM2COL

@@ -492,8 +492,10 @@ int launch_dw_bwd_tiled_any(const float* du, const float* z, const float* kabc, 
 // ------------------------------------------------------------------------------------------------ K8: stem wgrad
 // dW[co,ci,kh,kw] += sum_pix dz0[pix,co] * x[n, 2oh+kh-P, 2ow+kw-P, ci],  dz0 = ka*du+kb*z+kc
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ du, const float* __restrict__ z,
-                                                         const float* __restrict__ kabc, const float* __restrict__ x,
+                                                         const float* __restrict__ kabc, const void* __restrict__ xv, int x_u8,
                                                          float* __restrict__ dw, int N, int H, int W, int Ho, int Wo, int pad0) {
+  const float* x = reinterpret_cast<const float*>(xv);
+  const uint8_t* xb = reinterpret_cast<const uint8_t*>(xv);
   constexpr int CO = 32, TP = 64, TAPS = 27;
   __shared__ float dzt[TP][CO + 1];
   __shared__ float xt[TP][TAPS + 1];
@@ -523,7 +525,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         const int64_t t = pix / Wo;
         const int oh = (int)(t % Ho), n = (int)(t / Ho);
         const int ih = oh * 2 + kh - pad0, iw = ow * 2 + kw - pad0;
-        if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[(((int64_t)n * H + ih) * W + iw) * 3 + ci];
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+          const int64_t off = (((int64_t)n * H + ih) * W + iw) * 3 + ci;
+          v = x_u8 ? (float)xb[off] : x[off];
+        }
       }
       xt[p][tp] = v;
     }
@@ -635,11 +640,11 @@ extern "C" int mt_dwconv_bwd(const float* du, const float* z, const float* kabc,
   return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd: k=%d stride=%d unsupported", k, stride);
 }
 
-extern "C" int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const float* x, float* dw, int N, int H,
-                                  int W, void* stream) {
+extern "C" int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N,
+                                  int H, int W, void* stream) {
   if (!du || !z || !kabc || !x || !dw) return fail(MT_ERR_ARG, "mt_stem_conv_wgrad: null pointer");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int padt = max((Ho - 1) * 2 + 3 - H, 0);
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, du, z, kabc, x, dw, N, H, W, Ho, Wo, padt / 2);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, du, z, kabc, x, x_is_u8, dw, N, H, W, Ho, Wo, padt / 2);
   return check_launch("mt_stem_conv_wgrad");
 }

@@ -50,7 +50,9 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return fail(MT_ERR_ARG, "mt_gemm: null pointer");
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return fail(MT_ERR_ARG, "mt_gemm: bad shape %d %d %d", d->M, d->N, d->K);
   if ((d->lda & 3) || (d->ldb & 3)) return fail(MT_ERR_ARG, "mt_gemm: lda/ldb must be multiples of 4 floats");
-  if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15)) return fail(MT_ERR_ARG, "mt_gemm: A/B must be 16-byte aligned");
+  const bool u8_src = d->conv_src_u8 != 0;
+  if ((!(u8_src && d->prologue == MT_PRO_IM2COL) && ((uintptr_t)d->A & 15)) || (!(u8_src && d->b_prologue == MT_BPRO_IM2COL) && ((uintptr_t)d->B & 15)))
+    return fail(MT_ERR_ARG, "mt_gemm: A/B must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
 
   GemmArgs a;
@@ -64,7 +66,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   a.scale = d->scale; a.shift = d->shift; a.gate = d->gate; a.hw = d->hw > 0 ? d->hw : 1;
   a.C2 = d->C2; a.ldc2 = d->ldc2; a.stats = d->stats; a.stats_slots = d->stats_slots > 0 ? d->stats_slots : 1;
   a.n_half = d->n_half; a.k_chunk = 0;
-  a.conv = {d->conv_H, d->conv_W, d->conv_C, d->conv_Ho, d->conv_Wo, d->conv_k, d->conv_stride, d->conv_pad, d->conv_act};
+  a.conv = {d->conv_H, d->conv_W, d->conv_C, d->conv_Ho, d->conv_Wo, d->conv_k, d->conv_stride, d->conv_pad, d->conv_act, d->conv_src_u8};
   a.A2 = d->A2; a.b_scale = d->b_scale; a.b_shift = d->b_shift; a.b_gate = d->b_gate; a.b_hw = d->b_hw > 0 ? d->b_hw : 1;
 
   // K-contiguous operands need K % 4 == 0 (float4 along K); k-major operands need M resp. N % 4 == 0
@@ -81,6 +83,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   if (d->prologue == MT_PRO_IM2COL || d->b_prologue == MT_BPRO_IM2COL) {
     if (d->conv_k <= 0 || d->conv_stride <= 0 || d->conv_C <= 0 || d->conv_Ho <= 0 || d->conv_Wo <= 0)
       return fail(MT_ERR_ARG, "mt_gemm: im2col prologue needs the conv_* geometry");
+    if (d->conv_src_u8 && (d->conv_C & 3) == 0) return fail(MT_ERR_UNSUPPORTED, "mt_gemm: uint8 im2col source needs C %% 4 != 0 (3-channel crops)");
     if ((d->scale == nullptr) != (d->shift == nullptr) || (d->b_scale == nullptr) != (d->b_shift == nullptr))
       return fail(MT_ERR_ARG, "mt_gemm: im2col affine needs both scale and shift");
   }

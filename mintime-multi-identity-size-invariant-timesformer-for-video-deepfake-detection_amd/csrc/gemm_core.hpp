@@ -75,6 +75,7 @@ __device__ __forceinline__ int64_t map_row(const RowMap& rm, int r) {
 
 struct ConvDesc {   // geometry of an im2col prologue
   int H, W, C, Ho, Wo, k, stride, pad, act;   // act: 0 none, 2 relu (applied after the optional per-channel affine)
+  int src_u8;                                 // source image is uint8 (raw BGR crops), converted on the fly; scalar-gather path only
 };
 
 __device__ __forceinline__ float conv_act(float v, int act) { return act == 2 ? fmaxf(v, 0.f) : v; }
@@ -112,7 +113,8 @@ __device__ __forceinline__ float4 im2col_gather4(const float* __restrict__ x, co
       const int kh = tap / cd.k, kw = tap - kh * cd.k;
       const int ih = oh * cd.stride + kh - cd.pad, iw = ow * cd.stride + kw - cd.pad;
       if (ih >= 0 && ih < cd.H && iw >= 0 && iw < cd.W) {
-        v = x[(((int64_t)n * cd.H + ih) * cd.W + iw) * cd.C + ci];
+        const int64_t off = (((int64_t)n * cd.H + ih) * cd.W + iw) * cd.C + ci;
+        v = cd.src_u8 ? (float)reinterpret_cast<const uint8_t*>(x)[off] : x[off];
         if (scale) v = fmaf(v, scale[ci], shift[ci]);
         v = conv_act(v, cd.act);
       }

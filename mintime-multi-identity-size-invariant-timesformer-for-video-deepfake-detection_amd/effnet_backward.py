@@ -134,7 +134,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
             stem = saved["stem"]
             # the dedicated kernel (LDS-staged outer products) beats the im2col-gather wgrad GEMM here (1.15 vs 2.5 ms at 256 crops):
             # with 3 input channels the gather is scalar
-            L.check(lib.mt_stem_conv_wgrad(L.ptr(du_in), L.ptr(stem["z"]), L.ptr(kabc0), L.ptr(stem["x"]), L.ptr(grads[0]), N, H, W, st),
+            L.check(lib.mt_stem_conv_wgrad(L.ptr(du_in), L.ptr(stem["z"]), L.ptr(kabc0), L.ptr(stem["x"]), 1 if stem["x"].dtype == torch.uint8 else 0, L.ptr(grads[0]), N, H, W, st),
                     "mt_stem_conv_wgrad")
             dy = None
         del du_in

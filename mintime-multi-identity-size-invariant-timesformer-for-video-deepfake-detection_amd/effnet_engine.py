@@ -80,7 +80,7 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
     wp = _new(dev, arch.STEM_COUT, 28)
     L.check(lib.mt_conv_weight_pack(L.ptr(w_stem), L.ptr(wp), arch.STEM_COUT, 3, 3, 28, 0, st), "mt_conv_weight_pack")
     L.gemm(L.OP_NT, x_nhwc, wp, z, N * Hc * Wc, arch.STEM_COUT, 28, 28, 28, arch.STEM_COUT, prologue=L.PRO_IM2COL, epilogue=epi,
-           stats=bn.stats, stats_slots=SLOTS, conv=(H, W, 3, Hc, Wc, 3, 2, 0, 0))
+           stats=bn.stats, stats_slots=SLOTS, conv=(H, W, 3, Hc, Wc, 3, 2, 0, 0, 1 if x_nhwc.dtype == torch.uint8 else 0))
     _finalize(lib, st, model._bn0, bn, N * Hc * Wc, training, g0, b0)
     if save:
         saved["stem"] = dict(x=x_nhwc, z=z, bn=bn)
@@ -190,8 +190,10 @@ def effnet_apply(model, inputs, want_blocks=False):
     if inputs.shape[2] != model.image_size or inputs.shape[3] != model.image_size:
         raise ValueError(f"static TF-SAME padding was built for {model.image_size}x{model.image_size} inputs "
                          f"(utils.py:248-276); got {tuple(inputs.shape[2:])}")
-    # logical NCHW, physical NHWC: a view when the caller did `rearrange(videos, 'b f h w c -> (b f) c h w')` (train.py:341)
-    x_nhwc = inputs.float().permute(0, 2, 3, 1)
+    # logical NCHW, physical NHWC: a view when the caller did `rearrange(videos, 'b f h w c -> (b f) c h w')` (train.py:341).
+    # uint8 crops (what cv2 produces before deepfakes_dataset.py:339 casts them to float) are ingested as they are: the stem's
+    # gather converts on the fly, which cuts the H2D copy and the stem's input traffic 4x (next-row f2).
+    x_nhwc = (inputs if inputs.dtype == torch.uint8 else inputs.float()).permute(0, 2, 3, 1)
     if not x_nhwc.is_contiguous():
         x_nhwc = x_nhwc.contiguous()
     outs = _EffNetFunction.apply(model, want_blocks, x_nhwc, *param_list(model))

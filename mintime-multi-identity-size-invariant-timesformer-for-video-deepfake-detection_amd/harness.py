@@ -28,13 +28,16 @@ def make_optimizer(cfg, ef, tsf):
     return torch.optim.SGD(params, lr=t["lr"], weight_decay=t["weight-decay"])
 
 
-def device_batch(batch, num_frames=8, num_identities=2, seed=0, device="cuda", ragged=False):
-    """Synthetic clips resident on the device: videos are generated there (uint8-valued fp32, BGR 0..255)."""
+def device_batch(batch, num_frames=8, num_identities=2, seed=0, device="cuda", ragged=False, as_uint8=False):
+    """Synthetic clips resident on the device: videos are generated there (uint8-valued fp32, BGR 0..255; the reference's
+    dataset hands over fp32, deepfakes_dataset.py:339 -- `as_uint8` keeps the raw bytes, which the stems also accept)."""
     aux = synth.clip_inputs(batch, num_frames, num_identities, seed, ragged=ragged, with_video=False)
     g = torch.Generator(device=device).manual_seed(1000 + seed)
-    videos = torch.randint(0, 256, (batch, num_frames, 224, 224, 3), generator=g, device=device, dtype=torch.uint8).float()
+    videos = torch.randint(0, 256, (batch, num_frames, 224, 224, 3), generator=g, device=device, dtype=torch.uint8)
     if ragged:
-        videos = videos * aux["mask"].to(device)[:, :, None, None, None].float()
+        videos = videos * aux["mask"].to(device)[:, :, None, None, None].to(torch.uint8)
+    if not as_uint8:
+        videos = videos.float()
     return dict(videos=videos, mask=aux["mask"].to(device), identities_mask=aux["identities_mask"].to(device),
                 size_embedding=aux["size_embedding"], positions=aux["positions"].to(device),
                 labels=aux["labels"].to(device))

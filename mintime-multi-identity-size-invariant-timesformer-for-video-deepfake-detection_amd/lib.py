@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
                 ("A2", C.c_void_p), ("b_prologue", C.c_int), ("b_scale", C.c_void_p), ("b_shift", C.c_void_p),
                 ("b_gate", C.c_void_p), ("b_hw", C.c_int),
                 ("conv_H", C.c_int), ("conv_W", C.c_int), ("conv_C", C.c_int), ("conv_Ho", C.c_int), ("conv_Wo", C.c_int),
-                ("conv_k", C.c_int), ("conv_stride", C.c_int), ("conv_pad", C.c_int), ("conv_act", C.c_int)]
+                ("conv_k", C.c_int), ("conv_stride", C.c_int), ("conv_pad", C.c_int), ("conv_act", C.c_int), ("conv_src_u8", C.c_int)]
 
 
 OP_NT, OP_NN, OP_TN = 0, 1, 2
@@ -80,7 +80,7 @@ PROTOTYPES = {
     "mt_maxpool_add_fwd": [f32p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_maxpool_bwd": [f32p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_bn_bwd_apply": [f32p, f32p, f32p, f32p, i64, C.c_int, C.c_void_p],
-    "mt_stem_conv_wgrad": [f32p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_stem_conv_wgrad": [f32p] * 4 + [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
 }
 _RESTYPES = {"mt_last_error": C.c_char_p}
 
@@ -164,8 +164,9 @@ def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI
     d.C2, d.ldc2, d.stats, d.stats_slots = ptr(C2), ldc2, ptr(stats), stats_slots
     d.n_half, d.split_k = n_half, split_k
     d.A2, d.b_prologue, d.b_scale, d.b_shift, d.b_gate, d.b_hw = ptr(A2), b_prologue, ptr(b_scale), ptr(b_shift), ptr(b_gate), b_hw
-    if conv is not None:   # (H, W, C, Ho, Wo, k, stride, pad, act)
-        (d.conv_H, d.conv_W, d.conv_C, d.conv_Ho, d.conv_Wo, d.conv_k, d.conv_stride, d.conv_pad, d.conv_act) = conv
+    if conv is not None:   # (H, W, C, Ho, Wo, k, stride, pad, act[, src_u8])
+        (d.conv_H, d.conv_W, d.conv_C, d.conv_Ho, d.conv_Wo, d.conv_k, d.conv_stride, d.conv_pad, d.conv_act) = conv[:9]
+        d.conv_src_u8 = conv[9] if len(conv) > 9 else 0
     prof = PROFILE
     if prof is not None and prof["match"](d):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -88,14 +88,14 @@ def xception_forward(model, x, params, training, save):
         L.check(lib.mt_conv_weight_pack(L.ptr(w), L.ptr(out), Co, Ci, k, ld, transpose, L.stream_ptr()), "mt_conv_weight_pack")
         return out
 
-    def conv_im2col(src, wp, Cout, K, geom, bn_mod, gamma, beta):
+    def conv_im2col(src, wp, Cout, K, geom, bn_mod, gamma, beta, u8=False):
         """z = im2col(act(affine(src))) . wp^T  (+ BatchNorm statistics)."""
         Hh, Ww, Cc, Ho, Wo, k, s_, p_ = geom
         M = N * Ho * Wo
         ctx = _BNCtx(dev, Cout, training, pool)
         z = _new(dev, M, Cout)
         L.gemm(L.OP_NT, src.t, wp, z, M, Cout, K, K, K, Cout, prologue=L.PRO_IM2COL, epilogue=epi, scale=src.scale, shift=src.shift,
-               stats=ctx.stats, stats_slots=SLOTS, conv=(Hh, Ww, Cc, Ho, Wo, k, s_, p_, src.act))
+               stats=ctx.stats, stats_slots=SLOTS, conv=(Hh, Ww, Cc, Ho, Wo, k, s_, p_, src.act, 1 if u8 else 0))
         _finalize(lib, bn_mod, ctx, M, training, gamma, beta)
         return z, ctx
 
@@ -119,7 +119,7 @@ def xception_forward(model, x, params, training, save):
     w1, g1, b1, w2, g2, b2 = next(it), next(it), next(it), next(it), next(it), next(it)
     H1 = (H - 3) // 2 + 1
     wp1 = pack(w1, 32, 3, 3, 28)
-    z1, bn1 = conv_im2col(_Src(x, 3, H), wp1, 32, 28, (H, W, 3, H1, H1, 3, 2, 0), model.bn1, g1, b1)
+    z1, bn1 = conv_im2col(_Src(x, 3, H), wp1, 32, 28, (H, W, 3, H1, H1, 3, 2, 0), model.bn1, g1, b1, u8=x.dtype == torch.uint8)
     s1 = _Src(z1, 32, H1, bn1.scale, bn1.shift, RELU, bn1)
     H2 = H1 - 2
     wp2 = pack(w2, 64, 32, 3, 288)
@@ -315,7 +315,8 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
     k1 = bn_kabc(bn1, bn_sums(da1, z1, bn1, M1, act=RELU, dout=du1), 1)
     dwp1 = torch.zeros(32, 28, dtype=torch.float32, device=dev)
     L.gemm(L.OP_TN, du1, saved["x"], dwp1, 32, 28, M1, 32, 28, 28, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC, split_k=0, A2=z1,
-           scale=k1[0], shift=k1[1], gate=k1[2], b_prologue=L.BPRO_IM2COL, conv=(H, W, 3, H1, H1, 3, 2, 0, NONE))
+           scale=k1[0], shift=k1[1], gate=k1[2], b_prologue=L.BPRO_IM2COL,
+           conv=(H, W, 3, H1, H1, 3, 2, 0, NONE, 1 if saved["x"].dtype == torch.uint8 else 0))
     L.check(lib.mt_conv_weight_unpack_grad(L.ptr(dwp1), L.ptr(grads[0]), 32, 3, 3, 28, L.stream_ptr()), "mt_conv_weight_unpack_grad")
     side.wait()
     return [g_ if need else None for need, g_ in zip(need_dparams, grads)]
@@ -346,7 +347,7 @@ def xception_apply(model, inputs):
         raise L.MintimeHipError("Xception (MI355X build) needs device tensors; there is no CPU path")
     if inputs.dim() != 4 or inputs.shape[1] != 3:
         raise ValueError(f"expected [N,3,H,W] input, got {tuple(inputs.shape)}")
-    x = inputs.float().permute(0, 2, 3, 1)
+    x = (inputs if inputs.dtype == torch.uint8 else inputs.float()).permute(0, 2, 3, 1)      # uint8 crops are ingested as they are
     if not x.is_contiguous():
         x = x.contiguous()
     feat = _XceptionFunction.apply(model, x, *param_list(model))

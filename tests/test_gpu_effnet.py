@@ -91,3 +91,18 @@ def test_direct_stem_kernel_agrees_with_the_im2col_gemm_path():
     assert_close(z_direct, ref, 2e-5, "direct stem")
     assert_close(z_gemm, ref, 2e-5, "im2col GEMM stem")
     assert_close(st_direct.sum(0), st_gemm.sum(0), 1e-6, "BatchNorm sums")
+
+
+def test_uint8_crops_are_ingested_directly():
+    """Next-row f2: uint8 BGR crops (what the dataset holds before its .float()) give bit-identical features and gradients."""
+    for training in (False, True):
+        outs = []
+        for as_u8 in (False, True):
+            model, _ = _model(2, training)
+            x8 = torch.randint(0, 256, (3, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(9))
+            x = (x8 if as_u8 else x8.float()).permute(0, 3, 1, 2).cuda()
+            f = model(x)
+            f.sum().backward()
+            outs.append((f.detach().clone(), model._conv_stem.weight.grad.clone()))
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert_close(outs[1][1], outs[0][1], 1e-5, "stem weight gradient (atomics order only)")

@@ -94,3 +94,17 @@ def test_all_parameter_gradients_vs_oracle(training):
         assert ours <= 3 * REL_TOL + 3 * floor, f"grad {k}: ours {ours:.2e} vs fp32-reference floor {floor:.2e}"
         worst = max(worst, ours)
     print("worst relative gradient error vs fp64", worst)
+
+
+def test_uint8_crops_are_ingested_directly():
+    """Next-row f2: conv1's im2col gather reads uint8 crops; features and conv1's weight gradient equal the fp32-input run."""
+    outs = []
+    for as_u8 in (False, True):
+        model, _ = _model(4, True)
+        x = _input(2, 6)
+        x = (x.to(torch.uint8) if as_u8 else x).cuda()
+        f = model(x)
+        f.sum().backward()
+        outs.append((f.detach().clone(), model.conv1.weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert_close(outs[1][1], outs[0][1], 1e-5, "conv1 weight gradient (split-K atomics order only)")
