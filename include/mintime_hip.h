@@ -196,6 +196,14 @@ int mt_dwconv_bwd(const float* du, const float* z, const float* kabc, const floa
 int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N,
                        int H, int W, void* stream);   /* x fp32 or (x_is_u8) uint8 */
 
+/* Weight gradient of a 1x1 convolution with few channels and very many rows (MBConv expand / project convs of stages 1-4,
+ * efficientnet_pytorch/model.py:93-104 under train.py:371):  dw[Cout,Cin] += sum_r (ka*du+kb*z+kc)[r,Cout] * a[r,Cin] with
+ * a = x, or (gate != NULL) swish(sc*x+sh)*gate[r/hw].  The whole (32-padded) result stays in MFMA accumulators while the rows
+ * stream through; mt_conv1x1_wgrad_supported says whether a shape has an instance (otherwise use mt_gemm, MT_OP_TN). */
+int mt_conv1x1_wgrad_supported(int Cout, int Cin);
+int mt_conv1x1_wgrad(const float* du, const float* z, const float* kabc, const float* x, const float* sc, const float* sh,
+                     const float* gate, int hw, float* dw, int64_t rows, int Cout, int Cin, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Xception (config 5 extractor, reference models/xception.py).  Dense convolutions are mt_gemm with the IM2COL
  * prologue; separable convolutions are mt_dwconv_* (act 0/2) + mt_gemm; the rest:

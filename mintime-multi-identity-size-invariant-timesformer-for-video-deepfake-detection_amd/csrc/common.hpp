@@ -27,4 +27,23 @@ inline int check_launch(const char* what) {
 
 enum { MT_ERR_ARG = -1, MT_ERR_LAUNCH = -2, MT_ERR_UNSUPPORTED = -3 };
 
+// Work assignment for the persistent, channel-chunked NHWC tile kernels (depthwise conv forward / dgrad / wgrad).
+// A chunk of 16 channels is only 64 B of every pixel, so the chunks of ONE spatial tile must run on the same XCD at about
+// the same time: its L2 then fetches each 128 B line once and serves the neighbouring chunk from cache.  Block b runs on XCD
+// b % 8; within an XCD consecutive blocks take the chunks of one tile.  gridDim.x = 8 * chunks * tiles_per_xcd_in_flight.
+__device__ __forceinline__ void xcd_chunk_tile(int chunks, int& chunk, int64_t& tile0, int64_t& stride) {
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  chunk = j % chunks;
+  tile0 = (int64_t)(j / chunks) * 8 + xcd;
+  stride = (int64_t)((gridDim.x >> 3) / chunks) * 8;
+}
+
+inline unsigned xcd_chunk_grid(int chunks, int64_t ntiles, int target_blocks) {
+  int64_t per_xcd = target_blocks / (8 * chunks);
+  const int64_t need = (ntiles + 7) / 8;
+  if (per_xcd > need) per_xcd = need;
+  if (per_xcd < 1) per_xcd = 1;
+  return (unsigned)(8 * chunks * per_xcd);
+}
+
 }  // namespace mt

@@ -258,7 +258,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
   const int cq = tid % CQN, r = tid / CQN;
   const int kh = r % K, ps = r / K;
   const bool worker = ps < PS;
-  const int c0 = blockIdx.y * CC;
+  int chunk_id; int64_t tile0, tile_stride;
+  xcd_chunk_tile(C / CC, chunk_id, tile0, tile_stride);
+  const int c0 = chunk_id * CC;
   const int ty_n = (Ho + T - 1) / T, tx_n = (Wo + T - 1) / T;
   const int64_t ntiles = (int64_t)N * ty_n * tx_n;
 
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
 #pragma unroll
   for (int i = 0; i < K; ++i) acc[i] = f4(0, 0, 0, 0);
 
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t tile = tile0; tile < ntiles; tile += tile_stride) {
     const int tx = (int)(tile % tx_n);
     const int64_t t2 = tile / tx_n;
     const int ty = (int)(t2 % ty_n);
@@ -339,15 +341,13 @@ int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, co
   if (red > lds) lds = red;
   const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((Ho + T - 1) / T) * ((Wo + T - 1) / T);
-  int64_t bx = 4096 / chunks;
-  if (bx < 1) bx = 1;
-  if (bx > ntiles) bx = ntiles;
+  const unsigned bx = xcd_chunk_grid(chunks, ntiles, 4096);
   auto k = dwconv_wgrad_tiled_kernel<K, S, T, ACT, CC>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)bx, chunks), dim3(256), lds, s, du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(k, dim3(bx), dim3(256), lds, s, du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo);
   return check_launch("mt_dwconv_bwd(weight, tiled)");
 }
 
@@ -368,7 +368,9 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];   // dz_t [OT][OTP][CC]; later the stats reduction buffer
   const int tid = threadIdx.x;
   const int cq = tid % CQN, slot = tid / CQN;
-  const int c0 = blockIdx.y * CC;
+  int chunk_id; int64_t tile0, tile_stride;
+  xcd_chunk_tile(C / CC, chunk_id, tile0, tile_stride);
+  const int c0 = chunk_id * CC;
   const int ty_n = (H + T - 1) / T, tx_n = (W + T - 1) / T;
   const int64_t ntiles = (int64_t)N * ty_n * tx_n;
   const int c = c0 + cq * 4;
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
   for (int i = 0; i < K * K; ++i)
     wt[i] = f4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
   float4 s1 = f4(0, 0, 0, 0), s2 = s1;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t tile = tile0; tile < ntiles; tile += tile_stride) {
     const int tx = (int)(tile % tx_n);
     const int64_t t2 = tile / tx_n;
     const int ty = (int)(t2 % ty_n);
@@ -459,10 +461,8 @@ int launch_dw_dgrad_tiled(const float* du, const float* z, const float* kabc, co
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);
   const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((H + T - 1) / T) * ((W + T - 1) / T);
-  int64_t bx = 8192 / chunks;
-  if (bx < 1) bx = 1;
-  if (bx > ntiles) bx = ntiles;
-  hipLaunchKernelGGL((dwconv_dgrad_tiled_kernel<K, S, T, ACT, CC>), dim3((unsigned)bx, chunks), dim3(256), lds, s, du, z, kabc, w, zin,
+  const unsigned bx = xcd_chunk_grid(chunks, ntiles, 8192);
+  hipLaunchKernelGGL((dwconv_dgrad_tiled_kernel<K, S, T, ACT, CC>), dim3(bx), dim3(256), lds, s, du, z, kabc, w, zin,
                      scale_in, shift_in, mi_in, du_in, stats, slots > 0 ? slots : 1, N, H, W, C, Ho, Wo, res_pre, res_post);
   return check_launch("mt_dwconv_bwd(data, tiled)");
 }

@@ -151,7 +151,9 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) float lds[];   // a_t [IH][IWP][CC]; later the stats reduction buffer
   const int tid = threadIdx.x;
   const int cq = tid % CQN, slot = tid / CQN;
-  const int c0 = blockIdx.y * CC;
+  int chunk_id; int64_t tile0, tile_stride;
+  xcd_chunk_tile(C / CC, chunk_id, tile0, tile_stride);
+  const int c0 = chunk_id * CC;
   const int ty_n = (Ho + T - 1) / T, tx_n = (Wo + T - 1) / T;
   const int64_t ntiles = (int64_t)N * ty_n * tx_n;
   float4 wt[K * K];
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
       wt[i] = make_float4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
   }
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t tile = tile0; tile < ntiles; tile += tile_stride) {
     const int tx = (int)(tile % tx_n);
     const int64_t t2 = tile / tx_n;
     const int ty = (int)(t2 % ty_n);
@@ -225,15 +227,13 @@ int launch_dw_tiled(const float* zin, const float* scale, const float* shift, co
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);
   const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((Ho + T - 1) / T) * ((Wo + T - 1) / T);
-  int64_t bx = 8192 / chunks;
-  if (bx < 1) bx = 1;
-  if (bx > ntiles) bx = ntiles;
+  const unsigned bx = xcd_chunk_grid(chunks, ntiles, 8192);
   auto k = dwconv_tiled_kernel<K, S, T, ACT, CC>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)bx, chunks), dim3(256), lds, s, zin, scale, shift, w, zout, stats, slots > 0 ? slots : 1, N, H,
+  hipLaunchKernelGGL(k, dim3(bx), dim3(256), lds, s, zin, scale, shift, w, zout, stats, slots > 0 ? slots : 1, N, H,
                      W, C, Ho, Wo, pad0);
   return check_launch("mt_dwconv_fwd(tiled)");
 }
@@ -293,12 +293,25 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const float* __restrict__ 
   const int cq = blockIdx.y * CQB + cql;
   const int CQ = C >> 2;
   const int n = blockIdx.x;
+  // blockIdx.z = slice of the image's pixels (one image per block would leave a 256-crop batch at 1 block per CU)
+  const int per = (HW + gridDim.z - 1) / gridDim.z;
+  const int p_lo = blockIdx.z * per, p_hi = min(HW, p_lo + per);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (pl < PB && cq < CQ) {
     const float4 sc = *reinterpret_cast<const float4*>(scale + cq * 4);
     const float4 sh = *reinterpret_cast<const float4*>(shift + cq * 4);
     const float* base = z + (int64_t)n * HW * C + cq * 4;
-    for (int p = pl; p < HW; p += PB) {
+    int p = p_lo + pl;
+    for (; p + 3 * PB < p_hi; p += 4 * PB) {     // 4 independent loads in flight
+      const float4 v0 = *reinterpret_cast<const float4*>(base + (int64_t)p * C);
+      const float4 v1 = *reinterpret_cast<const float4*>(base + (int64_t)(p + PB) * C);
+      const float4 v2 = *reinterpret_cast<const float4*>(base + (int64_t)(p + 2 * PB) * C);
+      const float4 v3 = *reinterpret_cast<const float4*>(base + (int64_t)(p + 3 * PB) * C);
+      const float4 a0 = bn_swish4(v0, sc, sh), a1 = bn_swish4(v1, sc, sh), a2 = bn_swish4(v2, sc, sh), a3 = bn_swish4(v3, sc, sh);
+      s.x += (a0.x + a1.x) + (a2.x + a3.x); s.y += (a0.y + a1.y) + (a2.y + a3.y);
+      s.z += (a0.z + a1.z) + (a2.z + a3.z); s.w += (a0.w + a1.w) + (a2.w + a3.w);
+    }
+    for (; p < p_hi; p += PB) {
       const float4 a = bn_swish4(*reinterpret_cast<const float4*>(base + (int64_t)p * C), sc, sh);
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
@@ -307,12 +320,17 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const float* __restrict__ 
   __syncthreads();
   if (pl == 0 && cq < CQ) {
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = 0; p < PB; ++p) {
-      const float4 v = *reinterpret_cast<const float4*>(red + (p * CQB + cql) * 4);
+    for (int q = 0; q < PB; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(red + (q * CQB + cql) * 4);
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
     const float inv = 1.0f / (float)HW;
-    *reinterpret_cast<float4*>(pooled + (int64_t)n * C + cq * 4) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    float* out = pooled + (int64_t)n * C + cq * 4;
+    if (gridDim.z == 1) {
+      *reinterpret_cast<float4*>(out) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    } else {                                     // slices meet in the (pre-zeroed) output
+      atomicAdd(out + 0, t.x * inv); atomicAdd(out + 1, t.y * inv); atomicAdd(out + 2, t.z * inv); atomicAdd(out + 3, t.w * inv);
+    }
   }
 }
 
@@ -430,7 +448,12 @@ extern "C" int mt_se_pool_fwd(const float* z, const float* scale, const float* s
   if (!z || !scale || !shift || !pooled) return fail(MT_ERR_ARG, "mt_se_pool_fwd: null pointer");
   if (C & 3) return fail(MT_ERR_ARG, "mt_se_pool_fwd: C %% 4 != 0");
   const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
-  hipLaunchKernelGGL(se_pool_kernel, dim3(N, CQ / CQB), dim3(CQB * PB), (size_t)PB * CQB * 4 * sizeof(float),
+  // enough blocks to fill the chip: slice each image's pixels while a slice still has >= 16 pixels per thread
+  int parts = 1;
+  while ((int64_t)N * (CQ / CQB) * parts < 2048 && HW / (parts * 2) >= PB * 16) parts *= 2;
+  if (parts > 1 && hipMemsetAsync(pooled, 0, (size_t)N * C * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return fail(MT_ERR_LAUNCH, "mt_se_pool_fwd: memset failed");
+  hipLaunchKernelGGL(se_pool_kernel, dim3(N, CQ / CQB, parts), dim3(CQB * PB), (size_t)PB * CQB * 4 * sizeof(float),
                      (hipStream_t)stream, z, scale, shift, pooled, HW, C, CQB, PB);
   return check_launch("mt_se_pool_fwd");
 }

@@ -60,9 +60,17 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         kw = {}
         if b_pro is not None:
             kw = dict(b_prologue=L.BPRO_BN_SWISH_GATE, b_scale=b_pro[0], b_shift=b_pro[1], b_gate=b_pro[2], b_hw=b_pro[3])
-        side.launch(lambda: L.gemm(L.OP_TN, du, x_in, grads[gw_idx], cout, cin, rows, cout, cin, cin, prologue=L.PRO_BN_BWD,
-                                   epilogue=L.EPI_ATOMIC, split_k=0, A2=z, scale=kabc[0], shift=kabc[1], gate=kabc[2], **kw),
-                    reads=(du, z, x_in, kabc) + (tuple(b_pro[:3]) if b_pro is not None else ()))
+        reads = (du, z, x_in, kabc) + (tuple(b_pro[:3]) if b_pro is not None else ())
+        if rows >= 100000 and lib.mt_conv1x1_wgrad_supported(cout, cin):
+            # few channels, very many rows: the result stays in MFMA accumulators while the rows stream (skinny_wgrad.hip)
+            bp = b_pro if b_pro is not None else (None, None, None, 1)
+            side.launch(lambda: L.check(lib.mt_conv1x1_wgrad(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(x_in), L.ptr(bp[0]), L.ptr(bp[1]),
+                                                             L.ptr(bp[2]), bp[3], L.ptr(grads[gw_idx]), rows, cout, cin,
+                                                             L.stream_ptr()), "mt_conv1x1_wgrad"), reads=reads)
+        else:
+            side.launch(lambda: L.gemm(L.OP_TN, du, x_in, grads[gw_idx], cout, cin, rows, cout, cin, cin, prologue=L.PRO_BN_BWD,
+                                       epilogue=L.EPI_ATOMIC, split_k=0, A2=z, scale=kabc[0], shift=kabc[1], gate=kabc[2], **kw),
+                        reads=reads)
         if not need_dx_in:
             return None
         dx_in = _new(dev, rows, cin)
