@@ -25,6 +25,10 @@ inline int check_launch(const char* what) {
   return 0;
 }
 
+// skinny_wgrad.hip
+int stem_wgrad_mfma(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N, int H, int W,
+                    int Ho, int Wo, int pad0, hipStream_t st);
+
 enum { MT_ERR_ARG = -1, MT_ERR_LAUNCH = -2, MT_ERR_UNSUPPORTED = -3 };
 
 // Work assignment for the persistent, channel-chunked NHWC tile kernels (depthwise conv forward / dgrad / wgrad).

@@ -645,6 +645,7 @@ extern "C" int mt_stem_conv_wgrad(const float* du, const float* z, const float* 
   if (!du || !z || !kabc || !x || !dw) return fail(MT_ERR_ARG, "mt_stem_conv_wgrad: null pointer");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int padt = max((Ho - 1) * 2 + 3 - H, 0);
+  if (Wo <= 128) return stem_wgrad_mfma(du, z, kabc, x, x_is_u8, dw, N, H, W, Ho, Wo, padt / 2, (hipStream_t)stream);
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, du, z, kabc, x, x_is_u8, dw, N, H, W, Ho, Wo, padt / 2);
   return check_launch("mt_stem_conv_wgrad");
 }

@@ -27,7 +27,11 @@ struct WgradArgs {
   const float* sc; const float* sh; const float* gate;       // GATE mode: [Cin], [Cin], [rows / hw, Cin]
   float* dw;                                                 // [Cout, Cin], accumulated with atomics
   int64_t rows; int Cout, Cin, hw;
+  // STEM mode (3x3 stride-2 "same" conv on 3-channel crops, a = im2col(x) gathered on the fly; one chunk = one output row)
+  const void* img; int x_u8, H, W, Ho, Wo, pad0;
 };
+
+enum { A_PLAIN = 0, A_GATE = 1, A_STEM = 2 };
 
 __device__ __forceinline__ float swish_f(float v) { return v / (1.f + __expf(-v)); }
 // component-wise on purpose: `c ? a : zero4` on the structs makes the compiler select between two stack slots
@@ -35,9 +39,9 @@ __device__ __forceinline__ float4 keep_if(bool c, const float4& a) { return make
 
 constexpr int ld_for(int tiles) { return tiles * 32 + ((tiles & 1) ? 0 : 32); }   // ld % 64 == 32: the two k-rows of a fragment hit disjoint banks
 
-// MT x NT 32x32 output tiles, R rows per chunk, GATE selects the project-conv operand transform.  The block's 4 wavefronts are
+// MT x NT 32x32 output tiles, R rows per chunk, AMODE selects the `a` operand (plain / project-conv transform / stem im2col).  The block's 4 wavefronts are
 // arranged as WM x WN groups over the output tiles times WR = 4 / (WM*WN) groups over the chunk's rows.
-template <int MT, int NT, int R, bool GATE, int WM, int WN, bool KREG>
+template <int MT, int NT, int R, int AMODE, int WM, int WN, bool KREG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv1x1_wgrad_kernel(WgradArgs p) {
   constexpr int LDZ = ld_for(MT), LDA = ld_for(NT);
   constexpr int VZ = (R * MT * 32 / 4 + 255) / 256;      // float4 slots per thread covering [R, Cout]
@@ -59,6 +63,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     kab[MT * 32 + i] = ok ? p.kabc[p.Cout + i] : 0.f;
     kab[2 * MT * 32 + i] = ok ? p.kabc[2 * p.Cout + i] : 0.f;
   }
+  constexpr bool GATE = AMODE == A_GATE, STEM = AMODE == A_STEM;
+  constexpr int SV = STEM ? R / 8 : 1;       // STEM: scalar gather slots per thread (lane = tap, 8 pixels per pass)
+  static_assert(!STEM || (MT == 1 && NT == 1 && WM * WN == 1), "stem mode is a 32 x 27 result");
   if constexpr (GATE)
     for (int i = tid; i < NT * 32; i += 256) {
       const bool ok = i < p.Cin;
@@ -88,6 +95,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ac[i] = (idx - ar[i] * aq) * 4;
     if (ar[i] >= R) { ar[i] = -1; ac[i] = 0; }
   }
+  // STEM: this thread's tap (kh, kw, ci) is fixed; it gathers it for pixels (tid >> 5) + 8 i of the output row
+  const int tap = tid & 31, s_kh = tap / 9, s_kw = (tap % 9) / 3, s_ci = tap % 3;
+  float sx[SV];
+  unsigned sx_ok = 0;
 
   f32x16 acc[MTW][NTW];
 #pragma unroll
@@ -97,30 +108,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int64_t nchunks = (p.rows + R - 1) / R;
+  const int CR = STEM ? p.Wo : R;          // rows a chunk advances by
+  const int64_t nchunks = (p.rows + CR - 1) / CR;
   float4 rdu[VZ], rz[VZ], rx[VA];
 
   // Loads are unconditional (row clamped into the chunk): a `cond ? *p : 0` form makes the compiler select between the global
   // address and a stack slot and emit flat loads, which serialises the whole prefetch.  Rows past the end are zeroed in stage().
   auto fetch = [&](int64_t chunk) {
-    const int64_t r0 = chunk * R;
-    const int last = (int)((p.rows - r0) < R ? (p.rows - r0) : R) - 1;
+    const int64_t r0 = chunk * CR;
+    const int last = (int)((p.rows - r0) < CR ? (p.rows - r0) : CR) - 1;
     const float* du_c = p.du + r0 * p.Cout;
     const float* z_c = p.z + r0 * p.Cout;
-    const float* x_c = p.x + r0 * p.Cin;
 #pragma unroll
     for (int i = 0; i < VZ; ++i) {
       const int off = min(max(zr[i], 0), last) * p.Cout + zc[i];
       rdu[i] = *reinterpret_cast<const float4*>(du_c + off);
       rz[i] = *reinterpret_cast<const float4*>(z_c + off);
     }
+    if constexpr (STEM) {
+      const int n = (int)(chunk / p.Ho), oh = (int)(chunk - (int64_t)n * p.Ho);
+      const int ih = 2 * oh + s_kh - p.pad0;
+      const bool row_ok = tap < 27 && ih >= 0 && ih < p.H;
+      const int64_t base = ((int64_t)n * p.H + min(max(ih, 0), p.H - 1)) * p.W * 3 + s_ci;
+      sx_ok = 0;
 #pragma unroll
-    for (int i = 0; i < VA; ++i) rx[i] = *reinterpret_cast<const float4*>(x_c + min(max(ar[i], 0), last) * p.Cin + ac[i]);
+      for (int i = 0; i < SV; ++i) {
+        const int ow = (tid >> 5) + 8 * i;
+        const int iw = 2 * ow + s_kw - p.pad0;
+        if (row_ok && ow < p.Wo && iw >= 0 && iw < p.W) sx_ok |= 1u << i;
+        const int64_t off = base + (int64_t)min(max(iw, 0), p.W - 1) * 3;
+        if (p.x_u8) sx[i] = (float)reinterpret_cast<const uint8_t*>(p.img)[off];
+        else sx[i] = reinterpret_cast<const float*>(p.img)[off];
+      }
+    } else {
+      const float* x_c = p.x + r0 * p.Cin;
+#pragma unroll
+      for (int i = 0; i < VA; ++i) rx[i] = *reinterpret_cast<const float4*>(x_c + min(max(ar[i], 0), last) * p.Cin + ac[i]);
+    }
   };
 
   auto stage = [&](int64_t chunk) {   // registers -> LDS, operand transforms applied here
-    const int64_t r0 = chunk * R;
-    const int left = (int)((p.rows - r0) < R ? (p.rows - r0) : R);
+    const int64_t r0 = chunk * CR;
+    const int left = (int)((p.rows - r0) < CR ? (p.rows - r0) : CR);
 #pragma unroll
     for (int i = 0; i < VZ; ++i) {
       if (zr[i] >= 0) {
@@ -163,6 +192,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           *reinterpret_cast<float4*>(as + ar[i] * LDA + ac[i]) = v;
         }
       }
+    } else if constexpr (STEM) {
+#pragma unroll
+      for (int i = 0; i < SV; ++i) as[((tid >> 5) + 8 * i) * LDA + tap] = ((sx_ok >> i) & 1u) ? sx[i] : 0.f;
     } else {
 #pragma unroll
       for (int i = 0; i < VA; ++i)
@@ -229,7 +261,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     for (int i = tid; i < p.Cout * p.Cin; i += 256) {
       const int co = i / p.Cin, ci = i - co * p.Cin;
-      atomicAdd(p.dw + i, red[co * LDR + ci]);
+      // STEM: column ci is the tap (kh*3 + kw)*3 + c; torch keeps the weight as [co][c][kh][kw]
+      const int dst = STEM ? co * 27 + (ci % 3) * 9 + ci / 3 : i;
+      atomicAdd(p.dw + dst, red[co * LDR + ci]);
     }
   }
 }
@@ -248,12 +282,24 @@ int launch(const WgradArgs& a, bool gate, hipStream_t st) {
     if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), smem, st, a);
   };
-  if (gate) go(conv1x1_wgrad_kernel<MT, NT, R, true, WM, WN, KREG>);
-  else go(conv1x1_wgrad_kernel<MT, NT, R, false, WM, WN, KREG>);
+  if (gate) go(conv1x1_wgrad_kernel<MT, NT, R, A_GATE, WM, WN, KREG>);
+  else go(conv1x1_wgrad_kernel<MT, NT, R, A_PLAIN, WM, WN, KREG>);
   return check_launch("mt_conv1x1_wgrad");
 }
 
 }  // namespace
+
+// _conv_stem weight gradient on the same kernel (one chunk = one output row of <= 128 pixels); called by mt_stem_conv_wgrad
+int mt::stem_wgrad_mfma(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N, int H, int W,
+                        int Ho, int Wo, int pad0, hipStream_t st) {
+  constexpr int R = 128;
+  WgradArgs a{du, z, kabc, nullptr, nullptr, nullptr, nullptr, dw, (int64_t)N * Ho * Wo, 32, 27, 1, x, x_is_u8, H, W, Ho, Wo, pad0};
+  const size_t smem = ((size_t)R * (ld_for(1) + ld_for(1)) + 3 * 32 + 2 * 32) * 4;
+  const int64_t nchunks = (int64_t)N * Ho;
+  const int blocks = (int)(nchunks < 512 ? nchunks : 512);
+  hipLaunchKernelGGL((conv1x1_wgrad_kernel<1, 1, R, A_STEM, 1, 1, true>), dim3(blocks), dim3(256), smem, st, a);
+  return check_launch("mt_stem_conv_wgrad(mfma)");
+}
 
 // instances: (Cout tiles, Cin tiles, rows per chunk, tile groups along Cout, along Cin, resident blocks per CU to launch,
 //             BatchNorm-backward coefficients in registers [1] or LDS [0])
@@ -280,7 +326,7 @@ extern "C" int mt_conv1x1_wgrad(const float* du, const float* z, const float* ka
   const bool g = gate != nullptr;
   if (g && (!sc || !sh || hw <= 0)) return fail(MT_ERR_ARG, "mt_conv1x1_wgrad: gate needs scale, shift and hw");
   if (((uintptr_t)du | (uintptr_t)z | (uintptr_t)x | (uintptr_t)kabc) & 15) return fail(MT_ERR_ARG, "mt_conv1x1_wgrad: 16-byte alignment");
-  WgradArgs a{du, z, kabc, x, sc, sh, gate, dw, rows, Cout, Cin, hw};
+  WgradArgs a{du, z, kabc, x, sc, sh, gate, dw, rows, Cout, Cin, hw, nullptr, 0, 0, 0, 0, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   const int mt_ = (Cout + 31) / 32, nt = (Cin + 31) / 32;
 #define MT_CASE(M_, N_, R_, WM_, WN_, B_, K_) if (mt_ == M_ && nt == N_) return launch<M_, N_, R_, WM_, WN_, B_, K_>(a, g, st);
