@@ -114,13 +114,17 @@ int mt_bn_finalize(const double* stats, int slots, double count, const float* ga
                    float* running_mean, float* running_var, float* scale, float* shift, float* mean_invstd,
                    int C, float eps, float momentum, int training, void* stream);
 
-/* squeeze: pooled[n,c] = mean_hw swish(bn(z)) (model.py:104-108). */
-int mt_se_pool_fwd(const float* z, const float* scale, const float* shift, float* pooled, int N, int HW, int C, void* stream);
+/* squeeze: mean_hw swish(bn(z)) (model.py:104-108), computed as `parts` pixel slices per image so that small batches still
+ * fill the chip: partial[n, part, c] (already divided by HW); parts = mt_se_pool_parts(N, HW, C).  No atomics. */
+int mt_se_pool_parts(int N, int HW, int C);
+int mt_se_pool_fwd(const float* z, const float* scale, const float* shift, float* partial, int N, int HW, int C, int parts,
+                   void* stream);
 
-/* excite: gate = sigmoid(_se_expand(swish(_se_reduce(pooled)))) (model.py:109-112). w1 [CS,C], w2 [C,CS];
+/* excite: pooled = sum of the slices (written to `pooled` [N,C] when not NULL: kept for backward);
+ * gate = sigmoid(_se_expand(swish(_se_reduce(pooled)))) (model.py:109-112). w1 [CS,C], w2 [C,CS];
  * hidden (optional) [N,CS] receives the pre-activation of the squeeze layer (kept for backward). */
-int mt_se_gate_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
-                   float* gate, float* hidden, int N, int C, int CS, void* stream);
+int mt_se_gate_fwd(const float* partial, int parts, const float* w1, const float* b1, const float* w2, const float* b2,
+                   float* pooled, float* gate, float* hidden, int N, int C, int CS, void* stream);
 
 /* y = act(z*scale+shift) * rowscale[row / rows_per_group] (+ res): _bn2 + drop_connect + identity skip
  * (model.py:117-127, utils.py:129-154; act=0) and head _bn1+swish (model.py:286; act=1). rowscale may be NULL. */

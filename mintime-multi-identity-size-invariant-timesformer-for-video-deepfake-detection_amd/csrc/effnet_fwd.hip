@@ -325,26 +325,28 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const float* __restrict__ 
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
     const float inv = 1.0f / (float)HW;
-    float* out = pooled + (int64_t)n * C + cq * 4;
-    if (gridDim.z == 1) {
-      *reinterpret_cast<float4*>(out) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
-    } else {                                     // slices meet in the (pre-zeroed) output
-      atomicAdd(out + 0, t.x * inv); atomicAdd(out + 1, t.y * inv); atomicAdd(out + 2, t.z * inv); atomicAdd(out + 3, t.w * inv);
-    }
+    // partial[n][slice][c]: the slices are summed, in a fixed order, by the gate kernel (no atomics: eval stays deterministic)
+    float* out = pooled + ((int64_t)n * gridDim.z + blockIdx.z) * C + cq * 4;
+    *reinterpret_cast<float4*>(out) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ SE: gate
 // gate[n,c] = sigmoid(W2[c,:] . swish(W1 . pooled[n,:] + b1) + b2[c]);  one block per image
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ partial, int parts, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
-                                                      const float* __restrict__ b2, float* __restrict__ gate,
-                                                      float* __restrict__ hidden, int C, int CS) {
+                                                      const float* __restrict__ b2, float* __restrict__ pooled,
+                                                      float* __restrict__ gate, float* __restrict__ hidden, int C, int CS) {
   extern __shared__ float sm[];    // pooled[C] + hid[CS]
   float* pv = sm;
   float* hid = sm + C;
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < C; i += 256) pv[i] = pooled[(int64_t)n * C + i];
+  for (int i = tid; i < C; i += 256) {
+    float v = 0.f;
+    for (int q = 0; q < parts; ++q) v += partial[((int64_t)n * parts + q) * C + i];
+    pv[i] = v;
+    if (pooled) pooled[(int64_t)n * C + i] = v;
+  }
   __syncthreads();
   for (int j = wave; j < CS; j += 4) {
     float a = 0.f;
@@ -443,26 +445,32 @@ extern "C" int mt_bn_finalize(const double* stats, int slots, double count, cons
   return check_launch("mt_bn_finalize");
 }
 
-extern "C" int mt_se_pool_fwd(const float* z, const float* scale, const float* shift, float* pooled, int N, int HW, int C,
-                              void* stream) {
-  if (!z || !scale || !shift || !pooled) return fail(MT_ERR_ARG, "mt_se_pool_fwd: null pointer");
-  if (C & 3) return fail(MT_ERR_ARG, "mt_se_pool_fwd: C %% 4 != 0");
-  const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
+static int se_pool_parts(int N, int HW, int C) {
   // enough blocks to fill the chip: slice each image's pixels while a slice still has >= 16 pixels per thread
+  const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
   int parts = 1;
   while ((int64_t)N * (CQ / CQB) * parts < 2048 && HW / (parts * 2) >= PB * 16) parts *= 2;
-  if (parts > 1 && hipMemsetAsync(pooled, 0, (size_t)N * C * sizeof(float), (hipStream_t)stream) != hipSuccess)
-    return fail(MT_ERR_LAUNCH, "mt_se_pool_fwd: memset failed");
+  return parts;
+}
+
+extern "C" int mt_se_pool_parts(int N, int HW, int C) { return (C & 3) || C <= 0 ? 1 : se_pool_parts(N, HW, C); }
+
+extern "C" int mt_se_pool_fwd(const float* z, const float* scale, const float* shift, float* partial, int N, int HW, int C,
+                              int parts, void* stream) {
+  if (!z || !scale || !shift || !partial) return fail(MT_ERR_ARG, "mt_se_pool_fwd: null pointer");
+  if (C & 3) return fail(MT_ERR_ARG, "mt_se_pool_fwd: C %% 4 != 0");
+  if (parts != se_pool_parts(N, HW, C)) return fail(MT_ERR_ARG, "mt_se_pool_fwd: parts must come from mt_se_pool_parts");
+  const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
   hipLaunchKernelGGL(se_pool_kernel, dim3(N, CQ / CQB, parts), dim3(CQB * PB), (size_t)PB * CQB * 4 * sizeof(float),
-                     (hipStream_t)stream, z, scale, shift, pooled, HW, C, CQB, PB);
+                     (hipStream_t)stream, z, scale, shift, partial, HW, C, CQB, PB);
   return check_launch("mt_se_pool_fwd");
 }
 
-extern "C" int mt_se_gate_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
-                              float* gate, float* hidden, int N, int C, int CS, void* stream) {
-  if (!pooled || !w1 || !b1 || !w2 || !b2 || !gate) return fail(MT_ERR_ARG, "mt_se_gate_fwd: null pointer");
-  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), (size_t)(C + CS) * sizeof(float), (hipStream_t)stream, pooled, w1, b1,
-                     w2, b2, gate, hidden, C, CS);
+extern "C" int mt_se_gate_fwd(const float* partial, int parts, const float* w1, const float* b1, const float* w2, const float* b2,
+                              float* pooled, float* gate, float* hidden, int N, int C, int CS, void* stream) {
+  if (!partial || !w1 || !b1 || !w2 || !b2 || !gate || parts < 1) return fail(MT_ERR_ARG, "mt_se_gate_fwd: null pointer");
+  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), (size_t)(C + CS) * sizeof(float), (hipStream_t)stream, partial, parts, w1,
+                     b1, w2, b2, pooled, gate, hidden, C, CS);
   return check_launch("mt_se_gate_fwd");
 }
 

@@ -114,9 +114,12 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
         pooled, gate = _new(dev, N, s.cexp), _new(dev, N, s.cexp)
         hidden = _new(dev, N, s.cse) if save else None
         hw = s.hout * s.hout
-        L.check(lib.mt_se_pool_fwd(L.ptr(z_d), L.ptr(bn_d.scale), L.ptr(bn_d.shift), L.ptr(pooled), N, hw, s.cexp, st), "mt_se_pool_fwd")
-        L.check(lib.mt_se_gate_fwd(L.ptr(pooled), L.ptr(w_r), L.ptr(b_r), L.ptr(w_x), L.ptr(b_x), L.ptr(gate), L.ptr(hidden), N,
-                                   s.cexp, s.cse, st), "mt_se_gate_fwd")
+        parts = lib.mt_se_pool_parts(N, hw, s.cexp)
+        partial = _new(dev, N, parts, s.cexp)
+        L.check(lib.mt_se_pool_fwd(L.ptr(z_d), L.ptr(bn_d.scale), L.ptr(bn_d.shift), L.ptr(partial), N, hw, s.cexp, parts, st),
+                "mt_se_pool_fwd")
+        L.check(lib.mt_se_gate_fwd(L.ptr(partial), parts, L.ptr(w_r), L.ptr(b_r), L.ptr(w_x), L.ptr(b_x), L.ptr(pooled), L.ptr(gate),
+                                   L.ptr(hidden), N, s.cexp, s.cse, st), "mt_se_gate_fwd")
         w_p, g, b = next(it), next(it), next(it)
         bn_p = _BNCtx(dev, s.cout, training, pool)
         z_p = _new(dev, M_out, s.cout)

@@ -59,8 +59,9 @@ PROTOTYPES = {
                       C.c_int, C.c_void_p],
     "mt_bn_finalize": [C.c_void_p, C.c_int, C.c_double, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_float,
                        C.c_float, C.c_int, C.c_void_p],
-    "mt_se_pool_fwd": [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
-    "mt_se_gate_fwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_se_pool_parts": [C.c_int, C.c_int, C.c_int],
+    "mt_se_pool_fwd": [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_se_gate_fwd": [f32p, C.c_int, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_bn_act_fwd": [f32p, f32p, f32p, f32p, f32p, i64, C.c_int, C.c_int, f32p, C.c_int, C.c_void_p],
     "mt_attn_aggregate": [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "mt_layernorm_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],

@@ -98,7 +98,7 @@ def test_effnet_backward_all_parameters_vs_oracle(training):
 
 
 def test_hip_graph_replay_matches_eager_eval():
-    """The whole eval forward captured in a HIP graph: replays bit-identically and on new inputs."""
+    """The whole eval forward captured in a HIP graph: replays bit-identically (the eval forward has no atomics) and on new inputs."""
     from mintime_amd import harness
     cfg, ef, tsf, _, _ = _models(0, 8, False, require_attention=False)
     ef.eval(); tsf.eval()
@@ -115,3 +115,47 @@ def test_hip_graph_replay_matches_eager_eval():
         eager1 = harness.forward(ef, tsf, b1).clone()
     assert not torch.equal(eager1, eager0)
     assert torch.equal(graphed(b1), eager1)
+
+
+_RCCL_SCRIPT = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+import mintime_amd
+from mintime_amd import harness, ddp
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[1])
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.cuda.set_device(0)
+finals = []
+for overlapped in (False, True):
+    cfg, ef, tsf = harness.build_models(seed=3, device="cuda", drop_connect_rate=0.0)
+    opt = harness.make_optimizer(cfg, ef, tsf)
+    red = ddp.OverlappedGradReducer([list(tsf.parameters()), list(ef.parameters())], force=True) if overlapped else None
+    for step in range(3):
+        batch = harness.device_batch(2, seed=step)
+        loss = harness.train_step(ef, tsf, opt, batch, red)
+    torch.cuda.synchronize()
+    finals.append([p.detach().double().sum().item() for p in list(tsf.parameters())[:6] + list(ef.parameters())[:6]] + [float(loss)])
+    if red is not None: stats = dict(red.stats)
+dist.destroy_process_group()
+print("RESULT " + json.dumps({"finals": finals, "stats": stats}))
+"""
+
+
+def test_overlapped_allreduce_runs_on_rccl_single_rank(tmp_path):
+    """The bucketed, backward-overlapped gradient reducer on a real RCCL communicator (1 rank: averaging is the identity, so
+    three optimisation steps must land where the un-reduced run lands) -- exercises the hooks, the async launch from the
+    autograd thread and the in-place flat-buffer path on the GPU."""
+    import json, subprocess, sys, os
+    script = tmp_path / "rccl_overlap.py"
+    script.write_text(_RCCL_SCRIPT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), str(23456 + os.getpid() % 1000)], capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    st = res["stats"]
+    assert st["synchronous"] == 2 and st["overlapped_launches"] == 4, st
+    assert st["in_place"] == 6 and st["staged"] == 0, st           # p.grad aliases the engines' flat gradient buffers: no copies
+    a, b = res["finals"]
+    for x, y in zip(a, b):
+        assert abs(x - y) <= 1e-3 * max(1.0, abs(x)), (x, y)

@@ -154,3 +154,73 @@ def test_gradient_allreduce_world_size_2_gloo():
         assert torch.allclose(g0, torch.full((5, 3), 1.5))
         assert torch.allclose(g1, torch.arange(7.0) * 1.5)
         assert g2 is None
+
+
+class _FlatGradFn(torch.autograd.Function):
+    """Mimics the engines: gradients of all parameters are views of one flat buffer."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        ctx.shapes = [p.shape for p in params]
+        ctx.save_for_backward(x)
+        return x.sum() * sum(p.sum() for p in params)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        total = sum((torch.Size(s).numel() + 3) // 4 * 4 for s in ctx.shapes)
+        flat = torch.full((total,), float(x.sum()) * float(g))
+        out, off = [], 0
+        for s in ctx.shapes:
+            n = torch.Size(s).numel()
+            out.append(flat[off:off + n].view(s))
+            off += (n + 3) // 4 * 4
+        return (None,) + tuple(out)
+
+
+def _overlap_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.ones(5, 3)), torch.nn.Parameter(torch.ones(7))]          # "TimeSformer": flat-view gradients
+    lin = torch.nn.Linear(4, 2)                                                              # "EfficientNet": ordinary gradients
+    unused = torch.nn.Parameter(torch.zeros(3))                                              # like _fc: never gets a gradient
+    red = ddp.OverlappedGradReducer([a, list(lin.parameters()) + [unused]])
+    res = []
+    for step in range(3):
+        for p in a + list(lin.parameters()):
+            p.grad = None
+        x = torch.full((2, 4), float(rank + 1 + step))
+        loss = _FlatGradFn.apply(lin(x), *a) + lin(x).sum()
+        loss.backward()
+        n = red.allreduce()
+        res.append((n, a[0].grad.clone(), a[1].grad.clone(), lin.weight.grad.clone(), unused.grad))
+    out[rank] = (res, dict(red.stats))
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucketed_allreduce_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_overlap_worker, args=(2, port, out), nprocs=2, join=True)
+    (r0, s0), (r1, s1) = out[0], out[1]
+    assert s0 == s1
+    assert s0["synchronous"] == 2 and s0["overlapped_launches"] == 4          # step 0 learns the layout, steps 1-2 overlap
+    assert s0["in_place"] >= 3 and s0["staged"] >= 3                          # flat-view bucket in place, Linear bucket staged
+    for step in range(3):
+        for k in range(1, 4):
+            assert torch.equal(r0[step][k], r1[step][k])                      # every rank ends with the same averaged gradient
+        assert r0[step][4] is None
+    # the averaged gradient is the mean of what each rank computed alone
+    lin = torch.nn.Linear(4, 2)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(4, 2)
+    want = 0
+    for rank in (0, 1):
+        x = torch.full((2, 4), float(rank + 1 + 2))
+        want = want + float(lin(x).sum().detach()) / 2
+    assert torch.allclose(r0[2][1], torch.full((5, 3), want), rtol=1e-5)
