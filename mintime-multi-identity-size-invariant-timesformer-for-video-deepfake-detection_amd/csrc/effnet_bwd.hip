@@ -109,13 +109,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ K2: BN backward finalize
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, int slots, double count, const float* __restrict__ gamma,
-                                       const float* __restrict__ mean_invstd, float* __restrict__ kabc, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int C, int training) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// block = 32 channels x 8 slot groups (see bn_finalize_kernel)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ stats, int slots, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean_invstd,
+                                                              float* __restrict__ kabc, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int C, int training) {
+  __shared__ double red[8][32][2];
+  const int cl = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int i = sg; i < slots; i += 8) { a += stats[((int64_t)i * 2) * C + c]; b += stats[((int64_t)i * 2 + 1) * C + c]; }
+  red[sg][cl][0] = a; red[sg][cl][1] = b;
+  __syncthreads();
+  if (sg != 0 || c >= C) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < slots; ++i) { s1 += stats[((int64_t)i * 2) * C + c]; s2 += stats[((int64_t)i * 2 + 1) * C + c]; }
+#pragma unroll
+  for (int g = 0; g < 8; ++g) { s1 += red[g][cl][0]; s2 += red[g][cl][1]; }
   const float mean = mean_invstd[c], istd = mean_invstd[C + c];
   const float ka = gamma[c] * istd;
   float kb = 0.f, kc = 0.f;
@@ -144,7 +154,18 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
   if (pl < PB && cq < CQ) {
     const float4 sc = ld4(scale + cq * 4), sh = ld4(shift + cq * 4);
     const int64_t base = (int64_t)n * HW * C + cq * 4;
-    for (int p = pl; p < HW; p += PB) {
+    // blockIdx.z = slice of the image's pixels (one image per block leaves a 256-crop batch at one block per CU)
+    const int per = (HW + gridDim.z - 1) / gridDim.z;
+    const int p_lo = blockIdx.z * per, p_hi = min(HW, p_lo + per);
+    int p = p_lo + pl;
+    for (; p + PB < p_hi; p += 2 * PB) {      // two independent pixel pairs in flight
+      const float4 z0 = ld4(z + base + (int64_t)p * C), z1 = ld4(z + base + (int64_t)(p + PB) * C);
+      const float4 d0 = ld4(da + base + (int64_t)p * C), d1 = ld4(da + base + (int64_t)(p + PB) * C);
+      const float4 u0 = fma4(z0, sc, sh), u1 = fma4(z1, sc, sh);
+      s = f4(fmaf(d0.x, swishf_(u0.x), s.x), fmaf(d0.y, swishf_(u0.y), s.y), fmaf(d0.z, swishf_(u0.z), s.z), fmaf(d0.w, swishf_(u0.w), s.w));
+      s = f4(fmaf(d1.x, swishf_(u1.x), s.x), fmaf(d1.y, swishf_(u1.y), s.y), fmaf(d1.z, swishf_(u1.z), s.z), fmaf(d1.w, swishf_(u1.w), s.w));
+    }
+    for (; p < p_hi; p += PB) {
       const float4 u = fma4(ld4(z + base + (int64_t)p * C), sc, sh);
       const float4 d = ld4(da + base + (int64_t)p * C);
       s = f4(fmaf(d.x, swishf_(u.x), s.x), fmaf(d.y, swishf_(u.y), s.y), fmaf(d.z, swishf_(u.z), s.z), fmaf(d.w, swishf_(u.w), s.w));
@@ -155,7 +176,12 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
   if (pl == 0 && cq < CQ) {
     float4 t = f4(0, 0, 0, 0);
     for (int p = 0; p < PB; ++p) t = add4(t, ld4(red + (p * CQB + cql) * 4));
-    st4(dgate + (int64_t)n * C + cq * 4, t);
+    float* out = dgate + (int64_t)n * C + cq * 4;
+    if (gridDim.z == 1) {
+      st4(out, t);
+    } else {                                   // slices meet in the pre-zeroed output
+      atomicAdd(out + 0, t.x); atomicAdd(out + 1, t.y); atomicAdd(out + 2, t.z); atomicAdd(out + 3, t.w);
+    }
   }
 }
 
@@ -593,7 +619,7 @@ extern "C" int mt_bn_act_bwd(const float* din, const float* z, const float* scal
 extern "C" int mt_bn_bwd_finalize(const double* stats, int slots, double count, const float* gamma, const float* mean_invstd,
                                   float* kabc, float* dgamma, float* dbeta, int C, int training, void* stream) {
   if (!stats || !gamma || !mean_invstd || !kabc) return fail(MT_ERR_ARG, "mt_bn_bwd_finalize: null pointer");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, slots, count, gamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, stats, slots, count, gamma,
                      mean_invstd, kabc, dgamma, dbeta, C, training);
   return check_launch("mt_bn_bwd_finalize");
 }
@@ -609,8 +635,12 @@ extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, co
   if (CS > CS_MAX) return fail(MT_ERR_UNSUPPORTED, "mt_se_bwd: squeeze width %d > %d", CS, CS_MAX);
   hipStream_t s = (hipStream_t)stream;
   const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
-  hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(N, CQ / CQB), dim3(CQB * PB), (size_t)PB * CQB * 4 * sizeof(float), s, da, z, scale,
-                     shift, dgate, HW, C, CQB, PB);
+  int parts = 1;
+  while ((int64_t)N * (CQ / CQB) * parts < 2048 && HW / (parts * 2) >= PB * 16) parts *= 2;
+  if (parts > 1 && hipMemsetAsync(dgate, 0, (size_t)N * C * sizeof(float), s) != hipSuccess)
+    return fail(MT_ERR_LAUNCH, "mt_se_bwd: memset failed");
+  hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(N, CQ / CQB, parts), dim3(CQB * PB), (size_t)PB * CQB * 4 * sizeof(float), s, da, z,
+                     scale, shift, dgate, HW, C, CQB, PB);
   int rc = check_launch("mt_se_bwd(reduce)");
   if (rc) return rc;
   hipLaunchKernelGGL(se_bwd_kernel, dim3(N), dim3(256), (size_t)(C + CS) * sizeof(float), s, dgate, gate, hidden, w1, w2, dpre2, dhid,
