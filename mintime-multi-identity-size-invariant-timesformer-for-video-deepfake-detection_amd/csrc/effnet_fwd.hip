@@ -156,32 +156,75 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
   const int c0 = chunk_id * CC;
   const int ty_n = (Ho + T - 1) / T, tx_n = (Wo + T - 1) / T;
   const int64_t ntiles = (int64_t)N * ty_n * tx_n;
-  float4 wt[K * K];
+  // 3x3 weights live in registers; the 25 float4 of a 5x5 would cost 100 VGPRs on top of the prefetch registers (occupancy 1),
+  // so they sit in LDS behind the input tile ([K*K][CC], read as 4 broadcast addresses per wavefront)
+  constexpr bool WLDS = K > 3;
+  float* w_t = lds + IH * IWP * CC;
+  float4 wt[WLDS ? 1 : K * K];
   {
     const int c = c0 + cq * 4;
+    if constexpr (WLDS) {
+      if (slot == 0)
+        for (int i = 0; i < K * K; ++i)
+          *reinterpret_cast<float4*>(w_t + i * CC + cq * 4) =
+              make_float4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
+    } else {
 #pragma unroll
-    for (int i = 0; i < K * K; ++i)
-      wt[i] = make_float4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
+      for (int i = 0; i < K * K; ++i)
+        wt[i] = make_float4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
+    }
   }
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-  for (int64_t tile = tile0; tile < ntiles; tile += tile_stride) {
+  // Input tiles are software-pipelined through registers: the global loads of the block's NEXT tile are in flight while the
+  // current one is convolved out of LDS (strided / 5x5 tiles are load-heavy: 4.3 input pixels per output at stride 2).
+  // Loads are unconditional on clamped addresses + a validity mask; a predicated `ok ? *p : 0` would de-pipeline them.
+  constexpr int NSL = 256 / CQN;                           // pixels covered per pass of the block
+  constexpr int NL = (IH * IH + NSL - 1) / NSL;            // float4 slots per thread
+  static_assert(NL <= 32, "validity mask is 32 bits");
+  const float4 sc_q = *reinterpret_cast<const float4*>(scale + c0 + cq * 4);
+  const float4 sh_q = *reinterpret_cast<const float4*>(shift + c0 + cq * 4);
+  float4 pre[NL];
+  unsigned pre_ok = 0;
+  auto fetch = [&](int64_t tile) {
+    const int tx = (int)(tile % tx_n);
+    const int64_t t2 = tile / tx_n;
+    const int ty = (int)(t2 % ty_n);
+    const int n = (int)(t2 / ty_n);
+    const int ih0 = ty * T * S - pad0, iw0 = tx * T * S - pad0;
+    const float* img = zin + (int64_t)n * H * W * C + c0 + cq * 4;
+    pre_ok = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int pix = slot + i * NSL;
+      const int iy = pix / IH, ix = pix - iy * IH;
+      const int ih = ih0 + iy, iw = iw0 + ix;
+      if (pix < IH * IH && ih >= 0 && ih < H && iw >= 0 && iw < W) pre_ok |= 1u << i;
+      const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
+      pre[i] = *reinterpret_cast<const float4*>(img + ((int64_t)ihc * W + iwc) * C);
+    }
+  };
+  int64_t tile = tile0;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += tile_stride) {
     const int tx = (int)(tile % tx_n);
     const int64_t t2 = tile / tx_n;
     const int ty = (int)(t2 % ty_n);
     const int n = (int)(t2 / ty_n);
     const int oh0 = ty * T, ow0 = tx * T;
     __syncthreads();
-    for (int idx = tid; idx < IH * IH * CQN; idx += 256) {
-      const int q = idx % CQN, pix = idx / CQN;
-      const int iy = pix / IH, ix = pix - iy * IH;
-      const int ih = oh0 * S - pad0 + iy, iw = ow0 * S - pad0 + ix;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ih >= 0 && ih < H && iw >= 0 && iw < W)
-        v = act_affine4<ACT>(*reinterpret_cast<const float4*>(zin + (((int64_t)n * H + ih) * W + iw) * C + c0 + q * 4),
-                             *reinterpret_cast<const float4*>(scale + c0 + q * 4), *reinterpret_cast<const float4*>(shift + c0 + q * 4));
-      *reinterpret_cast<float4*>(lds + (iy * IWP + ix) * CC + q * 4) = v;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int pix = slot + i * NSL;
+      if (pix < IH * IH) {
+        const int iy = pix / IH, ix = pix - iy * IH;
+        const float4 a = act_affine4<ACT>(pre[i], sc_q, sh_q);
+        const bool ok = (pre_ok >> i) & 1u;
+        *reinterpret_cast<float4*>(lds + (iy * IWP + ix) * CC + cq * 4) =
+            make_float4(ok ? a.x : 0.f, ok ? a.y : 0.f, ok ? a.z : 0.f, ok ? a.w : 0.f);
+      }
     }
     __syncthreads();
+    if (tile + tile_stride < ntiles) fetch(tile + tile_stride);
     for (int p = slot; p < T * T; p += NSLOT) {
       const int oy = p / T, ox = p - oy * T;
       const int oh = oh0 + oy, ow = ow0 + ox;
@@ -193,7 +236,9 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
 #pragma unroll
           for (int kw = 0; kw < K; ++kw) {
             const float4 a = *reinterpret_cast<const float4*>(base + (kh * IWP + kw) * CC);
-            const float4 ww = wt[kh * K + kw];
+            float4 ww;
+            if constexpr (WLDS) ww = *reinterpret_cast<const float4*>(w_t + (kh * K + kw) * CC + cq * 4);
+            else ww = wt[kh * K + kw];
             acc.x = fmaf(a.x, ww.x, acc.x); acc.y = fmaf(a.y, ww.y, acc.y);
             acc.z = fmaf(a.z, ww.z, acc.z); acc.w = fmaf(a.w, ww.w, acc.w);
           }
@@ -223,7 +268,7 @@ int launch_dw_tiled(const float* zin, const float* scale, const float* shift, co
                     int N, int H, int W, int C, int Ho, int Wo, int pad0, hipStream_t s) {
   constexpr int IH = (T - 1) * S + K;
   constexpr int IWP = IH | 1;
-  size_t lds = (size_t)IH * IWP * CC * sizeof(float);
+  size_t lds = (size_t)(IH * IWP * CC + (K > 3 ? K * K * CC : 0)) * sizeof(float);
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);
   const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((Ho + T - 1) / T) * ((Wo + T - 1) / T);
