@@ -298,35 +298,68 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
 #pragma unroll
   for (int i = 0; i < K; ++i) acc[i] = f4(0, 0, 0, 0);
 
-  for (int64_t tile = tile0; tile < ntiles; tile += tile_stride) {
+  // Software pipeline: the loads of the block's NEXT tile (input tile with halo, du and z tiles) are in flight while the current
+  // one is multiplied out of LDS.  Unconditional loads on clamped addresses + validity masks (a predicated load de-pipelines).
+  constexpr int NSL = 256 / CQN;
+  constexpr int NL = (IH * IH + NSL - 1) / NSL, ND = (T * T + NSL - 1) / NSL;
+  static_assert(NL <= 32 && ND <= 32, "validity masks are 32 bits");
+  const int slot = tid / CQN;
+  float4 pre[NL], pdu[ND], pz[ND];
+  unsigned pre_ok = 0, pd_ok = 0;
+  auto fetch = [&](int64_t tile) {
     const int tx = (int)(tile % tx_n);
     const int64_t t2 = tile / tx_n;
     const int ty = (int)(t2 % ty_n);
     const int n = (int)(t2 / ty_n);
     const int oh0 = ty * T, ow0 = tx * T;
-    __syncthreads();                              // previous tile fully consumed
-    for (int idx = tid; idx < IH * IH * CQN; idx += 256) {
-      const int q = idx % CQN, pix = idx / CQN;
+    const int ih0 = oh0 * S - P, iw0 = ow0 * S - P;
+    const float* img = zin + (int64_t)n * H * W * C + c0 + cq * 4;
+    pre_ok = 0; pd_ok = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int pix = slot + i * NSL;
       const int iy = pix / IH, ix = pix - iy * IH;
-      const int ih = oh0 * S - P + iy, iw = ow0 * S - P + ix;
-      float4 v = f4(0, 0, 0, 0);
-      if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
-        v = act4<ACT>(fma4(ld4(zin + (((int64_t)n * H + ih) * W + iw) * C + c0 + q * 4), ld4(scale_in + c0 + q * 4), ld4(shift_in + c0 + q * 4)));
-      }
-      st4(a_t + (iy * IWP + ix) * CC + q * 4, v);
+      const int ih = ih0 + iy, iw = iw0 + ix;
+      if (pix < IH * IH && ih >= 0 && ih < H && iw >= 0 && iw < W) pre_ok |= 1u << i;
+      pre[i] = ld4(img + ((int64_t)min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1)) * C);
     }
-    for (int idx = tid; idx < T * T * CQN; idx += 256) {
-      const int q = idx % CQN, pix = idx / CQN;
+    const int64_t obase = (int64_t)n * Ho * Wo * C + c0 + cq * 4;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int pix = slot + i * NSL;
       const int oy = pix / T, ox = pix - oy * T;
       const int oh = oh0 + oy, ow = ow0 + ox;
-      float4 v = f4(0, 0, 0, 0);
-      if (oh < Ho && ow < Wo) {
-        const int64_t off = (((int64_t)n * Ho + oh) * Wo + ow) * C + c0 + q * 4;
-        v = fma4(ld4(kabc + c0 + q * 4), ld4(du + off), fma4(ld4(kabc + C + c0 + q * 4), ld4(z + off), ld4(kabc + 2 * C + c0 + q * 4)));
+      if (pix < T * T && oh < Ho && ow < Wo) pd_ok |= 1u << i;
+      const int64_t off = obase + ((int64_t)min(oh, Ho - 1) * Wo + min(ow, Wo - 1)) * C;
+      pdu[i] = ld4(du + off);
+      pz[i] = ld4(z + off);
+    }
+  };
+  int64_t tile = tile0;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += tile_stride) {
+    __syncthreads();                              // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int pix = slot + i * NSL;
+      if (pix < IH * IH) {
+        const int iy = pix / IH, ix = pix - iy * IH;
+        const float4 v = act4<ACT>(fma4(pre[i], sc, sh));
+        const bool ok = (pre_ok >> i) & 1u;
+        st4(a_t + (iy * IWP + ix) * CC + cq * 4, f4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f));
       }
-      st4(dz_t + pix * CC + q * 4, v);
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int pix = slot + i * NSL;
+      if (pix < T * T) {
+        const float4 v = fma4(ka, pdu[i], fma4(kb, pz[i], kc));
+        const bool ok = (pd_ok >> i) & 1u;
+        st4(dz_t + pix * CC + cq * 4, f4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f));
+      }
     }
     __syncthreads();
+    if (tile + tile_stride < ntiles) fetch(tile + tile_stride);
     if (worker) {
       for (int p = ps; p < T * T; p += PS) {
         const int oy = p / T, ox = p - oy * T;
@@ -402,34 +435,72 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
   const int c = c0 + cq * 4;
   const float4 sc = ld4(scale_in + c), sh = ld4(shift_in + c);
   const float4 mean = mi_in ? ld4(mi_in + c) : f4(0, 0, 0, 0), istd = mi_in ? ld4(mi_in + C + c) : f4(0, 0, 0, 0);
-  float4 wt[K * K];
+  // 3x3 weights in registers; 5x5 (25 float4 = 100 VGPRs) in LDS behind the dz tile, read as broadcasts
+  constexpr bool WLDS = K > 3;
+  float* w_t = lds + OT * OTP * CC;
+  float4 wt[WLDS ? 1 : K * K];
+  if constexpr (WLDS) {
+    if (slot == 0)
+      for (int i = 0; i < K * K; ++i)
+        st4(w_t + i * CC + cq * 4, f4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]));
+  } else {
 #pragma unroll
-  for (int i = 0; i < K * K; ++i)
-    wt[i] = f4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
+    for (int i = 0; i < K * K; ++i)
+      wt[i] = f4(w[(c + 0) * K * K + i], w[(c + 1) * K * K + i], w[(c + 2) * K * K + i], w[(c + 3) * K * K + i]);
+  }
+  const float4 ka = ld4(kabc + c), kb = ld4(kabc + C + c), kc = ld4(kabc + 2 * C + c);
   float4 s1 = f4(0, 0, 0, 0), s2 = s1;
-  for (int64_t tile = tile0; tile < ntiles; tile += tile_stride) {
+  // Software pipeline: du / z of the outputs reachable from the block's NEXT tile are in flight while the current tile is
+  // gathered out of LDS (prefetching the tile's own raw inputs as well cost more in registers than it hid).  Unconditional loads on clamped addresses + a validity mask.
+  constexpr int ND = (OT * OT + NSLOT - 1) / NSLOT;
+  static_assert(ND <= 32, "validity mask is 32 bits");
+  float4 pdu[ND], pz[ND];
+  unsigned pd_ok = 0;
+  auto lows = [&](int64_t tile, int& n, int& ih0, int& iw0, int& oh_lo, int& ow_lo) {
     const int tx = (int)(tile % tx_n);
     const int64_t t2 = tile / tx_n;
     const int ty = (int)(t2 % ty_n);
-    const int n = (int)(t2 / ty_n);
-    const int ih0 = ty * T, iw0 = tx * T;
+    n = (int)(t2 / ty_n);
+    ih0 = ty * T; iw0 = tx * T;
     // first output row/col reachable from this tile: ceil((ih0 + P - (K-1)) / S), possibly negative
     const int nh = ih0 + P - (K - 1), nw = iw0 + P - (K - 1);
-    const int oh_lo = nh >= 0 ? (nh + S - 1) / S : -((-nh) / S);
-    const int ow_lo = nw >= 0 ? (nw + S - 1) / S : -((-nw) / S);
-    __syncthreads();
-    for (int idx = tid; idx < OT * OT * CQN; idx += 256) {
-      const int q = idx % CQN, pix = idx / CQN;
+    oh_lo = nh >= 0 ? (nh + S - 1) / S : -((-nh) / S);
+    ow_lo = nw >= 0 ? (nw + S - 1) / S : -((-nw) / S);
+  };
+  auto fetch = [&](int64_t tile) {
+    int n, ih0, iw0, oh_lo, ow_lo;
+    lows(tile, n, ih0, iw0, oh_lo, ow_lo);
+    const int64_t obase = (int64_t)n * Ho * Wo * C + c;
+    pd_ok = 0;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int pix = slot + i * NSLOT;
       const int oy = pix / OT, ox = pix - oy * OT;
       const int oh = oh_lo + oy, ow = ow_lo + ox;
-      float4 v = f4(0, 0, 0, 0);
-      if (oh >= 0 && oh < Ho && ow >= 0 && ow < Wo) {
-        const int64_t off = (((int64_t)n * Ho + oh) * Wo + ow) * C + c0 + q * 4;
-        v = fma4(ld4(kabc + c0 + q * 4), ld4(du + off), fma4(ld4(kabc + C + c0 + q * 4), ld4(z + off), ld4(kabc + 2 * C + c0 + q * 4)));
+      if (pix < OT * OT && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo) pd_ok |= 1u << i;
+      const int64_t off = obase + ((int64_t)min(max(oh, 0), Ho - 1) * Wo + min(max(ow, 0), Wo - 1)) * C;
+      pdu[i] = ld4(du + off);
+      pz[i] = ld4(z + off);
+    }
+  };
+  int64_t tile = tile0;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += tile_stride) {
+    int n, ih0, iw0, oh_lo, ow_lo;
+    lows(tile, n, ih0, iw0, oh_lo, ow_lo);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int pix = slot + i * NSLOT;
+      if (pix < OT * OT) {
+        const int oy = pix / OT, ox = pix - oy * OT;
+        const float4 v = fma4(ka, pdu[i], fma4(kb, pz[i], kc));
+        const bool ok = (pd_ok >> i) & 1u;
+        st4(lds + (oy * OTP + ox) * CC + cq * 4, f4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f));
       }
-      st4(lds + (oy * OTP + ox) * CC + q * 4, v);
     }
     __syncthreads();
+    if (tile + tile_stride < ntiles) fetch(tile + tile_stride);
     for (int p = slot; p < T * T; p += NSLOT) {
       const int iy = p / T, ix = p - iy * T;
       const int ih = ih0 + iy, iw = iw0 + ix;
@@ -447,7 +518,10 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
             if (S == 2 && (own & 1)) continue;
             if (own < 0) continue;
             const int ox = own / S - ow_lo;
-            acc = fma4(ld4(lds + (oy * OTP + ox) * CC + cq * 4), wt[kh * K + kw], acc);
+            float4 ww;
+            if constexpr (WLDS) ww = ld4(w_t + (kh * K + kw) * CC + cq * 4);
+            else ww = wt[kh * K + kw];
+            acc = fma4(ld4(lds + (oy * OTP + ox) * CC + cq * 4), ww, acc);
           }
         }
         const int64_t off = (((int64_t)n * H + ih) * W + iw) * C + c;
@@ -483,7 +557,7 @@ int launch_dw_dgrad_tiled(const float* du, const float* z, const float* kabc, co
                           int N, int H, int W, int C, int Ho, int Wo, const float* res_pre, const float* res_post, hipStream_t s) {
   constexpr int OT = (T - 1 + K - 1) / S + 2;
   constexpr int OTP = OT | 1;
-  size_t lds = (size_t)OT * OTP * CC * sizeof(float);
+  size_t lds = (size_t)(OT * OTP * CC + (K > 3 ? K * K * CC : 0)) * sizeof(float);
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);
   const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((H + T - 1) / T) * ((W + T - 1) / T);
