@@ -10,6 +10,7 @@
 //   mt_embed_bwd       cls / pos_emb / size_emb scatter-adds
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
+#include <stdlib.h>
 #include <float.h>
 
 using namespace mt;
@@ -267,6 +268,204 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const float* __restric
   }
   for (; j < N; ++j) a0 = fmaf(ds_[j], kb[(int64_t)j * ld], a0);
   dbase[lane] = scale * ((a0 + a1) + (a2 + a3));
+}
+
+// ---------------------------------------------------------------------------------------- space attention backward on the matrix cores
+// One wavefront per (b, h, frame), same transposed formulation as attn_space_fwd_mfma_kernel (tsf_fwd.hip): every product is
+// arranged so that its B operand is an accumulator of the previous product used in place, and its A operand is read from global
+// memory either by rows (128 contiguous bytes per lane) or by columns (coalesced across lanes).  No LDS except 512 B of
+// per-query softmax statistics handed from phase A to phase B.
+//   phase A, lane = query:  S^T = K (sQ)^T, dP^T = V dO^T  ->  P^T, delta, dS^T (all in-lane)  ->  dQ^T = K^T dS^T
+//   phase B, lane = key  :  S = (sQ) K^T,  dP = dO V^T     ->  P, dS (statistics from phase A)  ->  dV^T = dO^T P,  dK^T = (sQ)^T dS
+// 896 v_mfma_f32_32x32x2_f32 per group.  dq is stored; dk / dv are added onto the cls query's contribution written by
+// attn_cls_bwd_kernel (read-modify-write: a patch key belongs to exactly one group; fp32 atomics for the shared cls key).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int mfma_slot_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
+
+__device__ __forceinline__ void load_row32(const float* __restrict__ p, float (&dst)[32], float mul) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float4 v = *reinterpret_cast<const float4*>(p + 4 * t);
+    dst[4 * t] = v.x * mul; dst[4 * t + 1] = v.y * mul; dst[4 * t + 2] = v.z * mul; dst[4 * t + 3] = v.w * mul;
+  }
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void attn_space_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                      float* __restrict__ dqkv, int B, int H, int F, int n,
+                                                                      float scale) {
+  __shared__ float2 stat_all[WPB][64];                      // (logsumexp, delta) per query of the wavefront's group
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = lane & 31, hf = lane >> 5;
+  float2* stat = stat_all[wave];
+  const int N = 1 + F * n, inner = H * DH, ld = 3 * inner;
+  const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
+  if (wid >= (int64_t)B * H * F) return;                    // wave-uniform (no block-level barrier below)
+  const int f = (int)(wid % F);
+  const int bh = (int)(wid / F);
+  const int h = bh % H, b = bh / H;
+  const float* base = qkv + (int64_t)b * N * ld + h * DH;
+  float* dbase = dqkv + (int64_t)b * N * ld + h * DH;
+  const float* dobase = dout + (int64_t)b * N * inner + h * DH;
+  const int t0 = 1 + f * n;
+  auto tok_k = [&](int key) { return key == 0 ? 0 : t0 + min(key, n) - 1; };
+  auto tok_q = [&](int q) { return t0 + min(q, n - 1); };
+
+  // ---------------------------------------------------------------- phase A: lane = query (32 j + c)
+#pragma unroll 1
+  for (int j = 0; j < 2; ++j) {
+    const int q = 32 * j + c;
+    float qb[32], dob[32];
+    load_row32(base + (int64_t)tok_q(q) * ld + hf * 32, qb, scale);
+    load_row32(dobase + (int64_t)tok_q(q) * inner + hf * 32, dob, 1.0f);
+    f32x16 st[2], dpt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float ka[32], va[32];
+      load_row32(base + (int64_t)tok_k(32 * i + c) * ld + inner + hf * 32, ka, 1.0f);
+      load_row32(base + (int64_t)tok_k(32 * i + c) * ld + 2 * inner + hf * 32, va, 1.0f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[i][r] = 0.f; dpt[i][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) {
+        st[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[ks], qb[ks], st[i], 0, 0, 0);
+        dpt[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[ks], dob[ks], dpt[i], 0, 0, 0);
+      }
+    }
+    // K by columns in the order the dS^T accumulators are consumed; in flight during the softmax
+    float kc[2][32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      const float* kr = base + (int64_t)tok_k(32 * (ks >> 4) + mfma_slot_row(ks & 15, hf)) * ld + inner;
+      kc[0][ks] = kr[c];
+      kc[1][ks] = kr[32 + c];
+    }
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (32 * i + mfma_slot_row(r, hf) <= n) mx = fmaxf(mx, st[i][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = (32 * i + mfma_slot_row(r, hf) <= n) ? __expf(st[i][r] - mx) : 0.f;
+        st[i][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    float delta = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[i][r] *= inv; delta = fmaf(st[i][r], dpt[i][r], delta); }
+    delta += __shfl_xor(delta, 32);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[i][r] *= dpt[i][r] - delta;          // dS^T (zero on padded keys: P^T is zero there)
+    if (hf == 0) stat[q] = make_float2(mx + __logf(sum), delta);
+    f32x16 dq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) dq[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[i][ks], st[ks >> 4][ks & 15], dq[i], 0, 0, 0);
+    if (q < n) {
+      float* drow = dbase + (int64_t)(t0 + q) * ld;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(drow + 32 * i + 8 * g + 4 * hf) =
+              make_float4(scale * dq[i][4 * g], scale * dq[i][4 * g + 1], scale * dq[i][4 * g + 2], scale * dq[i][4 * g + 3]);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the statistics are in LDS
+  __builtin_amdgcn_wave_barrier();
+
+  // ---------------------------------------------------------------- phase B: lane = key (32 j + c)
+#pragma unroll 1
+  for (int j = 0; j < 2; ++j) {
+    const int key = 32 * j + c;
+    float kb[32], vb[32];
+    load_row32(base + (int64_t)tok_k(key) * ld + inner + hf * 32, kb, 1.0f);
+    load_row32(base + (int64_t)tok_k(key) * ld + 2 * inner + hf * 32, vb, 1.0f);
+    f32x16 pp[2], ds[2];                      // P and dS tiles [query tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float qa[32], da[32];
+      load_row32(base + (int64_t)tok_q(32 * i + c) * ld + hf * 32, qa, scale);
+      load_row32(dobase + (int64_t)tok_q(32 * i + c) * inner + hf * 32, da, 1.0f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { pp[i][r] = 0.f; ds[i][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) {
+        pp[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[ks], kb[ks], pp[i], 0, 0, 0);
+        ds[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[ks], vb[ks], ds[i], 0, 0, 0);
+      }
+    }
+    // dO and scaled Q by columns, in the query order the P / dS accumulators are consumed in
+    float dc[2][32], qc[2][32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      const int tq = tok_q(32 * (ks >> 4) + mfma_slot_row(ks & 15, hf));
+      const float* dr = dobase + (int64_t)tq * inner;
+      const float* qr = base + (int64_t)tq * ld;
+      dc[0][ks] = dr[c]; dc[1][ks] = dr[32 + c];
+      qc[0][ks] = qr[c] * scale; qc[1][ks] = qr[32 + c] * scale;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = 32 * i + mfma_slot_row(r, hf);
+        const float2 sd = stat[q];
+        const float p = (q < n && key <= n) ? __expf(pp[i][r] - sd.x) : 0.f;
+        ds[i][r] = p * (ds[i][r] - sd.y);
+        pp[i][r] = p;
+      }
+    f32x16 dv[2], dk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dv[i][r] = 0.f; dk[i][r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        dv[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[i][ks], pp[ks >> 4][ks & 15], dv[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[i][ks], ds[ks >> 4][ks & 15], dk[i], 0, 0, 0);
+      }
+    if (key <= n) {
+      float* krow = dbase + (int64_t)tok_k(key) * ld + inner;
+      float* vrow = dbase + (int64_t)tok_k(key) * ld + 2 * inner;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = 32 * i + 8 * g + 4 * hf;
+          if (key == 0) {                       // the cls key is shared by every frame of the clip
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { atomicAdd(krow + d0 + e, dk[i][4 * g + e]); atomicAdd(vrow + d0 + e, dv[i][4 * g + e]); }
+          } else {
+            float4 a = *reinterpret_cast<const float4*>(krow + d0), v = *reinterpret_cast<const float4*>(vrow + d0);
+            a.x += dk[i][4 * g]; a.y += dk[i][4 * g + 1]; a.z += dk[i][4 * g + 2]; a.w += dk[i][4 * g + 3];
+            v.x += dv[i][4 * g]; v.y += dv[i][4 * g + 1]; v.z += dv[i][4 * g + 2]; v.w += dv[i][4 * g + 3];
+            *reinterpret_cast<float4*>(krow + d0) = a;
+            *reinterpret_cast<float4*>(vrow + d0) = v;
+          }
+        }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------- attention backward: patch queries
@@ -571,7 +770,14 @@ extern "C" int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, con
   hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(64), 2 * N * sizeof(float), s, qkv, dout, dqkv, mask, B, H, F, n, scale);
   int rc = check_launch("mt_attn_bwd(cls)");
   if (rc) return rc;
-  if (mode == 1) return launch_patch_bwd<1, 50, 1, 64, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);
+  if (mode == 1) {
+    static const bool valu = getenv("MT_ATTN_VALU") != nullptr;     // A/B aid: the one-lane-per-query kernel
+    if (valu) return launch_patch_bwd<1, 50, 1, 64, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);
+    const int64_t waves = (int64_t)B * H * F;
+    hipLaunchKernelGGL(attn_space_bwd_mfma_kernel<4>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n,
+                       scale);
+    return check_launch("mt_attn_bwd(space, mfma)");
+  }
   switch (F) {
     case 8: return launch_patch_bwd<0, 9, 7, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);
     case 16: return launch_patch_bwd<0, 17, 4, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);

@@ -16,6 +16,7 @@
 //     [(B*H*49), F, F+1] frame mask (:252-255) never exists.  Masked logits are FILLED with -FLT_MAX (:82-85).
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
+#include <stdlib.h>
 #include <float.h>
 
 using namespace mt;
@@ -237,6 +238,128 @@ __global__ __launch_bounds__(WPB * 64) void attn_patch_fwd_kernel(const float* _
   }
 }
 
+// ---------------------------------------------------------------------------------------- space attention on the matrix cores
+// One wavefront per (b, h, frame): n = 49 patch queries x (cls + 49) keys x dim_head 64, padded to 64 x 64 and computed TRANSPOSED
+// so that nothing ever has to change layout between the two products (no LDS at all):
+//   S^T[key][q] = sum_d K[key][d] * (scale Q)[q][d]     A = K rows, B = Q rows: lane (row, half) holds d = 32*half .. +31 of its row,
+//                                                       one 128-byte contiguous read per lane; the k index of MFMA step ks is
+//                                                       d = 32*half + ks on both operands (any bijection works if A and B agree)
+//   softmax over keys = over the accumulator slots of ONE lane (+ one xor-32 exchange): the C layout of S^T keeps a query per lane
+//   O^T[d][q]   = sum_key V[key][d] * P^T[key][q]       B = P^T straight out of the accumulators: step ks feeds slot (ks>>4, ks&15),
+//                                                       i.e. key(ks, half) = 32*(ks>>4) + (ks&3) + 8*((ks&15)>>2) + 4*half;
+//                                                       A = V read by columns for exactly that key order (coalesced across d)
+// 256 v_mfma_f32_32x32x2_f32 per group against ~100 k VALU FMAs + 100 LDS reads per lane in the one-lane-per-query kernel.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int mfma_slot_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void attn_space_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                      int B, int H, int F, int n, float scale) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = lane & 31, hf = lane >> 5;
+  const int N = 1 + F * n, inner = H * DH, ld = 3 * inner;
+  const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
+  if (wid >= (int64_t)B * H * F) return;                 // wave-uniform
+  const int f = (int)(wid % F);
+  const int bh = (int)(wid / F);
+  const int h = bh % H, b = bh / H;
+  const float* base = qkv + (int64_t)b * N * ld + h * DH;
+  const int t0 = 1 + f * n;                              // first patch token of the frame
+  auto tok_k = [&](int key) { return key == 0 ? 0 : t0 + min(key, n) - 1; };   // keys >= n+1 are padding (masked below)
+  auto tok_q = [&](int q) { return t0 + min(q, n - 1); };
+
+  float ka[2][32], qb[2][32];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float* kr = base + (int64_t)tok_k(32 * i + c) * ld + inner + hf * 32;
+    const float* qr = base + (int64_t)tok_q(32 * i + c) * ld + hf * 32;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 kk = *reinterpret_cast<const float4*>(kr + 4 * t);
+      const float4 qq = *reinterpret_cast<const float4*>(qr + 4 * t);
+      ka[i][4 * t] = kk.x; ka[i][4 * t + 1] = kk.y; ka[i][4 * t + 2] = kk.z; ka[i][4 * t + 3] = kk.w;
+      qb[i][4 * t] = qq.x * scale; qb[i][4 * t + 1] = qq.y * scale; qb[i][4 * t + 2] = qq.z * scale; qb[i][4 * t + 3] = qq.w * scale;
+    }
+  }
+  f32x16 st[2][2];                                        // S^T tiles [key tile][query tile]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[i][j][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) st[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[i][ks], qb[j][ks], st[i][j], 0, 0, 0);
+
+  // V by columns in the key order the accumulators will be consumed in; issued now, consumed after the softmax
+  float va[2][32];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) {
+    const int key = 32 * (ks >> 4) + mfma_slot_row(ks & 15, hf);
+    const float* vr = base + (int64_t)tok_k(key) * ld + 2 * inner;
+    va[0][ks] = vr[c];
+    va[1][ks] = vr[32 + c];
+  }
+
+  // softmax over the keys of each query (two queries per lane: tiles j = 0, 1)
+  float inv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (32 * i + mfma_slot_row(r, hf) <= n) mx = fmaxf(mx, st[i][j][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = (32 * i + mfma_slot_row(r, hf) <= n) ? __expf(st[i][j][r] - mx) : 0.f;
+        st[i][j][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32);
+    inv[j] = 1.0f / sum;
+  }
+
+  f32x16 ot[2][2];                                        // O^T tiles [d tile][query tile]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[i][j][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        ot[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i][ks], st[ks >> 4][j][ks & 15], ot[i][j], 0, 0, 0);
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = 32 * j + c;
+    if (q < n) {
+      float* orow = out + ((int64_t)b * N + t0 + q) * inner + h * DH;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)          // slots 4g..4g+3 are d = 32 i + 8 g + 4 half + (0..3)
+          *reinterpret_cast<float4*>(orow + 32 * i + 8 * g + 4 * hf) =
+              make_float4(ot[i][j][4 * g] * inv[j], ot[i][j][4 * g + 1] * inv[j], ot[i][j][4 * g + 2] * inv[j], ot[i][j][4 * g + 3] * inv[j]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------- attention: cls query
 // one wavefront per (b,h): the (scaled) cls query attends to all N keys, padded frames masked (:120, :259-260)
 __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
@@ -365,7 +488,13 @@ extern "C" int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const u
   hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(64), N * sizeof(float), s, qkv, out, cls_att, mask, B, H, F, n, scale);
   int rc = check_launch("mt_attn_fwd(cls)");
   if (rc) return rc;
-  if (mode == 1) return launch_patch<1, 50, 1, 64, 2>(qkv, out, mask, ident, B, H, F, n, scale, s);
+  if (mode == 1) {
+    static const bool valu = getenv("MT_ATTN_VALU") != nullptr;     // A/B aid: the one-lane-per-query kernel
+    if (valu) return launch_patch<1, 50, 1, 64, 2>(qkv, out, mask, ident, B, H, F, n, scale, s);
+    const int64_t waves = (int64_t)B * H * F;
+    hipLaunchKernelGGL(attn_space_fwd_mfma_kernel<4>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, out, B, H, F, n, scale);
+    return check_launch("mt_attn_fwd(space, mfma)");
+  }
   switch (F) {
     case 8: return launch_patch<0, 9, 7, 68, 4>(qkv, out, mask, ident, B, H, F, n, scale, s);
     case 16: return launch_patch<0, 17, 4, 68, 4>(qkv, out, mask, ident, B, H, F, n, scale, s);
