@@ -53,7 +53,16 @@ def _finalize(lib, st, bn_mod, ctx, count, training, gamma, beta):
                                L.ptr(bn_mod.running_var), L.ptr(ctx.scale), L.ptr(ctx.shift), L.ptr(ctx.mean_invstd), ctx.C,
                                bn_mod.eps, bn_mod.momentum, 1 if training else 0, st), "mt_bn_finalize")
     if training:
-        bn_mod.num_batches_tracked += 1
+        _TRACKED.append(bn_mod.num_batches_tracked)
+
+
+_TRACKED = []   # num_batches_tracked counters touched by the running forward: bumped by ONE multi-tensor add at its end
+
+
+def _bump_tracked():
+    if _TRACKED:
+        torch._foreach_add_(_TRACKED, 1)
+        _TRACKED.clear()
 
 
 def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
@@ -158,6 +167,7 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
                               st), "mt_bn_act_fwd")
     if save:
         saved["head"] = dict(y_in=y, z=z_h, bn=bn_h)
+    _bump_tracked()
     return feat, saved, ys
 
 
