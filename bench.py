@@ -80,6 +80,18 @@ def cpu_baseline(num_frames, seed, budget_s=20.0):
             "sample": f"{n} fwd+bwd steps of {B} clips (8-frame, 2-identity, 224x224), train-mode BN, fp32 torch CPU ops"}
 
 
+def pmc_traffic(B):
+    """HBM/fabric bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (separate runs, gfx950
+    correction applied; profiles/r01_ff1_geglu_gemm_pmc.json).  Only valid for the shape they were taken on (B = 32)."""
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_ff1_geglu_gemm_pmc.json")
+    if B != 32 or not os.path.exists(f):
+        return {"traffic": None}
+    d = json.load(open(f))
+    return {"traffic": d["traffic_bytes_per_launch"], "traffic_unit": "bytes/launch",
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/r01_ff1_geglu_gemm_pmc.json)",
+            "algorithmic_bytes": sum(d["algorithmic_bytes_per_launch"].values())}
+
+
 def attention_modules_leg(dev, B, F=8, reps=3):
     """north_star sub-metric: forward of the divided space-time attention MODULES (QKV GEMM + attention core + out-proj GEMM,
     time and space, 9 layers = 18 modules) at batch B, as a fraction of the fp32 MFMA peak.  Timed with HIP events."""
@@ -201,7 +213,7 @@ def main():
                        "loss": round(float(loss.item()), 5)},
             "roofline": {"bound": "mfma", "kernel": "mt::gemm_kernel<2,2,2,2,NT,EPI_GEGLU> (FF1 512->4096 + GEGLU, M=B*393)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved / (PEAK_FP32_MFMA / 1e12), 4), "traffic": None,
+                         "frac": round(achieved / (PEAK_FP32_MFMA / 1e12), 4), **pmc_traffic(B),
                          "launches_timed": len(durs), "avg_launch_us": round(avg * 1e6, 1),
                          "flops_per_launch": flops},
         }
