@@ -46,6 +46,10 @@ int launch(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
+static long long* g_trace = nullptr;
+// tuning aid, not part of the ABI header: per-block phase timestamps of the following mt_gemm launches (NULL = off)
+extern "C" void mt_debug_gemm_trace(long long* buf) { g_trace = buf; }
+
 extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return fail(MT_ERR_ARG, "mt_gemm: null pointer");
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return fail(MT_ERR_ARG, "mt_gemm: bad shape %d %d %d", d->M, d->N, d->K);
@@ -100,6 +104,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   dim3 grid(m_tiles * n_tiles, 1, 1);
   a.group_n = 0;
   a.stagger = 0;
+  a.trace = g_trace;
   if (const char* e = getenv("MT_STAGGER")) a.stagger = atoi(e);
   if (m_tiles >= 32 && n_tiles >= 2 && !getenv("MT_NO_L2_BLOCKING")) {
     // size a column group so its B panels take ~2 MB of the XCD's 4 MB L2

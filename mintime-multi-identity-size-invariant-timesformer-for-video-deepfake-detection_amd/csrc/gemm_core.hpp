@@ -23,6 +23,9 @@
 
 #ifndef MT_BK
 #define MT_BK 16
+#ifndef MT_STORE_POS
+#define MT_STORE_POS 0
+#endif
 #endif
 #ifndef MT_MIN_WAVES
 #define MT_MIN_WAVES 3
@@ -145,6 +148,7 @@ struct GemmArgs {
   ConvDesc conv;                        // PRO_IM2COL / BPRO_IM2COL geometry
   int group_n;                          // > 0: L2-blocked tile order with this many tile columns per group
   int stagger;                          // s_sleep(127) units (8128 cycles) of start skew per residency class, 0 = off
+  long long* trace;                     // tuning aid (mt_debug_gemm_trace): per block {t_start, t_prologue, t_loop, t_end, hw_id}
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -408,9 +412,12 @@ void gemm_kernel(const GemmArgs p) {
     const int cls = (blockIdx.x >> 8) % 3;
     for (int i = 0; i < cls * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
+  long long* tr = p.trace ? p.trace + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  if (tr && threadIdx.x == 0) { tr[0] = wall_clock64(); tr[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
   load_tiles(0);
   store_tiles(0);
   __syncthreads();
+  if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
 
   const int a_row = wm * TM * 32 + (lane & 31);
   const int b_frag = wn * TN * 32 + (lane & 31);
@@ -443,15 +450,16 @@ void gemm_kernel(const GemmArgs p) {
       }
     }
   };
-  auto mma_group = [&](const float (&af)[TM][4], const float (&bf)[TN][4]) {
+  auto mma_steps = [&](const float (&af)[TM][4], const float (&bf)[TN][4], int t0, int t1) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = t0; t < t1; ++t)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
   };
+  auto mma_group = [&](const float (&af)[TM][4], const float (&bf)[TN][4]) { mma_steps(af, bf, 0, 4); };
   constexpr int NG = BK / 8;
   static_assert(NG == 2 || NG == 4, "BK must be 16 or 32");
 
@@ -468,12 +476,26 @@ void gemm_kernel(const GemmArgs p) {
       load_frags(as, bs, g + 1, fa1, fb1);
       mma_group(fa0, fb0);
       if (g + 2 < NG) load_frags(as, bs, g + 2, fa0, fb0);
+#if MT_STORE_POS == 0
       if (g == NG - 2 && more) store_tiles(buf ^ 1);      // before the last MFMA group of the tile
       mma_group(fa1, fb1);
+#elif MT_STORE_POS == 1
+      if (g == NG - 2) {                                   // before the last k-step of the tile
+        mma_steps(fa1, fb1, 0, 3);
+        if (more) store_tiles(buf ^ 1);
+        mma_steps(fa1, fb1, 3, 4);
+      } else {
+        mma_group(fa1, fb1);
+      }
+#else
+      mma_group(fa1, fb1);
+      if (g == NG - 2 && more) store_tiles(buf ^ 1);      // after the tile's last MFMA
+#endif
     }
     __syncthreads();
   }
 
+  if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
   // ------------------------------------------------------------------ epilogue
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col_l = lane & 31;
@@ -501,6 +523,7 @@ void gemm_kernel(const GemmArgs p) {
         }
       }
     }
+    if (tr && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); tr[3] = wall_clock64(); }
     return;
   } else {
 #pragma unroll
@@ -553,6 +576,7 @@ void gemm_kernel(const GemmArgs p) {
       }
     }
   }
+  if (tr && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); tr[3] = wall_clock64(); }
 }
 
 }  // namespace mt
