@@ -159,3 +159,50 @@ def test_overlapped_allreduce_runs_on_rccl_single_rank(tmp_path):
     a, b = res["finals"]
     for x, y in zip(a, b):
         assert abs(x - y) <= 1e-3 * max(1.0, abs(x)), (x, y)
+
+
+def test_config5_xception_timesformer_step_vs_oracle():
+    """BASELINE config 5 (the "XS" variant): Xception extractor -> TimeSformer with 16 face slots of 3 identities [7,5,4],
+    one ragged clip, eval extractor (what train.py does when the extractor is frozen) and train-mode loss/backward through
+    the TimeSformer and the extractor.  Logits, loss and a spread of gradients against the CPU oracle on the same inputs."""
+    from mintime_amd import xception
+    F = 16
+    cfg = arch.default_tsf_config(2048, F)
+    xc_sd, tsf_sd = synth.xception_state(2), synth.tsf_state(cfg, 2)
+    xc = xception(num_classes=1, pretrain_path=None)
+    xc.load_state_dict(xc_sd)
+    xc.cuda().eval()
+    tsf = SizeInvariantTimeSformer(config=cfg, require_attention=False)
+    tsf.load_state_dict(tsf_sd)
+    tsf.cuda()
+    inp = synth.clip_inputs(1, F, 3, 4, ragged=True)
+    labels = torch.tensor([[1.0]])
+
+    feats, out = _step(xc, tsf, inp, require_attention=False)
+    assert feats.shape == (1, F, 2048, 7, 7)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out, labels.cuda())
+    loss.backward()
+
+    v = inp["videos"]
+    vid = v.reshape(F, 224, 224, 3).permute(0, 3, 1, 2)
+    o_xc = {k: t.clone().requires_grad_(t.is_floating_point() and "running_" not in k) for k, t in xc_sd.items()}
+    o_tsf = {k: t.clone().requires_grad_(True) for k, t in tsf_sd.items()}
+    ofeat = O.xception_forward(o_xc, vid, training=False)
+    ologits = O.tsf_forward(o_tsf, cfg, ofeat.reshape(1, F, 2048, 7, 7), inp["mask"], inp["identities_mask"], inp["size_embedding"],
+                            inp["positions"])
+    oloss = O.bce_with_logits(ologits, labels)
+    oloss.backward()
+
+    assert_close(feats.reshape(F, 2048, 7, 7), ofeat.detach(), REL_TOL, "Xception features")
+    assert_close(out, ologits.detach(), REL_TOL, "logits")
+    assert abs(float(loss.detach()) - float(oloss.detach())) <= 1e-4 * max(1.0, abs(float(oloss.detach())))
+    tsf_named = dict(tsf.named_parameters())
+    for k in ("to_patch_embedding.weight", "pos_emb.weight", "layers.0.0.fn.to_qkv.weight", "layers.4.1.fn.to_out.0.weight",
+              "layers.8.2.fn.net.0.weight", "to_out.1.weight"):
+        assert_close(tsf_named[k].grad, o_tsf[k].grad, 3 * REL_TOL, "grad " + k)
+    xc_named = dict(xc.named_parameters())
+    for k in ("conv4.pointwise.weight", "block12.rep.4.pointwise.weight", "block6.rep.1.conv1.weight", "block1.skip.weight",
+              "conv1.weight"):
+        got, ref = xc_named[k].grad, o_xc[k].grad
+        e = float((got.cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert e <= 2e-2, f"grad {k}: relative L2 error {e:.3e}"      # ReLU/max-pool mask flips: see test_gpu_xception.py
