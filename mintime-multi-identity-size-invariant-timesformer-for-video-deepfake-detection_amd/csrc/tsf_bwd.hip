@@ -195,17 +195,33 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------- attention backward: cls query
-// one wavefront per (b,h).  Writes dq (row 0) and INITIALISES dk, dv for every key row of this head with the cls
-// query's contribution; the patch kernel then accumulates on top.
-__global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                         float* __restrict__ dqkv, const uint8_t* __restrict__ mask,
-                                                         int B, int H, int F, int n, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // p[N], dS[N]
-  const int lane = threadIdx.x;
+// one block of CLS_W wavefronts per (b,h).  Writes dq (row 0) and INITIALISES dk, dv for every key row of this head with the cls
+// query's contribution; the patch kernels then accumulate on top.  Keys are spread over all lanes of the block for the per-key
+// work and over its wavefronts for the dq reduction.
+constexpr int CLS_W = 4;
+
+__device__ __forceinline__ float block_reduce(float v, float* red, int wave, int lane, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int w = 1; w < CLS_W; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+__global__ __launch_bounds__(CLS_W * 64) void attn_cls_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                 float* __restrict__ dqkv, const uint8_t* __restrict__ mask,
+                                                                 int B, int H, int F, int n, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // p[N], dS[N], CLS_W reduction slots, CLS_W x 64 partial dq
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, h = bh % H, b = bh / H;
   const int N = 1 + F * n, inner = H * DH, ld = 3 * inner;
   float* pl_ = lds;
   float* ds_ = lds + N;
+  float* red = ds_ + N;
+  float* part = red + CLS_W;
   const float* base = qkv + (int64_t)b * N * ld + h * DH;
   float* dbase = dqkv + (int64_t)b * N * ld + h * DH;
   const float* dob = dout + (int64_t)b * N * inner + h * DH;   // row 0
@@ -218,7 +234,7 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const float* __restric
     dO[4 * i] = d.x; dO[4 * i + 1] = d.y; dO[4 * i + 2] = d.z; dO[4 * i + 3] = d.w;
   }
   float mx = -FLT_MAX;
-  for (int j = lane; j < N; j += 64) {
+  for (int j = tid; j < N; j += CLS_W * 64) {
     const float* kr = base + (int64_t)j * ld + inner;
     const float* vr = base + (int64_t)j * ld + 2 * inner;
     float a = 0.f, dp = 0.f;
@@ -234,16 +250,16 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const float* __restric
     pl_[j] = a; ds_[j] = dp;
     mx = fmaxf(mx, a);
   }
-  mx = wave_max(mx);
+  mx = block_reduce(mx, red, wave, lane, true);
   float sum = 0.f;
-  for (int j = lane; j < N; j += 64) { const float e = expf(pl_[j] - mx); pl_[j] = e; sum += e; }
-  sum = wave_sum(sum);
+  for (int j = tid; j < N; j += CLS_W * 64) { const float e = expf(pl_[j] - mx); pl_[j] = e; sum += e; }
+  sum = block_reduce(sum, red, wave, lane, false);
   const float inv = 1.0f / sum;
   float delta = 0.f;
-  for (int j = lane; j < N; j += 64) { const float p = pl_[j] * inv; pl_[j] = p; delta += p * ds_[j]; }
-  delta = wave_sum(delta);
+  for (int j = tid; j < N; j += CLS_W * 64) { const float p = pl_[j] * inv; pl_[j] = p; delta += p * ds_[j]; }
+  delta = block_reduce(delta, red, wave, lane, false);
   // per key: dS, write dk_j = dS*q_scaled, dv_j = p*dO
-  for (int j = lane; j < N; j += 64) {
+  for (int j = tid; j < N; j += CLS_W * 64) {
     const float p = pl_[j];
     const float dS = p * (ds_[j] - delta);
     ds_[j] = dS;
@@ -256,18 +272,23 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const float* __restric
     }
   }
   __syncthreads();
-  // dq[d] = scale * sum_j dS_j k_j[d], lane = d
+  // dq[d] = scale * sum_j dS_j k_j[d], lane = d, keys strided over the wavefronts
   const float* kb = base + inner + lane;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int j = 0;
-  for (; j + 4 <= N; j += 4) {
+  float a0 = 0.f, a1 = 0.f;
+  int j = wave;
+  for (; j + CLS_W < N; j += 2 * CLS_W) {
     a0 = fmaf(ds_[j], kb[(int64_t)j * ld], a0);
-    a1 = fmaf(ds_[j + 1], kb[(int64_t)(j + 1) * ld], a1);
-    a2 = fmaf(ds_[j + 2], kb[(int64_t)(j + 2) * ld], a2);
-    a3 = fmaf(ds_[j + 3], kb[(int64_t)(j + 3) * ld], a3);
+    a1 = fmaf(ds_[j + CLS_W], kb[(int64_t)(j + CLS_W) * ld], a1);
   }
-  for (; j < N; ++j) a0 = fmaf(ds_[j], kb[(int64_t)j * ld], a0);
-  dbase[lane] = scale * ((a0 + a1) + (a2 + a3));
+  if (j < N) a0 = fmaf(ds_[j], kb[(int64_t)j * ld], a0);
+  part[wave * 64 + lane] = a0 + a1;
+  __syncthreads();
+  if (wave == 0) {
+    float t = part[lane];
+#pragma unroll
+    for (int w = 1; w < CLS_W; ++w) t += part[w * 64 + lane];
+    dbase[lane] = scale * t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------- space attention backward on the matrix cores
@@ -767,7 +788,7 @@ extern "C" int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, con
   if (n != 49) return fail(MT_ERR_UNSUPPORTED, "mt_attn_bwd: num-patches %d unsupported (49)", n);
   hipStream_t s = (hipStream_t)stream;
   const int N = 1 + F * n;
-  hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(64), 2 * N * sizeof(float), s, qkv, dout, dqkv, mask, B, H, F, n, scale);
+  hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(CLS_W * 64), (2 * N + CLS_W + CLS_W * 64) * sizeof(float), s, qkv, dout, dqkv, mask, B, H, F, n, scale);
   int rc = check_launch("mt_attn_bwd(cls)");
   if (rc) return rc;
   if (mode == 1) {

@@ -361,14 +361,31 @@ __global__ __launch_bounds__(WPB * 64) void attn_space_fwd_mfma_kernel(const flo
 }
 
 // ---------------------------------------------------------------------------------------- attention: cls query
-// one wavefront per (b,h): the (scaled) cls query attends to all N keys, padded frames masked (:120, :259-260)
-__global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                         float* __restrict__ att, const uint8_t* __restrict__ mask,
-                                                         int B, int H, int F, int n, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // N probabilities
-  const int lane = threadIdx.x;
+// one block of CLS_W wavefronts per (b,h): the (scaled) cls query attends to all N keys, padded frames masked (:120, :259-260).
+// Keys are spread over all the block's lanes for the scores (one 256-byte K row per lane) and over its wavefronts for the
+// weighted V sum (lane = d, coalesced rows); one wavefront per (b,h) left 3/4 of the chip idle at B*H = 256.
+constexpr int CLS_W = 4;
+
+__device__ __forceinline__ float block_reduce(float v, float* red, int wave, int lane, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();                                   // red may still be read from the previous reduction
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int w = 1; w < CLS_W; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+__global__ __launch_bounds__(CLS_W * 64) void attn_cls_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                 float* __restrict__ att, const uint8_t* __restrict__ mask,
+                                                                 int B, int H, int F, int n, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // N probabilities, CLS_W reduction slots, CLS_W x 64 partial outputs
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, h = bh % H, b = bh / H;
   const int N = 1 + F * n, inner = H * DH, ld = 3 * inner;
+  float* red = lds + N;
+  float* part = red + CLS_W;
   const float* base = qkv + (int64_t)b * N * ld + h * DH;
   float q[DH];
 #pragma unroll
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const float* __restric
     q[4 * i] = v.x * scale; q[4 * i + 1] = v.y * scale; q[4 * i + 2] = v.z * scale; q[4 * i + 3] = v.w * scale;
   }
   float mx = -FLT_MAX;
-  for (int j = lane; j < N; j += 64) {
+  for (int j = tid; j < N; j += CLS_W * 64) {
     const float* kr = base + (int64_t)j * ld + inner;
     float a = 0.f;
 #pragma unroll
@@ -390,30 +407,34 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const float* __restric
     lds[j] = a;
     mx = fmaxf(mx, a);
   }
-  mx = wave_max(mx);
+  mx = block_reduce(mx, red, wave, lane, true);
   float sum = 0.f;
-  for (int j = lane; j < N; j += 64) { const float e = expf(lds[j] - mx); lds[j] = e; sum += e; }
-  sum = wave_sum(sum);
+  for (int j = tid; j < N; j += CLS_W * 64) { const float e = expf(lds[j] - mx); lds[j] = e; sum += e; }
+  sum = block_reduce(sum, red, wave, lane, false);
   const float inv = 1.0f / sum;
-  for (int j = lane; j < N; j += 64) {
+  for (int j = tid; j < N; j += CLS_W * 64) {
     const float pj = lds[j] * inv;
     lds[j] = pj;
     if (att) att[(int64_t)bh * N + j] = pj;
   }
-  __builtin_amdgcn_wave_barrier();
   __syncthreads();
-  // out[d] = sum_j p_j v_j[d], lane = d
+  // out[d] = sum_j p_j v_j[d], lane = d, keys strided over the wavefronts
   const float* vb = base + 2 * inner + lane;
-  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-  int j = 0;
-  for (; j + 4 <= N; j += 4) {
+  float o0 = 0.f, o1 = 0.f;
+  int j = wave;
+  for (; j + CLS_W < N; j += 2 * CLS_W) {
     o0 = fmaf(lds[j], vb[(int64_t)j * ld], o0);
-    o1 = fmaf(lds[j + 1], vb[(int64_t)(j + 1) * ld], o1);
-    o2 = fmaf(lds[j + 2], vb[(int64_t)(j + 2) * ld], o2);
-    o3 = fmaf(lds[j + 3], vb[(int64_t)(j + 3) * ld], o3);
+    o1 = fmaf(lds[j + CLS_W], vb[(int64_t)(j + CLS_W) * ld], o1);
   }
-  for (; j < N; ++j) o0 = fmaf(lds[j], vb[(int64_t)j * ld], o0);
-  out[(int64_t)b * N * inner + h * DH + lane] = (o0 + o1) + (o2 + o3);
+  if (j < N) o0 = fmaf(lds[j], vb[(int64_t)j * ld], o0);
+  part[wave * 64 + lane] = o0 + o1;
+  __syncthreads();
+  if (wave == 0) {
+    float o = part[lane];
+#pragma unroll
+    for (int w = 1; w < CLS_W; ++w) o += part[w * 64 + lane];
+    out[(int64_t)b * N * inner + h * DH + lane] = o;
+  }
 }
 
 // ---------------------------------------------------------------------------------------- classification head
@@ -485,7 +506,7 @@ extern "C" int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const u
   if (n != 49) return fail(MT_ERR_UNSUPPORTED, "mt_attn_fwd: num-patches %d unsupported (49)", n);
   hipStream_t s = (hipStream_t)stream;
   const int N = 1 + F * n;
-  hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(64), N * sizeof(float), s, qkv, out, cls_att, mask, B, H, F, n, scale);
+  hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(CLS_W * 64), (N + CLS_W + CLS_W * 64) * sizeof(float), s, qkv, out, cls_att, mask, B, H, F, n, scale);
   int rc = check_launch("mt_attn_fwd(cls)");
   if (rc) return rc;
   if (mode == 1) {
