@@ -37,8 +37,13 @@ class _Aux:
         self.ident = identities_mask.to(device=dev, dtype=torch.uint8).contiguous()
         self.sizes = None
         if model.enable_size_emb:
-            # arrives as a CPU int32 tensor in the reference call sites (train.py:355); moved here like :245
-            self.sizes = size_embedding.to(device=dev, dtype=torch.int32).contiguous()
+            # arrives as a CPU int32 tensor in the reference call sites (train.py:355); moved here like :245 -- through a pinned
+            # staging buffer and an async copy: a pageable H2D copy blocks the host until the stream has drained the whole
+            # extractor forward, and the GPU then idles (~0.3 ms per step) while the host re-fills the launch queue
+            se = size_embedding.to(dtype=torch.int32)
+            if not se.is_cuda:
+                se = se.contiguous().pin_memory().to(dev, non_blocking=True)
+            self.sizes = se.to(device=dev).contiguous()
         self.positions = None
         if model.enable_pos_emb:
             self.positions = positions.to(device=dev, dtype=torch.int64).contiguous()
