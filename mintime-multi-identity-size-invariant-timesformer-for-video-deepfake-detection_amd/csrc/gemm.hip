@@ -13,10 +13,13 @@ enum { CFG_BIG = 0, CFG_MID = 1, CFG_NARROW = 2, CFG_SMALL = 3 };
 struct Cfg { int bm, bn, threads; };
 constexpr Cfg kCfg[4] = {{128, 128, 256}, {128, 64, 256}, {256, 32, 256}, {64, 64, 256}};
 
-int pick_cfg(int N, int epilogue) {
+int pick_cfg(int M, int N, int epilogue) {
   if (epilogue == MT_EPI_GEGLU) return CFG_BIG;
   if (const char* f = getenv("MT_FORCE_CFG")) return atoi(f);   // tuning experiments only
   if (N <= 32) return CFG_NARROW;
+  // tall problems with so few 128x128 tiles that they cannot even fill the resident slots once (e.g. 12576 x 512: 396 tiles on
+  // 256 CUs x 3-4 blocks): 64x64 tiles quadruple the block count and even out the per-CU load (out-proj 97 -> 81 us)
+  if (M >= 4096 && N >= 128 && (int64_t)((M + 127) / 128) * ((N + 127) / 128) <= 768) return CFG_SMALL;
   const int pad_big = (N + 127) / 128 * 128;
   const int pad_mid = (N + 63) / 64 * 64;
   return pad_mid < pad_big ? CFG_MID : CFG_BIG;
@@ -98,7 +101,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   if (d->b_prologue == MT_BPRO_IM2COL && d->op != MT_OP_TN) return fail(MT_ERR_ARG, "mt_gemm: im2col B prologue needs op TN");
   if (d->prologue == MT_PRO_BN_SWISH_GATE && !d->gate) return fail(MT_ERR_ARG, "mt_gemm: gate prologue needs gate");
 
-  const int cfg = pick_cfg(d->N, d->epilogue);
+  const int cfg = pick_cfg(d->op == MT_OP_TN ? 0 : d->M, d->N, d->epilogue);
   const int m_tiles = (d->M + kCfg[cfg].bm - 1) / kCfg[cfg].bm;
   const int n_tiles = (d->N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
   dim3 grid(m_tiles * n_tiles, 1, 1);

@@ -50,7 +50,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         """out[M,D] = dY[M,K_] . Wm[K_,D]: only 396 output tiles -> K-slices + fp32 atomics onto a zeroed output when K is long."""
         if M >= 4096 and K_ >= 1024:
             out.zero_()
-            L.gemm(L.OP_NN, dY, Wm, out, M, D, K_, K_, D, D, epilogue=L.EPI_ATOMIC, split_k=5 if K_ >= 2048 else 3)
+            L.gemm(L.OP_NN, dY, Wm, out, M, D, K_, K_, D, D, epilogue=L.EPI_ATOMIC, split_k=4 if K_ >= 2048 else 3)   # measured optimum with 64x64 tiles
         else:
             L.gemm(L.OP_NN, dY, Wm, out, M, D, K_, K_, D, D)
 
