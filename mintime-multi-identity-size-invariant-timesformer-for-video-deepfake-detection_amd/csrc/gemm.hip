@@ -13,13 +13,20 @@ enum { CFG_BIG = 0, CFG_MID = 1, CFG_NARROW = 2, CFG_SMALL = 3 };
 struct Cfg { int bm, bn, threads; };
 constexpr Cfg kCfg[4] = {{128, 128, 256}, {128, 64, 256}, {256, 32, 256}, {64, 64, 256}};
 
-int pick_cfg(int M, int N, int epilogue) {
+// Tile choice.  Replaying every GEMM of a B = 32 training step alone under each configuration (tools/tune_gemm_cfg.py, 70
+// shapes) favours 64x64 tiles almost everywhere, but inside the real step -- where the weight-gradient GEMMs of a second stream
+// share the CUs -- only the cases below kept their gain (and Xception's large pointwise GEMMs lost 7 % with 64x64 everywhere):
+//   * tall problems with so few 128x128 tiles that they cannot fill the resident slots once (12576 x 512: 396 tiles on 256 CUs
+//     x 3-4 blocks): 64x64 quadruples the block count and evens out the per-CU load (out-proj 97 -> 81 us);
+//   * the GEGLU-backward epilogue (reads the pre-activations, writes two gradients per element): small tiles let one block's
+//     epilogue hide under its neighbours' main loops (365 -> 298 us).
+int pick_cfg(int op, int M, int N, int prologue, int epilogue) {
+  (void)prologue;
   if (epilogue == MT_EPI_GEGLU) return CFG_BIG;
   if (const char* f = getenv("MT_FORCE_CFG")) return atoi(f);   // tuning experiments only
   if (N <= 32) return CFG_NARROW;
-  // tall problems with so few 128x128 tiles that they cannot even fill the resident slots once (e.g. 12576 x 512: 396 tiles on
-  // 256 CUs x 3-4 blocks): 64x64 tiles quadruple the block count and even out the per-CU load (out-proj 97 -> 81 us)
-  if (M >= 4096 && N >= 128 && (int64_t)((M + 127) / 128) * ((N + 127) / 128) <= 768) return CFG_SMALL;
+  if (epilogue == MT_EPI_GEGLU_BWD) return CFG_SMALL;
+  if (op != MT_OP_TN && M >= 4096 && N >= 128 && (int64_t)((M + 127) / 128) * ((N + 127) / 128) <= 768) return CFG_SMALL;
   const int pad_big = (N + 127) / 128 * 128;
   const int pad_mid = (N + 63) / 64 * 64;
   return pad_mid < pad_big ? CFG_MID : CFG_BIG;
@@ -40,9 +47,10 @@ int launch(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
       else hipLaunchKernelGGL((gemm_kernel<4, 1, 2, 1, AL, BL, PRO, EPI, BPRO>), grid, dim3(256), 0, s, a);
       break;
     case CFG_SMALL:
-      if constexpr (EPI == EPI_GEGLU) return fail(MT_ERR_UNSUPPORTED, "GEGLU needs the 128x128 tile");
+      if constexpr (EPI == EPI_GEGLU) return fail(MT_ERR_UNSUPPORTED, "GEGLU needs a 128-column tile");
       else hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, AL, BL, PRO, EPI, BPRO>), grid, dim3(256), 0, s, a);
       break;
+
   }
   return check_launch("mt_gemm");
 }
@@ -101,7 +109,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   if (d->b_prologue == MT_BPRO_IM2COL && d->op != MT_OP_TN) return fail(MT_ERR_ARG, "mt_gemm: im2col B prologue needs op TN");
   if (d->prologue == MT_PRO_BN_SWISH_GATE && !d->gate) return fail(MT_ERR_ARG, "mt_gemm: gate prologue needs gate");
 
-  const int cfg = pick_cfg(d->op == MT_OP_TN ? 0 : d->M, d->N, d->epilogue);
+  const int cfg = pick_cfg(d->op, d->M, d->N, d->prologue, d->epilogue);
   const int m_tiles = (d->M + kCfg[cfg].bm - 1) / kCfg[cfg].bm;
   const int n_tiles = (d->N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
   dim3 grid(m_tiles * n_tiles, 1, 1);
