@@ -134,10 +134,12 @@ for overlapped in (False, True):
         batch = harness.device_batch(2, seed=step)
         loss = harness.train_step(ef, tsf, opt, batch, red)
     torch.cuda.synchronize()
-    finals.append([p.detach().double().sum().item() for p in list(tsf.parameters())[:6] + list(ef.parameters())[:6]] + [float(loss)])
+    finals.append([p.detach().clone() for p in list(tsf.parameters()) + list(ef.parameters())] + [loss.detach().reshape(1)])
     if red is not None: stats = dict(red.stats)
 dist.destroy_process_group()
-print("RESULT " + json.dumps({"finals": finals, "stats": stats}))
+# whole-tensor relative L2 distance between the two runs (sums of parameters cancel and would amplify the atomics' run-to-run noise)
+worst = max(float((a - b).norm() / a.norm().clamp_min(1e-12)) for a, b in zip(*finals))
+print("RESULT " + json.dumps({"worst_rel_l2": worst, "stats": stats}))
 """
 
 
@@ -156,9 +158,7 @@ def test_overlapped_allreduce_runs_on_rccl_single_rank(tmp_path):
     st = res["stats"]
     assert st["synchronous"] == 2 and st["overlapped_launches"] == 4, st
     assert st["in_place"] == 6 and st["staged"] == 0, st           # p.grad aliases the engines' flat gradient buffers: no copies
-    a, b = res["finals"]
-    for x, y in zip(a, b):
-        assert abs(x - y) <= 1e-3 * max(1.0, abs(x)), (x, y)
+    assert res["worst_rel_l2"] <= 1e-3, res
 
 
 def test_config5_xception_timesformer_step_vs_oracle():
