@@ -104,10 +104,11 @@ def test_backward_matches_reference_fixture(name):
     assert_close(x.grad.permute(0, 1, 3, 4, 2).reshape(-1)[:512], g["dfeats_slice"], 2 * REL_TOL, "dfeats slice")
 
 
-@pytest.mark.parametrize("B,Fr,C,ids", [(2, 8, 1280, 2), (1, 16, 2048, 3)])
+@pytest.mark.parametrize("B,Fr,C,ids", [(2, 8, 1280, 2), (1, 16, 2048, 3), (1, 32, 1280, 3)])
 def test_backward_all_parameters_vs_oracle(B, Fr, C, ids):
     """Every parameter gradient (not just the fixture's sample) against torch autograd over the CPU oracle;
-    the second case is the XS configuration (Xception features, 16 frames, 3 identities [7,5,4])."""
+    the second case is the XS configuration (Xception features, 16 frames, 3 identities [7,5,4]), the third the largest
+    frame count the reference accepts (train.py:101: 32 slots, identities [14,10,8], 1569 tokens)."""
     seed = 5
     cfg = arch.default_tsf_config(C, Fr)
     model, sd = _build(cfg, seed, require_attention=False)
@@ -137,3 +138,26 @@ def test_attention_aggregation_matches_reference_rule():
     got, got_id = harness.aggregate_attentions([s_att.cuda(), t_att.cuda()], 8, 8, [4, 8], scale_factor=50000)
     assert_close(torch.tensor(got), torch.tensor(ref), 1e-4, "aggregated attentions")
     assert_close(torch.tensor(got_id), torch.tensor(ref_id), 1e-4, "identity attentions")
+
+
+def test_clip_with_a_fully_padded_identity_and_a_single_valid_slot():
+    """Edge of the masking rules (:252-260): one identity has no valid face at all (all its slots padded) and the other has a
+    single valid slot; every masked key must still get exactly zero probability and the logits must match the oracle."""
+    Fr, C, seed = 8, 1280, 11
+    cfg = arch.default_tsf_config(C, Fr)
+    model, sd = _build(cfg, seed, require_attention=True)
+    feats = synth.features(1, Fr, C, seed)
+    aux = synth.clip_inputs(1, Fr, 2, seed, ragged=False, with_video=False)
+    mask = torch.zeros(1, Fr, dtype=torch.bool)
+    mask[0, 0] = True                                       # identity 0: slot 0 valid only; identity 1: nothing valid
+    size = aux["size_embedding"].clone()
+    size[~mask] = 0
+    out, (space, time_) = model(feats.cuda(), mask=mask.cuda(), identities_mask=aux["identities_mask"].cuda(), size_embedding=size,
+                                positions=aux["positions"].cuda())
+    oout, (ospace, otime) = O.tsf_forward(sd, cfg, feats, mask, aux["identities_mask"], size, aux["positions"], require_attention=True)
+    assert_close(out, oout, REL_TOL, "logits")
+    assert_close(space, ospace, REL_TOL, "space cls attention")
+    assert_close(time_, otime, REL_TOL, "time cls attention")
+    padded_tokens = (~mask[0]).repeat_interleave(49)
+    assert float(space[:, 0, 1:][:, padded_tokens.cuda()].abs().max()) == 0.0
+    assert torch.isfinite(out).all()
