@@ -114,9 +114,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   const int n_tiles = (d->N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
   dim3 grid(m_tiles * n_tiles, 1, 1);
   a.group_n = 0;
-  a.stagger = 0;
   a.trace = g_trace;
-  if (const char* e = getenv("MT_STAGGER")) a.stagger = atoi(e);
   if (m_tiles >= 32 && n_tiles >= 2 && !getenv("MT_NO_L2_BLOCKING")) {
     // size a column group so its B panels take ~2 MB of the XCD's 4 MB L2
     const int64_t panel = (int64_t)kCfg[cfg].bn * d->K * 4;

@@ -23,15 +23,9 @@
 
 #ifndef MT_BK
 #define MT_BK 16
-#ifndef MT_STORE_POS
-#define MT_STORE_POS 0
-#endif
 #endif
 #ifndef MT_MIN_WAVES
 #define MT_MIN_WAVES 3
-#endif
-#ifndef MT_ROWMAJOR_LDS
-#define MT_ROWMAJOR_LDS 0
 #endif
 
 namespace mt {
@@ -147,7 +141,6 @@ struct GemmArgs {
   const float* b_scale; const float* b_shift; const float* b_gate; int b_hw;   // B prologue
   ConvDesc conv;                        // PRO_IM2COL / BPRO_IM2COL geometry
   int group_n;                          // > 0: L2-blocked tile order with this many tile columns per group
-  int stagger;                          // s_sleep(127) units (8128 cycles) of start skew per residency class, 0 = off
   long long* trace;                     // tuning aid (mt_debug_gemm_trace): per block {t_start, t_prologue, t_loop, t_end, hw_id}
 };
 
@@ -186,12 +179,12 @@ void gemm_kernel(const GemmArgs p) {
   //                                           the 16-lane b128 service groups hit 16 distinct 16-byte slots)
   //   k-major operand      -> [BK][rows+4]  (fragment = ds_read_b32 of 32 consecutive rows, conflict-free)
   // Both use the same k order inside a tile: MFMA step (g,t), lane half kh consumes k = 8g + 4kh + t.
-  constexpr bool A_ROWS = MT_ROWMAJOR_LDS && AL == LAYOUT_KCONTIG;   // LDS tile stored [rows][BK+4] (else [BK][rows+4])
-  constexpr bool B_ROWS = MT_ROWMAJOR_LDS && BL == LAYOUT_KCONTIG;
-  constexpr int LDA_S = A_ROWS ? BK + 4 : BM + 4;
-  constexpr int LDB_S = B_ROWS ? BK + 4 : BN + 4;
-  constexpr int A_TILE = A_ROWS ? BM * LDA_S : BK * LDA_S;
-  constexpr int B_TILE = B_ROWS ? BN * LDB_S : BK * LDB_S;
+  // LDS tiles are k-major [BK][rows + 4]: the MFMA fragment read is a conflict-free ds_read_b32 in exactly the operand layout
+  // (a row-major [rows][BK + 4] image read with ds_read_b128 measured the same, so the simpler one stayed)
+  constexpr int LDA_S = BM + 4;
+  constexpr int LDB_S = BN + 4;
+  constexpr int A_TILE = BK * LDA_S;
+  constexpr int B_TILE = BK * LDB_S;
   constexpr int A_UNITS = (BM * BK / 4 + NT - 1) / NT;   // float4 units per thread
   constexpr int B_UNITS = (BN * BK / 4 + NT - 1) / NT;
   constexpr bool A_EXACT = (BM * BK / 4) % NT == 0;
@@ -362,12 +355,8 @@ void gemm_kernel(const GemmArgs p) {
       if (A_EXACT || u < BM * BK / 4) {
         if constexpr (AL == LAYOUT_KCONTIG) {
           const int row = u / KQ, kq = u % KQ;
-          if constexpr (A_ROWS) {
-            *reinterpret_cast<float4*>(as + row * LDA_S + kq * 4) = ra[i];
-          } else {
-            as[(kq * 4 + 0) * LDA_S + row] = ra[i].x; as[(kq * 4 + 1) * LDA_S + row] = ra[i].y;
-            as[(kq * 4 + 2) * LDA_S + row] = ra[i].z; as[(kq * 4 + 3) * LDA_S + row] = ra[i].w;
-          }
+          as[(kq * 4 + 0) * LDA_S + row] = ra[i].x; as[(kq * 4 + 1) * LDA_S + row] = ra[i].y;
+          as[(kq * 4 + 2) * LDA_S + row] = ra[i].z; as[(kq * 4 + 3) * LDA_S + row] = ra[i].w;
         } else {
           constexpr int QPR = BM / 4;
           const int kk = u / QPR, mq = u - kk * QPR;
@@ -381,12 +370,8 @@ void gemm_kernel(const GemmArgs p) {
       if (B_EXACT || u < BN * BK / 4) {
         if constexpr (BL == LAYOUT_KCONTIG) {
           const int row = u / KQ, kq = u % KQ;
-          if constexpr (B_ROWS) {
-            *reinterpret_cast<float4*>(bs + row * LDB_S + kq * 4) = rb[i];
-          } else {
-            bs[(kq * 4 + 0) * LDB_S + row] = rb[i].x; bs[(kq * 4 + 1) * LDB_S + row] = rb[i].y;
-            bs[(kq * 4 + 2) * LDB_S + row] = rb[i].z; bs[(kq * 4 + 3) * LDB_S + row] = rb[i].w;
-          }
+          bs[(kq * 4 + 0) * LDB_S + row] = rb[i].x; bs[(kq * 4 + 1) * LDB_S + row] = rb[i].y;
+          bs[(kq * 4 + 2) * LDB_S + row] = rb[i].z; bs[(kq * 4 + 3) * LDB_S + row] = rb[i].w;
         } else {
           constexpr int QPR = BN / 4;
           const int kk = u / QPR, nq = u - kk * QPR;
@@ -404,14 +389,6 @@ void gemm_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // De-phase the co-resident workgroups.  All blocks of the first dispatch round start together, compete for the SIMD's
-  // matrix pipe, finish together and are replaced together: their load/epilogue phases stay ALIGNED and are never covered by
-  // another block's MFMAs (measured: 2 -> 4 waves/SIMD changed nothing).  Delaying the 2nd/3rd block of each CU by 1/3 and 2/3
-  // of a tile once, at kernel start, staggers every later round as well (blocks are replaced as they finish).
-  if (p.stagger > 0 && blockIdx.x < 768 && blockIdx.y == 0) {
-    const int cls = (blockIdx.x >> 8) % 3;
-    for (int i = 0; i < cls * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   long long* tr = p.trace ? p.trace + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
   if (tr && threadIdx.x == 0) { tr[0] = wall_clock64(); tr[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
   load_tiles(0);
@@ -431,23 +408,13 @@ void gemm_kernel(const GemmArgs p) {
   auto load_frags = [&](const float* as, const float* bs, int g, float (&af)[TM][4], float (&bf)[TN][4]) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      if constexpr (A_ROWS) {
-        const float4 v = *reinterpret_cast<const float4*>(as + (a_row + i * 32) * LDA_S + g * 8 + khalf * 4);
-        af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
-      } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) af[i][t] = as[(g * 8 + khalf * 4 + t) * LDA_S + a_row + i * 32];
-      }
+      for (int t = 0; t < 4; ++t) af[i][t] = as[(g * 8 + khalf * 4 + t) * LDA_S + a_row + i * 32];
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      if constexpr (B_ROWS) {
-        const float4 v = *reinterpret_cast<const float4*>(bs + (b_frag + j * 32) * LDB_S + g * 8 + khalf * 4);
-        bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
-      } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bf[j][t] = bs[(g * 8 + khalf * 4 + t) * LDB_S + b_frag + j * 32];
-      }
+      for (int t = 0; t < 4; ++t) bf[j][t] = bs[(g * 8 + khalf * 4 + t) * LDB_S + b_frag + j * 32];
     }
   };
   auto mma_steps = [&](const float (&af)[TM][4], const float (&bf)[TN][4], int t0, int t1) {
@@ -476,21 +443,8 @@ void gemm_kernel(const GemmArgs p) {
       load_frags(as, bs, g + 1, fa1, fb1);
       mma_group(fa0, fb0);
       if (g + 2 < NG) load_frags(as, bs, g + 2, fa0, fb0);
-#if MT_STORE_POS == 0
-      if (g == NG - 2 && more) store_tiles(buf ^ 1);      // before the last MFMA group of the tile
+      if (g == NG - 2 && more) store_tiles(buf ^ 1);      // before the last MFMA group of the tile (later placements measured the same)
       mma_group(fa1, fb1);
-#elif MT_STORE_POS == 1
-      if (g == NG - 2) {                                   // before the last k-step of the tile
-        mma_steps(fa1, fb1, 0, 3);
-        if (more) store_tiles(buf ^ 1);
-        mma_steps(fa1, fb1, 3, 4);
-      } else {
-        mma_group(fa1, fb1);
-      }
-#else
-      mma_group(fa1, fb1);
-      if (g == NG - 2 && more) store_tiles(buf ^ 1);      // after the tile's last MFMA
-#endif
     }
     __syncthreads();
   }
