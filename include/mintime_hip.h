@@ -209,6 +209,17 @@ int mt_conv1x1_wgrad(const float* du, const float* z, const float* kabc, const f
                      const float* gate, int hw, float* dw, int64_t rows, int Cout, int Cin, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training-step ends (next-row f4).
+ * mt_bce_logits: torch.nn.BCEWithLogitsLoss(pos_weight)(logits, labels) with mean reduction (train.py:261,367-368) and its
+ *   gradient in one launch: loss[1], dlogits[n] (may be NULL) = d loss / d logits.
+ * mt_sgd_multi: torch.optim.SGD(lr, weight_decay) (train.py:186,378; no momentum) over many tensors in one launch:
+ *   p -= lr * (g + weight_decay * p).  items = device array of {float* p; const float* g; int64 n; int64 block0} sorted by
+ *   block0 = index of the tensor's first 4096-element block; total_blocks = sum over tensors of ceil(n / 4096).
+ * ------------------------------------------------------------------------------------------------ */
+int mt_bce_logits(const float* logits, const float* labels, float pos_weight, float* loss, float* dlogits, int n, void* stream);
+int mt_sgd_multi(const void* items, int count, int64_t total_blocks, float lr, float weight_decay, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Xception (config 5 extractor, reference models/xception.py).  Dense convolutions are mt_gemm with the IM2COL
  * prologue; separable convolutions are mt_dwconv_* (act 0/2) + mt_gemm; the rest:
  * ------------------------------------------------------------------------------------------------ */

@@ -7,7 +7,7 @@ There is no CPU or eager-PyTorch fallback: every op raises if the library is mis
 from . import arch, synth, lib  # noqa: F401
 from . import timesformer, tsf_engine, tsf_backward  # noqa: F401
 from . import efficientnet, effnet_engine, effnet_backward  # noqa: F401
-from . import ddp, harness  # noqa: F401
+from . import ddp, optim, harness  # noqa: F401
 from .timesformer import SizeInvariantTimeSformer  # noqa: F401
 from .efficientnet import EfficientNet  # noqa: F401
 from . import xception as xception_module, xception_engine  # noqa: F401

@@ -1,0 +1,77 @@
+// Next-row f4: the two ends of a training step that sit outside the networks -- BCE-with-logits on the [B,1] logits (forward value
+// and gradient in one launch; reference train.py:261,367-368 does it on the CPU after a D2H copy) and the SGD update over every
+// parameter in ONE multi-tensor launch (reference train.py:186 torch.optim.SGD(lr, weight_decay), :378).
+#include "common.hpp"
+#include <stdint.h>
+
+namespace {
+using namespace mt;
+
+// loss = mean_i (1 - y) x + (1 + (pw - 1) y) softplus(-x);   dloss/dx_i = ((1 - y) - (1 + (pw - 1) y) sigmoid(-x)) / n
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, const float* __restrict__ y, float pos_weight,
+                                                         float* __restrict__ loss, float* __restrict__ dx, int n) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float xi = x[i], yi = y[i];
+    const float lw = 1.0f + (pos_weight - 1.0f) * yi;
+    const float sp = log1pf(expf(-fabsf(xi))) + fmaxf(-xi, 0.f);            // softplus(-x), the stable form torch uses
+    acc += (1.0f - yi) * xi + lw * sp;
+    if (dx) dx[i] = ((1.0f - yi) - lw / (1.0f + expf(xi))) / (float)n;        // sigmoid(-x) = 1 / (1 + e^x)
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+}
+
+struct SgdItem { float* p; const float* g; int64_t n; int64_t block0; };     // block0 = first 4096-element block of this tensor
+constexpr int SGD_CHUNK = 4096;
+
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdItem* __restrict__ items, int count, float lr, float wd) {
+  // which tensor does this block belong to: binary search over the (sorted) first-block table
+  int lo = 0, hi = count - 1;
+  const int64_t b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const SgdItem it = items[lo];
+  const int64_t off = (b - it.block0) * SGD_CHUNK;
+  float* p = it.p + off;
+  const float* g = it.g + off;
+  const int64_t left = it.n - off;
+  const bool vec = ((((uintptr_t)p | (uintptr_t)g) & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < SGD_CHUNK / 1024; ++i) {
+    const int e = (i * 256 + threadIdx.x) * 4;
+    if (vec && e + 3 < left) {
+      float4 pv = *reinterpret_cast<float4*>(p + e);
+      const float4 gv = *reinterpret_cast<const float4*>(g + e);
+      pv.x -= lr * fmaf(wd, pv.x, gv.x); pv.y -= lr * fmaf(wd, pv.y, gv.y);
+      pv.z -= lr * fmaf(wd, pv.z, gv.z); pv.w -= lr * fmaf(wd, pv.w, gv.w);
+      *reinterpret_cast<float4*>(p + e) = pv;
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (e + k < left) p[e + k] -= lr * fmaf(wd, p[e + k], g[e + k]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mt_bce_logits(const float* logits, const float* labels, float pos_weight, float* loss, float* dlogits, int n,
+                             void* stream) {
+  if (!logits || !labels || !loss || n <= 0) return fail(MT_ERR_ARG, "mt_bce_logits: null pointer / empty batch");
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, pos_weight, loss, dlogits, n);
+  return check_launch("mt_bce_logits");
+}
+
+extern "C" int mt_sgd_multi(const void* items, int count, int64_t total_blocks, float lr, float weight_decay, void* stream) {
+  if (!items || count <= 0 || total_blocks <= 0) return fail(MT_ERR_ARG, "mt_sgd_multi: empty table");
+  if (total_blocks > 0x7fffffff) return fail(MT_ERR_ARG, "mt_sgd_multi: too many blocks");
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const SgdItem*>(items), count, lr, weight_decay);
+  return check_launch("mt_sgd_multi");
+}

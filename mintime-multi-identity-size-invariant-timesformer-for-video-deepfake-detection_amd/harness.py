@@ -4,7 +4,7 @@ this reproduces exactly what they do with the two models (same rearranges, same 
 import torch
 import torch.nn.functional as F
 
-from . import arch, synth
+from . import arch, optim, synth
 from .efficientnet import EfficientNet
 from .timesformer import SizeInvariantTimeSformer
 
@@ -25,6 +25,8 @@ def make_optimizer(cfg, ef, tsf):
     """train.py:180-190: optimizer over chain(extractor, model) parameters; SGD(lr, weight_decay) from the YAML."""
     t = cfg["training"]
     params = list(ef.parameters()) + list(tsf.parameters())
+    if params[0].is_cuda:   # one multi-tensor launch per step instead of torch's ~15 foreach kernels (same update rule)
+        return optim.FusedSGD(params, lr=t["lr"], weight_decay=t["weight-decay"])
     return torch.optim.SGD(params, lr=t["lr"], weight_decay=t["weight-decay"])
 
 
@@ -59,8 +61,7 @@ def train_step(ef, tsf, optimizer, batch, reducer=None, pos_weight=None):
     y_pred = forward(ef, tsf, batch)
     if isinstance(y_pred, tuple):
         y_pred = y_pred[0]
-    pw = None if pos_weight is None else torch.as_tensor([pos_weight], device=y_pred.device)
-    loss = F.binary_cross_entropy_with_logits(y_pred, batch["labels"].reshape(-1, 1), pos_weight=pw)
+    loss = optim.bce_with_logits(y_pred, batch["labels"], pos_weight)          # value + gradient in one launch, on the device
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     if reducer is not None:

@@ -1,0 +1,78 @@
+"""Training-step ends on libmintime_hip (next-row f4): a drop-in for the reference's `torch.optim.SGD(parameters, lr=...,
+weight_decay=...)` (train.py:186) whose step() is ONE multi-tensor launch, and BCE-with-logits (train.py:261,367-368) computed on
+the device together with its gradient."""
+import torch
+
+from . import lib as L
+
+_CHUNK = 4096
+
+
+class FusedSGD(torch.optim.Optimizer):
+    """`p -= lr * (grad + weight_decay * p)` (torch.optim.SGD without momentum) for every parameter of a group in one launch.
+    param_groups / lr schedulers work as with torch.optim.SGD (lr and weight_decay are read from the group at every step)."""
+
+    def __init__(self, params, lr=1e-3, weight_decay=0.0):
+        if lr < 0.0 or weight_decay < 0.0:
+            raise ValueError("lr and weight_decay must be non-negative")
+        super().__init__(params, dict(lr=lr, weight_decay=weight_decay))
+        self._tables = {}
+
+    def _table(self, gi, ps):
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
+        hit = self._tables.get(gi)
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        rows, block = [], 0
+        for p in ps:
+            rows.append((p.data_ptr(), p.grad.data_ptr(), p.numel(), block))
+            block += (p.numel() + _CHUNK - 1) // _CHUNK
+        table = torch.tensor(rows, dtype=torch.int64).to(ps[0].device)
+        self._tables[gi] = (key, table, block)
+        return table, block
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = L.get()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise L.MintimeHipError("FusedSGD needs contiguous fp32 parameters and gradients")
+                L.ptr(p)                                   # refuses CPU tensors: there is no CPU path
+            table, blocks = self._table(gi, ps)
+            L.check(lib.mt_sgd_multi(table.data_ptr(), len(ps), blocks, float(group["lr"]), float(group["weight_decay"]),
+                                     L.stream_ptr()), "mt_sgd_multi")
+        return loss
+
+
+class _BCEWithLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, pos_weight):
+        x = logits.reshape(-1).contiguous().float()
+        y = labels.reshape(-1).contiguous().float()
+        if x.numel() != y.numel():
+            raise ValueError("logits and labels must have the same number of elements")
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        L.check(L.get().mt_bce_logits(L.ptr(x), L.ptr(y), float(pos_weight), L.ptr(loss), L.ptr(dx), x.numel(), L.stream_ptr()),
+                "mt_bce_logits")
+        ctx.save_for_backward(dx)
+        ctx.shape = logits.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return (dx * g).reshape(ctx.shape), None, None
+
+
+def bce_with_logits(logits, labels, pos_weight=None):
+    """torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([w]))(logits, labels) on the device (mean reduction)."""
+    return _BCEWithLogits.apply(logits, labels, 1.0 if pos_weight is None else float(pos_weight))

@@ -206,3 +206,42 @@ def test_config5_xception_timesformer_step_vs_oracle():
         got, ref = xc_named[k].grad, o_xc[k].grad
         e = float((got.cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
         assert e <= 2e-2, f"grad {k}: relative L2 error {e:.3e}"      # ReLU/max-pool mask flips: see test_gpu_xception.py
+
+
+def test_native_bce_and_fused_sgd_match_torch():
+    """Next-row f4: mt_bce_logits (value + gradient) against torch's BCEWithLogitsLoss(pos_weight) and the one-launch
+    multi-tensor SGD against torch.optim.SGD(lr, weight_decay) over tensors of awkward sizes (scalar, odd, unaligned views)."""
+    from mintime_amd import optim
+    g = torch.Generator().manual_seed(3)
+    for n, pw in ((1, None), (7, 2.5), (32, 0.4), (300, None)):
+        x = (torch.randn(n, 1, generator=g) * 4).requires_grad_(True)
+        y = (torch.rand(n, 1, generator=g) > 0.5).float()
+        ref = torch.nn.BCEWithLogitsLoss(pos_weight=None if pw is None else torch.tensor([pw]))(x, y)
+        ref.backward()
+        xd = x.detach().cuda().requires_grad_(True)
+        got = optim.bce_with_logits(xd, y.cuda(), pw)
+        (got * 1.5).backward()
+        assert abs(float(got.detach()) - float(ref.detach())) <= 1e-5 * max(1.0, abs(float(ref.detach())))
+        assert_close(xd.grad, 1.5 * x.grad, 1e-5, "d loss / d logits")
+    sizes = [(1,), (3, 5), (4097,), (128, 64), (2, 3, 3, 3), (100003,)]
+    flat = torch.randn(sum(torch.Size(s).numel() for s in sizes) + 8, generator=g)
+    ps_ref, ps_gpu, off = [], [], 1                                  # offset 1: parameters that are NOT 16-byte aligned
+    for s in sizes:
+        n = torch.Size(s).numel()
+        w = flat[off:off + n].reshape(s).clone()
+        ps_ref.append(torch.nn.Parameter(w.clone()))
+        ps_gpu.append(torch.nn.Parameter(w.clone().cuda()))
+        off += n
+    o_ref = torch.optim.SGD(ps_ref, lr=0.05, weight_decay=1e-2)
+    o_gpu = optim.FusedSGD(ps_gpu, lr=0.05, weight_decay=1e-2)
+    sched = torch.optim.lr_scheduler.StepLR(o_gpu, step_size=1, gamma=0.5)       # schedulers drive param_groups as usual
+    sched_ref = torch.optim.lr_scheduler.StepLR(o_ref, step_size=1, gamma=0.5)
+    for step in range(3):
+        for pr, pg in zip(ps_ref, ps_gpu):
+            gr = torch.randn(pr.shape, generator=g)
+            pr.grad, pg.grad = gr.clone(), gr.clone().cuda()
+        ps_gpu[1].grad = None if step == 1 else ps_gpu[1].grad               # a parameter without gradient is skipped
+        ps_ref[1].grad = None if step == 1 else ps_ref[1].grad
+        o_ref.step(); o_gpu.step(); sched.step(); sched_ref.step()
+    for pr, pg in zip(ps_ref, ps_gpu):
+        assert_close(pg.detach(), pr.detach(), 1e-6, "parameters after 3 SGD steps")
