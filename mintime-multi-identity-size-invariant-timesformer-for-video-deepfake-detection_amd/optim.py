@@ -17,18 +17,25 @@ class FusedSGD(torch.optim.Optimizer):
             raise ValueError("lr and weight_decay must be non-negative")
         super().__init__(params, dict(lr=lr, weight_decay=weight_decay))
         self._tables = {}
+        self.table_uploads = 0
 
     def _table(self, gi, ps):
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
-        hit = self._tables.get(gi)
-        if hit is not None and hit[0] == key:
-            return hit[1], hit[2]
+        """Device table of (param ptr, grad ptr, numel, first block).  Gradient buffers come from the caching allocator, so their
+        addresses repeat after a step or two: tables are kept per address set (a few KB each) and uploaded through pinned memory
+        without blocking the host."""
+        key = (gi,) + tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
+        hit = self._tables.get(key)
+        if hit is not None:
+            return hit
         rows, block = [], 0
         for p in ps:
             rows.append((p.data_ptr(), p.grad.data_ptr(), p.numel(), block))
             block += (p.numel() + _CHUNK - 1) // _CHUNK
-        table = torch.tensor(rows, dtype=torch.int64).to(ps[0].device)
-        self._tables[gi] = (key, table, block)
+        table = torch.tensor(rows, dtype=torch.int64).pin_memory().to(ps[0].device, non_blocking=True)
+        if len(self._tables) >= 8:
+            self._tables.pop(next(iter(self._tables)))
+        self._tables[key] = (table, block)
+        self.table_uploads += 1
         return table, block
 
     @torch.no_grad()
