@@ -47,37 +47,59 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int q = lane + i * 64;
     g[i] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int row = wave_global; row < rows; row += nwaves) {
-    const float mean = stats[2 * (int64_t)row], rstd = stats[2 * (int64_t)row + 1];
-    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
-    const float4* dyr = reinterpret_cast<const float4*>(dy + (int64_t)row * D);
-    float4 xh[4], gy[4];
-    float c1 = 0.f, c2 = 0.f;
+  // two rows per trip: a wave walks ~12 rows and each row is a dependent chain of load -> wave reduction -> store, so the
+  // second row's loads ride under the first row's reductions
+  for (int row0 = wave_global; row0 < rows; row0 += 2 * nwaves) {
+    const int row1 = row0 + nwaves;
+    const bool has1 = row1 < rows;
+    const int r1 = has1 ? row1 : row0;
+    const float mean0 = stats[2 * (int64_t)row0], rstd0 = stats[2 * (int64_t)row0 + 1];
+    const float mean1 = stats[2 * (int64_t)r1], rstd1 = stats[2 * (int64_t)r1 + 1];
+    const float4* xr0 = reinterpret_cast<const float4*>(x + (int64_t)row0 * D);
+    const float4* dyr0 = reinterpret_cast<const float4*>(dy + (int64_t)row0 * D);
+    const float4* xr1 = reinterpret_cast<const float4*>(x + (int64_t)r1 * D);
+    const float4* dyr1 = reinterpret_cast<const float4*>(dy + (int64_t)r1 * D);
+    float4 xh0[4], gy0[4], xh1[4], gy1[4];
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    const float w1 = has1 ? 1.f : 0.f;          // the duplicated tail row must not count twice in dgamma / dbeta
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = lane + i * 64;
       if (q < nq) {
-        const float4 xv = xr[q], d = dyr[q];
-        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-        gy[i] = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
-        c1 += gy[i].x + gy[i].y + gy[i].z + gy[i].w;
-        c2 += gy[i].x * xh[i].x + gy[i].y * xh[i].y + gy[i].z * xh[i].z + gy[i].w * xh[i].w;
-        dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
-        db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+        const float4 xv0 = xr0[q], d0 = dyr0[q], xv1 = xr1[q], d1 = dyr1[q];
+        xh0[i] = make_float4((xv0.x - mean0) * rstd0, (xv0.y - mean0) * rstd0, (xv0.z - mean0) * rstd0, (xv0.w - mean0) * rstd0);
+        xh1[i] = make_float4((xv1.x - mean1) * rstd1, (xv1.y - mean1) * rstd1, (xv1.z - mean1) * rstd1, (xv1.w - mean1) * rstd1);
+        gy0[i] = make_float4(d0.x * g[i].x, d0.y * g[i].y, d0.z * g[i].z, d0.w * g[i].w);
+        gy1[i] = make_float4(d1.x * g[i].x, d1.y * g[i].y, d1.z * g[i].z, d1.w * g[i].w);
+        a1 += gy0[i].x + gy0[i].y + gy0[i].z + gy0[i].w;
+        a2 += gy0[i].x * xh0[i].x + gy0[i].y * xh0[i].y + gy0[i].z * xh0[i].z + gy0[i].w * xh0[i].w;
+        b1 += gy1[i].x + gy1[i].y + gy1[i].z + gy1[i].w;
+        b2 += gy1[i].x * xh1[i].x + gy1[i].y * xh1[i].y + gy1[i].z * xh1[i].z + gy1[i].w * xh1[i].w;
+        dg[i].x += d0.x * xh0[i].x + w1 * d1.x * xh1[i].x; dg[i].y += d0.y * xh0[i].y + w1 * d1.y * xh1[i].y;
+        dg[i].z += d0.z * xh0[i].z + w1 * d1.z * xh1[i].z; dg[i].w += d0.w * xh0[i].w + w1 * d1.w * xh1[i].w;
+        db[i].x += d0.x + w1 * d1.x; db[i].y += d0.y + w1 * d1.y; db[i].z += d0.z + w1 * d1.z; db[i].w += d0.w + w1 * d1.w;
       }
     }
-    c1 = wave_sum(c1) / (float)D;
-    c2 = wave_sum(c2) / (float)D;
-    float4* dxr = reinterpret_cast<float4*>(dx + (int64_t)row * D);
+    a1 = wave_sum(a1) / (float)D; a2 = wave_sum(a2) / (float)D;
+    b1 = wave_sum(b1) / (float)D; b2 = wave_sum(b2) / (float)D;
+    float4* dxr0 = reinterpret_cast<float4*>(dx + (int64_t)row0 * D);
+    float4* dxr1 = reinterpret_cast<float4*>(dx + (int64_t)r1 * D);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = lane + i * 64;
       if (q < nq) {
         float4 o;
-        o.x = rstd * (gy[i].x - c1 - xh[i].x * c2); o.y = rstd * (gy[i].y - c1 - xh[i].y * c2);
-        o.z = rstd * (gy[i].z - c1 - xh[i].z * c2); o.w = rstd * (gy[i].w - c1 - xh[i].w * c2);
-        if (accumulate) { const float4 p = dxr[q]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-        dxr[q] = o;
+        o.x = rstd0 * (gy0[i].x - a1 - xh0[i].x * a2); o.y = rstd0 * (gy0[i].y - a1 - xh0[i].y * a2);
+        o.z = rstd0 * (gy0[i].z - a1 - xh0[i].z * a2); o.w = rstd0 * (gy0[i].w - a1 - xh0[i].w * a2);
+        if (accumulate) { const float4 p = dxr0[q]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+        dxr0[q] = o;
+        if (has1) {
+          float4 t;
+          t.x = rstd1 * (gy1[i].x - b1 - xh1[i].x * b2); t.y = rstd1 * (gy1[i].y - b1 - xh1[i].y * b2);
+          t.z = rstd1 * (gy1[i].z - b1 - xh1[i].z * b2); t.w = rstd1 * (gy1[i].w - b1 - xh1[i].w * b2);
+          if (accumulate) { const float4 p = dxr1[q]; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }
+          dxr1[q] = t;
+        }
       }
     }
   }
