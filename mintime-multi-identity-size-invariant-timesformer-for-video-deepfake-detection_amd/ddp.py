@@ -59,15 +59,19 @@ class OverlappedGradReducer:
     """Gradient averaging overlapped with the backward pass, one bucket per network.
 
     The hot path runs backwards through the TimeSformer first and the EfficientNet second, and 77 % of the gradient bytes
-    (48 of 62.4 M floats) are the TimeSformer's: its all-reduce is launched (async, on RCCL's own stream) the moment its last
-    parameter has accumulated and rides under the ~20 ms EfficientNet backward; only the EfficientNet bucket (16 MB) is exposed.
+    (48 of 62.4 M floats) are the TimeSformer's: its all-reduce is launched (async, on RCCL's own stream) the moment its
+    backward has finished and rides under the ~19 ms EfficientNet backward; only the EfficientNet bucket (16 MB) is exposed.
     xGMI is point-to-point, so the buckets are as large as the dependency structure allows (two), not 25 MB slices.
 
-    Both engines hand autograd views of ONE flat gradient buffer per network (lib.zero_grads); when `p.grad` still aliases that
-    buffer the bucket is reduced in place with no copies, otherwise it goes through a persistent flat staging buffer.
-    The first step runs synchronously and records which parameters receive gradients (`_fc` never does, model.py:206-208).
+    A bucket is either
+      * an engine-backed module (EfficientNet / SizeInvariantTimeSformer / Xception): its backward produces every parameter
+        gradient as a view of ONE flat buffer and announces it through `lib.grads_ready`; the buffer is reduced in place, with
+        no per-parameter Python hooks (366 hook calls cost ~5 ms of launch-thread time per step) and no copies; or
+      * a plain list of parameters (any torch module): post-accumulate hooks count arrivals, the bucket is launched when the
+        last one has arrived (in place when the gradients alias one storage, else through a persistent staging buffer); the
+        first step runs synchronously and records which parameters receive gradients (`_fc` never does, model.py:206-208).
 
-        reducer = OverlappedGradReducer([tsf.parameters(), ef.parameters()])   # order = order in which backward finishes them
+        reducer = OverlappedGradReducer([tsf, ef])          # order = order in which backward finishes them
         loss.backward(); reducer.allreduce(); optimizer.step()
     """
 
@@ -75,17 +79,45 @@ class OverlappedGradReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or force
-        self.buckets = [[p for p in b if p.requires_grad] for b in buckets]
-        self.live = [None] * len(self.buckets)        # parameters that get gradients (known after the first step)
+        self.modules = [b if isinstance(b, torch.nn.Module) else None for b in buckets]
+        self.buckets = [[p for p in (b.parameters() if isinstance(b, torch.nn.Module) else b) if p.requires_grad] for b in buckets]
+        self.live = [None] * len(self.buckets)        # hook buckets: parameters that get gradients (known after the first step)
         self.seen = [0] * len(self.buckets)
+        self.launched = [False] * len(self.buckets)
         self.pending = []
         self.staging = [None] * len(self.buckets)
         self.stats = {"overlapped_launches": 0, "in_place": 0, "staged": 0, "synchronous": 0}
         if self.active:
             for bi, b in enumerate(self.buckets):
-                for p in b:
-                    p.register_post_accumulate_grad_hook(self._make_hook(bi))
+                if self.modules[bi] is not None:
+                    self.modules[bi]._grads_ready_hook = self._make_engine_hook(bi)
+                else:
+                    for p in b:
+                        p.register_post_accumulate_grad_hook(self._make_hook(bi))
 
+    # ---- engine-backed buckets ------------------------------------------------------------------------------------
+    def _make_engine_hook(self, bi):
+        def hook(params, flat):
+            # gradients that already exist would be ADDED to by autograd while the collective is in flight: leave such a
+            # bucket to the synchronous path (the harness always starts from grad = None)
+            if any(p.grad is not None for p in params):
+                return
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pending.append((work, flat, ("engine", bi, params)))
+            self.launched[bi] = True
+            self.stats["overlapped_launches"] += 1
+            self.stats["in_place"] += 1
+        return hook
+
+    @staticmethod
+    def _views_like_zero_grads(params, flat):
+        views, off = [], 0
+        for p in params:
+            views.append(flat[off:off + p.numel()].view(p.shape))
+            off += (p.numel() + 3) // 4 * 4
+        return views
+
+    # ---- plain parameter buckets ----------------------------------------------------------------------------------
     def _make_hook(self, bi):
         def hook(p):
             if self.live[bi] is None:
@@ -93,11 +125,12 @@ class OverlappedGradReducer:
             self.seen[bi] += 1
             if self.seen[bi] == len(self.live[bi]):
                 self._launch(bi, async_op=True)
+                self.launched[bi] = True
                 self.stats["overlapped_launches"] += 1
         return hook
 
-    def _launch(self, bi, async_op):
-        params = self.live[bi]
+    def _launch(self, bi, async_op, params=None):
+        params = self.live[bi] if params is None else params
         grads = [p.grad for p in params]
         base = grads[0].untyped_storage()
         aliased = all(g.untyped_storage().data_ptr() == base.data_ptr() for g in grads)
@@ -116,17 +149,25 @@ class OverlappedGradReducer:
                 self.staging[bi] = (flat, views)
             flat, views = self.staging[bi]
             torch._foreach_copy_(views, grads)
-            back = (grads, views)
+            back = ("copy", grads, views)
             self.stats["staged"] += 1
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         self.pending.append((work, flat, back))
 
+    # ---- after backward() -----------------------------------------------------------------------------------------
     def allreduce(self):
         """Call after backward(): waits for the launched buckets (launching any that could not be overlapped) and averages."""
         if not self.active:
             return 0
         for bi, b in enumerate(self.buckets):
-            if self.live[bi] is None:                                   # first step: learn the layout, reduce synchronously
+            if self.launched[bi]:
+                continue
+            if self.modules[bi] is not None:                             # engine bucket that could not be launched early
+                ps = [p for p in b if p.grad is not None]
+                if ps:
+                    self._launch(bi, async_op=False, params=ps)
+                    self.stats["synchronous"] += 1
+            elif self.live[bi] is None:                                   # first step: learn the layout, reduce synchronously
                 self.live[bi] = [p for p in b if p.grad is not None]
                 if self.live[bi]:
                     self._launch(bi, async_op=False)
@@ -139,9 +180,18 @@ class OverlappedGradReducer:
             if work is not None:
                 work.wait()
             flat.mul_(1.0 / self.world)
-            if back is not None:
-                torch._foreach_copy_(back[0], back[1])
+            if back is not None and back[0] == "copy":
+                torch._foreach_copy_(back[1], back[2])
+            elif back is not None:                                        # engine bucket: p.grad must still alias the buffer
+                _, bi, params = back
+                base = flat.untyped_storage().data_ptr()
+                stale = [(p, v) for p, v in zip(params, self._views_like_zero_grads(params, flat))
+                         if p.grad is not None and p.grad.untyped_storage().data_ptr() != base]
+                if stale:                                                 # autograd cloned instead of adopting the views
+                    torch._foreach_copy_([p.grad for p, _ in stale], [v for _, v in stale])
+                    self.stats["staged"] += 1
             n += flat.numel()
         self.pending = []
         self.seen = [0] * len(self.buckets)
+        self.launched = [False] * len(self.buckets)
         return n

@@ -21,7 +21,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
     N, H, W = shape
     blocks = model._blocks
     P = list(params)
-    grads = L.zero_grads(list(params))
+    grads, flat_grads = L.zero_grads(list(params), with_flat=True)
     # parameter index map (same order as effnet_engine.param_list)
     pos = 3
     bidx = []
@@ -152,5 +152,6 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
     if need_dx:
         raise NotImplementedError("gradient w.r.t. the input crops is not part of the MINTIME training path "
                                   "(train.py never sets requires_grad on videos)")
+    L.grads_ready(model, params, flat_grads)
     out = [g if need else None for need, g in zip(need_dparams, grads)]
     return None, out

@@ -183,9 +183,10 @@ def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI
     check(get().mt_gemm(C.byref(d), stream_ptr()), "mt_gemm")
 
 
-def zero_grads(params):
+def zero_grads(params, with_flat=False):
     """Zero-filled gradient tensors for `params` carved out of ONE flat buffer (one memset instead of hundreds);
-    every view starts on a 16-byte boundary.  Entries for None params are None."""
+    every view starts on a 16-byte boundary.  Entries for None params are None.  with_flat=True also returns the buffer
+    (what the data-parallel reducer all-reduces in place)."""
     offs, total = [], 0
     for p in params:
         offs.append(total)
@@ -193,7 +194,16 @@ def zero_grads(params):
             total += (p.numel() + 3) // 4 * 4
     dev = next(p for p in params if p is not None).device
     flat = torch.zeros(total, dtype=torch.float32, device=dev)
-    return [None if p is None else flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)]
+    views = [None if p is None else flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)]
+    return (views, flat) if with_flat else views
+
+
+def grads_ready(model, params, flat):
+    """End of a network's backward: every parameter gradient of `model` is complete and lives in `flat`.  A data-parallel reducer
+    registered on the module (ddp.OverlappedGradReducer) starts its all-reduce here, under the rest of the backward pass."""
+    hook = getattr(model, "_grads_ready_hook", None)
+    if hook is not None:
+        hook(params, flat)
 
 
 class SideStream:

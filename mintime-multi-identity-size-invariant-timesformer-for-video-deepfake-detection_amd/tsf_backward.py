@@ -32,7 +32,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
     eps = arch.LN_EPS
     scale = float(dh) ** -0.5
     sk = _splits(M)
-    grads = L.zero_grads(list(params))
+    grads, flat_grads = L.zero_grads(list(params), with_flat=True)
     P = list(params)
     idx = len(P)
 
@@ -122,6 +122,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         L.gemm(L.OP_NN, dx2, w_pe, dfeat, Mt, C_in, D, D, C_in, C_in, a_map=tok_map)
     side.wait()
     assert idx == 0
+    L.grads_ready(model, params, flat_grads)
     out = []
     for gneed, gr in zip(need_dparams, grads):
         out.append(gr if gneed else None)

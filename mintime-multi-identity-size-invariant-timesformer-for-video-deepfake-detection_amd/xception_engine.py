@@ -179,7 +179,7 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
     dev = dfeat.device
     N, H, W = shape
     P = list(params)
-    grads = L.zero_grads(P)
+    grads, flat_grads = L.zero_grads(P, with_flat=True)
     consts = saved["consts"]
     pool = _StatsPool(dev, 2 * _total_channels(model) + 4096)
     tr = 1 if training else 0
@@ -320,6 +320,7 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
            conv=(H, W, 3, H1, H1, 3, 2, 0, NONE, 1 if saved["x"].dtype == torch.uint8 else 0))
     L.check(lib.mt_conv_weight_unpack_grad(L.ptr(dwp1), L.ptr(grads[0]), 32, 3, 3, 28, L.stream_ptr()), "mt_conv_weight_unpack_grad")
     side.wait()
+    L.grads_ready(model, P, flat_grads)
     return [g_ if need else None for need, g_ in zip(need_dparams, grads)]
 
 

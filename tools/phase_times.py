@@ -7,6 +7,10 @@ import torch
 import mintime_amd
 from mintime_amd import harness
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+if os.environ.get("PHASE_INIT_RCCL"):          # what does merely creating a 1-rank RCCL communicator cost the step?
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29588")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
 cfg, ef, tsf = harness.build_models(8, 0, "cuda")
 opt = harness.make_optimizer(cfg, ef, tsf)
 batch = harness.device_batch(B, 8, 2, 0, "cuda")
