@@ -224,3 +224,78 @@ def test_overlapped_bucketed_allreduce_world_size_2_gloo():
         x = torch.full((2, 4), float(rank + 1 + 2))
         want = want + float(lin(x).sum().detach()) / 2
     assert torch.allclose(r0[2][1], torch.full((5, 3), want), rtol=1e-5)
+
+
+class _EngineLike(torch.nn.Module):
+    """Stands in for an engine-backed network on the CPU: its backward builds every gradient as a view of one flat buffer with
+    lib.zero_grads and announces it with lib.grads_ready, exactly like tsf_backward / effnet_backward do on the GPU."""
+
+    def __init__(self, shapes, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes])
+
+    def forward(self, x):
+        model = self
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, *params):
+                ctx.save_for_backward(x)
+                return x * sum(p.sum() for p in params)
+
+            @staticmethod
+            def backward(ctx, gout):
+                (x,) = ctx.saved_tensors
+                params = list(model.ps)
+                grads, flat = lib.zero_grads(params, with_flat=True)
+                for gr in grads:
+                    gr += float((gout * x).sum())
+                lib.grads_ready(model, params, flat)
+                return (gout * sum(p.sum() for p in params).detach(),) + tuple(grads)
+
+        return Fn.apply(x, *self.ps)
+
+
+def _engine_hook_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    second, first = _EngineLike([(3, 5), (7,), (2, 2, 2)], 1), _EngineLike([(4,), (6, 2)], 2)     # "tsf" consumes "ef"'s output
+    red = ddp.OverlappedGradReducer([second, first])                # order in which backward finishes them
+    res = []
+    for step in range(3):
+        for p in list(first.parameters()) + list(second.parameters()):
+            p.grad = None
+        x = torch.full((3,), float(rank + 1 + step))
+        second(first(x)).sum().backward()
+        n = red.allreduce()
+        res.append((n, [p.grad.clone() for p in second.parameters()], [p.grad.clone() for p in first.parameters()]))
+    # a step that starts from existing gradients must not be reduced under autograd's feet: it falls back to the synchronous path
+    x = torch.full((3,), float(rank + 7))
+    second(first(x)).sum().backward()
+    red.allreduce()
+    out[rank] = (res, dict(red.stats), [p.grad.clone() for p in second.parameters()])
+    dist.destroy_process_group()
+
+
+def test_engine_level_bucket_hooks_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_engine_hook_worker, args=(2, port, out), nprocs=2, join=True)
+    (r0, s0, acc0), (r1, s1, acc1) = out[0], out[1]
+    assert s0 == s1
+    assert s0["overlapped_launches"] == 6 and s0["synchronous"] == 2, s0      # 3 clean steps x 2 buckets early; the 4th step late
+    for step in range(3):
+        assert r0[step][0] == r1[step][0] > 0
+        for a, b in zip(r0[step][1] + r0[step][2], r1[step][1] + r1[step][2]):
+            assert torch.equal(a, b)                                           # same averaged gradient on both ranks
+    # value check: gradient of every element of `second`'s parameters is sum(first(x)) on each rank; the average of ranks 0 and 1
+    first = _EngineLike([(4,), (6, 2)], 2)
+    want = sum(float(first(torch.full((3,), float(rank + 1 + 2))).sum().detach()) for rank in (0, 1)) / 2
+    assert torch.allclose(r0[2][1][0], torch.full((3, 5), want), rtol=1e-5)
+    for a, b in zip(acc0, acc1):
+        assert torch.equal(a, b)
