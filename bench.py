@@ -201,6 +201,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    out = None
     if rank == 0:
         ms = 1e3 * dt / a.steps
         clips_s = world * B * a.steps / dt
@@ -230,9 +231,15 @@ def main():
             out["attention_modules"] = attention_modules_leg(dev, B, a.frames)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(a.frames)
-        print(json.dumps(out))
+    line = json.dumps(out) if rank == 0 else None
     if world > 1 or a.force_reducer:
+        dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)   # RCCL's version banner sits in C stdio's buffer and would otherwise land after the line
+        sys.stdout.flush()
+        print(line, flush=True)          # the last thing on stdout
 
 
 if __name__ == "__main__":
