@@ -1,5 +1,7 @@
 """Launch sequences (forward, backward) of EfficientNet-B0 on libmintime_hip.  Plumbing only: device buffers via
 torch, raw pointers + current stream into the C ABI, one torch.autograd.Function for the whole extractor."""
+import threading
+
 import torch
 
 from . import arch
@@ -53,16 +55,25 @@ def _finalize(lib, st, bn_mod, ctx, count, training, gamma, beta):
                                L.ptr(bn_mod.running_var), L.ptr(ctx.scale), L.ptr(ctx.shift), L.ptr(ctx.mean_invstd), ctx.C,
                                bn_mod.eps, bn_mod.momentum, 1 if training else 0, st), "mt_bn_finalize")
     if training:
-        _TRACKED.append(bn_mod.num_batches_tracked)
+        _track(bn_mod.num_batches_tracked)
 
 
-_TRACKED = []   # num_batches_tracked counters touched by the running forward: bumped by ONE multi-tensor add at its end
+# num_batches_tracked counters touched by the running forward: bumped by ONE multi-tensor add at its end.  Per thread: forwards of
+# different replicas may run concurrently from different Python threads (the reference's nn.DataParallel does that).
+_TLS = threading.local()
+
+
+def _track(counter):
+    if not hasattr(_TLS, "tracked"):
+        _TLS.tracked = []
+    _TLS.tracked.append(counter)
 
 
 def _bump_tracked():
-    if _TRACKED:
-        torch._foreach_add_(_TRACKED, 1)
-        _TRACKED.clear()
+    tracked = getattr(_TLS, "tracked", None)
+    if tracked:
+        torch._foreach_add_(tracked, 1)
+        tracked.clear()
 
 
 def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):

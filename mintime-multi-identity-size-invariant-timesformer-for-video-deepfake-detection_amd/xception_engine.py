@@ -8,7 +8,7 @@ import torch
 
 from . import arch
 from . import lib as L
-from .effnet_engine import SLOTS, _StatsPool, _BNCtx, _TRACKED, _bump_tracked
+from .effnet_engine import SLOTS, _StatsPool, _BNCtx, _track, _bump_tracked
 
 RELU, NONE = 2, 0
 
@@ -70,7 +70,7 @@ def _finalize(lib, bn_mod, ctx, count, training, gamma, beta):
                                L.ptr(bn_mod.running_var), L.ptr(ctx.scale), L.ptr(ctx.shift), L.ptr(ctx.mean_invstd), ctx.C,
                                bn_mod.eps, bn_mod.momentum, 1 if training else 0, L.stream_ptr()), "mt_bn_finalize")
     if training:
-        _TRACKED.append(bn_mod.num_batches_tracked)
+        _track(bn_mod.num_batches_tracked)
 
 
 def xception_forward(model, x, params, training, save):
