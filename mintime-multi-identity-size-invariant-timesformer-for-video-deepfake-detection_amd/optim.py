@@ -26,15 +26,17 @@ class FusedSGD(torch.optim.Optimizer):
         key = (gi,) + tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
         hit = self._tables.get(key)
         if hit is not None:
-            return hit
+            return hit[0], hit[1]
         rows, block = [], 0
         for p in ps:
             rows.append((p.data_ptr(), p.grad.data_ptr(), p.numel(), block))
             block += (p.numel() + _CHUNK - 1) // _CHUNK
-        table = torch.tensor(rows, dtype=torch.int64).pin_memory().to(ps[0].device, non_blocking=True)
+        host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+        table = host.to(ps[0].device, non_blocking=True)
         if len(self._tables) >= 8:
             self._tables.pop(next(iter(self._tables)))
-        self._tables[key] = (table, block)
+        # the pinned source stays alive with the entry: under HIP-graph capture the upload is a memcpy node that re-reads it at replay
+        self._tables[key] = (table, block, host)
         self.table_uploads += 1
         return table, block
 
