@@ -179,6 +179,16 @@ def main():
     def step():
         return harness.train_step(ef, tsf, opt, batch, reducer)
 
+    if reducer is not None:
+        try:                                 # never lose a scaling run to the overlapped path: fall back to the plain flat all-reduce
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:               # noqa: BLE001
+            print(f"[bench] overlapped gradient reducer failed ({type(e).__name__}: {e}); using the plain flat all-reduce",
+                  file=sys.stderr)
+            ef._grads_ready_hook = tsf._grads_ready_hook = None
+            opt.zero_grad(set_to_none=True)
+            reducer = ddp.GradAllReducer(list(ef.parameters()) + list(tsf.parameters()))
     for _ in range(a.warmup):
         step()
     # live timing of the dominant kernel: FF1 GEMM + GEGLU epilogue (9 launches per step), HIP events on its stream
