@@ -208,6 +208,17 @@ int mt_conv1x1_wgrad_supported(int Cout, int Cin);
 int mt_conv1x1_wgrad(const float* du, const float* z, const float* kabc, const float* x, const float* sc, const float* sh,
                      const float* gate, int hw, float* dw, int64_t rows, int Cout, int Cin, void* stream);
 
+/* 1x1 convolution with few channels and very many rows as a streaming kernel (MBConv expand / project convs of stages 1-4 and
+ * their data gradients, efficientnet_pytorch/model.py:93-118): out[rows,Cout] = a[rows,Cin] . W^T (+ res), with
+ *   amode 0: a = x;   1: a = swish(c0*x + c1) * c2[row / hw]  (c2 = SE gate [rows/hw, Cin]);   2: a = c0*x + c1*x2 + c2 (BatchNorm backward).
+ * w is [Cout, ldw] (w_transposed = 0) or the forward weight [Cin, ldw] used transposed (w_transposed = 1, data gradient).
+ * stats (optional) receives the BatchNorm sums of `out` like MT_EPI_STATS.  mt_conv1x1_rows_supported tells whether this kernel is
+ * the measured better choice for a channel pair and mode (otherwise use mt_gemm). */
+int mt_conv1x1_rows_supported(int Cin, int Cout, int amode);
+int mt_conv1x1_rows(const float* x, const float* x2, const float* w, int ldw, int w_transposed, const float* c0, const float* c1,
+                    const float* c2, int hw, int amode, const float* res, float* out, double* stats, int slots, int64_t rows,
+                    int Cin, int Cout, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training-step ends (next-row f4).
  * mt_bce_logits: torch.nn.BCEWithLogitsLoss(pos_weight)(logits, labels) with mean reduction (train.py:261,367-368) and its

@@ -3,7 +3,7 @@ import torch
 
 from . import arch
 from . import lib as L
-from .effnet_engine import SLOTS, _StatsPool
+from .effnet_engine import SLOTS, STREAM_ROWS, _StatsPool
 
 
 def _new(dev, *shape):
@@ -74,6 +74,11 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         if not need_dx_in:
             return None
         dx_in = _new(dev, rows, cin)
+        if rows >= STREAM_ROWS and lib.mt_conv1x1_rows_supported(cout, cin, 2):
+            # data gradient as a streaming kernel: a = dz (BatchNorm backward folded on load), W used transposed
+            L.check(lib.mt_conv1x1_rows(L.ptr(du), L.ptr(z), L.ptr(w), cin, 1, L.ptr(kabc[0]), L.ptr(kabc[1]), L.ptr(kabc[2]), 1, 2,
+                                        L.ptr(res), L.ptr(dx_in), None, 1, rows, cout, cin, st), "mt_conv1x1_rows")
+            return dx_in
         if res is not None:
             L.gemm(L.OP_NN, du, w, dx_in, rows, cin, cout, cout, cin, cin, prologue=L.PRO_BN_BWD, epilogue=L.EPI_BIAS_RES, A2=z,
                    scale=kabc[0], shift=kabc[1], gate=kabc[2], R=res, ldr=cin)

@@ -8,6 +8,7 @@ from . import arch
 from . import lib as L
 
 SLOTS = 32   # replicated fp64 BatchNorm accumulators (spreads atomic traffic)
+STREAM_ROWS = int(__import__("os").environ.get("MT_STREAM_ROWS", "100000"))   # 1x1 convs with at least this many rows use the streaming kernels
 
 
 def _new(dev, *shape):
@@ -118,7 +119,11 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
             w_e, g, b = next(it), next(it), next(it)
             bn_e = _BNCtx(dev, s.cexp, training, pool)
             z_e = _new(dev, M_in, s.cexp)
-            L.gemm(L.OP_NT, y, w_e, z_e, M_in, s.cexp, s.cin, s.cin, s.cin, s.cexp, epilogue=epi, stats=bn_e.stats, stats_slots=SLOTS)
+            if M_in >= STREAM_ROWS and lib.mt_conv1x1_rows_supported(s.cin, s.cexp, 0):   # few channels, very many rows: streaming kernel
+                L.check(lib.mt_conv1x1_rows(L.ptr(y), None, L.ptr(w_e), s.cin, 0, None, None, None, 1, 0, None, L.ptr(z_e),
+                                            L.ptr(bn_e.stats), SLOTS, M_in, s.cin, s.cexp, st), "mt_conv1x1_rows")
+            else:
+                L.gemm(L.OP_NT, y, w_e, z_e, M_in, s.cexp, s.cin, s.cin, s.cin, s.cexp, epilogue=epi, stats=bn_e.stats, stats_slots=SLOTS)
             _finalize(lib, st, blk._bn0, bn_e, M_in, training, g, b)
             rec.update(z_e=z_e, bn_e=bn_e)
             dw_in, dw_bn = z_e, bn_e
@@ -143,8 +148,12 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
         w_p, g, b = next(it), next(it), next(it)
         bn_p = _BNCtx(dev, s.cout, training, pool)
         z_p = _new(dev, M_out, s.cout)
-        L.gemm(L.OP_NT, z_d, w_p, z_p, M_out, s.cout, s.cexp, s.cexp, s.cexp, s.cout, prologue=L.PRO_BN_SWISH_GATE, epilogue=epi,
-               scale=bn_d.scale, shift=bn_d.shift, gate=gate, hw=hw, stats=bn_p.stats, stats_slots=SLOTS)
+        if M_out >= STREAM_ROWS and lib.mt_conv1x1_rows_supported(s.cexp, s.cout, 1):
+            L.check(lib.mt_conv1x1_rows(L.ptr(z_d), None, L.ptr(w_p), s.cexp, 0, L.ptr(bn_d.scale), L.ptr(bn_d.shift), L.ptr(gate), hw, 1,
+                                        None, L.ptr(z_p), L.ptr(bn_p.stats), SLOTS, M_out, s.cexp, s.cout, st), "mt_conv1x1_rows")
+        else:
+            L.gemm(L.OP_NT, z_d, w_p, z_p, M_out, s.cout, s.cexp, s.cexp, s.cexp, s.cout, prologue=L.PRO_BN_SWISH_GATE, epilogue=epi,
+                   scale=bn_d.scale, shift=bn_d.shift, gate=gate, hw=hw, stats=bn_p.stats, stats_slots=SLOTS)
         _finalize(lib, st, blk._bn2, bn_p, M_out, training, g, b)
         # block output: bn2(z_p) [* drop-connect gate] [+ block input]
         dc = None

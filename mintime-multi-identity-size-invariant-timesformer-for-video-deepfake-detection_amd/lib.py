@@ -81,6 +81,9 @@ PROTOTYPES = {
     "mt_maxpool_add_fwd": [f32p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_maxpool_bwd": [f32p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_bn_bwd_apply": [f32p, f32p, f32p, f32p, i64, C.c_int, C.c_void_p],
+    "mt_conv1x1_rows_supported": [C.c_int, C.c_int, C.c_int],
+    "mt_conv1x1_rows": [f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p, C.c_void_p, C.c_int, C.c_int64,
+                        C.c_int, C.c_int, C.c_void_p],
     "mt_bce_logits": [f32p, f32p, C.c_float, f32p, f32p, C.c_int, C.c_void_p],
     "mt_sgd_multi": [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_void_p],
     "mt_conv1x1_wgrad_supported": [C.c_int, C.c_int],

@@ -134,3 +134,40 @@ def test_skinny_conv1x1_wgrad_kernel(cout, cin, rows, gated):
         a = torch.nn.functional.silu(sc.double() * a + sh.double()) * gate.double().repeat_interleave(hw, 0)[:rows]
     want = dz.t() @ a + 0.5
     assert_close(dw, want.float(), 1e-4, f"dW {cout}x{cin}")
+
+
+@pytest.mark.parametrize("cin,cout,rows,mode", [(16, 96, 100003, 0), (32, 16, 70001, 1), (96, 24, 50000, 1), (24, 144, 10007, 0),
+                                                (96, 16, 40001, 2), (16, 32, 30000, 2), (24, 96, 30001, 2), (24, 144, 20000, 2)])
+def test_streaming_conv1x1_kernel(cin, cout, rows, mode):
+    """mt_conv1x1_rows (forward / data gradient of many-row 1x1 convs as a streaming kernel) against fp64 torch: every operand
+    transform, the residual input, the transposed-weight form and the BatchNorm statistics of the output."""
+    from mintime_amd import lib as L
+    lib = L.get()
+    g = torch.Generator(device="cuda").manual_seed(cin * 1000 + cout + mode)
+    hw = 49
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    x, x2 = r(rows, cin), r(rows, cin)
+    c0, c1 = r(cin), r(cin)
+    n_img = (rows + hw - 1) // hw
+    c2 = torch.rand(n_img, cin, device="cuda", generator=g) if mode == 1 else r(cin)
+    transposed = mode == 2
+    w = r(cin, cout) if transposed else r(cout, cin)            # data gradient: the forward weight [k, out] is used transposed
+    res = r(rows, cout) if mode == 2 else None
+    out = torch.empty(rows, cout, device="cuda")
+    stats = torch.zeros(32, 2, cout, dtype=torch.float64, device="cuda") if mode != 2 else None
+    L.check(lib.mt_conv1x1_rows(L.ptr(x), L.ptr(x2) if mode == 2 else None, L.ptr(w), w.shape[1], 1 if transposed else 0,
+                                L.ptr(c0) if mode else None, L.ptr(c1) if mode else None, L.ptr(c2) if mode else None, hw, mode,
+                                L.ptr(res), L.ptr(out), L.ptr(stats), 32, rows, cin, cout, L.stream_ptr()), "mt_conv1x1_rows")
+    a = x.double()
+    if mode == 1:
+        a = torch.nn.functional.silu(c0.double() * a + c1.double()) * c2.double().repeat_interleave(hw, 0)[:rows]
+    elif mode == 2:
+        a = c0.double() * a + c1.double() * x2.double() + c2.double()
+    want = a @ (w.double() if transposed else w.double().t())
+    if res is not None:
+        want = want + res.double()
+    assert_close(out, want.float(), 1e-5, f"out {cin}->{cout} mode {mode}")
+    if stats is not None:
+        s = stats.sum(0)
+        assert_close(s[0].float(), want.sum(0).float(), 1e-4, "column sums")
+        assert_close(s[1].float(), (want * want).sum(0).float(), 1e-4, "column sums of squares")
