@@ -721,7 +721,7 @@ extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, co
                      dpooled, C, CS);
   rc = check_launch("mt_se_bwd(image)");
   if (rc) return rc;
-  const int ipb = 8;
+  const int ipb = 16;      // images per block: 8 / 16 / 32 / 64 measured 56 / 43 / 51 / 86 us (atomics vs parallelism)
   hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 127) / 128, (N + ipb - 1) / ipb), dim3(128), 0, s, dpre2, dhid, hidden, pooled, dw1,
                      db1, dw2, db2, N, C, CS, ipb);
   return check_launch("mt_se_bwd(wgrad)");
