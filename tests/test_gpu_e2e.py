@@ -245,3 +245,53 @@ def test_native_bce_and_fused_sgd_match_torch():
         o_ref.step(); o_gpu.step(); sched.step(); sched_ref.step()
     for pr, pg in zip(ps_ref, ps_gpu):
         assert_close(pg.detach(), pr.detach(), 1e-6, "parameters after 3 SGD steps")
+
+
+_DP2_SCRIPT = r"""
+import os, sys, json, torch, torch.distributed as dist
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+sys.path.insert(0, os.getcwd())
+rank = int(sys.argv[1]); port = sys.argv[2]
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = port
+import mintime_amd
+from mintime_amd import harness, ddp
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=2)           # two ranks share the one GPU of the test box; gloo moves CUDA tensors
+cfg, ef, tsf = harness.build_models(seed=3, device="cuda", drop_connect_rate=0.0)
+opt = harness.make_optimizer(cfg, ef, tsf)
+red = ddp.OverlappedGradReducer([tsf, ef])
+lo, hi = ddp.shard_range(4, rank, 2)                                # global batch of 4 clips, 2 per rank
+for step in range(2):
+    full = harness.device_batch(4, seed=10 + step)
+    mine = {k: (v[lo:hi] if torch.is_tensor(v) else v) for k, v in full.items()}
+    loss = harness.train_step(ef, tsf, opt, mine, red)
+torch.cuda.synchronize()
+sig = [float(p.detach().double().norm()) for p in list(tsf.parameters())[:8] + list(ef.parameters())[:8]]
+gsig = [float(p.grad.detach().double().norm()) for p in list(tsf.parameters())[:8] + list(ef.parameters())[:8] if p.grad is not None]
+print("RESULT " + json.dumps({"rank": rank, "params": sig, "grads": gsig, "stats": dict(red.stats)}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_data_parallel_step_keeps_replicas_identical(tmp_path):
+    """Row (e) end to end with the real engines: two processes (sharing this box's single GPU, gloo transport) each train on their
+    shard of a 4-clip batch; the engine-level bucket hooks must fire on both, and after two steps parameters and (averaged) gradients
+    must agree between the ranks."""
+    import json, subprocess, sys, os
+    script = tmp_path / "dp2.py"
+    script.write_text(_DP2_SCRIPT)
+    port = str(24500 + os.getpid() % 1000)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              cwd=root) for r in (0, 1)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    res = [json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]) for so, _ in outs]
+    for r in res:
+        assert r["stats"]["overlapped_launches"] == 4 and r["stats"]["synchronous"] == 0, r["stats"]
+    for a, b in zip(res[0]["params"], res[1]["params"]):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (a, b)
+    for a, b in zip(res[0]["grads"], res[1]["grads"]):
+        assert abs(a - b) <= 1e-6 * max(1e-3, abs(a)), (a, b)
