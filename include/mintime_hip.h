@@ -55,7 +55,8 @@ typedef struct {
   const float* bias;
   const float* R; int64_t ldr;      /* residual (BIAS_RES)                                               */
   const float* scale; const float* shift; const float* gate; int hw;   /* prologue vectors               */
-  float* C2; int64_t ldc2;          /* GEGLU: optional pre-activation store; GEGLU_BWD: pre-activations  */
+  float* C2; int64_t ldc2;          /* GEGLU: optional pre-activation store, row = (a_0,g_0,a_1,g_1,...) -- private
+                                       to the GEGLU / GEGLU_BWD pair; GEGLU_BWD: those pre-activations (ldc2 even)        */
   double* stats; int stats_slots;   /* STATS: [slots][2][N] fp64 accumulators (sum, sum of squares)      */
   int n_half;
   int split_k;                      /* TN: number of K splits; <= 0 picks one that fills the chip        */

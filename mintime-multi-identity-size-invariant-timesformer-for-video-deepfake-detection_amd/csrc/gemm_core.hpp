@@ -53,7 +53,7 @@ enum : int { BPRO_NONE = 0, BPRO_BN_SWISH_GATE = 1, BPRO_IM2COL = 2 };   // BPRO
 enum : int {
   EPI_STORE = 0,        // C = acc (+bias[n])
   EPI_BIAS_RES = 1,     // C = acc + bias[n] + R[m,n]
-  EPI_GEGLU = 2,        // h[m,j] = (acc_a+ba[j]) * gelu(acc_g+bg[j]);  optional u store (pre-activations)
+  EPI_GEGLU = 2,        // h[m,j] = (acc_a+ba[j]) * gelu(acc_g+bg[j]);  optional u store (pre-activations, interleaved a_j,g_j)
   EPI_STATS = 3,        // C = acc ; per-column sum / sum-of-squares accumulated in fp64 (BatchNorm batch statistics)
   EPI_ATOMIC = 4,       // C += acc (+bias on the first K-slice) via fp32 atomics (split-K); C pre-zeroed or holding the residual
   EPI_GEGLU_BWD = 5,    // acc = dh[m,j]; du[m,j] = dh*gelu(g), du[m,Nh+j] = dh*a*gelu'(g)   (a,g from u)
@@ -471,8 +471,8 @@ void gemm_kernel(const GemmArgs p) {
           const float g = acc[i][1][r] + bg;
           p.C[(int64_t)m * p.ldc + j] = a * gelu_erf(g);
           if (p.C2) {
-            p.C2[(int64_t)m * p.ldc2 + j] = a;
-            p.C2[(int64_t)m * p.ldc2 + p.n_half + j] = g;
+            // pre-activations interleaved (a_j, g_j): one 8-byte store per lane here, one 8-byte load in GEGLU_BWD
+            *reinterpret_cast<float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * j) = make_float2(a, g);
           }
         }
       }
@@ -511,8 +511,8 @@ void gemm_kernel(const GemmArgs p) {
               atomicAdd(p.C + crow * p.ldc + n, v + bias);
             } else if constexpr (EPI == EPI_GEGLU_BWD) {
               // n indexes h columns [0, n_half); u = [a | g] pre-activations
-              const float a = p.C2[(int64_t)m * p.ldc2 + n];
-              const float g = p.C2[(int64_t)m * p.ldc2 + p.n_half + n];
+              const float2 ag = *reinterpret_cast<const float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * n);
+              const float a = ag.x, g = ag.y;
               p.C[crow * p.ldc + n] = v * gelu_erf(g);
               p.C[crow * p.ldc + p.n_half + n] = v * a * gelu_erf_grad(g);
             }

@@ -53,7 +53,7 @@ def test_nt_geglu(M):
            n_half=4 * D)
     uref = A.double() @ W.double().T + b.double()
     a, g = uref.chunk(2, dim=-1)
-    assert_close(u, uref, TOL, "GEGLU pre-activations")
+    assert_close(u, torch.stack((a, g), dim=-1).reshape(M, 8 * D), TOL, "GEGLU pre-activations (stored interleaved a_j, g_j)")
     assert_close(h, a * torch.nn.functional.gelu(g), TOL, "GEGLU output")
 
 
@@ -93,7 +93,8 @@ def test_nn_geglu_bwd():
     dy, W2 = _rand(M, D, seed=1), _rand(D, 4 * D, seed=2, scale=0.05)
     u = _rand(M, 8 * D, seed=3)
     du = torch.empty(M, 8 * D, device="cuda")
-    L.gemm(L.OP_NN, dy.cuda(), W2.cuda(), du, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=u.cuda(), ldc2=8 * D,
+    u_il = torch.stack(u.chunk(2, dim=-1), dim=-1).reshape(M, 8 * D).contiguous()      # the layout EPI_GEGLU stores: (a_j, g_j) pairs
+    L.gemm(L.OP_NN, dy.cuda(), W2.cuda(), du, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=u_il.cuda(), ldc2=8 * D,
            n_half=4 * D)
     ud = u.double().requires_grad_(True)
     a, g = ud.chunk(2, dim=-1)
