@@ -138,6 +138,20 @@ int mt_bn_act_fwd(const float* z, const float* scale, const float* shift, const 
 int mt_attn_aggregate(const float* space_att, const float* time_att, float* out, int BH, int N, int F,
                       float scale_factor, void* stream);
 
+/* Input-sequence builder (next-row f1): the side inputs of SizeInvariantTimeSformer.forward for a batch of clips, built in HBM
+ * from the compact description a loader produces.  Replaces the list-building code of deepfakes_dataset.py:259-287 (size
+ * buckets via SIZE_EMB_DICT :30-31, padded slots), :315-321 (identities_mask), :324-329 (temporal positions) and
+ * predict.py:285-309,335-347.  Inputs (device, int32): slots[B][max_identities] = slots per identity in slot order (0 = unused),
+ * valid[B][max_identities] = faces actually present (<= slots; the rest of the identity's slots are padding), frames[B][F] =
+ * video-frame number per slot (ignored at padded slots: they take the largest frame number seen so far, :271-275),
+ * ratio[B][F] = int(face_area*100/video_area) per slot (0..100).  Outputs: mask [B][F] u8, identities_mask [B][F][F] u8,
+ * size_embedding [B][F] int32 (bucket 1..20, 0 = padding), positions [B][1+F*num_patches] int64.
+ * mask_mode 0 = the dataset's behaviour (mask all ones: its padding test at :281 runs after the list was already extended),
+ * mask_mode 1 = predict.py:304 (padded slots masked out). */
+int mt_build_clip_inputs(const int* slots, const int* valid, const int* frames, const int* ratio, unsigned char* mask,
+                         unsigned char* identities_mask, int* size_embedding, int64_t* positions, int B, int F,
+                         int num_patches, int max_identities, int mask_mode, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Size-Invariant TimeSformer backward, non-GEMM pieces.  The reference derives these through torch autograd
  * from the same source lines as the forward entry points; here they are explicit adjoint kernels.

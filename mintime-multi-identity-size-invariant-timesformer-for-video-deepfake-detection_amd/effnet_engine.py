@@ -109,7 +109,23 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
     y = None                     # materialised block output (narrow tensor)
     ys = [] if want_blocks else None
 
-    # per-sample drop-connect gates (utils.py:129-154), train mode only
+    # per-sample drop-connect gates (utils.py:129-154), train mode only: floor(keep + U[0,1)) / keep, keep = 1 - rate*idx/16
+    # (model.py:280-282).  ONE draw for all gated blocks (rows in block order); `model.drop_connect_uniform`, when set, supplies
+    # the uniforms instead of torch.rand (callable (n_rows, N, device) -> [n_rows, N]; parity tests feed the oracle's draws).
+    dc_gates = {}
+    if training and model.drop_connect_rate > 0:
+        gated = [bi for bi, blk in enumerate(blocks) if blk.spec.skip and model.drop_connect_rate * float(bi) / len(blocks) > 0]
+        if gated:
+            sampler = getattr(model, "drop_connect_uniform", None)
+            u = sampler(len(gated), N, dev) if sampler is not None else torch.rand(len(gated), N, device=dev, dtype=torch.float32)
+            cache = model.__dict__.setdefault("_dc_keep_cache", {})
+            key = (str(dev), model.drop_connect_rate)
+            if key not in cache:    # uploaded once, not per step
+                cache[key] = torch.tensor([1.0 - model.drop_connect_rate * float(bi) / len(blocks) for bi in gated],
+                                          dtype=torch.float32, device=dev).unsqueeze(1)
+            keep = cache[key]
+            gates = torch.floor(keep + u.to(device=dev, dtype=torch.float32)) / keep
+            dc_gates = {bi: gates[j] for j, bi in enumerate(gated)}
     for bi, blk in enumerate(blocks):
         s = blk.spec
         M_in = N * s.hin * s.hin
@@ -156,12 +172,7 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
                    scale=bn_d.scale, shift=bn_d.shift, gate=gate, hw=hw, stats=bn_p.stats, stats_slots=SLOTS)
         _finalize(lib, st, blk._bn2, bn_p, M_out, training, g, b)
         # block output: bn2(z_p) [* drop-connect gate] [+ block input]
-        dc = None
-        if s.skip and training and model.drop_connect_rate > 0:
-            rate = model.drop_connect_rate * float(bi) / len(blocks)          # model.py:280-282
-            if rate > 0:
-                keep = 1.0 - rate
-                dc = torch.floor(keep + torch.rand(N, device=dev, dtype=torch.float32)) / keep   # utils.py:148-153
+        dc = dc_gates.get(bi)
         y_new = _new(dev, M_out, s.cout)
         L.check(lib.mt_bn_act_fwd(L.ptr(z_p), L.ptr(bn_p.scale), L.ptr(bn_p.shift), L.ptr(y if s.skip else None), L.ptr(y_new),
                                   M_out, s.cout, 0, L.ptr(dc), hw, st), "mt_bn_act_fwd")

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "mt_se_gate_fwd": [f32p, C.c_int, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_bn_act_fwd": [f32p, f32p, f32p, f32p, f32p, i64, C.c_int, C.c_int, f32p, C.c_int, C.c_void_p],
     "mt_attn_aggregate": [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
+    "mt_build_clip_inputs": [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_void_p],
     "mt_layernorm_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_colsum": [f32p, i64, RowMap, C.c_int, C.c_int, f32p, C.c_void_p],
     "mt_head_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,

@@ -82,15 +82,29 @@ def _bn(x, sd, prefix, training, bn_state: Optional[BNState]):
     return y
 
 
+def drop_connect_uniforms(seed: int, n_img: int, drop_connect_rate: float = _DROP_CONNECT):
+    """The U[0,1) draws the reference's drop_connect makes in one train-mode forward after torch.manual_seed(seed):
+    one torch.rand([N,1,1,1], fp32) per block that has a skip connection and a non-zero rate, in block order
+    (model.py:280-282 scales the rate by idx/16; `if drop_connect_rate:` skips the call when it is 0; utils.py:148-150)."""
+    torch.manual_seed(seed)
+    out = {}
+    for i, b in enumerate(_b0_blocks()):
+        if b["skip"] and b["cin"] == b["cout"] and drop_connect_rate * float(i) / len(_b0_blocks()):
+            out[i] = torch.rand([n_img, 1, 1, 1], dtype=torch.float32)
+    return out
+
+
 def effnet_b0_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool = False,
                       drop_connect_rate: float = 0.0, bn_state: Optional[BNState] = None,
-                      taps: Optional[dict] = None):
+                      taps: Optional[dict] = None, dc_uniform: Optional[dict] = None):
     """x [N,3,224,224] (any strides) -> features [N,1280,7,7].  model.py:267-288.
 
-    training=True uses batch statistics in every BN (train.py:157).  drop_connect_rate must be 0 for
-    parity runs (the reference's per-sample Bernoulli gate, utils.py:129-154, is RNG-dependent).
+    training=True uses batch statistics in every BN (train.py:157).  With drop_connect_rate > 0 (train mode only) the
+    per-sample Bernoulli gate of utils.py:129-154 is applied from the uniform draws in dc_uniform ({block index: [N,1,1,1]},
+    see drop_connect_uniforms) so that a parity run can feed the same draws to both sides.
     """
-    assert drop_connect_rate == 0.0 or not training, "oracle parity is defined for drop_connect_rate=0"
+    assert drop_connect_rate == 0.0 or not training or dc_uniform is not None, \
+        "train-mode drop-connect needs the uniform draws (dc_uniform) to be reproducible"
     x = _swish(_bn(_same_conv(x, sd["_conv_stem.weight"], 2), sd, "_bn0", training, bn_state))  # model.py:276
     if taps is not None:
         taps["stem"] = x
@@ -108,7 +122,12 @@ def effnet_b0_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bo
         x = torch.sigmoid(s) * x
         x = _bn(F.conv2d(x, sd[p + "_project_conv.weight"]), sd, p + "_bn2", training, bn_state)  # :116-117
         if b["skip"] and b["cin"] == b["cout"]:
-            x = x + inp                                                     # model.py:123-127 (drop_connect = id)
+            p_drop = drop_connect_rate * float(i) / len(_b0_blocks())      # model.py:280-282
+            if training and p_drop:                                         # model.py:125-126, utils.py:141-153
+                keep = 1 - p_drop
+                binary = torch.floor(keep + dc_uniform[i].to(x.dtype))
+                x = x / keep * binary
+            x = x + inp                                                     # model.py:127
         if taps is not None:
             taps[f"block{i}"] = x
     x = _swish(_bn(F.conv2d(x, sd["_conv_head.weight"]), sd, "_bn1", training, bn_state))   # model.py:286
@@ -298,11 +317,12 @@ def tsf_forward(sd: Dict[str, torch.Tensor], cfg: dict, x: torch.Tensor, mask: t
 # --------------------------------------------------------------------------------------------
 
 def clip_forward(ef_sd, tsf_sd, cfg, batch, training_extractor=False, require_attention=False,
-                 bn_state=None, taps=None):
+                 bn_state=None, taps=None, drop_connect_rate=0.0, dc_uniform=None):
     v = batch["videos"]
     b, f, h, w, c = v.shape
     vid = v.reshape(b * f, h, w, c).permute(0, 3, 1, 2)                     # train.py:341 (view; NHWC strides)
-    feats = effnet_b0_forward(ef_sd, vid, training=training_extractor, bn_state=bn_state, taps=taps)
+    feats = effnet_b0_forward(ef_sd, vid, training=training_extractor, bn_state=bn_state, taps=taps,
+                              drop_connect_rate=drop_connect_rate, dc_uniform=dc_uniform)
     if taps is not None:
         taps["features"] = feats
     feats = feats.reshape(b, f, *feats.shape[1:])                           # train.py:354
@@ -342,3 +362,136 @@ def aggregate_attentions(attentions, heads, num_frames, frames_per_identity, sca
         else:
             ident.append(sum(out[-1][frames_per_identity[index - 1] - 1:frames - 1]))
     return out, ident
+
+
+# --------------------------------------------------------------------------------------------
+# Input-sequence builder (next-row f1): deepfakes_dataset.py:130-186, 216-339; predict.py:183-352
+# --------------------------------------------------------------------------------------------
+# PARITY PIN (partial): slot assignment (sort + assign_slots) is pinned against the reference's
+# DeepFakesDataset.get_sorted_identities run on throw-away directory trees (tests/golden/slots.json, made by
+# tools/make_golden.py).  The per-clip tensor construction (build_clip_tensors) is PARITY UNPINNED: __getitem__ /
+# generate_masks call cv2.imread / cv2.VideoCapture / albumentations, which are not installed here and may not be faked, so
+# it is restated from the source lines cited below and tested against hand-derived cases only.
+
+_RANGE_SIZE = 5
+SIZE_EMB_DICT = [(1 + i * _RANGE_SIZE, (i + 1) * _RANGE_SIZE) if i != 0 else (0, _RANGE_SIZE) for i in range(20)]   # :30-31
+
+
+def max_faces_per_identity(num_frames, identities_number):
+    """deepfakes_dataset.py:50-53 / predict.py:207-210."""
+    table = {1: [num_frames],
+             2: [int(num_frames / 2), int(num_frames / 2)],
+             3: [int(num_frames / 3), int(num_frames / 3), int(num_frames / 4)],
+             4: [int(num_frames / 3), int(num_frames / 3), int(num_frames / 8), int(num_frames / 8)]}
+    return table[identities_number]
+
+
+def sort_identities(infos, ordering=0, max_identities=3):
+    """infos: list of (name, mean_side, number_of_faces).  deepfakes_dataset.py:149-158: ordering 0 = by mean face side, 1 = by
+    number of faces, both descending and stable (Python's sort keeps ties in input order); then truncate."""
+    infos = [list(r) for r in infos]
+    if ordering == 0:
+        infos = sorted(infos, key=lambda x: x[1], reverse=True)
+    elif ordering == 1:
+        infos = sorted(infos, key=lambda x: x[2], reverse=True)
+    else:
+        raise ValueError("random identity order (ordering 2) is not reproducible")
+    return infos[:max_identities]
+
+
+def assign_slots(face_counts, num_frames):
+    """Slots per identity from the available face counts of the already sorted/truncated identities
+    (deepfakes_dataset.py:160-186 == predict.py:203-243)."""
+    n = len(face_counts)
+    faces = list(face_counts)
+    extra = []
+    if n > 1:
+        cap = max_faces_per_identity(num_frames, n)
+        for i in range(n):
+            if faces[i] < cap[i] and i < n - 1:
+                faces[i + 1] += cap[i] - faces[i]          # :166 (the next identity's COUNT grows, not its cap)
+                extra.append(0)
+            elif faces[i] > cap[i]:
+                extra.append(faces[i] - cap[i])
+                faces[i] = cap[i]
+            else:
+                extra.append(0)
+    else:
+        faces[0] = num_frames                              # :173-175
+        extra.append(0)
+    total = sum(faces)
+    if total < num_frames:                                  # :178-190
+        for i in range(n):
+            need = num_frames - total
+            if extra[i] > 0:
+                add = min(extra[i], need)
+                faces[i] += add
+                total += add
+                if total == num_frames:
+                    break
+        if total < num_frames:
+            faces[-1] += num_frames - total
+    return faces
+
+
+def select_faces(n_available, max_faces, index=1, variant="dataset"):
+    """Indices of the faces kept when an identity has more faces than slots: uniform, alternating start by sample parity
+    (deepfakes_dataset.py:236-242); predict.py:277-279 always uses the odd-index rule."""
+    import numpy as np
+    if n_available <= max_faces:
+        return list(range(n_available))
+    if variant == "predict" or index % 2:
+        idx = np.round(np.linspace(0, n_available - 2, max_faces)).astype(int)
+    else:
+        idx = np.round(np.linspace(1, n_available - 1, max_faces)).astype(int)
+    return [int(i) for i in idx]
+
+
+def size_bucket(face_h, face_w, video_w, video_h, variant="dataset"):
+    """Face/frame area ratio -> bucket 1..20 (deepfakes_dataset.py:246-263; predict.py:285-296 omits the /2 on the face)."""
+    import numpy as np
+    video_area = video_w * video_h / 2
+    face_area = face_h * face_w / 2 if variant == "dataset" else face_h * face_w
+    ratio = int(face_area * 100 / video_area)
+    hits = [ratio in range(a, b + 1) for (a, b) in SIZE_EMB_DICT]
+    return int(np.where(hits)[0][0] + 1)       # IndexError for ratio > 100, like the reference
+
+
+def build_clip_tensors(identities, num_frames, num_patches=49, video_wh=(1280, 720), variant="dataset",
+                       enable_identity_attention=True):
+    """identities: per identity dict(slots=int, faces=[(frame_number, face_h, face_w), ...]) AFTER select_faces, in slot order.
+    Returns (size_embedding int32 [F], mask bool [F], identities_mask bool [F,F], positions int64 [1+F*49]) -- the non-image
+    members of the tuple at deepfakes_dataset.py:339 / predict.py:352.
+
+    Faithful quirk: in the DATASET the padding test at :281 runs after identity_images was already extended to max_faces
+    (:268-272), so its mask is all ones even for padded slots; predict.py:301-309 builds the intended mask."""
+    mask, sizes, frames = [], [], []
+    for ident in identities:
+        max_faces = ident["slots"]
+        got = ident["faces"][:max_faces]
+        id_sizes = [size_bucket(h, w, video_wh[0], video_wh[1], variant) for (_, h, w) in got]
+        frames.extend(fr for (fr, _, _) in got)
+        if len(got) < max_faces:
+            diff = max_faces - len(got)
+            id_sizes = id_sizes + [0] * diff                                   # :269
+            frames.extend([max(frames) if frames else 0] * diff)               # :271-275 (max over ALL frames so far)
+            if variant == "predict" and enable_identity_attention:
+                mask.extend([1 if i < max_faces - diff else 0 for i in range(max_faces)])     # predict.py:304
+            else:
+                mask.extend([1] * max_faces)                                   # dataset :281-284 (see docstring)
+        else:
+            mask.extend([1] * max_faces)
+        sizes.extend(id_sizes)
+    assert len(mask) == num_frames, (len(mask), num_frames)
+    ident_mask = []
+    start = 0
+    for ident in identities:                                                   # :315-321
+        row = [start <= i < start + ident["slots"] for i in range(num_frames)]
+        ident_mask.extend([row] * ident["slots"])
+        start += ident["slots"]
+    rank = {k: v + 1 for v, k in enumerate(sorted(set(frames)))}              # :324
+    positions = [0]                                                            # :329 cls
+    for fr in frames:
+        p = rank[fr]
+        positions.extend(range((p - 1) * num_patches + 1, p * num_patches + 1))   # :327
+    return (torch.tensor(sizes).int(), torch.tensor(mask).bool(), torch.tensor(ident_mask).bool(), torch.tensor(positions))

@@ -97,6 +97,61 @@ def test_effnet_backward_all_parameters_vs_oracle(training):
     print("worst relative gradient error", worst)
 
 
+def test_config3_full_size_training_step_vs_oracle():
+    """BASELINE config 3 exactly as bench.py times it: B = 32 clips x 8 slots (256 crops), 2 identities [4,4], train-mode
+    BatchNorm, drop-connect 0.2 (gates fed from the reference's RNG draws), BCE loss, backward.  Logits, loss and sampled
+    gradients of both networks against the CPU oracle run in float64 (train.py:332-378)."""
+    import time
+    B, Fr, seed, rate = 32, 8, 4, 0.2
+    cfg = arch.default_tsf_config(1280, Fr)
+    ef = EfficientNet.from_name("efficientnet-b0", drop_connect_rate=rate)
+    ef_sd = synth.effnet_b0_state(seed)
+    ef.load_state_dict(ef_sd)
+    ef.train(True).cuda()
+    tsf = SizeInvariantTimeSformer(config=cfg, require_attention=False)
+    tsf_sd = synth.tsf_state(cfg, seed)
+    tsf.load_state_dict(tsf_sd)
+    tsf.cuda()
+    u = O.drop_connect_uniforms(seed, B * Fr, rate)
+    ef.drop_connect_uniform = lambda rows, N, dev: torch.stack([u[i].reshape(N) for i in sorted(u)]).to(dev)
+    inp = synth.clip_inputs(B, Fr, 2, seed, ragged=False)
+    _, y_pred = _step(ef, tsf, inp, require_attention=False)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(y_pred.cpu(), inp["labels"].reshape(-1, 1))
+    loss.backward()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    eo = {k: (v.double().requires_grad_("running_" not in k) if v.is_floating_point() else v) for k, v in ef_sd.items()}
+    to = {k: v.double().requires_grad_(True) for k, v in tsf_sd.items()}
+    inp64 = dict(inp)
+    inp64["videos"] = inp["videos"].double()
+    yo = O.clip_forward(eo, to, cfg, inp64, training_extractor=True, drop_connect_rate=rate, dc_uniform=u)
+    lo = O.bce_with_logits(yo, inp["labels"])
+    lo.backward()
+    print(f"oracle fp64 config-3 step on the host: {time.time() - t0:.1f} s")
+    assert_close(y_pred, yo, REL_TOL, "logits (config 3, B=32)")
+    assert bool(((y_pred.detach().cpu().double() - yo.detach()).abs() <= 1e-3 * yo.detach().abs() + 1e-5).all())
+    assert_close(loss, lo, REL_TOL, "loss")
+    worst = 0.0
+    for k, p in tsf.named_parameters():
+        ref = to[k].grad
+        if float(ref.abs().max()) == 0.0:
+            assert float(p.grad.abs().max()) == 0.0, k
+        else:
+            worst = max(worst, assert_close(p.grad, ref, 2 * REL_TOL, "tsf grad " + k))
+    for k, p in ef.named_parameters():
+        if k.startswith("_fc"):
+            continue
+        ref = eo[k].grad
+        if k.endswith("_bn2.bias") or k == "_bn1.bias" and False:
+            wn = float(dict(ef.named_parameters())[k.replace(".bias", ".weight")].grad.norm())
+            if float(ref.norm()) < 1e-3 * wn:       # analytically zero (see test_effnet_backward_all_parameters_vs_oracle)
+                assert float(p.grad.norm()) < 1e-3 * wn, k
+                continue
+        worst = max(worst, assert_close(p.grad, ref, 3 * REL_TOL, "ef grad " + k))
+    print("config 3 full size: worst relative gradient error", worst)
+
+
 def test_hip_graph_replay_matches_eager_eval():
     """The whole eval forward captured in a HIP graph: replays bit-identically (the eval forward has no atomics) and on new inputs."""
     from mintime_amd import harness

@@ -94,18 +94,91 @@ def test_direct_stem_kernel_agrees_with_the_im2col_gemm_path():
 
 
 def test_uint8_crops_are_ingested_directly():
-    """Next-row f2: uint8 BGR crops (what the dataset holds before its .float()) give bit-identical features and gradients."""
+    """Next-row f2: uint8 BGR crops (what the dataset holds before its .float(), deepfakes_dataset.py:257,339) go straight into the
+    stem's gather.  Judged against the ORACLE run on x8.float() (features and every parameter gradient), eval and train mode."""
+    x8 = torch.randint(0, 256, (3, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(9))
+    gw = torch.randn(3, 1280, 7, 7, generator=torch.Generator().manual_seed(10)) * 0.1
     for training in (False, True):
-        outs = []
-        for as_u8 in (False, True):
-            model, _ = _model(2, training)
-            x8 = torch.randint(0, 256, (3, 224, 224, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(9))
-            x = (x8 if as_u8 else x8.float()).permute(0, 3, 1, 2).cuda()
-            f = model(x)
-            f.sum().backward()
-            outs.append((f.detach().clone(), model._conv_stem.weight.grad.clone()))
-        assert_close(outs[1][0], outs[0][0], 1e-5, "features (fp32 atomics order only)")
-        assert_close(outs[1][1], outs[0][1], 1e-4, "stem weight gradient (atomics order only)")
+        model, sd = _model(2, training)
+        f = model(x8.permute(0, 3, 1, 2).cuda())
+        (f * gw.cuda()).sum().backward()
+        osd = {k: (v.double().requires_grad_("running_" not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+        fo = O.effnet_b0_forward(osd, x8.double().permute(0, 3, 1, 2), training=training)
+        (fo * gw.double()).sum().backward()
+        assert_close(f, fo, REL_TOL, f"uint8 features vs oracle (training={training})")
+        for k, p in model.named_parameters():
+            if k.startswith("_fc"):
+                continue
+            assert_close(p.grad, osd[k].grad, 3e-3, f"uint8 grad {k} (training={training})")
+
+
+def _dc_model(g):
+    n, seed, rate = int(g["n_img"]), int(g["seed"]), float(g["rate"])
+    model = EfficientNet.from_name("efficientnet-b0", drop_connect_rate=rate)
+    sd = synth.effnet_b0_state(seed)
+    model.load_state_dict(sd, strict=True)
+    model.train(True)
+    u = O.drop_connect_uniforms(seed, n, rate)          # the reference's own draws (torch.manual_seed(seed), block order)
+    model.drop_connect_uniform = lambda rows, N, dev: torch.stack([u[i].reshape(N) for i in sorted(u)]).to(dev)
+    return model.cuda(), sd, u, n, seed, rate
+
+
+def test_drop_connect_matches_reference_fixture():
+    """a5: train mode WITH drop-connect 0.2 (what bench.py runs).  The per-sample gate floor(keep + U)/keep (utils.py:148-153)
+    is fed the reference's own uniform draws; features, gated block outputs and sampled gradients vs the reference fixture,
+    every parameter gradient vs the oracle in fp64."""
+    import numpy as np
+    g = golden("ef_train_dc")
+    model, sd, u, n, seed, rate = _dc_model(g)
+    x = _input(n, seed)
+    gw = torch.from_numpy(np.random.Generator(np.random.Philox(key=[seed, 777])).standard_normal((n, 1280, 7, 7)) * 0.1).float()
+    from mintime_amd import effnet_engine
+    feats, ys = effnet_engine.effnet_apply(model, x.cuda(), want_blocks=True)
+    (feats * gw.cuda()).sum().backward()
+    assert_close(feats, g["features"], REL_TOL, "features vs reference (drop-connect 0.2)")
+    for i in (2, 7, 10, 14):
+        assert_close(ys[i][:, :, :3, :3], g[f"block{i}_slice"], REL_TOL, f"block {i} output")
+    named = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith("gnorm."):
+            key = k[len("gnorm."):]
+            assert_close(named[key].grad.norm(), g[k], 3e-3, k)
+            assert_close(named[key].grad.reshape(-1)[:256], g["gslice." + key], 3e-3, "gslice." + key)
+    # a dropped sample's block output is exactly its block input (the gate is exactly 0)
+    keep14 = 1 - rate * 14 / 16
+    dropped = (torch.floor(keep14 + u[14].reshape(-1)) == 0).nonzero().reshape(-1).tolist()
+    for smp in dropped:
+        assert torch.equal(ys[14][smp], ys[13][smp])
+    osd = {k: (v.double().requires_grad_("running_" not in k) if v.is_floating_point() else v) for k, v in sd.items()}
+    fo = O.effnet_b0_forward(osd, x.double(), training=True, drop_connect_rate=rate, dc_uniform=u)
+    (fo * gw.double()).sum().backward()
+    for k, p in named.items():
+        if k.startswith("_fc"):
+            continue
+        assert_close(p.grad, osd[k].grad, 3e-3, "grad " + k)
+
+
+def test_drop_connect_default_sampler_statistics():
+    """Without an injected sampler the gate comes from torch's device RNG: values are exactly {0, 1/keep} and eval ignores it."""
+    from mintime_amd import effnet_engine
+    model = EfficientNet.from_name("efficientnet-b0", drop_connect_rate=0.2)
+    model.load_state_dict(synth.effnet_b0_state(0), strict=True)
+    model = model.cuda().train(True)
+    x = _input(6, 4).cuda()
+    torch.manual_seed(0)
+    feat, saved, _ = effnet_engine.effnet_forward(model, x.permute(0, 2, 3, 1).contiguous(), effnet_engine.param_list(model), True, True)
+    for bi, rec in enumerate(saved["blocks"]):
+        dc = rec["dc"]
+        if bi in (2, 4, 6, 7, 9, 10, 12, 13, 14):
+            keep = 1 - 0.2 * bi / 16
+            vals = set(round(float(v), 5) for v in dc.cpu())
+            assert vals <= {0.0, round(1 / keep, 5)}, (bi, vals)
+        else:
+            assert dc is None
+    model.eval()
+    with torch.no_grad():
+        a, b = model(x), model(x)
+    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("cout,cin,rows,gated", [(96, 16, 100003, False), (16, 32, 70001, True), (24, 96, 50000, True),

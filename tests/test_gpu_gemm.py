@@ -150,3 +150,108 @@ def test_im2col_conv_matches_torch_conv():
             a = a.clamp_min(0)
         ref = F.conv2d(a.permute(0, 3, 1, 2), w.double(), None, s, p).permute(0, 2, 3, 1).reshape(n * Ho * Ho, Cout)
         assert_close(out, ref, 5e-5, f"im2col conv {Cin}->{Cout} k{k} s{s} p{p}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The shapes bench.py actually times (config 3: B = 32 -> M = 32*393 = 12576 token rows).  At this size the host and the
+# library take different branches than at fixture size: 64x64 tiles for M >= 4096 (gemm.hip pick_cfg), the L2-blocked tile
+# order with its padding-block early return (m_tiles >= 32 && n_tiles >= 2), split-K + fp32 atomics for FF2 and the skinny
+# N = 512 data gradients, auto split-K for the weight gradients.
+# ---------------------------------------------------------------------------------------------------------------------
+M_FULL = 32 * 393
+ATOL_SPLITK = 5e-5
+
+
+def _dmm(a, b):
+    return a.double() @ b.double()
+
+
+def test_full_size_ff1_geglu_l2_blocked():
+    D = 512
+    A, W, b = _rand(M_FULL, D, seed=1), _rand(8 * D, D, seed=2, scale=0.05), _rand(8 * D, seed=3, scale=0.1)
+    h = torch.full((M_FULL, 4 * D), float("nan"), device="cuda")
+    u = torch.full((M_FULL, 8 * D), float("nan"), device="cuda")
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), h, M_FULL, 8 * D, D, D, D, 4 * D, epilogue=L.EPI_GEGLU, bias=b.cuda(), C2=u, ldc2=8 * D,
+           n_half=4 * D)
+    uref = _dmm(A, W.T) + b.double()
+    a, g = uref.chunk(2, dim=-1)
+    assert_close(u, torch.stack((a, g), dim=-1).reshape(M_FULL, 8 * D), TOL, "FF1 pre-activations at M=12576")
+    assert_close(h, a * torch.nn.functional.gelu(g), TOL, "FF1 + GEGLU at M=12576")
+    assert not bool(torch.isnan(h).any()) and not bool(torch.isnan(u).any())       # every tile was written (no skipped block)
+
+
+def test_full_size_geglu_backward_dgrad():
+    D = 512
+    dy, W2 = _rand(M_FULL, D, seed=1), _rand(D, 4 * D, seed=2, scale=0.05)
+    u = _rand(M_FULL, 8 * D, seed=3)
+    du = torch.full((M_FULL, 8 * D), float("nan"), device="cuda")
+    u_il = torch.stack(u.chunk(2, dim=-1), dim=-1).reshape(M_FULL, 8 * D).contiguous()
+    L.gemm(L.OP_NN, dy.cuda(), W2.cuda(), du, M_FULL, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=u_il.cuda(),
+           ldc2=8 * D, n_half=4 * D)
+    ud = u.double().requires_grad_(True)
+    a, g = ud.chunk(2, dim=-1)
+    (a * torch.nn.functional.gelu(g) * _dmm(dy, W2)).sum().backward()
+    assert_close(du, ud.grad, 5e-5, "GEGLU backward at M=12576")
+
+
+@pytest.mark.parametrize("N,K", [(1536, 512), (512, 512), (512, 1280)])
+def test_full_size_nt_store_and_bias_residual(N, K):
+    A, W, b, R = _rand(M_FULL, K, seed=1), _rand(N, K, seed=2, scale=0.05), _rand(N, seed=3), _rand(M_FULL, N, seed=4)
+    Cd = torch.full((M_FULL, N), float("nan"), device="cuda")
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), Cd, M_FULL, N, K, K, K, N)
+    ref = _dmm(A, W.T)
+    assert_close(Cd, ref, TOL, f"NT store {N}x{K} at M=12576")
+    Rd = R.cuda()
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), Rd, M_FULL, N, K, K, K, N, epilogue=L.EPI_BIAS_RES, bias=b.cuda(), R=Rd, ldr=N)
+    assert_close(Rd, ref + b.double() + R.double(), TOL, f"NT bias+residual in place {N}x{K} at M=12576")
+
+
+def test_full_size_patch_embedding_rowmap():
+    B, Fn, N, K = 32, 392, 512, 1280
+    A, W, b = _rand(B * Fn, K, seed=1, scale=0.3), _rand(N, K, seed=2, scale=0.05), _rand(N, seed=3)
+    Xd = torch.zeros(B, Fn + 1, N, device="cuda")
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), Xd, B * Fn, N, K, K, K, N, bias=b.cuda(), c_map=(Fn, Fn + 1, 1))
+    assert_close(Xd[:, 1:], (_dmm(A, W.T) + b.double()).reshape(B, Fn, N), TOL, "patch embedding at B=32")
+    assert float(Xd[:, 0].abs().max()) == 0.0
+
+
+def test_full_size_ff2_split_k_atomic():
+    """tsf_engine.py: FF2 for M >= 4096 = 5 K-slices, fp32 atomics onto the residual, bias on slice 0."""
+    N, K = 512, 2048
+    A, W, b, R = _rand(M_FULL, K, seed=1), _rand(N, K, seed=2, scale=0.05), _rand(N, seed=3), _rand(M_FULL, N, seed=4)
+    Cd = R.cuda().clone()
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), Cd, M_FULL, N, K, K, K, N, epilogue=L.EPI_ATOMIC, bias=b.cuda(), split_k=5)
+    assert_close(Cd, R.double() + b.double() + _dmm(A, W.T), ATOL_SPLITK, "FF2 split-K at M=12576")
+
+
+@pytest.mark.parametrize("K,split", [(4096, 4), (1536, 3), (512, 1)])
+def test_full_size_skinny_dgrad(K, split):
+    """tsf_backward.dgrad_skinny: dxn[M,512] = dY[M,K] . W[K,512]; K-slices + atomics onto zeros for K >= 1024."""
+    N = 512
+    dY, W = _rand(M_FULL, K, seed=1), _rand(K, N, seed=2, scale=0.05)
+    if split > 1:
+        Cd = torch.zeros(M_FULL, N, device="cuda")
+        L.gemm(L.OP_NN, dY.cuda(), W.cuda(), Cd, M_FULL, N, K, K, N, N, epilogue=L.EPI_ATOMIC, split_k=split)
+    else:
+        Cd = torch.full((M_FULL, N), float("nan"), device="cuda")
+        L.gemm(L.OP_NN, dY.cuda(), W.cuda(), Cd, M_FULL, N, K, K, N, N)
+    assert_close(Cd, _dmm(dY, W), ATOL_SPLITK, f"skinny dgrad K={K} at M=12576")
+
+
+@pytest.mark.parametrize("N1,N2", [(512, 2048), (4096, 512), (1536, 512), (512, 512)])
+def test_full_size_wgrad_auto_split(N1, N2):
+    """tsf_backward.wgrad: dW[N1,N2] = dY[M,N1]^T . X[M,N2] with split_k=0 (auto) + atomics onto zero-filled grads."""
+    dY, X = _rand(M_FULL, N1, seed=1), _rand(M_FULL, N2, seed=2)
+    dW = torch.zeros(N1, N2, device="cuda")
+    L.gemm(L.OP_TN, dY.cuda(), X.cuda(), dW, N1, N2, M_FULL, N1, N2, N2, epilogue=L.EPI_ATOMIC, split_k=0)
+    assert_close(dW, _dmm(dY.T, X), 5e-5, f"wgrad {N1}x{N2} over 12576 rows")
+
+
+def test_full_size_wgrad_with_token_rowmap():
+    """Patch-embedding weight gradient: A rows skip the cls slot (a_map), K = 32*392 rows."""
+    B, Fn, D, Cin = 32, 392, 512, 1280
+    dx = _rand(B, Fn + 1, D, seed=1)
+    feat = _rand(B * Fn, Cin, seed=2)
+    dW = torch.zeros(D, Cin, device="cuda")
+    L.gemm(L.OP_TN, dx.cuda(), feat.cuda(), dW, D, Cin, B * Fn, D, Cin, Cin, epilogue=L.EPI_ATOMIC, split_k=0, a_map=(Fn, Fn + 1, 1))
+    assert_close(dW, _dmm(dx[:, 1:].reshape(B * Fn, D).T, feat), 5e-5, "patch-embedding wgrad at B=32")

@@ -129,15 +129,18 @@ def test_backward_all_parameters_vs_oracle(B, Fr, C, ids):
             assert_close(p.grad, ref, REL_TOL, "grad " + k)
 
 
-def test_attention_aggregation_matches_reference_rule():
-    """Next-row f3: utils.py:68-96 aggregate_attentions on the device vs its numpy restatement."""
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_attention_aggregation_matches_reference_fixture(tag):
+    """Next-row f3: mt_attn_aggregate against utils.py:68-96 ITSELF (tests/golden/agg_att.npz was produced by importing the
+    reference's utils.py in the build container), on the cls attentions of three fixtures (2 ids ragged, XS 3 ids, 1 id)."""
     from mintime_amd import harness
-    g = golden("tsf_2id_ragged")
-    s_att, t_att = torch.as_tensor(g["space_att"]), torch.as_tensor(g["time_att"])
-    ref, ref_id = O.aggregate_attentions([s_att, t_att], 8, 8, [4, 8], scale_factor=50000)
-    got, got_id = harness.aggregate_attentions([s_att.cuda(), t_att.cuda()], 8, 8, [4, 8], scale_factor=50000)
-    assert_close(torch.tensor(got), torch.tensor(ref), 1e-4, "aggregated attentions")
-    assert_close(torch.tensor(got_id), torch.tensor(ref_id), 1e-4, "identity attentions")
+    g = golden("agg_att")
+    fx = golden(str(g[tag + "_fixture"]))
+    frames, fpi = int(g[tag + "_frames"]), [int(v) for v in g[tag + "_fpi"]]
+    s_att, t_att = torch.as_tensor(fx["space_att"]), torch.as_tensor(fx["time_att"])
+    got, got_id = harness.aggregate_attentions([s_att.cuda(), t_att.cuda()], 8, frames, fpi, scale_factor=50000)
+    assert_close(torch.tensor(got), g[tag + "_agg"], 1e-4, "aggregated attentions vs reference")
+    assert_close(torch.tensor(got_id), g[tag + "_ident"], 1e-4, "identity attentions vs reference")
 
 
 def test_clip_with_a_fully_padded_identity_and_a_single_valid_slot():
@@ -161,3 +164,35 @@ def test_clip_with_a_fully_padded_identity_and_a_single_valid_slot():
     padded_tokens = (~mask[0]).repeat_interleave(49)
     assert float(space[:, 0, 1:][:, padded_tokens.cuda()].abs().max()) == 0.0
     assert torch.isfinite(out).all()
+
+
+def test_full_size_batch_logits_and_all_gradients_vs_oracle():
+    """The configuration bench.py times (config 3: B = 32, 8 slots, 2 identities, M = 12 576 token rows): at this size the engine
+    takes its large-M branches (FF2 and the N = 512 data gradients as split-K + atomics, 64x64 tiles, L2-blocked tile order).
+    Logits, both cls attentions and EVERY parameter gradient against the CPU oracle (size_invariant_timesformer.py:263-268)."""
+    B, Fr, C, seed = 32, 8, 1280, 7
+    cfg = arch.default_tsf_config(C, Fr)
+    model, sd = _build(cfg, seed, require_attention=True)
+    feats = synth.features(B, Fr, C, seed)
+    aux = synth.clip_inputs(B, Fr, 2, seed, ragged=True, with_video=False)
+    x = feats.cuda().requires_grad_(True)
+    out, (s_att, t_att) = model(x, mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(),
+                                size_embedding=aux["size_embedding"], positions=aux["positions"].cuda())
+    w = torch.linspace(-1.0, 1.0, B).reshape(B, 1)
+    (out.cpu() * w).sum().backward()
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = feats.clone().requires_grad_(True)
+    oout, (o_s, o_t) = O.tsf_forward(osd, cfg, xo, aux["mask"], aux["identities_mask"], aux["size_embedding"], aux["positions"],
+                                     require_attention=True)
+    (oout * w).sum().backward()
+    assert_close(out, oout, REL_TOL, "logits at B=32")
+    assert bool(((out.detach().cpu() - oout.detach()).abs() <= 1e-3 * oout.detach().abs() + 1e-5).all())
+    assert_close(s_att, o_s, REL_TOL, "space cls attention at B=32")
+    assert_close(t_att, o_t, REL_TOL, "time cls attention at B=32")
+    assert_close(x.grad, xo.grad, REL_TOL, "feature gradient at B=32")
+    for k, p in model.named_parameters():
+        ref = osd[k].grad
+        if float(ref.abs().max()) == 0.0:
+            assert float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert_close(p.grad, ref, REL_TOL, "grad " + k)

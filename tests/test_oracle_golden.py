@@ -173,3 +173,48 @@ def test_xception_matches_reference(name):
             key = k[len("gnorm64."):]
             assert_close(sd64[key].grad.norm(), g[k], 1e-8, k)
             assert_close(sd64[key].grad.reshape(-1)[:256], g["gslice64." + key], 1e-8, "gslice64." + key)
+
+
+def _dc_run(g, dtype=torch.float32):
+    n, seed, rate = int(g["n_img"]), int(g["seed"]), float(g["rate"])
+    sd = {k: (v.to(dtype).requires_grad_("running_" not in k) if v.is_floating_point() else v)
+          for k, v in synth.effnet_b0_state(seed).items()}
+    x = synth.clip_inputs(1, n, 1, seed)["videos"].reshape(n, 224, 224, 3).permute(0, 3, 1, 2)
+    assert abs(checksum(x) - float(g["input_sum"])) < 1e-9 * abs(float(g["input_sum"]))
+    u = O.drop_connect_uniforms(seed, n, rate)
+    taps = {}
+    feats = O.effnet_b0_forward(sd, x.to(dtype), training=True, drop_connect_rate=rate, dc_uniform=u, taps=taps)
+    gw = torch.from_numpy(np.random.Generator(np.random.Philox(key=[seed, 777])).standard_normal((n, 1280, 7, 7)) * 0.1).to(dtype)
+    (feats * gw).sum().backward()
+    return sd, feats, taps, u
+
+
+def test_effnet_drop_connect_matches_reference():
+    """Train mode WITH drop-connect (utils.py:129-154, model.py:280-282): the oracle replays the reference's torch.rand draws
+    (same seed, same call order) and must reproduce its features, gated block outputs and gradients."""
+    g = golden("ef_train_dc")
+    sd, feats, taps, u = _dc_run(g)
+    assert sorted(u) == [2, 4, 6, 7, 9, 10, 12, 13, 14]
+    # the fixture seed actually drops something (otherwise the test would not exercise the gate)
+    keep = {i: 1 - float(g["rate"]) * i / 16 for i in u}
+    assert any(bool((torch.floor(keep[i] + u[i]) == 0).any()) for i in u)
+    assert_close(feats, g["features"], 1e-4, "features")
+    for i in (2, 7, 10, 14):
+        assert_close(taps[f"block{i}"][:, :, :3, :3], g[f"block{i}_slice"], 1e-4, f"block{i} slice")
+    for k in g.files:
+        if k.startswith("gnorm."):
+            key = k[len("gnorm."):]
+            assert_close(sd[key].grad.norm(), g[k], 1e-3, k)
+            assert_close(sd[key].grad.reshape(-1)[:256], g["gslice." + key], 1e-3, "gslice." + key)
+
+
+def test_aggregate_attentions_matches_reference():
+    """Next-row f3: O.aggregate_attentions against utils.py:68-96 itself (tools/make_golden.py imports the reference's utils.py
+    and runs it on the cls attentions of three TimeSformer fixtures)."""
+    g = golden("agg_att")
+    for tag in ("a", "b", "c"):
+        fx = golden(str(g[tag + "_fixture"]))
+        atts = [torch.as_tensor(fx["space_att"]), torch.as_tensor(fx["time_att"])]
+        agg, ident = O.aggregate_attentions(atts, 8, int(g[tag + "_frames"]), [int(v) for v in g[tag + "_fpi"]])
+        assert_close(np.asarray(agg), g[tag + "_agg"], 1e-12, "aggregated attentions " + tag)
+        assert_close(np.asarray(ident), g[tag + "_ident"], 1e-12, "identity attentions " + tag)

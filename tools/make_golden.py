@@ -47,6 +47,42 @@ def import_reference():
     return EfficientNet, SizeInvariantTimeSformer
 
 
+class _Placeholder(types.ModuleType):
+    """Empty stand-in for a module the reference imports at file scope but never touches on the code path being run
+    (cv2, magic, albumentations, torchvision, pytorchvideo ... are not installed here): every attribute is an inert
+    placeholder class, so `from x import A, B` and `class C(x.Base)` at import time succeed and nothing else works."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return type(name, (), {})
+
+
+def placeholder_modules(*names):
+    for n in names:
+        if not hasattr(sys.modules.get(n), "__file__"):      # absent, or the bare cv2 stub import_reference() installed
+            m = _Placeholder(n)
+            m.__path__ = []
+            sys.modules[n] = m
+
+
+def import_reference_file(modname, relpath):
+    """Import one top-level reference file (utils.py, deepfakes_dataset.py) under a private module name."""
+    import importlib.util
+    saved_path = list(sys.path)
+    sys.path[:] = [REF] + [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
+    try:
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+        mod = importlib.util.module_from_spec(spec)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            spec.loader.exec_module(mod)
+    finally:
+        sys.path[:] = saved_path
+    return mod
+
+
 def checksum(t):
     return float(t.double().sum())
 
@@ -161,6 +197,86 @@ def ef_case(EF, name, n_img, training, seed):
          n_img=n_img, training=int(training), seed=seed, **extra)
 
 
+def ef_dc_case(EF, name, n_img, seed, rate=0.2):
+    """Train-mode EfficientNet WITH drop-connect (utils.py:129-154): the reference draws torch.rand([N,1,1,1]) once per gated
+    block after torch.manual_seed(seed); oracle.drop_connect_uniforms(seed, N) replays exactly those draws."""
+    model = EF.from_name("efficientnet-b0", drop_connect_rate=rate)
+    sd = synth.effnet_b0_state(seed)
+    model.load_state_dict(sd, strict=True)
+    model.train(True)
+    vid = synth.clip_inputs(1, n_img, 1, seed)["videos"]
+    x = vid.reshape(n_img, 224, 224, 3).permute(0, 3, 1, 2)
+    taps = {}
+    hooks = [model._blocks[i].register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(i, o.detach().clone()))
+             for i in (2, 7, 10, 14)]
+    gw = torch.from_numpy(np.random.Generator(np.random.Philox(key=[seed, 777])).standard_normal((n_img, 1280, 7, 7)) * 0.1).float()
+    torch.manual_seed(seed)
+    feats = model(x)
+    for h in hooks:
+        h.remove()
+    (feats * gw).sum().backward()
+    named = dict(model.named_parameters())
+    grads = {}
+    for key in GRAD_KEYS_EF:
+        g = named[key].grad
+        grads["gnorm." + key] = g.norm()
+        grads["gslice." + key] = g.reshape(-1)[:256].clone()
+    save(name, features=feats.detach(), input_sum=checksum(x), rate=rate, n_img=n_img, seed=seed,
+         **{f"block{i}_slice": taps[i][:, :, :3, :3].clone() for i in taps}, **grads)
+
+
+def agg_case(name):
+    """utils.py:68-96 aggregate_attentions run on the cls attentions of the tsf_2id_ragged / tsf_xs_3id fixtures."""
+    placeholder_modules("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms._transforms_video",
+                        "pytorchvideo", "pytorchvideo.data", "pytorchvideo.data.encoded_video", "pytorchvideo.transforms")
+    ref_utils = import_reference_file("_ref_utils", "utils.py")
+    out = {}
+    for tag, fx, frames, fpi in (("a", "tsf_2id_ragged", 8, [4, 8]), ("b", "tsf_xs_3id", 16, [7, 12, 16]), ("c", "tsf_cfg1", 8, [8])):
+        g = np.load(os.path.join(OUT, fx + ".npz"))
+        atts = [torch.as_tensor(g["space_att"]), torch.as_tensor(g["time_att"])]
+        agg, ident = ref_utils.aggregate_attentions(atts, 8, frames, fpi)
+        out[tag + "_agg"] = np.asarray([np.asarray(r, dtype=np.float64) for r in agg])
+        out[tag + "_ident"] = np.asarray(ident, dtype=np.float64)
+        out[tag + "_fixture"] = fx
+        out[tag + "_frames"] = frames
+        out[tag + "_fpi"] = np.asarray(fpi)
+    save(name, **out)
+
+
+def slots_case(name):
+    """deepfakes_dataset.py:130-186 get_sorted_identities run on throw-away directory trees (identities_ordering=1: by number of
+    faces, so neither python-magic nor cv2 is reached; distinct counts so os.listdir order cannot matter)."""
+    import itertools, shutil, tempfile
+    placeholder_modules("cv2", "magic", "albumentations", "albumentations.augmentations", "albumentations.augmentations.functional")
+    ds_mod = import_reference_file("_ref_dataset", "deepfakes_dataset.py")
+    rng = np.random.Generator(np.random.Philox(key=[11, 22]))
+    cases = []
+    for num_frames in (8, 16, 32):
+        for max_id in (1, 2, 3, 4):
+            for n_id in (1, 2, 3, 4, 5):
+                for _ in range(6):
+                    counts = rng.choice(np.arange(1, 3 * num_frames), size=n_id, replace=False)
+                    cases.append((num_frames, max_id, [int(c) for c in counts]))
+    rows = []
+    for (num_frames, max_id, counts) in cases:
+        root = tempfile.mkdtemp(prefix="slots_")
+        try:
+            for i, c in enumerate(counts):
+                d = os.path.join(root, f"identity_{i}")
+                os.makedirs(d)
+                for k in range(c):
+                    open(os.path.join(d, f"{k * 3}_{i}.jpg"), "w").close()
+            ds = ds_mod.DeepFakesDataset([], [], "", "", 224, num_frames=num_frames, max_identities=max_id, identities_ordering=1)
+            ids, _ = ds.get_sorted_identities(root)
+            got = [(int(os.path.basename(p).split("_")[1]), int(n)) for p, _, n in ids]
+        finally:
+            shutil.rmtree(root)
+        rows.append(dict(num_frames=num_frames, max_identities=max_id, counts=counts, order=[g[0] for g in got], slots=[g[1] for g in got]))
+    with open(os.path.join(OUT, name + ".json"), "w") as fh:
+        json.dump(rows, fh)
+    print(f"wrote {name}.json ({len(rows)} cases)")
+
+
 def e2e_case(EF, TSF, name, batch, frames, identities, ragged, training, seed):
     """Whole step.  Stored twice: the reference in fp32 (what a user would run) and in fp64 (its exact arithmetic;
     the fp32 run of an ill-conditioned case -- train-mode BN over a batch with padded all-zero crops -- deviates from
@@ -257,10 +373,15 @@ def main():
         t = TSF(config=arch.default_tsf_config(c, fr))
         man[f"tsf_c{c}_f{fr}"] = [[k, list(v.shape), str(v.dtype)] for k, v in t.state_dict().items()]
         man[f"tsf_c{c}_f{fr}_no_weight_decay"] = sorted(t.no_weight_decay())
-    with open(os.path.join(OUT, "state_manifest.json"), "w") as fh:
-        json.dump(man, fh)
-    print("wrote state_manifest.json")
-
+    only = os.environ.get("GOLDEN_ONLY", "")
+    if only in ("", "dc"):
+        ef_dc_case(EF, "ef_train_dc", n_img=4, seed=3)
+    if only in ("", "agg"):
+        agg_case("agg_att")
+    if only in ("", "slots"):
+        slots_case("slots")
+    if only in ("dc", "agg", "slots"):
+        return
     from models.xception import xception as _xc
     man["xception"] = [[k, list(v.shape), str(v.dtype)] for k, v in _xc(num_classes=1).state_dict().items()]
     with open(os.path.join(OUT, "state_manifest.json"), "w") as fh:
