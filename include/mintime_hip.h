@@ -79,7 +79,11 @@ int mt_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
 /* cls token + positional + size embeddings (:231-248), in place on x [B, 1+F*n, dim] whose rows 1.. hold the
  * patch-embedding output.  positions int64 [B,1+F*n]; sizes int32 [B,F] (NULL size_emb: enable-size-emb False). */
 int mt_embed_fwd(float* x, const float* cls, const float* pos_emb, const float* size_emb,
-                 const int64_t* positions, const int32_t* sizes, int B, int F, int n, int dim, void* stream);
+                 const int64_t* positions, const int32_t* sizes, int B, int F, int n, int dim, int pos_rows, int size_rows,
+                 int* err_flag, void* stream);
+/* pos_rows / size_rows = rows of the two tables.  nn.Embedding raises on an out-of-range index; here such an index is clamped
+ * into the table (no out-of-bounds access, forward or backward) and *err_flag (optional, device int32, sticky) gets bit 0
+ * (positions) / bit 1 (size_embedding) set, which the host checks at its next synchronisation point. */
 
 /* Divided attention core (:80-87 attn(), :112-141 of Attention.forward) on the QKV GEMM output
  * qkv [B, 1+F*n, 3*H*64] -> out [B, 1+F*n, H*64] (merged heads).  mode 0 = time (identity-masked), 1 = space.
@@ -172,7 +176,7 @@ int mt_head_bwd(const float* dlogits, const float* x, const float* gamma, const 
 
 /* adjoint of mt_embed_fwd: scatter-adds into dcls [dim], dpos_emb, dsize_emb (zero-filled by the caller). */
 int mt_embed_bwd(const float* dx, float* dcls, float* dpos_emb, float* dsize_emb, const int64_t* positions,
-                 const int32_t* sizes, int B, int F, int n, int dim, void* stream);
+                 const int32_t* sizes, int B, int F, int n, int dim, int pos_rows, int size_rows, void* stream);
 
 /* adjoint of mt_attn_fwd: dout [B,N,H*64] -> dqkv [B,N,3*H*64] (fully written). Probabilities are recomputed from qkv. */
 int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, const uint8_t* mask, const uint8_t* ident,

@@ -199,14 +199,16 @@ __global__ void head_bwd_kernel(const float* __restrict__ dlogits, const float* 
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dcls,
                                                         float* __restrict__ dpos, float* __restrict__ dsize,
                                                         const int64_t* __restrict__ positions, const int* __restrict__ sizes,
-                                                        int B, int N, int n, int F, int D) {
+                                                        int B, int N, int n, int F, int D, int pos_rows, int size_rows) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= B * N) return;
   const int b = row / N, t = row - b * N;
-  const int64_t pi = positions ? positions[row] : (int64_t)t;
+  int64_t pi = positions ? positions[row] : (int64_t)t;
   int si = 0;
   if (t > 0 && sizes) si = sizes[b * F + (t - 1) / n];
+  pi = pi < 0 ? 0 : (pi >= pos_rows ? pos_rows - 1 : pi);          // same clamp as the forward (which raised the flag)
+  si = si < 0 ? 0 : (si >= size_rows ? size_rows - 1 : si);
   const float* dr = dx + (int64_t)row * D;
   for (int i = lane; i < D; i += 64) {
     const float v = dr[i];
@@ -795,11 +797,12 @@ extern "C" int mt_head_bwd(const float* dlogits, const float* x, const float* ga
 }
 
 extern "C" int mt_embed_bwd(const float* dx, float* dcls, float* dpos_emb, float* dsize_emb, const int64_t* positions,
-                            const int32_t* sizes, int B, int F, int n, int dim, void* stream) {
+                            const int32_t* sizes, int B, int F, int n, int dim, int pos_rows, int size_rows, void* stream) {
   if (!dx) return fail(MT_ERR_ARG, "mt_embed_bwd: null pointer");
+  if (pos_rows <= 0 || (dsize_emb && size_rows <= 0)) return fail(MT_ERR_ARG, "mt_embed_bwd: empty embedding table");
   const int N = 1 + F * n;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3((B * N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dx, dcls, dpos_emb, dsize_emb,
-                     positions, sizes, B, N, n, F, dim);
+                     positions, sizes, B, N, n, F, dim, pos_rows, dsize_emb ? size_rows : 1);
   return check_launch("mt_embed_bwd");
 }
 

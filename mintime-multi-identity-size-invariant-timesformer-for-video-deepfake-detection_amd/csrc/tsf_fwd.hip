@@ -92,14 +92,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void embed_fwd_kernel(float* __restrict__ x, const float* __restrict__ cls,
                                                         const float* __restrict__ pos_emb, const float* __restrict__ size_emb,
                                                         const int64_t* __restrict__ positions, const int* __restrict__ sizes,
-                                                        int B, int N, int n, int F, int D) {
+                                                        int B, int N, int n, int F, int D, int pos_rows, int size_rows,
+                                                        int* __restrict__ err) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= B * N) return;
   const int b = row / N, t = row - b * N;
-  const int64_t pi = positions ? positions[row] : (int64_t)t;
+  int64_t pi = positions ? positions[row] : (int64_t)t;
   int si = 0;
   if (t > 0 && sizes) si = sizes[b * F + (t - 1) / n];
+  // nn.Embedding raises on an out-of-range index; here the access is clamped into the table and a sticky flag is raised
+  if (pi < 0 || pi >= pos_rows || si < 0 || si >= size_rows) {
+    if (err && lane == 0) atomicOr(err, (pi < 0 || pi >= pos_rows) ? 1 : 2);
+    pi = pi < 0 ? 0 : (pi >= pos_rows ? pos_rows - 1 : pi);
+    si = si < 0 ? 0 : (si >= size_rows ? size_rows - 1 : si);
+  }
   float4* xr = reinterpret_cast<float4*>(x + (int64_t)row * D);
   const float4* pr = reinterpret_cast<const float4*>(pos_emb + pi * D);
   const float4* sr = size_emb ? reinterpret_cast<const float4*>(size_emb + (int64_t)si * D) : nullptr;
@@ -472,12 +479,14 @@ extern "C" int mt_layernorm_fwd(const float* x, const float* gamma, const float*
 }
 
 extern "C" int mt_embed_fwd(float* x, const float* cls, const float* pos_emb, const float* size_emb,
-                            const int64_t* positions, const int32_t* sizes, int B, int F, int n, int dim, void* stream) {
+                            const int64_t* positions, const int32_t* sizes, int B, int F, int n, int dim, int pos_rows,
+                            int size_rows, int* err_flag, void* stream) {
   if (!x || !cls || !pos_emb) return fail(MT_ERR_ARG, "mt_embed_fwd: null pointer");
   if (dim & 3) return fail(MT_ERR_ARG, "mt_embed_fwd: dim %% 4 != 0");
+  if (pos_rows <= 0 || (size_emb && size_rows <= 0)) return fail(MT_ERR_ARG, "mt_embed_fwd: empty embedding table");
   const int N = 1 + F * n;
   hipLaunchKernelGGL(embed_fwd_kernel, dim3((B * N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, cls, pos_emb, size_emb,
-                     positions, sizes, B, N, n, F, dim);
+                     positions, sizes, B, N, n, F, dim, pos_rows, size_emb ? size_rows : 1, err_flag);
   return check_launch("mt_embed_fwd");
 }
 

@@ -6,8 +6,25 @@ Here every rank owns its shard of the clips end-to-end (BatchNorm statistics sta
 the only exchange is the gradient sum -- 62.4 M floats ~ 250 MB for EfficientNet-B0 + TimeSformer.
 Parameters that get no gradient (`_fc`, reference model.py:206-208) are skipped deterministically on every rank.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
+
+
+def broadcast_module_state(modules, group=None, src=0):
+    """Make every rank start from rank `src`'s parameters and buffers (what torch's DistributedDataParallel does at
+    construction); the reference's nn.DataParallel gets the same effect by replicating module 0 every step (train.py:294-296)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    n = 0
+    with torch.no_grad():
+        for m in modules:
+            tensors = list(m.parameters()) + list(m.buffers()) if isinstance(m, torch.nn.Module) else list(m)
+            for t in tensors:
+                dist.broadcast(t.data, src=src, group=group)
+                n += t.numel()
+    return n
 
 
 def shard_range(total, rank, world):
@@ -75,8 +92,11 @@ class OverlappedGradReducer:
         loss.backward(); reducer.allreduce(); optimizer.step()
     """
 
-    def __init__(self, buckets, group=None, force=False):
+    def __init__(self, buckets, group=None, force=False, broadcast_init=True):
         self.group = group
+        self.sync = True
+        if broadcast_init:
+            broadcast_module_state(buckets, group)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or force
         self.modules = [b if isinstance(b, torch.nn.Module) else None for b in buckets]
@@ -98,8 +118,19 @@ class OverlappedGradReducer:
     # ---- engine-backed buckets ------------------------------------------------------------------------------------
     def _make_engine_hook(self, bi):
         def hook(params, flat):
-            # gradients that already exist would be ADDED to by autograd while the collective is in flight: leave such a
-            # bucket to the synchronous path (the harness always starts from grad = None)
+            if not self.sync:                      # inside no_sync(): gradients only accumulate locally
+                return
+            params = [p for p in params if p is not None]      # optional parameters (size_emb off) hold no space in `flat`
+            if self.launched[bi]:
+                # a second backward in the same step: autograd is about to ADD into the buffer the in-flight collective owns,
+                # and that contribution would never be reduced.  Drain the collective so memory stays sane, then refuse.
+                for work, _, back in self.pending:
+                    if work is not None and back is not None and back[0] == "engine" and back[1] == bi:
+                        work.wait()
+                raise RuntimeError("OverlappedGradReducer: backward ran twice before allreduce(); wrap all but the last "
+                                   "micro-batch in `with reducer.no_sync():` to accumulate gradients")
+            # gradients that already exist (accumulated under no_sync) are ADDED to by autograd after this hook returns: leave
+            # such a bucket to the synchronous path in allreduce()
             if any(p.grad is not None for p in params):
                 return
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -111,16 +142,29 @@ class OverlappedGradReducer:
 
     @staticmethod
     def _views_like_zero_grads(params, flat):
+        """Same carving rule as lib.zero_grads (None entries, already filtered by the hook, take no space there either)."""
         views, off = [], 0
         for p in params:
+            if p is None:
+                continue
             views.append(flat[off:off + p.numel()].view(p.shape))
             off += (p.numel() + 3) // 4 * 4
         return views
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context only accumulate locally; the first backward outside it
+        (followed by allreduce()) reduces the accumulated sum -- synchronously, because autograd adds into existing gradients."""
+        prev, self.sync = self.sync, False
+        try:
+            yield
+        finally:
+            self.sync = prev
+
     # ---- plain parameter buckets ----------------------------------------------------------------------------------
     def _make_hook(self, bi):
         def hook(p):
-            if self.live[bi] is None:
+            if self.live[bi] is None or not self.sync:
                 return
             self.seen[bi] += 1
             if self.seen[bi] == len(self.live[bi]):
@@ -159,6 +203,8 @@ class OverlappedGradReducer:
         """Call after backward(): waits for the launched buckets (launching any that could not be overlapped) and averages."""
         if not self.active:
             return 0
+        if not self.sync:
+            raise RuntimeError("allreduce() called inside no_sync()")
         for bi, b in enumerate(self.buckets):
             if self.launched[bi]:
                 continue
@@ -172,6 +218,9 @@ class OverlappedGradReducer:
                 if self.live[bi]:
                     self._launch(bi, async_op=False)
                     self.stats["synchronous"] += 1
+            elif self.seen[bi] == 0 and all(p.grad is not None for p in self.live[bi]):
+                self._launch(bi, async_op=False)                          # accumulated under no_sync(): nothing was launched
+                self.stats["synchronous"] += 1
             elif self.seen[bi] != len(self.live[bi]):
                 raise RuntimeError(f"bucket {bi}: {self.seen[bi]} of {len(self.live[bi])} gradients arrived; the set of "
                                    "parameters receiving gradients must not change between steps")

@@ -219,6 +219,9 @@ class _EffNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dfeat, *unused):
+        if ctx.saved is None:
+            raise RuntimeError("EfficientNet: backward ran a second time through the same forward; the activation buffers are "
+                               "released after the first pass (retain_graph is not supported by the HIP engine)")
         from .effnet_backward import effnet_backward
         dx, dparams = effnet_backward(ctx.model, ctx.params, ctx.saved, ctx.shape, ctx.training, dfeat.contiguous(),
                                       ctx.needs_input_grad[2], ctx.needs_input_grad[3:])

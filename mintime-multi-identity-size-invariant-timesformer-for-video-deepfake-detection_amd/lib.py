@@ -50,7 +50,8 @@ PROTOTYPES = {
     "mt_last_error": [],
     "mt_gemm": [C.POINTER(GemmDesc), C.c_void_p],
     "mt_layernorm_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_void_p],
-    "mt_embed_fwd": [f32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_embed_fwd": [f32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                     C.c_void_p],
     "mt_attn_fwd": [f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                     C.c_void_p],
     "mt_head_fwd": [f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
@@ -69,7 +70,7 @@ PROTOTYPES = {
     "mt_colsum": [f32p, i64, RowMap, C.c_int, C.c_int, f32p, C.c_void_p],
     "mt_head_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                     C.c_void_p],
-    "mt_embed_bwd": [f32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_embed_bwd": [f32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_attn_bwd": [f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                     C.c_void_p],
     "mt_bn_act_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_void_p],

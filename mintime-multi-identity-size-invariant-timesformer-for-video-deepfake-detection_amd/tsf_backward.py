@@ -111,7 +111,8 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
     i0 = take(5)
     w_pe, b_pe, cls, pos_w, size_w = P[i0:i0 + 5]
     L.check(lib.mt_embed_bwd(L.ptr(dx), L.ptr(grads[i0 + 2]), L.ptr(grads[i0 + 3]), L.ptr(grads[i0 + 4]), L.ptr(aux.positions),
-                             L.ptr(aux.sizes), B, F, n, D, st), "mt_embed_bwd")
+                             L.ptr(aux.sizes), B, F, n, D, pos_w.shape[0], size_w.shape[0] if size_w is not None else 0, st),
+            "mt_embed_bwd")
     tok_map = (F * n, N, 1)      # token row r of the feature matrix lives at row (r/(F n))*N + 1 + r%(F n) of dx
     Mt = B * F * n
     side.wait()

@@ -36,7 +36,13 @@ class _Aux:
         self.mask = mask.to(device=dev, dtype=torch.uint8).contiguous()
         self.ident = identities_mask.to(device=dev, dtype=torch.uint8).contiguous()
         self.sizes = None
+        rows = model.pos_emb.weight.shape[0]
         if model.enable_size_emb:
+            if size_embedding is not None and not size_embedding.is_cuda and size_embedding.numel():
+                # the reference's callers leave it on the host (train.py:355): range-check for free, like nn.Embedding would
+                lo, hi = int(size_embedding.min()), int(size_embedding.max())
+                if lo < 0 or hi >= model.size_emb.weight.shape[0]:
+                    raise IndexError(f"size_embedding values must lie in [0, {model.size_emb.weight.shape[0]}); got [{lo}, {hi}]")
             # arrives as a CPU int32 tensor in the reference call sites (train.py:355); moved here like :245 -- through a pinned
             # staging buffer and an async copy: a pageable H2D copy blocks the host until the stream has drained the whole
             # extractor forward, and the GPU then idles (~0.3 ms per step) while the host re-fills the launch queue
@@ -46,7 +52,42 @@ class _Aux:
             self.sizes = se.to(device=dev).contiguous()
         self.positions = None
         if model.enable_pos_emb:
+            if not positions.is_cuda and positions.numel():
+                lo, hi = int(positions.min()), int(positions.max())
+                if lo < 0 or hi >= rows:
+                    raise IndexError(f"positions must lie in [0, {rows}); got [{lo}, {hi}]")
             self.positions = positions.to(device=dev, dtype=torch.int64).contiguous()
+        # device-resident indices cannot be checked without a sync: the embedding kernels clamp them and raise a sticky flag
+        # that is looked at when the NEXT forward starts (a deferred device-side assert, like nn.Embedding on a GPU)
+        self.err = _index_flag(model, dev)
+
+
+def _index_flag(model, dev):
+    st = model.__dict__.setdefault("_index_flags", {})
+    key = str(dev)
+    if key in st:
+        flag, host, ev = st[key]
+        if ev is not None and ev.query():
+            bad = int(host[0])
+            if bad:
+                flag.zero_()
+                host.zero_()
+                what = " and ".join(n for bit, n in ((1, "positions"), (2, "size_embedding")) if bad & bit)
+                raise IndexError(f"an earlier SizeInvariantTimeSformer.forward received out-of-range {what} indices "
+                                 "(they were clamped into the embedding tables)")
+    else:
+        st[key] = [torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+    return st[key]
+
+
+def _publish_index_flag(state):
+    if torch.cuda.is_current_stream_capturing():
+        return
+    flag, host, _ = state
+    host.copy_(flag, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    state[2] = ev
 
 
 def _new(dev, *shape):
@@ -70,7 +111,9 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
     x = _new(dev, B, N, D)
     L.gemm(L.OP_NT, feat, w_pe, x, B * F * n, D, C_in, C_in, C_in, D, bias=b_pe, c_map=(F * n, N, 1))
     L.check(lib.mt_embed_fwd(L.ptr(x), L.ptr(cls), L.ptr(pos_w), L.ptr(size_w), L.ptr(aux.positions), L.ptr(aux.sizes),
-                             B, F, n, D, st), "mt_embed_fwd")
+                             B, F, n, D, pos_w.shape[0], size_w.shape[0] if size_w is not None else 0, L.ptr(aux.err[0]), st),
+            "mt_embed_fwd")
+    _publish_index_flag(aux.err)
 
     saved = {"layers": []} if save else None
     want_att = model.require_attention
@@ -114,8 +157,9 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
         L.check(lib.mt_layernorm_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(xn), L.ptr(stats), M, D, eps, st), "mt_layernorm_fwd")
         L.gemm(L.OP_NT, xn, w1, hbuf, M, 8 * D, D, D, D, 4 * D, epilogue=L.EPI_GEGLU, bias=b1, C2=u, ldc2=8 * D, n_half=4 * D)
         # FF2 is skinny (N = 512 -> 396 output tiles on 256 CUs): 5 K-slices accumulated with fp32 atomics onto the residual
-        # even out the tail (measured 333 -> 270 us at B = 32)
-        if M >= 4096:
+        # even out the tail (measured 333 -> 270 us at B = 32).  Training only: atomics make the sum order -- the last bits of
+        # the logits -- vary from run to run, and inference (no saved buffers) stays bit-reproducible at every batch size.
+        if M >= 4096 and save:
             x_new = x.clone() if save else x
             L.gemm(L.OP_NT, hbuf, w2, x_new, M, D, 4 * D, 4 * D, 4 * D, D, epilogue=L.EPI_ATOMIC, bias=b2, split_k=5)
         else:
@@ -151,6 +195,9 @@ class _TSFFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits, *unused):
         from .tsf_backward import tsf_backward
+        if ctx.saved is None:
+            raise RuntimeError("SizeInvariantTimeSformer: backward ran a second time through the same forward; the activation "
+                               "buffers are released after the first pass (retain_graph is not supported by the HIP engine)")
         dfeat, dparams = tsf_backward(ctx.model, ctx.feat, ctx.aux, ctx.params, ctx.dims, ctx.saved,
                                       dlogits.contiguous(), ctx.needs_input_grad[3], ctx.needs_input_grad[4:])
         ctx.saved = None

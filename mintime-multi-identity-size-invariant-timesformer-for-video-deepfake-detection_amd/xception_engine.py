@@ -336,6 +336,9 @@ class _XceptionFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dfeat):
+        if ctx.saved is None:
+            raise RuntimeError("Xception: backward ran a second time through the same forward; the activation buffers are "
+                               "released after the first pass (retain_graph is not supported by the HIP engine)")
         if ctx.needs_input_grad[1]:
             raise NotImplementedError("gradient w.r.t. the input crops is not part of the MINTIME training path")
         dparams = xception_backward(ctx.model, ctx.params, ctx.saved, ctx.shape, ctx.training, dfeat.contiguous(),

@@ -306,47 +306,103 @@ _DP2_SCRIPT = r"""
 import os, sys, json, torch, torch.distributed as dist
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.getcwd())
-rank = int(sys.argv[1]); port = sys.argv[2]
+rank = int(sys.argv[1]); port = sys.argv[2]; mode = sys.argv[3]; outdir = sys.argv[4]
 os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = port
 import mintime_amd
-from mintime_amd import harness, ddp
+from mintime_amd import harness, ddp, optim
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=2)           # two ranks share the one GPU of the test box; gloo moves CUDA tensors
+lo, hi = ddp.shard_range(4, rank, 2)                                # global batch of 4 clips, 2 per rank
+
+def shard(step):
+    full = harness.device_batch(4, seed=10 + step)
+    return {k: (v[lo:hi] if torch.is_tensor(v) else v) for k, v in full.items()}
+
+def picked(ef, tsf):
+    tp, ep = list(tsf.named_parameters()), [(k, p) for k, p in ef.named_parameters() if not k.startswith("_fc") and not k.endswith("_bn2.bias")]   # _bn2.bias: analytically zero gradient (rounding noise only)
+    return tp[:6] + tp[-6:] + tp[40:44] + ep[:6] + ep[-6:] + ep[100:104]
+
+# (a) what this rank computes ALONE on its shard (no reducer, no process group involved)
+cfg, ef0, tsf0 = harness.build_models(seed=3, device="cuda", drop_connect_rate=0.0)
+y = harness.forward(ef0, tsf0, shard(0))
+optim.bce_with_logits(y, shard(0)["labels"], None).backward()
+alone = {k: p.grad.detach().cpu().clone() for k, p in picked(ef0, tsf0)}
+del ef0, tsf0
+# (b) the data-parallel step
 cfg, ef, tsf = harness.build_models(seed=3, device="cuda", drop_connect_rate=0.0)
 opt = harness.make_optimizer(cfg, ef, tsf)
-red = ddp.OverlappedGradReducer([tsf, ef])
-lo, hi = ddp.shard_range(4, rank, 2)                                # global batch of 4 clips, 2 per rank
-for step in range(2):
-    full = harness.device_batch(4, seed=10 + step)
-    mine = {k: (v[lo:hi] if torch.is_tensor(v) else v) for k, v in full.items()}
-    loss = harness.train_step(ef, tsf, opt, mine, red)
+if mode == "overlap":
+    red = ddp.OverlappedGradReducer([tsf, ef])
+else:
+    red = ddp.GradAllReducer(list(ef.parameters()) + list(tsf.parameters()))
+loss = harness.train_step(ef, tsf, opt, shard(0), red)
+torch.cuda.synchronize()
+averaged = {k: p.grad.detach().cpu().clone() for k, p in picked(ef, tsf)}
+torch.save({"alone": alone, "averaged": averaged}, os.path.join(outdir, f"grads_{mode}_{rank}.pt"))
+loss = harness.train_step(ef, tsf, opt, shard(1), red)
 torch.cuda.synchronize()
 sig = [float(p.detach().double().norm()) for p in list(tsf.parameters())[:8] + list(ef.parameters())[:8]]
 gsig = [float(p.grad.detach().double().norm()) for p in list(tsf.parameters())[:8] + list(ef.parameters())[:8] if p.grad is not None]
-print("RESULT " + json.dumps({"rank": rank, "params": sig, "grads": gsig, "stats": dict(red.stats)}), flush=True)
+print("RESULT " + json.dumps({"rank": rank, "params": sig, "grads": gsig, "stats": dict(getattr(red, "stats", {}))}), flush=True)
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
-def test_two_rank_data_parallel_step_keeps_replicas_identical(tmp_path):
+@pytest.mark.parametrize("mode", ["overlap", "flat"])
+def test_two_rank_data_parallel_step_keeps_replicas_identical(tmp_path, mode):
     """Row (e) end to end with the real engines: two processes (sharing this box's single GPU, gloo transport) each train on their
-    shard of a 4-clip batch; the engine-level bucket hooks must fire on both, and after two steps parameters and (averaged) gradients
-    must agree between the ranks."""
+    shard of a 4-clip batch.  VALUE check: the gradient every rank ends up with equals the mean of what each rank computes alone on
+    its shard (a separate, reducer-free run inside each process); the engine-level bucket hooks must fire on both ranks
+    (mode "overlap") / the flat fallback reducer bench.py falls back to must give the same result (mode "flat"); after two steps
+    parameters and gradients agree between the ranks."""
     import json, subprocess, sys, os
     script = tmp_path / "dp2.py"
     script.write_text(_DP2_SCRIPT)
-    port = str(24500 + os.getpid() % 1000)
+    port = str(24500 + os.getpid() % 1000 + (0 if mode == "overlap" else 1000))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), port], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                              cwd=root) for r in (0, 1)]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, mode, str(tmp_path)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, cwd=root) for r in (0, 1)]
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
     res = [json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]) for so, _ in outs]
-    for r in res:
-        assert r["stats"]["overlapped_launches"] == 4 and r["stats"]["synchronous"] == 0, r["stats"]
+    if mode == "overlap":
+        for r in res:
+            assert r["stats"]["overlapped_launches"] == 4 and r["stats"]["synchronous"] == 0, r["stats"]
     for a, b in zip(res[0]["params"], res[1]["params"]):
         assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (a, b)
     for a, b in zip(res[0]["grads"], res[1]["grads"]):
         assert abs(a - b) <= 1e-6 * max(1e-3, abs(a)), (a, b)
+    g0, g1 = (torch.load(tmp_path / f"grads_{mode}_{r}.pt") for r in (0, 1))
+    assert len(g0["alone"]) >= 30
+    for k in g0["alone"]:
+        want = (g0["alone"][k].double() + g1["alone"][k].double()) / 2
+        for g in (g0, g1):
+            got = g["averaged"][k].double()
+            den = float(want.norm())
+            if den == 0.0:
+                assert float(got.norm()) == 0.0, k
+            else:
+                assert float((got - want).norm()) <= 2e-4 * den, (k, float((got - want).norm()) / den)
+
+
+def test_nn_dataparallel_wrap_on_one_gpu_is_transparent():
+    """train.py:294-296 / test.py:129-133 / predict.py:378-379 wrap both modules in nn.DataParallel.  On one visible GPU that
+    wrapper scatters the inputs (moving the host-resident size_embedding to the device) and calls the module: forward, backward
+    and state_dict keys ('module.' prefix, as the reference's checkpoints have) must behave exactly like the bare modules."""
+    cfg, ef, tsf, _, _ = _models(0, 8, True, require_attention=True)
+    inp = synth.clip_inputs(2, 8, 2, 0, ragged=True)
+    _, (y0, (s0, t0)) = _step(ef, tsf, inp)
+    torch.nn.functional.binary_cross_entropy_with_logits(y0, inp["labels"].reshape(-1, 1).cuda()).backward()
+    g0 = {k: p.grad.clone() for k, p in list(tsf.named_parameters()) + list(ef.named_parameters()) if p.grad is not None}
+    cfg, ef1, tsf1, _, _ = _models(0, 8, True, require_attention=True)
+    dp_ef, dp_tsf = torch.nn.DataParallel(ef1, device_ids=[0]), torch.nn.DataParallel(tsf1, device_ids=[0])
+    assert all(k.startswith("module.") for k in dp_tsf.state_dict())
+    _, (y1, (s1, t1)) = _step(dp_ef, dp_tsf, inp)
+    torch.nn.functional.binary_cross_entropy_with_logits(y1, inp["labels"].reshape(-1, 1).cuda()).backward()
+    assert_close(y1, y0, 1e-5, "logits through DataParallel")
+    assert_close(s1, s0, 1e-5, "space attention through DataParallel")
+    for k, p in list(tsf1.named_parameters()) + list(ef1.named_parameters()):
+        if p.grad is not None:
+            assert_close(p.grad, g0[k], 2e-4, "grad through DataParallel " + k)      # atomics order only

@@ -196,3 +196,65 @@ def test_full_size_batch_logits_and_all_gradients_vs_oracle():
             assert float(p.grad.abs().max()) == 0.0, k
         else:
             assert_close(p.grad, ref, REL_TOL, "grad " + k)
+
+
+def test_out_of_range_indices_are_caught_not_dereferenced():
+    """nn.Embedding raises on a bad index (size_invariant_timesformer.py:236,248).  Host-resident indices are range-checked
+    immediately; device-resident ones are clamped in the kernels (no out-of-bounds read or atomic) and reported when the next
+    forward starts."""
+    Fr, C = 8, 1280
+    cfg = arch.default_tsf_config(C, Fr)
+    model, _ = _build(cfg, 0, require_attention=False)
+    feats = synth.features(1, Fr, C, 0).cuda()
+    aux = synth.clip_inputs(1, Fr, 1, 0, with_video=False)
+    kw = dict(mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda())
+    bad_size = aux["size_embedding"].clone()
+    bad_size[0, 3] = 10 ** 6
+    with pytest.raises(IndexError):
+        model(feats, size_embedding=bad_size, positions=aux["positions"].cuda(), **kw)
+    neg = aux["size_embedding"].clone()
+    neg[0, 0] = -1
+    with pytest.raises(IndexError):
+        model(feats, size_embedding=neg, positions=aux["positions"].cuda(), **kw)
+    bad_pos = aux["positions"].clone()
+    bad_pos[0, 5] = 10 ** 9
+    with pytest.raises(IndexError):
+        model(feats, size_embedding=aux["size_embedding"], positions=bad_pos, **kw)          # host tensor: immediate
+    x = feats.clone().requires_grad_(True)
+    out = model(x, size_embedding=aux["size_embedding"], positions=bad_pos.cuda(), **kw)     # device tensor: clamped + flagged
+    out.sum().backward()                                                                     # the scatter-add is clamped too
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.isfinite(model.pos_emb.weight.grad).all()
+    with pytest.raises(IndexError, match="positions"):
+        model(feats, size_embedding=aux["size_embedding"], positions=aux["positions"].cuda(), **kw)
+    good = model(feats, size_embedding=aux["size_embedding"], positions=aux["positions"].cuda(), **kw)   # flag was cleared
+    assert torch.isfinite(good).all()
+
+
+def test_eval_forward_is_bit_reproducible_at_large_batch():
+    """Inference never takes the split-K + atomics branch (tsf_engine: `M >= 4096 and save`): same bits every run at B = 16."""
+    B, Fr, C = 16, 8, 1280
+    cfg = arch.default_tsf_config(C, Fr)
+    model, _ = _build(cfg, 0, require_attention=False)
+    model.eval()
+    feats = synth.features(B, Fr, C, 1).cuda()
+    aux = synth.clip_inputs(B, Fr, 2, 1, ragged=True, with_video=False)
+    outs = []
+    with torch.no_grad():
+        for _ in range(3):
+            outs.append(model(feats, mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(),
+                              size_embedding=aux["size_embedding"], positions=aux["positions"].cuda()).clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_second_backward_through_the_same_forward_raises_clearly():
+    Fr, C = 8, 1280
+    cfg = arch.default_tsf_config(C, Fr)
+    model, _ = _build(cfg, 0, require_attention=False)
+    feats = synth.features(1, Fr, C, 0).cuda()
+    aux = synth.clip_inputs(1, Fr, 1, 0, with_video=False)
+    out = model(feats, mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(),
+                size_embedding=aux["size_embedding"], positions=aux["positions"].cuda())
+    out.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        out.sum().backward()

@@ -299,3 +299,90 @@ def test_engine_level_bucket_hooks_world_size_2_gloo():
     assert torch.allclose(r0[2][1][0], torch.full((3, 5), want), rtol=1e-5)
     for a, b in zip(acc0, acc1):
         assert torch.equal(a, b)
+
+
+class _EngineLikeOptional(_EngineLike):
+    """An engine whose parameter list has an empty slot (SizeInvariantTimeSformer._param_list() puts None where size_emb would
+    be when enable-size-emb is False): the None is handed to lib.zero_grads / lib.grads_ready exactly like tsf_backward does."""
+
+    def forward(self, x):
+        model = self
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, *params):
+                ctx.save_for_backward(x)
+                return x * sum(p.sum() for p in params)
+
+            @staticmethod
+            def backward(ctx, gout):
+                (x,) = ctx.saved_tensors
+                real = list(model.ps)
+                params = real[:1] + [None] + real[1:]
+                grads, flat = lib.zero_grads(params, with_flat=True)
+                for gr in grads:
+                    if gr is not None:
+                        gr += float((gout * x).sum())
+                lib.grads_ready(model, params, flat)
+                return (gout * sum(p.sum() for p in real).detach(),) + tuple(g for g in grads if g is not None)
+
+        return Fn.apply(x, *self.ps)
+
+
+def _advice_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    # (1) replicas that start from different weights are made identical at construction
+    net = _EngineLikeOptional([(3, 5), (7,), (2, 3)], seed=10 + rank)
+    before = [p.detach().clone() for p in net.parameters()]
+    red = ddp.OverlappedGradReducer([net])
+    res["init"] = ([p.detach().clone() for p in net.parameters()], before)
+    # (2) a None slot in the engine's parameter list (no space in the flat buffer) is reduced correctly, in place
+    x = torch.full((3,), float(rank + 1))
+    net(x).sum().backward()
+    red.allreduce()
+    res["none_slot"] = ([p.grad.clone() for p in net.parameters()], dict(red.stats))
+    # (3) gradient accumulation: two micro-batches, the first under no_sync()
+    for p in net.parameters():
+        p.grad = None
+    with red.no_sync():
+        net(torch.full((3,), float(rank + 1))).sum().backward()
+    net(torch.full((3,), float(10 * (rank + 1)))).sum().backward()
+    red.allreduce()
+    res["accum"] = [p.grad.clone() for p in net.parameters()]
+    # (4) two backward passes without no_sync(): refused loudly instead of silently dropping the second micro-batch
+    for p in net.parameters():
+        p.grad = None
+    net(x).sum().backward()
+    try:
+        net(x).sum().backward()
+        res["double"] = "no error"
+    except RuntimeError as e:
+        res["double"] = str(e)
+    red.allreduce()
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_reducer_broadcast_none_slot_accumulation_world_size_2_gloo():
+    """initial broadcast, None parameter slots, gradient accumulation (no_sync) and the double-backward guard."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_advice_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    for a, b in zip(r0["init"][0], r1["init"][0]):
+        assert torch.equal(a, b)                                   # rank 1 adopted rank 0's weights
+    assert any(not torch.equal(a, b) for a, b in zip(r1["init"][0], r1["init"][1]))
+    # after the broadcast both ranks hold rank 0's weights: d/dp = sum(x) = 3*(rank+1); mean over ranks = 4.5
+    for g0, g1 in zip(r0["none_slot"][0], r1["none_slot"][0]):
+        assert torch.equal(g0, g1) and torch.allclose(g0, torch.full_like(g0, 4.5))
+    assert r0["none_slot"][1]["overlapped_launches"] == 1
+    # accumulation: per rank 3*(r+1) + 30*(r+1) = 33*(r+1); mean of 33 and 66 = 49.5
+    for g0, g1 in zip(r0["accum"], r1["accum"]):
+        assert torch.equal(g0, g1) and torch.allclose(g0, torch.full_like(g0, 49.5))
+    assert "no_sync" in r0["double"] and "no_sync" in r1["double"]
