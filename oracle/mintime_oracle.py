@@ -178,10 +178,15 @@ def xception_block_units(cin, cout, reps, grow_first):
 
 
 def xception_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool = False,
-                     bn_state: Optional[BNState] = None, taps: Optional[dict] = None):
+                     bn_state: Optional[BNState] = None, taps: Optional[dict] = None, masks: Optional[list] = None):
     """x [N,3,224,224] -> bn4 output [N,2048,7,7] WITHOUT the final ReLU (xception.py:161-203, 215-217)."""
-    x = F.relu(_xc_bn(F.conv2d(x, sd["conv1.weight"], None, 2, 0), sd, "bn1", training, bn_state))
-    x = F.relu(_xc_bn(F.conv2d(x, sd["conv2.weight"], None, 1, 0), sd, "bn2", training, bn_state))
+    def relu(t):
+        if masks is not None:                    # the piecewise-linear decisions of the forward: ReLU signs, max-pool winners
+            masks.append(("relu", (t > 0).detach()))
+        return F.relu(t)
+
+    x = relu(_xc_bn(F.conv2d(x, sd["conv1.weight"], None, 2, 0), sd, "bn1", training, bn_state))
+    x = relu(_xc_bn(F.conv2d(x, sd["conv2.weight"], None, 1, 0), sd, "bn2", training, bn_state))
     for (name, cin, cout, reps, stride, start_relu, grow_first) in _XC_BLOCKS:
         inp = x
         units = xception_block_units(cin, cout, reps, grow_first)
@@ -190,12 +195,14 @@ def xception_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: boo
         idx = 0
         for u in range(len(units)):
             if u > 0 or start_relu:
-                x = F.relu(x)
+                x = relu(x)
                 idx += 1
             x = _xc_sep(x, sd, f"{name}.rep.{idx}")
             x = _xc_bn(x, sd, f"{name}.rep.{idx + 1}", training, bn_state)
             idx += 2
         if stride != 1:
+            if masks is not None:
+                masks.append(("maxpool", F.max_pool2d(x, 3, stride, 1, return_indices=True)[1].detach()))
             x = F.max_pool2d(x, 3, stride, 1)
         if cout != cin or stride != 1:
             skip = _xc_bn(F.conv2d(inp, sd[f"{name}.skip.weight"], None, stride), sd, f"{name}.skipbn", training, bn_state)
@@ -204,7 +211,7 @@ def xception_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: boo
         x = x + skip
         if taps is not None:
             taps[name] = x
-    x = F.relu(_xc_bn(_xc_sep(x, sd, "conv3"), sd, "bn3", training, bn_state))
+    x = relu(_xc_bn(_xc_sep(x, sd, "conv3"), sd, "bn3", training, bn_state))
     x = _xc_bn(_xc_sep(x, sd, "conv4"), sd, "bn4", training, bn_state)
     return x
 

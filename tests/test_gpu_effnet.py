@@ -106,10 +106,22 @@ def test_uint8_crops_are_ingested_directly():
         fo = O.effnet_b0_forward(osd, x8.double().permute(0, 3, 1, 2), training=training)
         (fo * gw.double()).sum().backward()
         assert_close(f, fo, REL_TOL, f"uint8 features vs oracle (training={training})")
-        for k, p in model.named_parameters():
-            if k.startswith("_fc"):
-                continue
-            assert_close(p.grad, osd[k].grad, 3e-3, f"uint8 grad {k} (training={training})")
+        _assert_all_grads(model, osd, training, f"uint8 (training={training})")
+
+
+def _assert_all_grads(model, osd, training, what):
+    """Every EfficientNet parameter gradient vs the oracle's.  In train mode d/d(_bn2.bias) is analytically zero (a per-channel
+    shift of a block output is removed by the train-mode BatchNorm behind the next 1x1 conv): both sides hold rounding noise."""
+    named = dict(model.named_parameters())
+    for k, p in named.items():
+        if k.startswith("_fc"):
+            continue
+        ref = osd[k].grad
+        if training and k.endswith("_bn2.bias"):
+            wn = float(named[k.replace(".bias", ".weight")].grad.norm())
+            assert float(p.grad.norm()) < 1e-3 * wn and float(ref.norm()) < 1e-3 * wn, k
+            continue
+        assert_close(p.grad, ref, 3e-3, f"{what}: grad {k}")
 
 
 def _dc_model(g):
@@ -152,10 +164,7 @@ def test_drop_connect_matches_reference_fixture():
     osd = {k: (v.double().requires_grad_("running_" not in k) if v.is_floating_point() else v) for k, v in sd.items()}
     fo = O.effnet_b0_forward(osd, x.double(), training=True, drop_connect_rate=rate, dc_uniform=u)
     (fo * gw.double()).sum().backward()
-    for k, p in named.items():
-        if k.startswith("_fc"):
-            continue
-        assert_close(p.grad, osd[k].grad, 3e-3, "grad " + k)
+    _assert_all_grads(model, osd, True, "drop-connect 0.2")
 
 
 def test_drop_connect_default_sampler_statistics():

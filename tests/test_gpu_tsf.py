@@ -178,7 +178,7 @@ def test_full_size_batch_logits_and_all_gradients_vs_oracle():
     x = feats.cuda().requires_grad_(True)
     out, (s_att, t_att) = model(x, mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(),
                                 size_embedding=aux["size_embedding"], positions=aux["positions"].cuda())
-    w = torch.linspace(-1.0, 1.0, B).reshape(B, 1)
+    w = torch.linspace(-1.0, 1.3, B).reshape(B, 1)          # (weights that do not sum to zero: d/d(head bias) = sum(w))
     (out.cpu() * w).sum().backward()
     osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     xo = feats.clone().requires_grad_(True)

@@ -218,3 +218,27 @@ def test_aggregate_attentions_matches_reference():
         agg, ident = O.aggregate_attentions(atts, 8, int(g[tag + "_frames"]), [int(v) for v in g[tag + "_fpi"]])
         assert_close(np.asarray(agg), g[tag + "_agg"], 1e-12, "aggregated attentions " + tag)
         assert_close(np.asarray(ident), g[tag + "_ident"], 1e-12, "identity attentions " + tag)
+
+
+def test_xception_fp32_rounding_flips_relu_and_maxpool_decisions():
+    """Why the Xception gradient tolerances are looser than 1e-3 (tests/test_gpu_xception.py, test_gpu_e2e.py config 5): the
+    network is piecewise linear, and float32 rounding alone flips some of its decisions.  Count them: the oracle in float32 vs
+    the same oracle in float64 (the reference's exact arithmetic) on the xc_train fixture inputs.  Every flipped ReLU sign or
+    max-pool winner reroutes a gradient path, so two correct fp32 implementations agree only up to these flips."""
+    g = golden("xc_train")
+    n, seed = int(g["n_img"]), int(g["seed"])
+    sd = synth.xception_state(seed)
+    x = synth.clip_inputs(1, n, 1, seed)["videos"].reshape(n, 224, 224, 3).permute(0, 3, 1, 2)
+    m32, m64 = [], []
+    with torch.no_grad():
+        O.xception_forward(sd, x, training=True, masks=m32)
+        O.xception_forward(O.to_dtype(sd, torch.float64), x.double(), training=True, masks=m64)
+    assert len(m32) == len(m64) == 34 + 4      # ReLUs: conv1, conv2, 1 + 2 + 2 + 8*3 + 2 in the blocks, conv3; 4 strided blocks' max-pools
+    flips = {"relu": 0, "maxpool": 0}
+    total = {"relu": 0, "maxpool": 0}
+    for (k, a), (_, b) in zip(m32, m64):
+        flips[k] += int((a != b).sum())
+        total[k] += a.numel()
+    print(f"fp32-vs-fp64 decision flips: ReLU {flips['relu']} of {total['relu']}, max-pool {flips['maxpool']} of {total['maxpool']}")
+    assert flips["relu"] > 0 and flips["maxpool"] > 0            # the phenomenon exists ...
+    assert flips["relu"] < 1e-3 * total["relu"] and flips["maxpool"] < 1e-3 * total["maxpool"]      # ... and is rare
