@@ -166,6 +166,127 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// ---- XCD-aware tile order.  Block b runs on XCD b % 8 (observed dispatch; used for speed only, never for correctness).
+// Returns false for a padding block of the L2-blocked order.
+template <int BM, int BN>
+__device__ __forceinline__ bool tile_coords(const GemmArgs& p, int& mt_, int& nt_) {
+  const int n_tiles = (p.N + BN - 1) / BN;     // for GEGLU p.N is the full GEMM width (2*n_half)
+  const int m_tiles = (p.M + BM - 1) / BM;
+  if (p.group_n > 0) {
+    // L2-blocked order for tall problems: every XCD owns a contiguous band of tile ROWS and sweeps it one group of
+    // `group_n` tile columns at a time, so the group's B panels (group_n x BN x K floats, sized to ~2 MB) stay in that XCD's
+    // 4 MB L2 while the A row-panels stream past once per group.  Without it an 8 MB weight matrix is re-fetched from
+    // the Infinity Cache for every 128-row panel (FETCH_SIZE 20x the algorithmic read on the FF1 GEMM).
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int q = m_tiles >> 3, r = m_tiles & 7;
+    const int row0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int rows = q + (xcd < r ? 1 : 0);
+    if (rows == 0) return false;
+    const int per_group = rows * p.group_n;
+    const int groups = (n_tiles + p.group_n - 1) / p.group_n;
+    int g = idx / per_group;
+    if (g > groups - 1) g = groups - 1;
+    const int rem = idx - g * per_group;
+    const int gw = (g == groups - 1) ? n_tiles - g * p.group_n : p.group_n;
+    const int ml = rem / gw;
+    if (ml >= rows) return false;               // padding block (bands differ by one row)
+    mt_ = row0 + ml;
+    nt_ = g * p.group_n + (rem - ml * gw);
+  } else {
+    // default: consecutive logical tiles (sharing an A row-panel) land on one XCD's L2
+    const int nblk = n_tiles * m_tiles;
+    int bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    mt_ = bid / n_tiles;
+    nt_ = bid - mt_ * n_tiles;
+  }
+  return true;
+}
+
+// Accumulator store with the fused epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane) {
+  const int col_l = lane & 31;
+  const int row_h = (lane >> 5) * 4;
+
+  if constexpr (EPI == EPI_GEGLU) {
+    // acc[i][0] = 'a' pre-activation, acc[i][1] = gate pre-activation, same (row, col) in one lane
+    const int j = (n0 >> 1) + wn * 32 + col_l;
+    const bool jok = j < p.n_half;
+    const float ba = (jok && p.bias) ? p.bias[j] : 0.f;
+    const float bg = (jok && p.bias) ? p.bias[p.n_half + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        if (m < p.M && jok) {
+          const float a = acc[i][0][r] + ba;
+          const float g = acc[i][1][r] + bg;
+          p.C[(int64_t)m * p.ldc + j] = a * gelu_erf(g);
+          if (p.C2) {
+            // pre-activations interleaved (a_j, g_j): one 8-byte store per lane here, one 8-byte load in GEGLU_BWD
+            *reinterpret_cast<float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * j) = make_float2(a, g);
+          }
+        }
+      }
+    }
+    return;
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+      const bool nok = n < p.N;
+      float bias = 0.f;
+      if constexpr (EPI == EPI_STORE || EPI == EPI_BIAS_RES || EPI == EPI_ACCUM)
+        bias = (nok && p.bias) ? p.bias[n] : 0.f;
+      if constexpr (EPI == EPI_ATOMIC)      // split-K: the bias rides on the first K-slice only
+        bias = (nok && p.bias && blockIdx.y == 0) ? p.bias[n] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+          if (m < p.M && nok) {
+            float v = acc[i][j][r];
+            const int64_t crow = map_row(p.c_map, m);
+            if constexpr (EPI == EPI_STORE) {
+              p.C[crow * p.ldc + n] = v + bias;
+            } else if constexpr (EPI == EPI_BIAS_RES) {
+              p.C[crow * p.ldc + n] = v + bias + p.R[crow * p.ldr + n];
+            } else if constexpr (EPI == EPI_ACCUM) {
+              p.C[crow * p.ldc + n] += v + bias;
+            } else if constexpr (EPI == EPI_STATS) {
+              p.C[crow * p.ldc + n] = v;
+              s1 += v; s2 += v * v;
+            } else if constexpr (EPI == EPI_ATOMIC) {
+              atomicAdd(p.C + crow * p.ldc + n, v + bias);
+            } else if constexpr (EPI == EPI_GEGLU_BWD) {
+              // n indexes h columns [0, n_half); u = [a | g] pre-activations
+              const float2 ag = *reinterpret_cast<const float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * n);
+              const float a = ag.x, g = ag.y;
+              p.C[crow * p.ldc + n] = v * gelu_erf(g);
+              p.C[crow * p.ldc + p.n_half + n] = v * a * gelu_erf_grad(g);
+            }
+          }
+        }
+      }
+      if constexpr (EPI == EPI_STATS) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lane < 32 && nok) {
+          double* st = p.stats + (int64_t)(blockIdx.x % p.stats_slots) * 2 * p.N;
+          atomicAdd(st + n, (double)s1);
+          atomicAdd(st + p.N + n, (double)s2);
+        }
+      }
+    }
+  }
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI, int BPRO = BPRO_NONE>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MT_MIN_WAVES)
 void gemm_kernel(const GemmArgs p) {
@@ -200,40 +321,8 @@ void gemm_kernel(const GemmArgs p) {
   const int wm = wave / WAVES_N;
   const int wn = wave % WAVES_N;
 
-  // ---- XCD-aware tile order.  Block b runs on XCD b % 8 (observed dispatch; used for speed only, never for correctness).
-  const int n_tiles = (p.N + BN - 1) / BN;     // for GEGLU p.N is the full GEMM width (2*n_half)
-  const int m_tiles = (p.M + BM - 1) / BM;
   int mt_, nt_;
-  if (p.group_n > 0) {
-    // L2-blocked order for tall problems: every XCD owns a contiguous band of tile ROWS and sweeps it one group of
-    // `group_n` tile columns at a time, so the group's B panels (group_n x BN x K floats, sized to ~2 MB) stay in that XCD's
-    // 4 MB L2 while the A row-panels stream past once per group.  Without it an 8 MB weight matrix is re-fetched from
-    // the Infinity Cache for every 128-row panel (FETCH_SIZE 20x the algorithmic read on the FF1 GEMM).
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int q = m_tiles >> 3, r = m_tiles & 7;
-    const int row0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const int rows = q + (xcd < r ? 1 : 0);
-    if (rows == 0) return;
-    const int per_group = rows * p.group_n;
-    const int groups = (n_tiles + p.group_n - 1) / p.group_n;
-    int g = idx / per_group;
-    if (g > groups - 1) g = groups - 1;
-    const int rem = idx - g * per_group;
-    const int gw = (g == groups - 1) ? n_tiles - g * p.group_n : p.group_n;
-    const int ml = rem / gw;
-    if (ml >= rows) return;                     // padding block (bands differ by one row)
-    mt_ = row0 + ml;
-    nt_ = g * p.group_n + (rem - ml * gw);
-  } else {
-    // default: consecutive logical tiles (sharing an A row-panel) land on one XCD's L2
-    const int nblk = n_tiles * m_tiles;
-    int bid = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    mt_ = bid / n_tiles;
-    nt_ = bid - mt_ * n_tiles;
-  }
+  if (!tile_coords<BM, BN>(p, mt_, nt_)) return;
   const int m0 = mt_ * BM;
   const int n0 = nt_ * BN;
 
@@ -450,86 +539,7 @@ void gemm_kernel(const GemmArgs p) {
   }
 
   if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
-  // ------------------------------------------------------------------ epilogue
-  // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int col_l = lane & 31;
-  const int row_h = (lane >> 5) * 4;
-
-  if constexpr (EPI == EPI_GEGLU) {
-    // acc[i][0] = 'a' pre-activation, acc[i][1] = gate pre-activation, same (row, col) in one lane
-    const int j = (n0 >> 1) + wn * 32 + col_l;
-    const bool jok = j < p.n_half;
-    const float ba = (jok && p.bias) ? p.bias[j] : 0.f;
-    const float bg = (jok && p.bias) ? p.bias[p.n_half + j] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-        if (m < p.M && jok) {
-          const float a = acc[i][0][r] + ba;
-          const float g = acc[i][1][r] + bg;
-          p.C[(int64_t)m * p.ldc + j] = a * gelu_erf(g);
-          if (p.C2) {
-            // pre-activations interleaved (a_j, g_j): one 8-byte store per lane here, one 8-byte load in GEGLU_BWD
-            *reinterpret_cast<float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * j) = make_float2(a, g);
-          }
-        }
-      }
-    }
-    if (tr && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); tr[3] = wall_clock64(); }
-    return;
-  } else {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * TN * 32 + j * 32 + col_l;
-      const bool nok = n < p.N;
-      float bias = 0.f;
-      if constexpr (EPI == EPI_STORE || EPI == EPI_BIAS_RES || EPI == EPI_ACCUM)
-        bias = (nok && p.bias) ? p.bias[n] : 0.f;
-      if constexpr (EPI == EPI_ATOMIC)      // split-K: the bias rides on the first K-slice only
-        bias = (nok && p.bias && blockIdx.y == 0) ? p.bias[n] : 0.f;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-          if (m < p.M && nok) {
-            float v = acc[i][j][r];
-            const int64_t crow = map_row(p.c_map, m);
-            if constexpr (EPI == EPI_STORE) {
-              p.C[crow * p.ldc + n] = v + bias;
-            } else if constexpr (EPI == EPI_BIAS_RES) {
-              p.C[crow * p.ldc + n] = v + bias + p.R[crow * p.ldr + n];
-            } else if constexpr (EPI == EPI_ACCUM) {
-              p.C[crow * p.ldc + n] += v + bias;
-            } else if constexpr (EPI == EPI_STATS) {
-              p.C[crow * p.ldc + n] = v;
-              s1 += v; s2 += v * v;
-            } else if constexpr (EPI == EPI_ATOMIC) {
-              atomicAdd(p.C + crow * p.ldc + n, v + bias);
-            } else if constexpr (EPI == EPI_GEGLU_BWD) {
-              // n indexes h columns [0, n_half); u = [a | g] pre-activations
-              const float2 ag = *reinterpret_cast<const float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * n);
-              const float a = ag.x, g = ag.y;
-              p.C[crow * p.ldc + n] = v * gelu_erf(g);
-              p.C[crow * p.ldc + p.n_half + n] = v * a * gelu_erf_grad(g);
-            }
-          }
-        }
-      }
-      if constexpr (EPI == EPI_STATS) {
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (lane < 32 && nok) {
-          double* st = p.stats + (int64_t)(blockIdx.x % p.stats_slots) * 2 * p.N;
-          atomicAdd(st + n, (double)s1);
-          atomicAdd(st + p.N + n, (double)s2);
-        }
-      }
-    }
-  }
+  gemm_epilogue<TM, TN, EPI>(p, acc, m0, n0, wm, wn, lane);
   if (tr && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); tr[3] = wall_clock64(); }
 }
 

@@ -1,0 +1,224 @@
+// fp32 MFMA GEMM, LDS-DMA pipeline (gfx950): the main loop for PLAIN operands (no prologue) -- every TimeSformer contraction
+// (QKV / out-proj / FF1+GEGLU / FF2 / their data and weight gradients) and the prologue-free EfficientNet / Xception 1x1 convs.
+//
+// What differs from gemm_core.hpp's register-staged loop:
+//   * operand tiles go HBM/L2 -> LDS directly (`global_load_lds_dwordx4`, 1 KiB per wave-instruction): no staging VGPRs, no
+//     ds_write pass, no VALU on the load path;
+//   * a ring of STAGES LDS buffers with the loads of the next STAGES-1 tiles in flight ACROSS the per-tile barrier: the wait is a
+//     counted `s_waitcnt vmcnt(N)` (only the tile about to be consumed must have landed) and the barrier is a raw `s_barrier`
+//     (`__syncthreads()` would drain every outstanding DMA).  A block therefore hides HBM latency by itself instead of relying on
+//     3-4 co-resident blocks, which is what the mid-size problems (a few hundred tiles) never had;
+//   * the DMA is written as inline asm: hipcc models the builtin as an LDS store and puts `s_waitcnt vmcnt(0)` in front of the
+//     next ds_read, which serialises the pipeline again (checked in the ISA).
+// LDS image of a tile (the DMA writes lane-linear, so the layout is produced by permuting the per-lane SOURCE address):
+//   k-contiguous operand: [rows][BK] floats, the BK/4 16-byte granules of a row XOR-swizzled with (row >> s) so that the
+//                         fragment read -- one ds_read_b128 per lane = 4 consecutive k of the lane's row -- hits 16 distinct
+//                         granule columns in every 16-lane service group (conflict-free);
+//   k-major operand:      [BK][cols] floats as in memory; fragment = ds_read_b32 of 32 consecutive columns (conflict-free).
+// MFMA step (g,t), lane half kh consumes k = 8g + 4kh + t on both operands (same pairing as gemm_core.hpp).
+#pragma once
+#include "gemm_core.hpp"
+
+namespace mt {
+
+__device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int EPI, int BK, int STAGES, int MINW>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW)
+void gemm_dma_kernel(const GemmArgs p) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int GPR = BK / 4;                       // 16-byte granules per k-contiguous row
+  constexpr int SW_SHIFT = BK == 16 ? 2 : 1;        // swizzle = (row >> SW_SHIFT) & (GPR - 1)
+  constexpr int A_TILE = BM * BK, B_TILE = BN * BK; // floats
+  constexpr int STAGE = A_TILE + B_TILE;
+  constexpr int A_INSTR = A_TILE / 256, B_INSTR = B_TILE / 256;   // 1 KiB wave-instructions per tile
+  static_assert(A_INSTR % NW == 0 && B_INSTR % NW == 0, "every wavefront must issue the same number of DMA instructions");
+  constexpr int A_IPW = A_INSTR / NW, B_IPW = B_INSTR / NW, IPW = A_IPW + B_IPW;
+  static_assert(BK == 16 || BK == 32, "BK must be 16 or 32");
+  static_assert(STAGES >= 2 && STAGES <= 4, "2..4 stages");
+  constexpr int NG = BK / 8;
+
+  extern __shared__ __attribute__((aligned(16))) float smem_dma[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem_dma;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+
+  int mt_, nt_;
+  if (!tile_coords<BM, BN>(p, mt_, nt_)) return;
+  const int m0 = mt_ * BM;
+  const int n0 = nt_ * BN;
+
+  int k_begin = 0, k_end = p.K;
+  if (p.k_chunk > 0) {
+    k_begin = blockIdx.y * p.k_chunk;
+    k_end = min(p.K, k_begin + p.k_chunk);
+    if (k_begin >= k_end) return;
+  }
+  const int nk = (k_end - k_begin) / BK;            // host guarantees (k_end - k_begin) % BK == 0
+
+  // ---- per-lane DMA sources.  Instruction q of an operand covers granules [64q, 64q+64) of its tile image.
+  // k-contiguous: granule gi -> row gi / GPR, physical slot gi % GPR holding logical k-granule slot ^ swizzle(row).
+  // k-major:      granule gi -> k row gi / (cols/4), column granule gi % (cols/4).
+  const float* a_src[A_IPW];
+  const float* b_src[B_IPW];
+  int a_k[A_IPW], b_k[B_IPW];                       // k-major: the lane's k offset inside a tile
+#pragma unroll
+  for (int j = 0; j < A_IPW; ++j) {
+    const int gi = (wave * A_IPW + j) * 64 + lane;
+    if constexpr (AL == LAYOUT_KCONTIG) {
+      const int row = gi / GPR, slot = gi % GPR;
+      const int kq = slot ^ ((row >> SW_SHIFT) & (GPR - 1));
+      int m = m0 + row;
+      m = m < p.M ? m : p.M - 1;                    // rows past the end are never stored: any valid row will do
+      a_src[j] = p.A + map_row(p.a_map, m) * p.lda + k_begin + kq * 4;
+      a_k[j] = 0;
+    } else {
+      constexpr int CPR = BM / 4;
+      const int kk = gi / CPR, cq = gi % CPR;
+      int m = m0 + cq * 4;
+      m = m < p.M ? m : p.M - 4;
+      a_src[j] = p.A + m;
+      a_k[j] = kk;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < B_IPW; ++j) {
+    const int gi = (wave * B_IPW + j) * 64 + lane;
+    if constexpr (BL == LAYOUT_KCONTIG) {
+      const int row = gi / GPR, slot = gi % GPR;
+      const int kq = slot ^ ((row >> SW_SHIFT) & (GPR - 1));
+      int n;
+      if constexpr (EPI == EPI_GEGLU) {            // tile row -> weight row: 'a' and 'gate' halves interleaved per 32 columns
+        static_assert(EPI != EPI_GEGLU || TN == 2, "GEGLU wants TN == 2");
+        const int w = row / 64, sel = (row >> 5) & 1, c = row & 31;
+        const int jj = (n0 >> 1) + w * 32 + c;
+        n = jj < p.n_half ? sel * p.n_half + jj : 0;
+      } else {
+        n = n0 + row;
+        n = n < p.N ? n : p.N - 1;
+      }
+      b_src[j] = p.B + (int64_t)n * p.ldb + k_begin + kq * 4;
+      b_k[j] = 0;
+    } else {
+      constexpr int CPR = BN / 4;
+      const int kk = gi / CPR, cq = gi % CPR;
+      int n = n0 + cq * 4;
+      n = n < p.N ? n : p.N - 4;
+      b_src[j] = p.B + n;
+      b_k[j] = kk;
+    }
+  }
+
+  auto issue = [&](int kt) {                        // DMA of k-tile kt into ring slot kt % STAGES
+    const unsigned st = lds_base + (unsigned)((kt % STAGES) * STAGE * 4);
+    const int k0 = k_begin + kt * BK;
+#pragma unroll
+    for (int j = 0; j < A_IPW; ++j) {
+      const float* src;
+      if constexpr (AL == LAYOUT_KCONTIG) src = a_src[j] + kt * BK;
+      else src = a_src[j] + map_row(p.a_map, k0 + a_k[j]) * p.lda;
+      lds_dma16(src, st + (unsigned)((wave * A_IPW + j) * 1024));
+    }
+#pragma unroll
+    for (int j = 0; j < B_IPW; ++j) {
+      const float* src;
+      if constexpr (BL == LAYOUT_KCONTIG) src = b_src[j] + kt * BK;
+      else src = b_src[j] + map_row(p.b_map, k0 + b_k[j]) * p.ldb;
+      lds_dma16(src, st + (unsigned)(A_TILE * 4 + (wave * B_IPW + j) * 1024));
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- fragment addressing
+  const int khalf = lane >> 5;
+  const int a_row = wm * TM * 32 + (lane & 31);
+  const int b_col = wn * TN * 32 + (lane & 31);
+  int a_off[NG], b_off[NG];                         // float offsets inside a tile image for MFMA group g (tile i / j adds a constant)
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if constexpr (AL == LAYOUT_KCONTIG) a_off[g] = a_row * BK + 4 * ((2 * g + khalf) ^ ((a_row >> SW_SHIFT) & (GPR - 1)));
+    else a_off[g] = (8 * g + 4 * khalf) * BM + a_row;
+    if constexpr (BL == LAYOUT_KCONTIG) b_off[g] = b_col * BK + 4 * ((2 * g + khalf) ^ ((b_col >> SW_SHIFT) & (GPR - 1)));
+    else b_off[g] = (8 * g + 4 * khalf) * BN + b_col;
+  }
+  auto load_frags = [&](const float* as, const float* bs, int g, float (&af)[TM][4], float (&bf)[TN][4]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if constexpr (AL == LAYOUT_KCONTIG) {
+        const float4 v = *reinterpret_cast<const float4*>(as + a_off[g] + i * 32 * BK);      // (row + 32 i) has the same swizzle
+        af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[i][t] = as[a_off[g] + t * BM + i * 32];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (BL == LAYOUT_KCONTIG) {
+        const float4 v = *reinterpret_cast<const float4*>(bs + b_off[g] + j * 32 * BK);
+        bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bf[j][t] = bs[b_off[g] + t * BN + j * 32];
+      }
+    }
+  };
+  auto mma_group = [&](const float (&af)[TM][4], const float (&bf)[TN][4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- pipeline: tiles kt+1 .. kt+STAGES-1 are in flight while tile kt is multiplied
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt must have landed; the tiles issued after it (at most STAGES-2) may stay in flight across the barrier
+    const int later = min(STAGES - 2, nk - 1 - kt);
+    if (later >= 2) wait_vmcnt<2 * IPW>();
+    else if (later == 1) wait_vmcnt<IPW>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                   // every wave's share of tile kt is visible; slot (kt-1) % STAGES is free
+    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+    const float* as = smem_dma + (kt % STAGES) * STAGE;
+    const float* bs = as + A_TILE;
+    float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
+    load_frags(as, bs, 0, fa0, fb0);
+#pragma unroll
+    for (int g = 0; g < NG; g += 2) {
+      load_frags(as, bs, g + 1, fa1, fb1);
+      mma_group(fa0, fb0);
+      if (g + 2 < NG) load_frags(as, bs, g + 2, fa0, fb0);
+      mma_group(fa1, fb1);
+    }
+  }
+
+  gemm_epilogue<TM, TN, EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
+}  // namespace mt

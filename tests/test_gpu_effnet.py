@@ -117,9 +117,9 @@ def _assert_all_grads(model, osd, training, what):
         if k.startswith("_fc"):
             continue
         ref = osd[k].grad
-        if training and k.endswith("_bn2.bias"):
-            wn = float(named[k.replace(".bias", ".weight")].grad.norm())
-            assert float(p.grad.norm()) < 1e-3 * wn and float(ref.norm()) < 1e-3 * wn, k
+        wn = float(named[k.replace(".bias", ".weight")].grad.norm()) if k.endswith("_bn2.bias") else 0.0
+        if training and k.endswith("_bn2.bias") and float(ref.norm()) < 1e-3 * wn:      # (not zero behind a drop-connect gate)
+            assert float(p.grad.norm()) < 1e-3 * wn, k
             continue
         assert_close(p.grad, ref, 3e-3, f"{what}: grad {k}")
 

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Joins the passes of tools/ef_pmc.sh (FETCH_SIZE, WRITE_SIZE, SQ counters, kernel trace) by dispatch order and prints, for the
+LAST step in the trace, per kernel family: launches, time, HBM-side bytes (gfx950 correction: FETCH_SIZE doubled, see
+MI355X_MICROARCH.md), GB/s, MFMA-busy fraction and VALU instructions -- plus every launch >= --min us with the same columns."""
+import argparse
+import csv
+import glob
+import re
+from collections import defaultdict
+
+ap = argparse.ArgumentParser()
+ap.add_argument("dir")
+ap.add_argument("--min", type=float, default=1e9)
+ap.add_argument("--start", default="5, 3, 0>", help="substring of the kernel that starts a step (EfficientNet: the im2col stem GEMM)")
+ap.add_argument("--fetch-scale", type=float, default=2.0)
+a = ap.parse_args()
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "").replace("mt::", "")
+    return re.sub(r"\(.*", "", n)[:60]
+
+
+def load_counters(sub):
+    f = glob.glob(f"{a.dir}/{sub}/**/*counter_collection.csv", recursive=True)
+    if not f:
+        return None
+    per = defaultdict(dict)
+    names = {}
+    for r in csv.DictReader(open(f[0])):
+        d = int(r["Dispatch_Id"])
+        per[d][r["Counter_Name"]] = per[d].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        names[d] = r["Kernel_Name"]
+    order = sorted(per)
+    return [(names[d], per[d]) for d in order]
+
+
+trace = glob.glob(f"{a.dir}/trace/**/*kernel_trace.csv", recursive=True)
+rows = sorted(csv.DictReader(open(trace[0])), key=lambda r: int(r["Start_Timestamp"]))
+kt = [(r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Grid_Size_X"] if "Grid_Size_X" in r else "") for r in rows]
+passes = {k: load_counters(k) for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES")}
+
+
+def last_step(seq, name_of):
+    starts = [i for i, x in enumerate(seq) if a.start in name_of(x)]
+    return seq[starts[-1]:] if starts else seq
+
+
+kt = last_step(kt, lambda x: x[0])
+for k in passes:
+    if passes[k] is not None:
+        passes[k] = last_step(passes[k], lambda x: x[0])
+        if len(passes[k]) != len(kt):
+            print(f"# warning: pass {k} has {len(passes[k])} dispatches in its last step, the trace {len(kt)}")
+fam = defaultdict(lambda: defaultdict(float))
+print(f"{'idx':>4} {'us':>8} {'rd MB':>8} {'wr MB':>8} {'GB/s':>7} {'mfma%':>6} {'valu/wave':>9}  kernel")
+for i, (name, us, grid) in enumerate(kt):
+    c = {}
+    for k in passes:
+        if passes[k] is not None and i < len(passes[k]) and short(passes[k][i][0]) == short(name):
+            c.update(passes[k][i][1])
+    rd = c.get("FETCH_SIZE", 0.0) * 1024 * a.fetch_scale        # FETCH_SIZE / WRITE_SIZE are reported in KiB
+    wr = c.get("WRITE_SIZE", 0.0) * 1024
+    busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+    gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+    mfma = busy / (gui * 256 * 4) if gui else 0.0                # 256 CUs x 4 SIMDs (counter summed over the chip)
+    waves = c.get("SQ_WAVES", 0.0)
+    f = fam[re.sub(r"<.*", "", short(name))]
+    f["n"] += 1; f["us"] += us; f["rd"] += rd; f["wr"] += wr; f["busy"] += busy; f["gui"] += gui
+    f["valu"] += c.get("SQ_INSTS_VALU", 0.0); f["wait"] += c.get("SQ_WAIT_ANY", 0.0); f["wcyc"] += c.get("SQ_WAVE_CYCLES", 0.0)
+    if us >= a.min:
+        print(f"{i:4d} {us:8.1f} {rd / 1e6:8.1f} {wr / 1e6:8.1f} {(rd + wr) / us / 1e3:7.0f} {100 * mfma:6.1f} {c.get('SQ_INSTS_VALU', 0.0):9.0f}  {short(name)}")
+tot = sum(f["us"] for f in fam.values())
+print(f"\nstep: {len(kt)} launches, kernel time {tot / 1e3:.2f} ms, HBM-side traffic {sum(f['rd'] + f['wr'] for f in fam.values()) / 1e9:.2f} GB")
+print(f"{'ms':>7} {'n':>4} {'rd GB':>7} {'wr GB':>7} {'TB/s':>6} {'mfma%':>6} {'wait%':>6}  family")
+for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["us"]):
+    mf = f["busy"] / (f["gui"] * 1024) if f["gui"] else 0.0
+    wt = f["wait"] / f["wcyc"] if f["wcyc"] else 0.0
+    print(f"{f['us'] / 1e3:7.2f} {int(f['n']):4d} {f['rd'] / 1e9:7.2f} {f['wr'] / 1e9:7.2f} {(f['rd'] + f['wr']) / f['us'] / 1e6:6.2f} {100 * mf:6.1f} {100 * wt:6.1f}  {k}")
