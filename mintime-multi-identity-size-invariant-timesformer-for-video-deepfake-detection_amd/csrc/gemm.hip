@@ -57,6 +57,8 @@ int launch(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
+namespace mt { int try_launch_dma(const mt_gemm_desc* d, GemmArgs a, hipStream_t s); }   // gemm_dma.hip
+
 static long long* g_trace = nullptr;
 // tuning aid, not part of the ABI header: per-block phase timestamps of the following mt_gemm launches (NULL = off)
 extern "C" void mt_debug_gemm_trace(long long* buf) { g_trace = buf; }
@@ -109,6 +111,11 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   if (d->b_prologue == MT_BPRO_IM2COL && d->op != MT_OP_TN) return fail(MT_ERR_ARG, "mt_gemm: im2col B prologue needs op TN");
   if (d->prologue == MT_PRO_BN_SWISH_GATE && !d->gate) return fail(MT_ERR_ARG, "mt_gemm: gate prologue needs gate");
 
+  // K-contiguous operands need K % 4 == 0 etc. were checked above; plain problems take the LDS-DMA pipeline when it has an instance
+  if (!g_trace) {
+    const int rc = try_launch_dma(d, a, s);
+    if (rc <= 0) return rc;
+  }
   const int cfg = pick_cfg(d->op, d->M, d->N, d->prologue, d->epilogue);
   const int m_tiles = (d->M + kCfg[cfg].bm - 1) / kCfg[cfg].bm;
   const int n_tiles = (d->N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;

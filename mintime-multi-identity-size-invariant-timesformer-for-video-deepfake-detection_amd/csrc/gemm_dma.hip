@@ -1,0 +1,137 @@
+// Dispatch of the LDS-DMA GEMM main loop (gemm_dma.hpp) for prologue-free problems.  mt_gemm (gemm.hip) asks try_launch_dma()
+// first and falls back to the register-staged kernels when a problem is not eligible.
+#include "../../include/mintime_hip.h"
+#include "common.hpp"
+#include "gemm_dma.hpp"
+#include <stdlib.h>
+#include <string.h>
+
+using namespace mt;
+
+namespace {
+
+// Variants (tile, BK, ring depth, waves/SIMD the register budget is held to).  Chosen from tools/lab/gemm_lab sweeps over the
+// shapes of a B = 32 training step (profiles/r02_gemm_dma_lab.txt): deeper rings stop paying once 2-3 blocks share a CU, BK = 32
+// halves the barrier count for the long-K problems, 64x64 tiles win whenever 128x128 leaves fewer than ~3 tiles per CU.
+enum { V_BIG32 = 0, V_BIG16 = 1, V_MID16 = 2, V_SMALL32 = 3, V_SMALL16 = 4, V_COUNT };
+struct Var { int bm, bn, bk, stages; };
+constexpr Var kVar[V_COUNT] = {{128, 128, 32, 2}, {128, 128, 16, 3}, {128, 64, 16, 3}, {64, 64, 32, 3}, {64, 64, 16, 3}};
+
+int pick_variant(const mt_gemm_desc* d) {
+  if (const char* f = getenv("MT_DMA_VARIANT")) return atoi(f);      // tuning experiments only
+  const bool k32 = (d->K % 32) == 0;
+  if (d->epilogue == MT_EPI_GEGLU) return k32 ? V_BIG32 : V_BIG16;
+  if (d->epilogue == MT_EPI_GEGLU_BWD) return V_MID16;
+  if (d->op == MT_OP_TN) {
+    if (d->M >= 1024 && d->N >= 512) return V_BIG16;
+    if ((int64_t)d->M * d->N >= (1 << 20)) return V_MID16;
+    return k32 ? V_SMALL32 : V_SMALL16;
+  }
+  if (d->N >= 1024 && d->M >= 4096) return k32 ? V_BIG32 : V_BIG16;
+  if (d->epilogue == MT_EPI_ATOMIC) {
+    if (d->op == MT_OP_NN) return (d->K >= 4096 && k32) ? V_BIG32 : V_BIG16;
+    return V_MID16;
+  }
+  return k32 ? V_SMALL32 : V_SMALL16;
+}
+
+template <int WM, int WN, int TM, int TN, int AL, int BL, int EPI, int BK, int ST, int MINW>
+int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
+  auto k = gemm_dma_kernel<WM, WN, TM, TN, AL, BL, EPI, BK, ST, MINW>;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t lds = (size_t)ST * (BM + BN) * BK * 4;
+  if constexpr (lds > 48 * 1024) {
+    static bool raised = false;        // idempotent; a benign race at worst repeats the call
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_gemm(dma): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, s, a);
+  return check_launch("mt_gemm(dma)");
+}
+
+template <int AL, int BL, int EPI>
+int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
+  switch (v) {
+    case V_BIG32: return launch_one<2, 2, 2, 2, AL, BL, EPI, 32, 2, 2>(a, grid, s);
+    case V_BIG16: return launch_one<2, 2, 2, 2, AL, BL, EPI, 16, 3, 3>(a, grid, s);
+    default: break;
+  }
+  if constexpr (EPI != EPI_GEGLU) {
+    switch (v) {
+      case V_MID16: return launch_one<2, 2, 2, 1, AL, BL, EPI, 16, 3, 3>(a, grid, s);
+      case V_SMALL32: return launch_one<2, 2, 1, 1, AL, BL, EPI, 32, 3, 4>(a, grid, s);
+      case V_SMALL16: return launch_one<2, 2, 1, 1, AL, BL, EPI, 16, 3, 4>(a, grid, s);
+      default: break;
+    }
+  }
+  return fail(MT_ERR_UNSUPPORTED, "mt_gemm(dma): no instance for variant %d", v);
+}
+
+}  // namespace
+
+namespace mt {
+
+// Returns 1 when the problem is not eligible (caller falls back), 0 on success, < 0 on error.  `a` is the argument block
+// mt_gemm already filled (pointers, shapes, maps, epilogue extras); tile-order and split-K fields are set here.
+int try_launch_dma(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
+  static const bool disabled = getenv("MT_GEMM_DMA") && atoi(getenv("MT_GEMM_DMA")) == 0;
+  if (disabled) return 1;
+  if (d->prologue != MT_PRO_NONE || d->b_prologue != MT_BPRO_NONE) return 1;
+  if (d->M < 64 || d->N < 64) return 1;
+  if (d->epilogue == MT_EPI_GEGLU && (d->n_half & 63)) return 1;
+  int v = pick_variant(d);
+  if (v < 0 || v >= V_COUNT) return 1;
+  if (d->K % kVar[v].bk) {
+    if (d->K % 16) return 1;
+    v = v == V_BIG32 ? V_BIG16 : (v == V_SMALL32 ? V_SMALL16 : v);
+    if (d->K % kVar[v].bk) return 1;
+  }
+  const Var var = kVar[v];
+  const int m_tiles = (d->M + var.bm - 1) / var.bm, n_tiles = (d->N + var.bn - 1) / var.bn;
+  dim3 grid(m_tiles * n_tiles, 1, 1);
+  a.group_n = 0;
+  a.k_chunk = 0;
+  a.trace = nullptr;
+  if (m_tiles >= 32 && n_tiles >= 2 && !getenv("MT_NO_L2_BLOCKING")) {
+    const int64_t panel = (int64_t)var.bn * d->K * 4;
+    int gn = (int)((2 << 20) / (panel > 0 ? panel : 1));
+    if (gn < 1) gn = 1;
+    if (gn > n_tiles) gn = n_tiles;
+    a.group_n = gn;
+    grid.x = 8 * ((m_tiles + 7) / 8) * n_tiles;
+  }
+  if (d->op == MT_OP_TN || d->epilogue == MT_EPI_ATOMIC) {
+    int splits = d->split_k;
+    if (d->op == MT_OP_TN && splits <= 0) {
+      const int tiles = m_tiles * n_tiles;
+      splits = (2048 + tiles - 1) / tiles;
+      const int max_splits = d->K / 256 > 0 ? d->K / 256 : 1;
+      if (splits > max_splits) splits = max_splits;
+    }
+    if (splits < 1) splits = 1;
+    int chunk = (d->K + splits - 1) / splits;
+    chunk = (chunk + var.bk - 1) / var.bk * var.bk;
+    a.k_chunk = chunk;
+    grid.y = (d->K + chunk - 1) / chunk;
+  }
+
+#define DMA_COMBO(OP, AL, BL, EPI)                                 \
+  if (d->op == OP && d->epilogue == EPI) return launch_variant<AL, BL, EPI>(v, a, grid, s);
+  DMA_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_STORE)
+  DMA_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_BIAS_RES)
+  DMA_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_GEGLU)
+  DMA_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_STATS)
+  DMA_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_ATOMIC)
+  DMA_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_STORE)
+  DMA_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_ACCUM)
+  DMA_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_GEGLU_BWD)
+  DMA_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_ATOMIC)
+  DMA_COMBO(MT_OP_TN, LAYOUT_KMAJOR, LAYOUT_KMAJOR, EPI_ATOMIC)
+#undef DMA_COMBO
+  return 1;
+}
+
+}  // namespace mt

@@ -255,3 +255,73 @@ def test_full_size_wgrad_with_token_rowmap():
     dW = torch.zeros(D, Cin, device="cuda")
     L.gemm(L.OP_TN, dx.cuda(), feat.cuda(), dW, D, Cin, B * Fn, D, Cin, Cin, epilogue=L.EPI_ATOMIC, split_k=0, a_map=(Fn, Fn + 1, 1))
     assert_close(dW, _dmm(dx[:, 1:].reshape(B * Fn, D).T, feat), 5e-5, "patch-embedding wgrad at B=32")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LDS-DMA main loop (csrc/gemm_dma.hpp): every variant (tile x BK x ring depth), every layout, ragged M / N tails, split-K,
+# row maps -- forced through MT_DMA_VARIANT so that the shapes below do not depend on the dispatch heuristics.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def dma_variant(monkeypatch):
+    def force(v):
+        monkeypatch.setenv("MT_DMA_VARIANT", str(v))
+    return force
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_dma_variants_all_layouts(variant, dma_variant):
+    dma_variant(variant)
+    # NT: ragged M (not a tile multiple), N with a partial tile, bias
+    M, N, K = 1000 + 37, 320, 288 if variant in (1, 2, 4) else 320
+    A, W, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.1), _rand(N, seed=3)
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), Cd, M, N, K, K, K, N, bias=b.cuda())
+    assert_close(Cd, _dmm(A, W.T) + b.double(), TOL, f"DMA v{variant} NT")
+    # NN: k-major B with a ragged N tail (N % 4 == 0 only)
+    M, N, K = 777, 196, 256
+    dY, W = _rand(M, K, seed=4), _rand(K, N, seed=5, scale=0.1)
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    L.gemm(L.OP_NN, dY.cuda(), W.cuda(), Cd, M, N, K, K, N, N)
+    assert_close(Cd, _dmm(dY, W), TOL, f"DMA v{variant} NN")
+    # TN with split-K + atomics, ragged M and N, K a multiple of 32 but not of the chunk
+    Kr, N1, N2 = 4000 * 0 + 4128, 200, 332
+    dY, X = _rand(Kr, N1, seed=6), _rand(Kr, N2, seed=7)
+    dW = torch.zeros(N1, N2, device="cuda")
+    L.gemm(L.OP_TN, dY.cuda(), X.cuda(), dW, N1, N2, Kr, N1, N2, N2, epilogue=L.EPI_ATOMIC, split_k=5)
+    assert_close(dW, _dmm(dY.T, X), 5e-5, f"DMA v{variant} TN split-K")
+    # NT split-K onto a residual (FF2 form) and the row-mapped store (patch-embedding form)
+    M, N, K = 600, 128, 640
+    A, W, b, R = _rand(M, K, seed=8), _rand(N, K, seed=9, scale=0.05), _rand(N, seed=10), _rand(M, N, seed=11)
+    Cd = R.cuda().clone()
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), Cd, M, N, K, K, K, N, epilogue=L.EPI_ATOMIC, bias=b.cuda(), split_k=3)
+    assert_close(Cd, R.double() + b.double() + _dmm(A, W.T), ATOL_SPLITK, f"DMA v{variant} NT split-K")
+    Xd = torch.zeros(3, 201, N, device="cuda")
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), Xd, M, N, K, K, K, N, bias=b.cuda(), c_map=(200, 201, 1))
+    assert_close(Xd[:, 1:], (_dmm(A, W.T) + b.double()).reshape(3, 200, N), TOL, f"DMA v{variant} row-mapped store")
+    assert float(Xd[:, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_dma_geglu_pair(variant, dma_variant):
+    dma_variant(variant)
+    M, D = 650, 256
+    A, W, b = _rand(M, D, seed=1), _rand(8 * D, D, seed=2, scale=0.05), _rand(8 * D, seed=3, scale=0.1)
+    h = torch.full((M, 4 * D), float("nan"), device="cuda")
+    u = torch.full((M, 8 * D), float("nan"), device="cuda")
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), h, M, 8 * D, D, D, D, 4 * D, epilogue=L.EPI_GEGLU, bias=b.cuda(), C2=u, ldc2=8 * D, n_half=4 * D)
+    uref = _dmm(A, W.T) + b.double()
+    a, g = uref.chunk(2, dim=-1)
+    assert_close(u, torch.stack((a, g), dim=-1).reshape(M, 8 * D), TOL, "DMA GEGLU pre-activations")
+    assert_close(h, a * torch.nn.functional.gelu(g), TOL, "DMA GEGLU output")
+
+
+def test_dma_wgrad_with_token_rowmap_small(dma_variant):
+    """k-major A with a row map on k (patch-embedding weight gradient form), every small/mid variant."""
+    for v in (2, 3, 4):
+        dma_variant(v)
+        B, Fn, D, Cin = 3, 64, 128, 192
+        dx = _rand(B, Fn + 1, D, seed=1)
+        feat = _rand(B * Fn, Cin, seed=2)
+        dW = torch.zeros(D, Cin, device="cuda")
+        L.gemm(L.OP_TN, dx.cuda(), feat.cuda(), dW, D, Cin, B * Fn, D, Cin, Cin, epilogue=L.EPI_ATOMIC, split_k=2, a_map=(Fn, Fn + 1, 1))
+        assert_close(dW, _dmm(dx[:, 1:].reshape(B * Fn, D).T, feat), 5e-5, f"DMA v{v} row-mapped wgrad")
