@@ -205,7 +205,8 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
 class _EffNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, want_blocks, x_nhwc, *params):
-        save = any(ctx.needs_input_grad)
+        want_blocks, grad_on = want_blocks
+        save = grad_on and any(ctx.needs_input_grad)      # see tsf_engine._TSFFunction.forward
         feat, saved, ys = effnet_forward(model, x_nhwc, params, model.training, save, want_blocks)
         ctx.model, ctx.saved, ctx.params, ctx.training = model, saved, params, model.training
         N, H, W, _ = x_nhwc.shape
@@ -243,7 +244,7 @@ def effnet_apply(model, inputs, want_blocks=False):
     x_nhwc = (inputs if inputs.dtype == torch.uint8 else inputs.float()).permute(0, 2, 3, 1)
     if not x_nhwc.is_contiguous():
         x_nhwc = x_nhwc.contiguous()
-    outs = _EffNetFunction.apply(model, want_blocks, x_nhwc, *param_list(model))
+    outs = _EffNetFunction.apply(model, (want_blocks, torch.is_grad_enabled()), x_nhwc, *param_list(model))
     feat = outs[0]
     n = inputs.shape[0]
     ho = model._blocks[-1].spec.hout

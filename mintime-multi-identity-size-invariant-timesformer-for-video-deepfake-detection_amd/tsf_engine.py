@@ -67,7 +67,7 @@ def _index_flag(model, dev):
     key = str(dev)
     if key in st:
         flag, host, ev = st[key]
-        if ev is not None and ev.query():
+        if ev is not None and not torch.cuda.is_current_stream_capturing() and ev.query():
             bad = int(host[0])
             if bad:
                 flag.zero_()
@@ -181,8 +181,12 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
 class _TSFFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, aux, dims, feat, *params):
-        B, F, n = dims
-        save = any(ctx.needs_input_grad)
+        B, F, n, grad_on = dims
+        dims = (B, F, n)
+        # needs_input_grad mirrors requires_grad even under torch.no_grad(), and grad mode is always off inside forward():
+        # the caller's grad mode comes in through `dims`.  Without it an eval forward would keep every activation and take
+        # the training-only split-K + atomics branch.
+        save = grad_on and any(ctx.needs_input_grad)
         logits, s_att, t_att, saved = tsf_forward(model, feat, aux, params, B, F, n, save)
         ctx.model, ctx.aux, ctx.dims, ctx.saved = model, aux, dims, saved
         ctx.feat, ctx.params = feat, params
@@ -216,7 +220,7 @@ def tsf_apply(model, x, mask, identities_mask, size_embedding, positions):
         raise ValueError(f"expected {model.num_patches} patches per slot, got {h * w}")
     aux = _Aux(model, x, mask, identities_mask, size_embedding, positions)
     feat = _as_tokens(x.float())
-    outs = _TSFFunction.apply(model, aux, (b, f, h * w), feat, *model._param_list())
+    outs = _TSFFunction.apply(model, aux, (b, f, h * w, torch.is_grad_enabled()), feat, *model._param_list())
     if model.require_attention:
         return outs[0], [outs[1], outs[2]]       # order [space, time] (reference :271)
     return outs[0]

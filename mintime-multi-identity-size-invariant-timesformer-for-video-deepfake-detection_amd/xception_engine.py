@@ -327,7 +327,8 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
 class _XceptionFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x_nhwc, *params):
-        save = any(ctx.needs_input_grad)
+        model, grad_on = model
+        save = grad_on and any(ctx.needs_input_grad)      # see tsf_engine._TSFFunction.forward
         feat, saved, ho = xception_forward(model, x_nhwc, params, model.training, save)
         ctx.model, ctx.saved, ctx.params, ctx.training = model, saved, params, model.training
         N, H, W, _ = x_nhwc.shape
@@ -355,7 +356,7 @@ def xception_apply(model, inputs):
     x = (inputs if inputs.dtype == torch.uint8 else inputs.float()).permute(0, 2, 3, 1)      # uint8 crops are ingested as they are
     if not x.is_contiguous():
         x = x.contiguous()
-    feat = _XceptionFunction.apply(model, x, *param_list(model))
+    feat = _XceptionFunction.apply((model, torch.is_grad_enabled()), x, *param_list(model))
     n = inputs.shape[0]
     ho = feat.shape[0] // n
     side = int(round(ho ** 0.5))
