@@ -64,6 +64,8 @@ typedef struct {
   int b_prologue; const float* b_scale; const float* b_shift; const float* b_gate; int b_hw;
   int conv_H, conv_W, conv_C, conv_Ho, conv_Wo, conv_k, conv_stride, conv_pad, conv_act;   /* im2col prologues */
   int conv_src_u8;                  /* im2col source image is uint8 (raw crops, 3 channels) instead of fp32      */
+  float* col_sum;                   /* GEGLU_BWD: optional [2*n_half] column sums of the stored gradient (= d bias of the
+                                       Linear that produced the pre-activations), atomically accumulated; caller zero-fills */
 } mt_gemm_desc;
 
 int mt_gemm(const mt_gemm_desc* d, void* stream);
@@ -162,9 +164,14 @@ int mt_build_clip_inputs(const int* slots, const int* valid, const int* frames, 
  * ------------------------------------------------------------------------------------------------ */
 
 /* LayerNorm adjoint. dx (+)= LN'(dy) (accumulate!=0 adds into dx: the residual stream's gradient);
- * dgamma/dbeta are accumulated atomically (caller zero-fills). stats = [rows,2] mean,rstd saved by the forward. */
+ * dgamma/dbeta are accumulated atomically (caller zero-fills). stats = [rows,2] mean,rstd saved by the forward.
+ * dx_colsum (optional, [dim], atomically accumulated): column sums of the UPDATED dx rows -- the bias gradient of the Linear
+ * whose output gradient dx is next (to_out.0.bias / net.3.bias / to_patch_embedding.bias), which the reference gets from
+ * autograd's sum over rows; rows with row % skip_period == 0 are left out when skip_period > 0 (the cls rows, which the patch
+ * embedding does not produce, :231-232). */
 int mt_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
-                     float* dgamma, float* dbeta, int rows, int dim, int accumulate, void* stream);
+                     float* dgamma, float* dbeta, int rows, int dim, int accumulate, float* dx_colsum, int skip_period,
+                     void* stream);
 
 /* out[n] += sum_m A[map(m)*lda + n]   (bias gradients). */
 int mt_colsum(const float* A, int64_t lda, mt_rowmap map, int M, int N, float* out, void* stream);

@@ -142,6 +142,7 @@ struct GemmArgs {
   ConvDesc conv;                        // PRO_IM2COL / BPRO_IM2COL geometry
   int group_n;                          // > 0: L2-blocked tile order with this many tile columns per group
   long long* trace;                     // tuning aid (mt_debug_gemm_trace): per block {t_start, t_prologue, t_loop, t_end, hw_id}
+  float* col_sum;                       // GEGLU_BWD: optional column sums of the stored values (bias gradient), fp32 atomics
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -268,9 +269,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
               // n indexes h columns [0, n_half); u = [a | g] pre-activations
               const float2 ag = *reinterpret_cast<const float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * n);
               const float a = ag.x, g = ag.y;
-              p.C[crow * p.ldc + n] = v * gelu_erf(g);
-              p.C[crow * p.ldc + p.n_half + n] = v * a * gelu_erf_grad(g);
+              const float da = v * gelu_erf(g), dg = v * a * gelu_erf_grad(g);
+              p.C[crow * p.ldc + n] = da;
+              p.C[crow * p.ldc + p.n_half + n] = dg;
+              s1 += da; s2 += dg;
             }
+          }
+        }
+      }
+      if constexpr (EPI == EPI_GEGLU_BWD) {
+        if (p.col_sum) {                      // bias gradient of the first feed-forward Linear: column sums of du
+          s1 += __shfl_xor(s1, 32);
+          s2 += __shfl_xor(s2, 32);
+          if (lane < 32 && nok) {
+            atomicAdd(p.col_sum + n, s1);
+            atomicAdd(p.col_sum + p.n_half + n, s2);
           }
         }
       }

@@ -54,6 +54,21 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
 
 template <int AL, int BL, int EPI>
 int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
+  static const bool st2 = getenv("MT_DMA_ST2") && atoi(getenv("MT_DMA_ST2")) != 0;   // experiment: 2-deep rings (smaller LDS footprint)
+  if (st2) {
+    switch (v) {
+      case V_BIG16: return launch_one<2, 2, 2, 2, AL, BL, EPI, 16, 2, 3>(a, grid, s);
+      default: break;
+    }
+    if constexpr (EPI != EPI_GEGLU) {
+      switch (v) {
+        case V_MID16: return launch_one<2, 2, 2, 1, AL, BL, EPI, 16, 2, 3>(a, grid, s);
+        case V_SMALL32: return launch_one<2, 2, 1, 1, AL, BL, EPI, 32, 2, 4>(a, grid, s);
+        case V_SMALL16: return launch_one<2, 2, 1, 1, AL, BL, EPI, 16, 2, 4>(a, grid, s);
+        default: break;
+      }
+    }
+  }
   switch (v) {
     case V_BIG32: return launch_one<2, 2, 2, 2, AL, BL, EPI, 32, 2, 2>(a, grid, s);
     case V_BIG16: return launch_one<2, 2, 2, 2, AL, BL, EPI, 16, 3, 3>(a, grid, s);

@@ -19,6 +19,16 @@
 #pragma once
 #include "gemm_core.hpp"
 
+#ifndef MT_DMA_FN_ALIGN         // code placement experiments (tools/lab)
+#define MT_DMA_FN_ALIGN 256
+#endif
+#ifndef MT_DMA_LOOP_ALIGN       // log2; 0 = none
+#define MT_DMA_LOOP_ALIGN 0
+#endif
+#ifndef MT_DMA_ABLATE          // tuning lab only (tools/lab): 1 no DMA, 2 no barrier, 4 no LDS fragment reads, 8 no epilogue
+#define MT_DMA_ABLATE 0
+#endif
+
 namespace mt {
 
 __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_byte_addr) {
@@ -29,8 +39,11 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_byte_a
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+#define MT_STR2(x) #x
+#define MT_STR(x) MT_STR2(x)
+
 template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int EPI, int BK, int STAGES, int MINW>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW)
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) __attribute__((aligned(MT_DMA_FN_ALIGN)))
 void gemm_dma_kernel(const GemmArgs p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * TM * 32;
@@ -122,6 +135,7 @@ void gemm_dma_kernel(const GemmArgs p) {
   }
 
   auto issue = [&](int kt) {                        // DMA of k-tile kt into ring slot kt % STAGES
+    if (MT_DMA_ABLATE & 1) return;
     const unsigned st = lds_base + (unsigned)((kt % STAGES) * STAGE * 4);
     const int k0 = k_begin + kt * BK;
 #pragma unroll
@@ -197,17 +211,32 @@ void gemm_dma_kernel(const GemmArgs p) {
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) issue(s);
 
+#if MT_DMA_LOOP_ALIGN
+  asm volatile(".p2align " MT_STR(MT_DMA_LOOP_ALIGN));
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt must have landed; the tiles issued after it (at most STAGES-2) may stay in flight across the barrier
     const int later = min(STAGES - 2, nk - 1 - kt);
     if (later >= 2) wait_vmcnt<2 * IPW>();
     else if (later == 1) wait_vmcnt<IPW>();
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                   // every wave's share of tile kt is visible; slot (kt-1) % STAGES is free
+    if (!(MT_DMA_ABLATE & 2)) __builtin_amdgcn_s_barrier();   // every wave's share of tile kt is visible; slot (kt-1) % STAGES is free
     if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
     const float* as = smem_dma + (kt % STAGES) * STAGE;
     const float* bs = as + A_TILE;
     float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
+    if (MT_DMA_ABLATE & 4) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { fa0[i][t] = (float)(lane + t + i + kt); fa1[i][t] = (float)(lane - t + i); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { fb0[j][t] = (float)(lane * 2 + t + j); fb1[j][t] = (float)(lane ^ (t + j + kt)); }
+      }
+#pragma unroll
+      for (int g = 0; g < NG; g += 2) { mma_group(fa0, fb0); mma_group(fa1, fb1); }
+      continue;
+    }
     load_frags(as, bs, 0, fa0, fb0);
 #pragma unroll
     for (int g = 0; g < NG; g += 2) {
@@ -218,6 +247,17 @@ void gemm_dma_kernel(const GemmArgs p) {
     }
   }
 
+  if (MT_DMA_ABLATE & 8) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 123.456f) p.C[0] = sacc;             // keeps the accumulators live without an epilogue
+    return;
+  }
   gemm_epilogue<TM, TN, EPI>(p, acc, m0, n0, wm, wn, lane);
 }
 

@@ -35,15 +35,16 @@ __device__ __forceinline__ float wave_max(float v) {
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             float* __restrict__ dx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int rows, int D, int accumulate) {
+                                                            float* __restrict__ dbeta, int rows, int D, int accumulate,
+                                                            float* __restrict__ dxsum, int skip_period) {
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
   const int nq = D >> 2;
-  float4 dg[4], db[4], g[4];
+  float4 dg[4], db[4], g[4], ds[4];     // ds: column sums of the UPDATED dx (the bias gradient of whoever consumes dx next)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i];
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i]; ds[i] = dg[i];
     const int q = lane + i * 64;
     g[i] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -84,6 +85,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     b1 = wave_sum(b1) / (float)D; b2 = wave_sum(b2) / (float)D;
     float4* dxr0 = reinterpret_cast<float4*>(dx + (int64_t)row0 * D);
     float4* dxr1 = reinterpret_cast<float4*>(dx + (int64_t)r1 * D);
+    // rows with row % skip_period == 0 (the cls rows of the token matrix) are left out of dxsum when skip_period > 0
+    const float c0 = (skip_period > 0 && row0 % skip_period == 0) ? 0.f : 1.f;
+    const float c1 = (!has1 || (skip_period > 0 && row1 % skip_period == 0)) ? 0.f : 1.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = lane + i * 64;
@@ -93,18 +97,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         o.z = rstd0 * (gy0[i].z - a1 - xh0[i].z * a2); o.w = rstd0 * (gy0[i].w - a1 - xh0[i].w * a2);
         if (accumulate) { const float4 p = dxr0[q]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
         dxr0[q] = o;
+        ds[i].x += c0 * o.x; ds[i].y += c0 * o.y; ds[i].z += c0 * o.z; ds[i].w += c0 * o.w;
         if (has1) {
           float4 t;
           t.x = rstd1 * (gy1[i].x - b1 - xh1[i].x * b2); t.y = rstd1 * (gy1[i].y - b1 - xh1[i].y * b2);
           t.z = rstd1 * (gy1[i].z - b1 - xh1[i].z * b2); t.w = rstd1 * (gy1[i].w - b1 - xh1[i].w * b2);
           if (accumulate) { const float4 p = dxr1[q]; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }
           dxr1[q] = t;
+          ds[i].x += c1 * t.x; ds[i].y += c1 * t.y; ds[i].z += c1 * t.z; ds[i].w += c1 * t.w;
         }
       }
     }
   }
   // block reduction over the 4 wavefronts, then one atomic per column per block
-  __shared__ float red[2][4][1024];
+  __shared__ float red[3][4][1024];
   const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -112,12 +118,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     if (q < nq) {
       *reinterpret_cast<float4*>(&red[0][wv][4 * q]) = dg[i];
       *reinterpret_cast<float4*>(&red[1][wv][4 * q]) = db[i];
+      *reinterpret_cast<float4*>(&red[2][wv][4 * q]) = ds[i];
     }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < D; c += 256) {
     atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
     atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    if (dxsum) atomicAdd(dxsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
   }
 }
 
@@ -765,14 +773,15 @@ int launch_patch_bwd(const float* qkv, const float* dout, float* dqkv, const uin
 }  // namespace
 
 extern "C" int mt_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
-                                float* dgamma, float* dbeta, int rows, int dim, int accumulate, void* stream) {
+                                float* dgamma, float* dbeta, int rows, int dim, int accumulate, float* dx_colsum, int skip_period,
+                                void* stream) {
   if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta) return fail(MT_ERR_ARG, "mt_layernorm_bwd: null pointer");
   if (dim <= 0 || (dim & 3) || dim > 1024) return fail(MT_ERR_ARG, "mt_layernorm_bwd: dim %d unsupported", dim);
   if (rows <= 0) return 0;
   int blocks = (rows + 3) / 4;
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dgamma, dbeta,
-                     rows, dim, accumulate);
+                     rows, dim, accumulate, dx_colsum, skip_period);
   return check_launch("mt_layernorm_bwd");
 }
 

@@ -36,7 +36,8 @@ class GemmDesc(C.Structure):
                 ("A2", C.c_void_p), ("b_prologue", C.c_int), ("b_scale", C.c_void_p), ("b_shift", C.c_void_p),
                 ("b_gate", C.c_void_p), ("b_hw", C.c_int),
                 ("conv_H", C.c_int), ("conv_W", C.c_int), ("conv_C", C.c_int), ("conv_Ho", C.c_int), ("conv_Wo", C.c_int),
-                ("conv_k", C.c_int), ("conv_stride", C.c_int), ("conv_pad", C.c_int), ("conv_act", C.c_int), ("conv_src_u8", C.c_int)]
+                ("conv_k", C.c_int), ("conv_stride", C.c_int), ("conv_pad", C.c_int), ("conv_act", C.c_int), ("conv_src_u8", C.c_int),
+                ("col_sum", C.c_void_p)]
 
 
 OP_NT, OP_NN, OP_TN = 0, 1, 2
@@ -66,7 +67,7 @@ PROTOTYPES = {
     "mt_bn_act_fwd": [f32p, f32p, f32p, f32p, f32p, i64, C.c_int, C.c_int, f32p, C.c_int, C.c_void_p],
     "mt_attn_aggregate": [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "mt_build_clip_inputs": [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_void_p],
-    "mt_layernorm_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_layernorm_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_void_p],
     "mt_colsum": [f32p, i64, RowMap, C.c_int, C.c_int, f32p, C.c_void_p],
     "mt_head_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                     C.c_void_p],
@@ -162,7 +163,7 @@ PROFILE = None
 def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI_STORE, bias=None, R=None, ldr=0,
          scale=None, shift=None, gate=None, hw=1, C2=None, ldc2=0, stats=None, stats_slots=1, n_half=0, split_k=1,
          a_map=(0, 0, 0), b_map=(0, 0, 0), c_map=(0, 0, 0), A2=None, b_prologue=BPRO_NONE, b_scale=None, b_shift=None,
-         b_gate=None, b_hw=1, conv=None):
+         b_gate=None, b_hw=1, conv=None, col_sum=None):
     d = GemmDesc()
     d.op, d.prologue, d.epilogue = op, prologue, epilogue
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
@@ -174,6 +175,7 @@ def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI
     d.C2, d.ldc2, d.stats, d.stats_slots = ptr(C2), ldc2, ptr(stats), stats_slots
     d.n_half, d.split_k = n_half, split_k
     d.A2, d.b_prologue, d.b_scale, d.b_shift, d.b_gate, d.b_hw = ptr(A2), b_prologue, ptr(b_scale), ptr(b_shift), ptr(b_gate), b_hw
+    d.col_sum = ptr(col_sum)
     if conv is not None:   # (H, W, C, Ho, Wo, k, stride, pad, act[, src_u8])
         (d.conv_H, d.conv_W, d.conv_C, d.conv_Ho, d.conv_Wo, d.conv_k, d.conv_stride, d.conv_pad, d.conv_act) = conv[:9]
         d.conv_src_u8 = conv[9] if len(conv) > 9 else 0

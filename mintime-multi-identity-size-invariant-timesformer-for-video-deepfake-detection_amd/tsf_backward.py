@@ -70,6 +70,9 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
                             L.ptr(grads[i0 + 1]), L.ptr(grads[i0 + 2]), L.ptr(grads[i0 + 3]), B, N, D, model.num_classes, eps,
                             st), "mt_head_bwd")
     dx2 = dx.view(M, D)
+    # Bias gradients of the Linears whose output gradient is the residual stream's (net.3 / to_out.0 / patch embedding) are the
+    # column sums of dx2 at that point.  The first one (last layer's net.3.bias) takes a column-sum launch over the head's dx;
+    # every later one is emitted by the LayerNorm backward that produced that dx2 (dx_colsum), so no pass re-reads dx2 for it.
     dxn = torch.empty(M, D, dtype=torch.float32, device=dev)
     du = torch.empty(M, 8 * D, dtype=torch.float32, device=dev)
     do = torch.empty(M, inner, dtype=torch.float32, device=dev)
@@ -82,13 +85,15 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         g, b_, w1, b1, w2, b2 = P[i0:i0 + 6]
         r = rec[2]
         side.wait()                                   # du / dx2 readers of the previous sub-block are done
-        e_dx = wgrad(dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D, bias_out=grads[i0 + 5])
-        L.gemm(L.OP_NN, dx2, w2, du, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D, n_half=4 * D)
-        wgrad(du, r["xn"], grads[i0 + 2], 8 * D, D, M, 8 * D, D, D, bias_out=grads[i0 + 3])
+        e_dx = wgrad(dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D,
+                     bias_out=grads[i0 + 5] if li == model.depth - 1 else None)
+        L.gemm(L.OP_NN, dx2, w2, du, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D, n_half=4 * D,
+               col_sum=grads[i0 + 3])                 # net.0.bias gradient = column sums of du, taken in the epilogue
+        wgrad(du, r["xn"], grads[i0 + 2], 8 * D, D, M, 8 * D, D, D)
         dgrad_skinny(du, w1, dxn, 8 * D)
         side.wait(e_dx)                               # LayerNorm backward updates dx2 in place
         L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
-                                     L.ptr(grads[i0 + 1]), M, D, 1, st), "mt_layernorm_bwd")
+                                     L.ptr(grads[i0 + 1]), M, D, 1, L.ptr(grads[i0 - 1]), 0, st), "mt_layernorm_bwd")   # -> space to_out.0.bias
         r.clear()
         # ---- attention blocks: x_out = o Wo^T + bo + x ; o = attn(qkv) ; qkv = LN(x) Wqkv^T
         for mode in (1, 0):
@@ -96,15 +101,22 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             g, b_, w_qkv, w_o, b_o = P[i0:i0 + 5]
             r = rec[mode]
             side.wait()                               # dqkv / dx2 readers of the previous sub-block are done
-            e_dx = wgrad(dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner, bias_out=grads[i0 + 4])
+            e_dx = wgrad(dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner)
             L.gemm(L.OP_NN, dx2, w_o, do, M, inner, D, D, inner, inner)
             L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
                                     scale, st), "mt_attn_bwd")
             wgrad(dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
             dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner)
             side.wait(e_dx)
+            # the updated dx2 feeds the sub-block below: time attention's to_out.0.bias (index i0 - 1), the previous layer's
+            # net.3.bias (i0 - 1 as well: parameter order is ..., w2, b2 | g, b, w_qkv, w_o, b_o | ...), or -- below layer 0 --
+            # the patch embedding's bias (index 1), which does not see the cls rows
+            if mode == 0 and li == 0:
+                tgt, skip = grads[1], N
+            else:
+                tgt, skip = grads[i0 - 1], 0
             L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
-                                         L.ptr(grads[i0 + 1]), M, D, 1, st), "mt_layernorm_bwd")
+                                         L.ptr(grads[i0 + 1]), M, D, 1, L.ptr(tgt), skip, st), "mt_layernorm_bwd")
             r.clear()
 
     # ---- embeddings + patch embedding
@@ -116,7 +128,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
     tok_map = (F * n, N, 1)      # token row r of the feature matrix lives at row (r/(F n))*N + 1 + r%(F n) of dx
     Mt = B * F * n
     side.wait()
-    wgrad(dx2, feat, grads[i0], D, C_in, Mt, D, C_in, C_in, bias_out=grads[i0 + 1], a_map=tok_map)
+    wgrad(dx2, feat, grads[i0], D, C_in, Mt, D, C_in, C_in, a_map=tok_map)     # (bias: emitted by the last LayerNorm backward)
     dfeat = None
     if need_dfeat:
         dfeat = torch.empty(Mt, C_in, dtype=torch.float32, device=dev)

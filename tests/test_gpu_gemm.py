@@ -186,12 +186,14 @@ def test_full_size_geglu_backward_dgrad():
     u = _rand(M_FULL, 8 * D, seed=3)
     du = torch.full((M_FULL, 8 * D), float("nan"), device="cuda")
     u_il = torch.stack(u.chunk(2, dim=-1), dim=-1).reshape(M_FULL, 8 * D).contiguous()
+    db1 = torch.zeros(8 * D, device="cuda")
     L.gemm(L.OP_NN, dy.cuda(), W2.cuda(), du, M_FULL, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=u_il.cuda(),
-           ldc2=8 * D, n_half=4 * D)
+           ldc2=8 * D, n_half=4 * D, col_sum=db1)
     ud = u.double().requires_grad_(True)
     a, g = ud.chunk(2, dim=-1)
     (a * torch.nn.functional.gelu(g) * _dmm(dy, W2)).sum().backward()
     assert_close(du, ud.grad, 5e-5, "GEGLU backward at M=12576")
+    assert_close(db1, ud.grad.sum(0), 2e-4, "net.0.bias gradient from the epilogue (column sums of du)")
 
 
 @pytest.mark.parametrize("N,K", [(1536, 512), (512, 512), (512, 1280)])

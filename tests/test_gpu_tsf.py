@@ -258,3 +258,29 @@ def test_second_backward_through_the_same_forward_raises_clearly():
     out.sum().backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="second time"):
         out.sum().backward()
+
+
+@pytest.mark.parametrize("rows,skip", [(2 * 393, 0), (5 * 393 + 0, 393), (1000, 0)])
+def test_layernorm_backward_emits_column_sums_of_updated_dx(rows, skip):
+    """mt_layernorm_bwd's dx_colsum: the bias gradient of the Linear below (sum over rows of the updated residual-stream
+    gradient), with the cls rows (row % skip == 0) left out for the patch embedding."""
+    from mintime_amd import lib as L
+    D = 512
+    g = torch.Generator().manual_seed(rows)
+    x, dy, dx0 = torch.randn(rows, D, generator=g), torch.randn(rows, D, generator=g), torch.randn(rows, D, generator=g)
+    gamma = torch.rand(D, generator=g) + 0.5
+    xd = x.double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xd, (D,), gamma.double(), torch.zeros(D, dtype=torch.float64), 1e-5)
+    (y * dy.double()).sum().backward()
+    dx_ref = dx0.double() + xd.grad
+    keep = torch.ones(rows, dtype=torch.bool)
+    if skip:
+        keep[::skip] = False
+    mean, var = x.double().mean(1), x.double().var(1, unbiased=False)
+    stats = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-5)], 1).float().cuda()
+    dxd, dg, db, cs = dx0.cuda().clone(), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    L.check(L.get().mt_layernorm_bwd(L.ptr(dy.cuda()), L.ptr(x.cuda()), L.ptr(stats), L.ptr(gamma.cuda()), L.ptr(dxd), L.ptr(dg), L.ptr(db),
+                                     rows, D, 1, L.ptr(cs), skip, L.stream_ptr()), "ln bwd")
+    assert_close(dxd, dx_ref, 1e-5, "dx")
+    assert_close(cs, dx_ref[keep].sum(0), 1e-4, "column sums of the updated dx")
+    assert_close(db, dy.double().sum(0), 1e-4, "dbeta")
