@@ -279,7 +279,8 @@ def test_layernorm_backward_emits_column_sums_of_updated_dx(rows, skip):
     mean, var = x.double().mean(1), x.double().var(1, unbiased=False)
     stats = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-5)], 1).float().cuda()
     dxd, dg, db, cs = dx0.cuda().clone(), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
-    L.check(L.get().mt_layernorm_bwd(L.ptr(dy.cuda()), L.ptr(x.cuda()), L.ptr(stats), L.ptr(gamma.cuda()), L.ptr(dxd), L.ptr(dg), L.ptr(db),
+    dy_d, x_d, gamma_d = dy.cuda(), x.cuda(), gamma.cuda()          # keep the device copies alive across the raw-pointer call
+    L.check(L.get().mt_layernorm_bwd(L.ptr(dy_d), L.ptr(x_d), L.ptr(stats), L.ptr(gamma_d), L.ptr(dxd), L.ptr(dg), L.ptr(db),
                                      rows, D, 1, L.ptr(cs), skip, L.stream_ptr()), "ln bwd")
     assert_close(dxd, dx_ref, 1e-5, "dx")
     assert_close(cs, dx_ref[keep].sum(0), 1e-4, "column sums of the updated dx")
