@@ -4,9 +4,15 @@ forward + backward + gradient all-reduce + SGD step) on 8-frame, 2-identity, 224
 
     python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the dominant kernel (FF1 GEMM with fused GEGLU, fp32 MFMA) timed live with HIP events on its launch stream
-  cpu_baseline  the CPU oracle (restatement pinned to the reference) timed on this host's cores, rank 0, N == 1 only
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline       the TIME-DOMINANT kernel family of the step (the TimeSformer's weight-gradient GEMMs, fp32 MFMA), timed live
+                 with HIP events on the stream it is launched on, over the timed region
+  roofline_ff1   the largest single GEMM (FF1 + GEGLU epilogue), same method (round 1's roofline object, kept for continuity)
+  roofline_hbm   the dominant HBM-bound kernel family (EfficientNet depthwise data gradient): algorithmic GB/s vs 8 TB/s
+  phases         event-timed phases of the step + the fraction of the fp32-MFMA peak each network reaches
+  forward_only   inference clips/s (eval-mode and train-mode BatchNorm), seeds: ms/step on synthetic seeds 0/1/2 + median
+  cpu_baseline   the CPU oracle (restatement pinned to the reference) timed on this host's cores, rank 0, N == 1 only
+--config 2 | 5 time BASELINE.json's other single-GPU configurations (B=16 1 identity; Xception "XS" B=32 x 16 frames x 3 ids).
 """
 import argparse
 import json
@@ -81,20 +87,28 @@ def cpu_baseline(num_frames, seed, budget_s=20.0):
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 8:
             break
-    return {"value": round(B * n / dt, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} fwd+bwd steps of {B} clips (8-frame, 2-identity, 224x224), train-mode BN, fp32 torch CPU ops"}
+    res = {"value": round(B * n / dt, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n} fwd+bwd steps of {B} clips (8-frame, 2-identity, 224x224), train-mode BN, fp32 torch CPU ops"}
+    # BASELINE config 1: the reference's own CPU-runnable case (2 clips, 1 identity, eval forward only)
+    inp1 = synth.clip_inputs(2, num_frames, 1, seed)
+    with torch.no_grad():
+        O.clip_forward(ef, ts, cfg, inp1, training_extractor=False)
+        t1, m = time.perf_counter(), 0
+        while time.perf_counter() - t1 < 4.0 and m < 10:
+            O.clip_forward(ef, ts, cfg, inp1, training_extractor=False)
+            m += 1
+    res["config1_forward_clips_s"] = round(2 * m / (time.perf_counter() - t1), 3)
+    return res
 
 
-def pmc_traffic(B):
-    """HBM/fabric bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (separate runs, gfx950
-    correction applied; profiles/r01_ff1_geglu_gemm_pmc.json).  Only valid for the shape they were taken on (B = 32)."""
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_ff1_geglu_gemm_pmc.json")
-    if B != 32 or not os.path.exists(f):
-        return {"traffic": None}
-    d = json.load(open(f))
-    return {"traffic": d["traffic_bytes_per_launch"], "traffic_unit": "bytes/launch",
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/r01_ff1_geglu_gemm_pmc.json)",
-            "algorithmic_bytes": sum(d["algorithmic_bytes_per_launch"].values())}
+def committed_counters(key):
+    """Per-launch HBM-side bytes of a kernel family from the committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE
+    runs, gfx950 correction applied: profiles/r02_pmc_families.json, written by tools/pmc_report.py --json).  Valid for the
+    default workload only."""
+    f = os.path.join(ROOT, "profiles", "r02_pmc_families.json")
+    if not os.path.exists(f):
+        return None
+    return json.load(open(f)).get(key)
 
 
 def attention_modules_leg(dev, B, F=8, reps=3):
@@ -135,20 +149,98 @@ def attention_modules_leg(dev, B, F=8, reps=3):
             "mfma_frac": round(flops / (ms * 1e-3) / PEAK_FP32_MFMA, 4), "target_frac": 0.40}
 
 
+WORKLOADS = {   # BASELINE.json configs that fit one GPU: (clips/GPU, frames, identities, extractor, fwd GFLOP/clip)
+    2: dict(B=16, frames=8, ids=1, extractor="efficientnet-b0", flop_fwd=FLOP_PER_CLIP_FWD, name="config 2"),
+    3: dict(B=32, frames=8, ids=2, extractor="efficientnet-b0", flop_fwd=FLOP_PER_CLIP_FWD, name="config 3"),
+    5: dict(B=32, frames=16, ids=3, extractor="xception", flop_fwd=2 * 111174895104, name="config 5 (XS)"),
+}
+
+
+def _probe_summary(pr):
+    durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in pr["events"]]
+    work = [w for _, _, w in pr["events"]]
+    tot_t, tot_w = sum(durs), sum(work)
+    return len(durs), tot_t, tot_w
+
+
+def phases_leg(ef, tsf, opt, batch, reps=3):
+    """Event-timed phases of the step on the main stream (side-stream work is inside the phase that waits for it)."""
+    from mintime_amd import harness, optim
+    acc = {}
+
+    def ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    for it in range(reps + 1):
+        t0 = ev()
+        v = batch["videos"]
+        b, f, h, w, c = v.shape
+        feats = ef(v.reshape(b * f, h, w, c).permute(0, 3, 1, 2))
+        t1 = ev()
+        y = tsf(feats.reshape(b, f, *feats.shape[1:]), mask=batch["mask"], size_embedding=batch["size_embedding"],
+                identities_mask=batch["identities_mask"], positions=batch["positions"])
+        loss = optim.bce_with_logits(y, batch["labels"], None)
+        t2 = ev()
+        opt.zero_grad(set_to_none=True)
+        mark = []
+        feats.register_hook(lambda g: mark.append(ev()))          # fires when the TimeSformer backward has produced dfeat
+        loss.backward()
+        t4 = ev()
+        opt.step()
+        t5 = ev()
+        torch.cuda.synchronize()
+        if it >= 1:
+            for k, (a, b_) in dict(ef_fwd=(t0, t1), tsf_fwd=(t1, t2), tsf_bwd=(t2, mark[0]), ef_bwd=(mark[0], t4), sgd=(t4, t5)).items():
+                acc.setdefault(k, []).append(a.elapsed_time(b_))
+    return {k: round(sum(v) / len(v), 3) for k, v in acc.items()}
+
+
+def forward_only_leg(ef, tsf, batch, iters=5):
+    """Inference throughput of the same path (no_grad; nothing is kept for a backward pass), eval-mode and train-mode BatchNorm."""
+    from mintime_amd import harness
+    out = {}
+    was = ef.training
+    for name, mode in (("eval_bn", False), ("train_bn", True)):
+        ef.train(mode)
+        with torch.no_grad():
+            for _ in range(2):
+                harness.forward(ef, tsf, batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                harness.forward(ef, tsf, batch)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        out[name + "_ms"] = round(dt * 1e3, 3)
+        out[name + "_clips_s"] = round(batch["videos"].shape[0] / dt, 1)
+    ef.train(was)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-per-gpu", type=int, default=32)
-    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(WORKLOADS), help="BASELINE.json configuration (3 = the headline)")
+    ap.add_argument("--batch-per-gpu", type=int, default=None)
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--ragged", action="store_true", help="config-3 variant with the last slot of each identity padded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the phase / forward-only / seed legs")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--force-reducer", action="store_true",
                     help="single-GPU check of the multi-GPU step: 1-rank RCCL group + the overlapped gradient reducer")
     a = ap.parse_args()
+    wl = dict(WORKLOADS[a.config])
+    if a.batch_per_gpu:
+        wl["B"] = a.batch_per_gpu
+    if a.frames:
+        wl["frames"] = a.frames
     if a.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(a.frames, 0)))
+        print(json.dumps(cpu_baseline(wl["frames"], 0)))
         return
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,16 +260,20 @@ def main():
     import mintime_amd
     from mintime_amd import harness, lib, ddp
     lib.get()
-    B = a.batch_per_gpu
-    cfg, ef, tsf = harness.build_models(a.frames, seed=0, device=dev)            # train-mode BN + drop-connect 0.2 (train.py:157)
+    B, frames = wl["B"], wl["frames"]
+    if wl["extractor"] == "xception":
+        cfg, ef, tsf = harness.build_models_xs(frames, seed=0, device=dev)
+    else:
+        cfg, ef, tsf = harness.build_models(frames, seed=0, device=dev)          # train-mode BN + drop-connect 0.2 (train.py:157)
     opt = harness.make_optimizer(cfg, ef, tsf)
-    batch = harness.device_batch(B, a.frames, 2, seed=rank, device=dev)          # config 3 masks: 2 identities [4,4]
+    batch = harness.device_batch(B, frames, wl["ids"], seed=rank, device=dev, ragged=a.ragged)
     # buckets in the order backward finishes them: the TimeSformer's 48 M gradients all-reduce under the EfficientNet backward
     reducer = (ddp.OverlappedGradReducer([tsf, ef], force=a.force_reducer)
                if world > 1 or a.force_reducer else None)
+    reducer_path = "none" if reducer is None else "overlapped"
 
-    def step():
-        return harness.train_step(ef, tsf, opt, batch, reducer)
+    def step(bt=None):
+        return harness.train_step(ef, tsf, opt, batch if bt is None else bt, reducer)
 
     if reducer is not None:
         try:                                 # never lose a scaling run to the overlapped path: fall back to the plain flat all-reduce
@@ -189,11 +285,16 @@ def main():
             ef._grads_ready_hook = tsf._grads_ready_hook = None
             opt.zero_grad(set_to_none=True)
             reducer = ddp.GradAllReducer(list(ef.parameters()) + list(tsf.parameters()))
+            reducer_path = "flat"
     for _ in range(a.warmup):
         step()
-    # live timing of the dominant kernel: FF1 GEMM + GEGLU epilogue (9 launches per step), HIP events on its stream
-    prof = {"match": lambda d: d.epilogue == lib.EPI_GEGLU, "events": []}
-    lib.PROFILE = prof
+    # live kernel timing over the timed region, HIP events on the stream each kernel is launched on:
+    #   the TimeSformer's weight-gradient GEMMs (TN, plain operands; side stream) = the time-dominant kernel family of the step,
+    #   FF1 + GEGLU (the largest single GEMM), the EfficientNet depthwise data gradient (the largest HBM-bound family)
+    p_wgrad = {"match": lambda d: d.op == lib.OP_TN and d.prologue == lib.PRO_NONE and d.b_prologue == lib.BPRO_NONE, "events": []}
+    p_ff1 = {"match": lambda d: d.epilogue == lib.EPI_GEGLU, "events": []}
+    p_dw = {"name": "dwconv_dgrad", "events": []}
+    lib.PROFILE = [p_ff1, p_wgrad, p_dw]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -215,32 +316,85 @@ def main():
     if rank == 0:
         ms = 1e3 * dt / a.steps
         clips_s = world * B * a.steps / dt
-        durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in prof["events"]]
-        flops = prof["events"][0][2] if prof["events"] else 0.0
-        avg = sum(durs) / max(len(durs), 1)
-        achieved = flops / avg / 1e12 if avg > 0 else 0.0
+        flop_step = 3 * wl["flop_fwd"]
+        headline = a.config == 3 and B == 32 and frames == 8 and not a.ragged
+        n_w, t_w, f_w = _probe_summary(p_wgrad)
+        n_f, t_f, f_f = _probe_summary(p_ff1)
+        n_d, t_d, b_d = _probe_summary(p_dw)
+        pmc = lambda key: (committed_counters(key) or {}) if headline else {}
         out = {
-            "metric": "clips/sec (8-frame, 2-identity, 224^2 crops) fwd+bwd", "value": round(clips_s, 2), "unit": "clips/s",
+            "metric": "clips/sec (8-frame, 2-identity, 224^2 crops) fwd+bwd" if a.config != 5 else
+                      "clips/sec (16-frame, 3-identity, 224^2 crops, Xception extractor) fwd+bwd",
+            "value": round(clips_s, 2), "unit": "clips/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config 3: EfficientNet-B0 + SizeInvariantTimeSformer(dim 512, depth 9, heads 8), "
-                                   f"B={B}/GPU, {a.frames} frames, 2 identities [4,4] identity-masked, 224x224 crops, random-init "
-                                   "seeded weights, train-mode BN + drop-connect, step = fwd + BCE loss + bwd"
+            "config": {"workload": f"{wl['name']}: {'Xception' if a.config == 5 else 'EfficientNet-B0'} + SizeInvariantTimeSformer(dim 512, "
+                                   f"depth 9, heads 8), B={B}/GPU, {frames} frames, {wl['ids']} identit{'y' if wl['ids'] == 1 else 'ies'} "
+                                   f"{'(identity-masked' + (', last slot of each identity padded' if a.ragged else '') + ')'}, 224x224 crops, "
+                                   "random-init seeded weights, train-mode BN" + (" + drop-connect 0.2" if a.config != 5 else "")
+                                   + ", step = fwd + BCE loss + bwd"
                                    + (" + RCCL grad all-reduce" if world > 1 else "") + " + SGD(lr .01, wd 1e-4)",
-                       "global_batch": world * B, "frames": a.frames, "parallelism": f"dp{world}",
-                       "model_tflops": round(clips_s * FLOP_PER_CLIP_STEP / 1e12, 2),
-                       "model_mfma_frac": round(clips_s * FLOP_PER_CLIP_STEP / (world * PEAK_FP32_MFMA), 4),
+                       "global_batch": world * B, "frames": frames, "parallelism": f"dp{world}", "reducer_path": reducer_path,
+                       "model_tflops": round(clips_s * flop_step / 1e12, 2),
+                       "model_mfma_frac": round(clips_s * flop_step / (world * PEAK_FP32_MFMA), 4),
                        "loss": round(float(loss.item()), 5)},
-            "roofline": {"bound": "mfma", "kernel": "mt::gemm_kernel<2,2,2,2,NT,EPI_GEGLU> (FF1 512->4096 + GEGLU, M=B*393)",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved / (PEAK_FP32_MFMA / 1e12), 4), **pmc_traffic(B),
-                         "launches_timed": len(durs), "avg_launch_us": round(avg * 1e6, 1),
-                         "flops_per_launch": flops},
+            # the time-dominant kernel family: in-step duration (next to the main stream's data-gradient GEMMs), all launches summed
+            "roofline": {"bound": "mfma", "kernel": "TimeSformer weight-gradient GEMMs: mt::gemm_dma_kernel<..., TN, EPI_ATOMIC> "
+                                                    "(dW = dY^T X over B*393 rows, split-K + fp32 atomics; side stream)",
+                         "achieved": round(f_w / t_w / 1e12, 2) if t_w else None, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
+                         "frac": round(f_w / t_w / PEAK_FP32_MFMA, 4) if t_w else None,
+                         "traffic": pmc("tsf_wgrad").get("bytes_per_launch"), "traffic_unit": "bytes/launch (family mean)",
+                         "traffic_source": pmc("tsf_wgrad").get("source"),
+                         "algorithmic_bytes": pmc("tsf_wgrad").get("algorithmic_bytes_per_launch"),
+                         "launches_timed": n_w, "launches_per_step": n_w // max(a.steps, 1),
+                         "avg_launch_us": round(t_w / max(n_w, 1) * 1e6, 1), "flops_per_launch": f_w / max(n_w, 1),
+                         "ms_per_step": round(t_w / max(a.steps, 1) * 1e3, 3)},
+            "roofline_ff1": {"bound": "mfma", "kernel": "mt::gemm_dma_kernel<128x128, NT, EPI_GEGLU> (FF1 512->4096 + GEGLU, M=B*393)",
+                             "achieved": round(f_f / t_f / 1e12, 2) if t_f else None, "peak": PEAK_FP32_MFMA / 1e12,
+                             "unit": "TFLOP/s", "frac": round(f_f / t_f / PEAK_FP32_MFMA, 4) if t_f else None,
+                             "traffic": pmc("tsf_ff1").get("bytes_per_launch"), "traffic_unit": "bytes/launch",
+                             "algorithmic_bytes": pmc("tsf_ff1").get("algorithmic_bytes_per_launch"),
+                             "launches_timed": n_f, "avg_launch_us": round(t_f / max(n_f, 1) * 1e6, 1),
+                             "flops_per_launch": f_f / max(n_f, 1)},
         }
-        if world == 1:
-            out["attention_modules"] = attention_modules_leg(dev, B, a.frames)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_subprocess(a.frames)
+        if n_d:
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": "EfficientNet depthwise-conv data gradient (dwconv_dgrad_tiled_kernel, 16 "
+                                                             "launches/step, main stream, next to the side stream's weight gradients)",
+                                   "achieved": round(b_d / t_d / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                   "frac": round(b_d / t_d / 8e12, 4),
+                                   "traffic": pmc("ef_dwconv_dgrad").get("bytes_per_step"), "traffic_unit": "bytes/step (16 launches)",
+                                   "algorithmic_bytes": round(b_d / max(a.steps, 1)), "launches_timed": n_d,
+                                   "ms_per_step": round(t_d / max(a.steps, 1) * 1e3, 3)}
+        if world == 1 and not a.no_extras:
+            ph = phases_leg(ef, tsf, opt, batch)
+            tsf_flop = 3 * B * (wl["flop_fwd"] - (2 * 3076278016 if a.config != 5 else 2 * 72813297152))
+            ef_flop = 3 * wl["flop_fwd"] * B - tsf_flop
+            ph["tsf_mfma_frac"] = round(tsf_flop / ((ph["tsf_fwd"] + ph["tsf_bwd"]) * 1e-3) / PEAK_FP32_MFMA, 4)
+            ph["extractor_mfma_frac"] = round(ef_flop / ((ph["ef_fwd"] + ph["ef_bwd"]) * 1e-3) / PEAK_FP32_MFMA, 4)
+            step_bytes = pmc("ef_step").get("bytes_per_step")
+            if step_bytes:
+                ph["extractor_hbm_GBps"] = round(step_bytes / ((ph["ef_fwd"] + ph["ef_bwd"]) * 1e-3) / 1e9, 1)
+                ph["extractor_hbm_frac"] = round(step_bytes / ((ph["ef_fwd"] + ph["ef_bwd"]) * 1e-3) / 8e12, 4)
+            out["phases"] = ph
+            out["forward_only"] = forward_only_leg(ef, tsf, batch)
+            seeds = {"0": round(ms, 3)}
+            for sd in (1, 2):
+                bt = harness.device_batch(B, frames, wl["ids"], seed=sd, device=dev, ragged=a.ragged)
+                for _ in range(2):
+                    step(bt)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n_sd = max(3, a.steps // 2)
+                for _ in range(n_sd):
+                    step(bt)
+                torch.cuda.synchronize()
+                seeds[str(sd)] = round(1e3 * (time.perf_counter() - t1) / n_sd, 3)
+            out["seeds"] = {"ms_per_step": seeds, "median_ms": sorted(seeds.values())[1],
+                            "median_clips_s": round(B / (sorted(seeds.values())[1] * 1e-3), 2)}
+            if a.config != 5:
+                out["attention_modules"] = attention_modules_leg(dev, B, frames)
+        if world == 1 and not a.no_cpu_baseline and a.config != 5:
+            out["cpu_baseline"] = cpu_baseline_subprocess(frames)
     line = json.dumps(out) if rank == 0 else None
     if world > 1 or a.force_reducer:
         dist.barrier()

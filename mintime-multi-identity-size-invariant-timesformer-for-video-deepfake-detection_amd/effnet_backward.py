@@ -134,7 +134,9 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                                       L.ptr(grads[_ix["d"]]), N, _s.hin, _s.hin, _s.cexp, _s.k, _s.s, parts, 1, None, None, L.stream_ptr()),
                     "mt_dwconv_bwd")
         side.launch(lambda: dw_part(1), reads=(da, rec["z_d"], kabc_d, rec["dw_in"], in_bn.scale, in_bn.shift))
-        dw_part(2)
+        # algorithmic HBM bytes of the data-gradient pass: read da, z_d (M_out x cexp each) and the dw input's pre-activation
+        # (M_in x cexp, for swish'), write du_in (M_in x cexp)
+        L.timed("dwconv_dgrad", lambda: dw_part(2), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
         del da
         if s.has_expand:
             # (h,i,j) bn0 + expand conv: z_e = y_in . We^T

@@ -21,6 +21,19 @@ def build_models(num_frames=8, seed=0, device="cuda", require_attention=False, d
     return cfg, ef, tsf
 
 
+def build_models_xs(num_frames=16, seed=0, device="cuda", require_attention=False):
+    """BASELINE config 5 (the "XS" variant): Xception extractor (models/xception.py) + TimeSformer over 2048-channel features."""
+    from .xception import xception
+    cfg = arch.default_tsf_config(2048, num_frames)
+    xc = xception(num_classes=1, pretrain_path=None)
+    xc.load_state_dict(synth.xception_state(seed))
+    tsf = SizeInvariantTimeSformer(config=cfg, require_attention=require_attention)
+    tsf.load_state_dict(synth.tsf_state(cfg, seed))
+    xc.to(device).train()
+    tsf.to(device).train()
+    return cfg, xc, tsf
+
+
 def make_optimizer(cfg, ef, tsf):
     """train.py:180-190: optimizer over chain(extractor, model) parameters; SGD(lr, weight_decay) from the YAML."""
     t = cfg["training"]

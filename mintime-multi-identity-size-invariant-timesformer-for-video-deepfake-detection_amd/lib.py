@@ -155,9 +155,26 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-# Optional live kernel timing (bench.py's roofline leg): {"match": fn(desc) -> bool, "events": [(start, end, flops)]}.
-# Events are recorded on the stream the kernel is launched on (torch's current stream).
+# Optional live kernel timing (bench.py's roofline legs): a list of probes {"match": fn(desc) -> bool, "events": [...]} for
+# mt_gemm launches, and named probes {"name": str, "events": [...]} for other entry points (timed(name, fn, work)).
+# Events are recorded on the stream the kernel is launched on (torch's current stream: inside SideStream.launch that is the
+# side stream), so a duration is what the launch took IN the step, next to whatever the other stream was running.
 PROFILE = None
+
+
+def timed(name, fn, work=0.0):
+    """Run fn() (one kernel launch); if a probe called `name` is active, bracket it with events and note `work` (bytes or flops)."""
+    prof = PROFILE
+    if prof is not None:
+        for pr in prof:
+            if pr.get("name") == name:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                pr["events"].append((e0, e1, work))
+                return
+    fn()
 
 
 def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI_STORE, bias=None, R=None, ldr=0,
@@ -180,13 +197,15 @@ def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI
         (d.conv_H, d.conv_W, d.conv_C, d.conv_Ho, d.conv_Wo, d.conv_k, d.conv_stride, d.conv_pad, d.conv_act) = conv[:9]
         d.conv_src_u8 = conv[9] if len(conv) > 9 else 0
     prof = PROFILE
-    if prof is not None and prof["match"](d):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(get().mt_gemm(C.byref(d), stream_ptr()), "mt_gemm")
-        e1.record()
-        prof["events"].append((e0, e1, 2.0 * M * N * K))
-        return
+    if prof is not None:
+        for pr in prof:
+            if "match" in pr and pr["match"](d):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(get().mt_gemm(C.byref(d), stream_ptr()), "mt_gemm")
+                e1.record()
+                pr["events"].append((e0, e1, 2.0 * M * N * K))
+                return
     check(get().mt_gemm(C.byref(d), stream_ptr()), "mt_gemm")
 
 

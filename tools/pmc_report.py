@@ -13,6 +13,8 @@ ap.add_argument("dir")
 ap.add_argument("--min", type=float, default=1e9)
 ap.add_argument("--start", default="5, 3, 0>", help="substring of the kernel that starts a step (EfficientNet: the im2col stem GEMM)")
 ap.add_argument("--fetch-scale", type=float, default=2.0)
+ap.add_argument("--json-out", default=None, help="merge family totals into this JSON file (profiles/r02_pmc_families.json)")
+ap.add_argument("--kind", default="ef", choices=["ef", "tsf"])
 a = ap.parse_args()
 
 
@@ -53,6 +55,7 @@ for k in passes:
         if len(passes[k]) != len(kt):
             print(f"# warning: pass {k} has {len(passes[k])} dispatches in its last step, the trace {len(kt)}")
 fam = defaultdict(lambda: defaultdict(float))
+per_launch = []
 print(f"{'idx':>4} {'us':>8} {'rd MB':>8} {'wr MB':>8} {'GB/s':>7} {'mfma%':>6} {'valu/wave':>9}  kernel")
 for i, (name, us, grid) in enumerate(kt):
     c = {}
@@ -61,6 +64,7 @@ for i, (name, us, grid) in enumerate(kt):
             c.update(passes[k][i][1])
     rd = c.get("FETCH_SIZE", 0.0) * 1024 * a.fetch_scale        # FETCH_SIZE / WRITE_SIZE are reported in KiB
     wr = c.get("WRITE_SIZE", 0.0) * 1024
+    per_launch.append({"rd": rd, "wr": wr})
     busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
     gui = c.get("GRBM_GUI_ACTIVE", 0.0)
     mfma = busy / (gui * 256 * 4) if gui else 0.0                # 256 CUs x 4 SIMDs (counter summed over the chip)
@@ -77,3 +81,42 @@ for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["us"]):
     mf = f["busy"] / (f["gui"] * 1024) if f["gui"] else 0.0
     wt = f["wait"] / f["wcyc"] if f["wcyc"] else 0.0
     print(f"{f['us'] / 1e3:7.2f} {int(f['n']):4d} {f['rd'] / 1e9:7.2f} {f['wr'] / 1e9:7.2f} {(f['rd'] + f['wr']) / f['us'] / 1e6:6.2f} {100 * mf:6.1f} {100 * wt:6.1f}  {k}")
+
+if a.json_out:
+    import json, os
+    doc = json.load(open(a.json_out)) if os.path.exists(a.json_out) else {}
+    src = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, side stream off (tools/ef_pmc.sh); FETCH_SIZE doubled "
+           "(gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section), WRITE_SIZE as reported")
+
+    def family(pred):
+        sel = [(us, c) for (name, us, _), c in zip(kt, per_launch) if pred(short(name))]
+        return sel
+
+    if a.kind == "ef":
+        tot = sum(f["rd"] + f["wr"] for f in fam.values())
+        dw = fam.get("dwconv_dgrad_tiled_kernel")
+        doc["ef_step"] = {"bytes_per_step": tot, "kernel_ms": round(sum(f["us"] for f in fam.values()) / 1e3, 3), "launches": len(kt),
+                          "source": src, "workload": "EfficientNet-B0 forward+backward, 256 crops (config 3), train-mode BN"}
+        if dw:
+            doc["ef_dwconv_dgrad"] = {"bytes_per_step": dw["rd"] + dw["wr"], "read_bytes": dw["rd"], "write_bytes": dw["wr"],
+                                      "launches": int(dw["n"]), "kernel_ms": round(dw["us"] / 1e3, 3), "source": src}
+        doc["ef_families"] = {k: {"ms": round(f["us"] / 1e3, 3), "n": int(f["n"]), "read_GB": round(f["rd"] / 1e9, 3),
+                                  "write_GB": round(f["wr"] / 1e9, 3)} for k, f in fam.items() if f["us"] > 100}
+    else:
+        M = 32 * 393
+        tn = family(lambda n: re.match(r"gemm_dma_kernel<\d+, \d+, \d+, \d+, 1, 1, 4,", n) is not None)
+        ff1 = family(lambda n: re.match(r"gemm_dma_kernel<2, 2, 2, 2, 0, 0, 2,", n) is not None)
+        shapes = [(512, 2048, 9), (4096, 512, 9), (1536, 512, 18), (512, 512, 18)]
+        alg = sum(4.0 * (M * (n1 + n2) + n1 * n2) * c for n1, n2, c in shapes) / sum(c for _, _, c in shapes)
+        if tn:
+            doc["tsf_wgrad"] = {"bytes_per_launch": sum(c["rd"] + c["wr"] for _, c in tn) / len(tn), "launches": len(tn),
+                                "kernel_ms": round(sum(us for us, _ in tn) / 1e3, 3), "algorithmic_bytes_per_launch": alg,
+                                "source": src}
+        if ff1:
+            doc["tsf_ff1"] = {"bytes_per_launch": sum(c["rd"] + c["wr"] for _, c in ff1) / len(ff1), "launches": len(ff1),
+                              "read_bytes": sum(c["rd"] for _, c in ff1) / len(ff1), "write_bytes": sum(c["wr"] for _, c in ff1) / len(ff1),
+                              "algorithmic_bytes_per_launch": 4.0 * (M * 512 + 4096 * 512 + 4096 + M * 2048 + M * 4096), "source": src}
+        doc["tsf_families"] = {k: {"ms": round(f["us"] / 1e3, 3), "n": int(f["n"]), "read_GB": round(f["rd"] / 1e9, 3),
+                                   "write_GB": round(f["wr"] / 1e9, 3)} for k, f in fam.items() if f["us"] > 100}
+    json.dump(doc, open(a.json_out, "w"), indent=1)
+    print("wrote", a.json_out)
