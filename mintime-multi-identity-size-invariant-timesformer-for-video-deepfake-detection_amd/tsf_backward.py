@@ -5,6 +5,8 @@ Walks the layers last-to-first on the saved buffers of tsf_engine.tsf_forward:
     the attention-core / LayerNorm / embedding / head adjoint kernels of csrc/tsf_bwd.hip.
 `dx` is the running gradient of the residual stream and is updated in place.
 """
+import os
+
 import torch
 
 from . import arch
@@ -46,13 +48,31 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
     def colsum(A, lda, rows, cols, out, amap=(0, 0, 0)):
         L.check(lib.mt_colsum(L.ptr(A), lda, L.RowMap(*amap), rows, cols, L.ptr(out), L.stream_ptr()), "mt_colsum")
 
+    # share of a long-K data gradient that is handed to the side stream (see dgrad_skinny); tuned in-step
+    side_share = float(os.environ.get("MT_DGRAD_SIDE_SHARE", "0.25"))
+
     def dgrad_skinny(dY, Wm, out, K_):
-        """out[M,D] = dY[M,K_] . Wm[K_,D]: only 396 output tiles -> K-slices + fp32 atomics onto a zeroed output when K is long."""
+        """out[M,D] = dY[M,K_] . Wm[K_,D]: only 396 output tiles -> K-slices + fp32 atomics onto a zeroed output when K is long.
+        The step is bound by the main stream's kernel time while the weight-gradient stream has slack (in-step trace: main
+        97 % busy, side 80-90 %), and a split-K sum does not care which stream a slice runs on: the last `side_share` of the
+        contraction goes to the side stream.  Returns the side launch's event (or None); the caller waits for it before `out`
+        is consumed."""
         if M >= 4096 and K_ >= 1024:
             out.zero_()
-            L.gemm(L.OP_NN, dY, Wm, out, M, D, K_, K_, D, D, epilogue=L.EPI_ATOMIC, split_k=4 if K_ >= 2048 else 3)   # measured optimum with 64x64 tiles
-        else:
-            L.gemm(L.OP_NN, dY, Wm, out, M, D, K_, K_, D, D)
+            splits = 4 if K_ >= 2048 else 3                      # measured optimum with 64x64 tiles
+            k_side = 0
+            if side.enabled and side_share > 0 and K_ >= 2048:
+                k_side = int(K_ * side_share) // 512 * 512
+            k_main = K_ - k_side
+            ev = None
+            if k_side:
+                dY_s, W_s = dY[:, k_main:], Wm[k_main:]
+                ev = side.launch(lambda: L.gemm(L.OP_NN, dY_s, W_s, out, M, D, k_side, K_, D, D, epilogue=L.EPI_ATOMIC,
+                                                split_k=max(1, round(splits * k_side / K_))), reads=(dY, Wm, out))
+            L.gemm(L.OP_NN, dY, Wm, out, M, D, k_main, K_, D, D, epilogue=L.EPI_ATOMIC, split_k=max(1, round(splits * k_main / K_)))
+            return ev
+        L.gemm(L.OP_NN, dY, Wm, out, M, D, K_, K_, D, D)
+        return None
 
     def wgrad(A, Bm, out, M_, N_, K_, lda, ldb, ldc, bias_out=None, **kw):
         """dW (+ db) on the side stream: reads A [K_,M_] and Bm [K_,N_], accumulates into zero-filled grads."""
@@ -90,8 +110,10 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         L.gemm(L.OP_NN, dx2, w2, du, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D, n_half=4 * D,
                col_sum=grads[i0 + 3])                 # net.0.bias gradient = column sums of du, taken in the epilogue
         wgrad(du, r["xn"], grads[i0 + 2], 8 * D, D, M, 8 * D, D, D)
-        dgrad_skinny(du, w1, dxn, 8 * D)
+        e_dg = dgrad_skinny(du, w1, dxn, 8 * D)
         side.wait(e_dx)                               # LayerNorm backward updates dx2 in place
+        if e_dg is not None:
+            side.wait(e_dg)                           # ... and reads dxn, part of which the side stream summed
         L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
                                      L.ptr(grads[i0 + 1]), M, D, 1, L.ptr(grads[i0 - 1]), 0, st), "mt_layernorm_bwd")   # -> space to_out.0.bias
         r.clear()
@@ -106,8 +128,10 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
                                     scale, st), "mt_attn_bwd")
             wgrad(dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
-            dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner)
+            e_dg = dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner)
             side.wait(e_dx)
+            if e_dg is not None:
+                side.wait(e_dg)
             # the updated dx2 feeds the sub-block below: time attention's to_out.0.bias (index i0 - 1), the previous layer's
             # net.3.bias (i0 - 1 as well: parameter order is ..., w2, b2 | g, b, w_qkv, w_o, b_o | ...), or -- below layer 0 --
             # the patch embedding's bias (index 1), which does not see the cls rows
