@@ -207,30 +207,34 @@ __device__ __forceinline__ bool tile_coords(const GemmArgs& p, int& mt_, int& nt
 }
 
 // Accumulator store with the fused epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <int TM, int TN, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane) {
+// FAST = the wavefront's whole tile lies inside the matrix and rows are not re-mapped: no per-element bounds test or row map,
+// one base pointer per lane and element offsets that are wave-uniform multiples of the leading dimension (the checked form costs
+// ~60 ISA instructions per stored element -- a tenth of a K = 512 problem's run time).
+template <int TM, int TN, int EPI, bool FAST>
+__device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane) {
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
+  const int mw = m0 + wm * TM * 32;               // first row of this wavefront's tile
 
   if constexpr (EPI == EPI_GEGLU) {
     // acc[i][0] = 'a' pre-activation, acc[i][1] = gate pre-activation, same (row, col) in one lane
     const int j = (n0 >> 1) + wn * 32 + col_l;
-    const bool jok = j < p.n_half;
+    const bool jok = FAST || j < p.n_half;
     const float ba = (jok && p.bias) ? p.bias[j] : 0.f;
     const float bg = (jok && p.bias) ? p.bias[p.n_half + j] : 0.f;
+    float* hp = p.C + (int64_t)(mw + row_h) * p.ldc + j;
+    float* up = p.C2 ? p.C2 + (int64_t)(mw + row_h) * p.ldc2 + 2 * j : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-        if (m < p.M && jok) {
+        const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+        if (FAST || (mw + row_h + dr < p.M && jok)) {
           const float a = acc[i][0][r] + ba;
           const float g = acc[i][1][r] + bg;
-          p.C[(int64_t)m * p.ldc + j] = a * gelu_erf(g);
-          if (p.C2) {
-            // pre-activations interleaved (a_j, g_j): one 8-byte store per lane here, one 8-byte load in GEGLU_BWD
-            *reinterpret_cast<float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * j) = make_float2(a, g);
-          }
+          hp[(int64_t)dr * p.ldc] = a * gelu_erf(g);
+          // pre-activations interleaved (a_j, g_j): one 8-byte store per lane here, one 8-byte load in GEGLU_BWD
+          if (up) *reinterpret_cast<float2*>(up + (int64_t)dr * p.ldc2) = make_float2(a, g);
         }
       }
     }
@@ -239,39 +243,53 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * TN * 32 + j * 32 + col_l;
-      const bool nok = n < p.N;
+      const bool nok = FAST || n < p.N;
       float bias = 0.f;
       if constexpr (EPI == EPI_STORE || EPI == EPI_BIAS_RES || EPI == EPI_ACCUM)
         bias = (nok && p.bias) ? p.bias[n] : 0.f;
       if constexpr (EPI == EPI_ATOMIC)      // split-K: the bias rides on the first K-slice only
         bias = (nok && p.bias && blockIdx.y == 0) ? p.bias[n] : 0.f;
       float s1 = 0.f, s2 = 0.f;
+      float* cp = p.C + (int64_t)(mw + row_h) * p.ldc + n;                         // FAST path bases
+      const float* rp = (EPI == EPI_BIAS_RES) ? p.R + (int64_t)(mw + row_h) * p.ldr + n : nullptr;
+      const float* up = (EPI == EPI_GEGLU_BWD) ? p.C2 + (int64_t)(mw + row_h) * p.ldc2 + 2 * n : nullptr;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-          if (m < p.M && nok) {
+          const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+          const int m = mw + row_h + dr;
+          if (FAST || (m < p.M && nok)) {
             float v = acc[i][j][r];
-            const int64_t crow = map_row(p.c_map, m);
+            float* c;
+            const float* rr = nullptr;
+            if constexpr (FAST) {
+              c = cp + (int64_t)dr * p.ldc;
+              if constexpr (EPI == EPI_BIAS_RES) rr = rp + (int64_t)dr * p.ldr;
+            } else {
+              const int64_t crow = map_row(p.c_map, m);
+              c = p.C + crow * p.ldc + n;
+              if constexpr (EPI == EPI_BIAS_RES) rr = p.R + crow * p.ldr + n;
+            }
             if constexpr (EPI == EPI_STORE) {
-              p.C[crow * p.ldc + n] = v + bias;
+              *c = v + bias;
             } else if constexpr (EPI == EPI_BIAS_RES) {
-              p.C[crow * p.ldc + n] = v + bias + p.R[crow * p.ldr + n];
+              *c = v + bias + *rr;
             } else if constexpr (EPI == EPI_ACCUM) {
-              p.C[crow * p.ldc + n] += v + bias;
+              *c += v + bias;
             } else if constexpr (EPI == EPI_STATS) {
-              p.C[crow * p.ldc + n] = v;
+              *c = v;
               s1 += v; s2 += v * v;
             } else if constexpr (EPI == EPI_ATOMIC) {
-              atomicAdd(p.C + crow * p.ldc + n, v + bias);
+              atomicAdd(c, v + bias);
             } else if constexpr (EPI == EPI_GEGLU_BWD) {
               // n indexes h columns [0, n_half); u = [a | g] pre-activations
-              const float2 ag = *reinterpret_cast<const float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * n);
+              const float2 ag = FAST ? *reinterpret_cast<const float2*>(up + (int64_t)dr * p.ldc2)
+                                     : *reinterpret_cast<const float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * n);
               const float a = ag.x, g = ag.y;
               const float da = v * gelu_erf(g), dg = v * a * gelu_erf_grad(g);
-              p.C[crow * p.ldc + n] = da;
-              p.C[crow * p.ldc + p.n_half + n] = dg;
+              c[0] = da;
+              c[p.n_half] = dg;
               s1 += da; s2 += dg;
             }
           }
@@ -298,6 +316,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
       }
     }
   }
+}
+
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane) {
+  // wave-uniform: is this wavefront's TM*32 x TN*32 tile entirely inside the output, with identity row order?
+  const int mw = m0 + wm * TM * 32;
+  bool interior = p.c_map.gin == 0 && mw + TM * 32 <= p.M;
+  if constexpr (EPI == EPI_GEGLU) interior = interior && (n0 >> 1) + wn * 32 + 32 <= p.n_half;
+  else interior = interior && n0 + wn * TN * 32 + TN * 32 <= p.N;
+  if (interior) gemm_epilogue_body<TM, TN, EPI, true>(p, acc, m0, n0, wm, wn, lane);
+  else gemm_epilogue_body<TM, TN, EPI, false>(p, acc, m0, n0, wm, wn, lane);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI, int BPRO = BPRO_NONE>

@@ -122,7 +122,8 @@ int try_launch_dma(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
     int splits = d->split_k;
     if (d->op == MT_OP_TN && splits <= 0) {
       const int tiles = m_tiles * n_tiles;
-      splits = (2048 + tiles - 1) / tiles;
+      static const int target = getenv("MT_WGRAD_BLOCKS") ? atoi(getenv("MT_WGRAD_BLOCKS")) : 2048;   // tuning knob
+      splits = (target + tiles - 1) / tiles;
       const int max_splits = d->K / 256 > 0 ? d->K / 256 : 1;
       if (splits > max_splits) splits = max_splits;
     }

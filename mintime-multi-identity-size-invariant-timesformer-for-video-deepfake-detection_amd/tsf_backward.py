@@ -57,7 +57,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         97 % busy, side 80-90 %), and a split-K sum does not care which stream a slice runs on: the last `side_share` of the
         contraction goes to the side stream.  Returns the side launch's event (or None); the caller waits for it before `out`
         is consumed."""
-        if M >= 4096 and K_ >= 1024:
+        if M >= 4096 and K_ >= 1024 and os.environ.get("MT_SKINNY_SPLIT") == "1":
             out.zero_()
             splits = 4 if K_ >= 2048 else 3                      # measured optimum with 64x64 tiles
             k_side = 0

@@ -160,7 +160,7 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
         # FF2 is skinny (N = 512 -> 396 output tiles on 256 CUs): 5 K-slices accumulated with fp32 atomics onto the residual
         # even out the tail (measured 333 -> 270 us at B = 32).  Training only: atomics make the sum order -- the last bits of
         # the logits -- vary from run to run, and inference (no saved buffers) stays bit-reproducible at every batch size.
-        if M >= 4096 and save:
+        if M >= 4096 and save and os.environ.get("MT_SKINNY_SPLIT") == "1":
             x_new = x.clone() if save else x
             L.gemm(L.OP_NT, hbuf, w2, x_new, M, D, 4 * D, 4 * D, 4 * D, D, epilogue=L.EPI_ATOMIC, bias=b2, split_k=5)
         else:
