@@ -414,12 +414,16 @@ int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, co
 // One block = one 16-channel chunk, grid-strided over T x T INPUT tiles.  dz = ka*du+kb*z+kc over the output positions
 // the tile's taps can reach is built once in LDS; thread (cq, slot) then gathers its input pixels' taps from LDS,
 // applies swish' of the input-side BatchNorm and accumulates that BatchNorm's backward sums in registers.
-template <int K, int S, int T, int ACT, int CC>
+// WG = true also accumulates the depthwise WEIGHT gradient in the same pass (input-centric form of the same sum:
+//   dW[kh,kw] = sum over input pixels of a_in[iy,ix] * dz[(iy+P-kh)/S, (ix+P-kw)/S]  -- exactly the taps the data gradient gathers),
+// so du, z and the dw input are streamed once instead of once per kernel (the separate weight-gradient kernel re-reads all three:
+// 10 of the EfficientNet step's 88 GB).  Per-thread tap accumulators persist across the block's tiles; reduced through LDS at the end.
+template <int K, int S, int T, int ACT, int CC, bool WG = false>
 __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
     const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ w,
     const float* __restrict__ zin, const float* __restrict__ scale_in, const float* __restrict__ shift_in,
     const float* __restrict__ mi_in, float* __restrict__ du_in, double* __restrict__ stats, int slots, int N, int H, int W,
-    int C, int Ho, int Wo, const float* __restrict__ res_pre, const float* __restrict__ res_post) {
+    int C, int Ho, int Wo, const float* __restrict__ res_pre, const float* __restrict__ res_post, float* __restrict__ dw) {
   constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
   constexpr int CQN = CC / 4, NSLOT = 256 / CQN;
   constexpr int OT = (T - 1 + K - 1) / S + 2;       // output rows/cols a T-wide input tile can touch (upper bound)
@@ -450,6 +454,9 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
   }
   const float4 ka = ld4(kabc + c), kb = ld4(kabc + C + c), kc = ld4(kabc + 2 * C + c);
   float4 s1 = f4(0, 0, 0, 0), s2 = s1;
+  float4 wacc[WG ? K * K : 1];
+#pragma unroll
+  for (int i = 0; i < (WG ? K * K : 1); ++i) wacc[i] = f4(0, 0, 0, 0);
   // Software pipeline: du / z of the outputs reachable from the block's NEXT tile are in flight while the current tile is
   // gathered out of LDS (prefetching the tile's own raw inputs as well cost more in registers than it hid).  Unconditional loads on clamped addresses + a validity mask.
   constexpr int ND = (OT * OT + NSLOT - 1) / NSLOT;
@@ -506,6 +513,11 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
       const int ih = ih0 + iy, iw = iw0 + ix;
       if (ih < H && iw < W) {
         float4 acc = f4(0, 0, 0, 0);
+        const int64_t off = (((int64_t)n * H + ih) * W + iw) * C + c;
+        const float4 zz = ld4(zin + off);
+        const float4 u = fma4(zz, sc, sh);
+        float4 ain = f4(0, 0, 0, 0);
+        if constexpr (WG) ain = act4<ACT>(u);       // the depthwise conv's input at this pixel
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
           const int ohn = ih + P - kh;
@@ -521,12 +533,11 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
             float4 ww;
             if constexpr (WLDS) ww = ld4(w_t + (kh * K + kw) * CC + cq * 4);
             else ww = wt[kh * K + kw];
-            acc = fma4(ld4(lds + (oy * OTP + ox) * CC + cq * 4), ww, acc);
+            const float4 dzv = ld4(lds + (oy * OTP + ox) * CC + cq * 4);
+            acc = fma4(dzv, ww, acc);
+            if constexpr (WG) wacc[kh * K + kw] = fma4(dzv, ain, wacc[kh * K + kw]);
           }
         }
-        const int64_t off = (((int64_t)n * H + ih) * W + iw) * C + c;
-        const float4 zz = ld4(zin + off);
-        const float4 u = fma4(zz, sc, sh);
         if (res_pre) acc = add4(acc, ld4(res_pre + off));       // another consumer of the same activated tensor
         float4 d = mul4(acc, dact4<ACT>(u));
         if (res_post) d = add4(d, ld4(res_post + off));         // a consumer of the raw (pre-activation) tensor
@@ -534,6 +545,25 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
         const float4 xh = f4((zz.x - mean.x) * istd.x, (zz.y - mean.y) * istd.y, (zz.z - mean.z) * istd.z, (zz.w - mean.w) * istd.w);
         s1 = add4(s1, d);
         s2 = fma4(d, xh, s2);
+      }
+    }
+  }
+  if constexpr (WG) {
+    // weight gradient: sum the per-thread tap accumulators over the block's NSLOT pixel slots, one kernel row at a time
+    // (K taps x NSLOT x CQN float4 fit the tile buffer), then one atomic per (channel, tap) per block
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+      __syncthreads();
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) st4(lds + ((slot * CQN + cq) * K + kw) * 4, wacc[kh * K + kw]);
+      __syncthreads();
+      if (tid < CQN * K) {
+        const int kw = tid % K, q = tid / K;
+        float4 t = f4(0, 0, 0, 0);
+        for (int sl = 0; sl < NSLOT; ++sl) t = add4(t, ld4(lds + ((sl * CQN + q) * K + kw) * 4));
+        const int ch = c0 + q * 4, tp = kh * K + kw;
+        atomicAdd(dw + (ch + 0) * K * K + tp, t.x); atomicAdd(dw + (ch + 1) * K * K + tp, t.y);
+        atomicAdd(dw + (ch + 2) * K * K + tp, t.z); atomicAdd(dw + (ch + 3) * K * K + tp, t.w);
       }
     }
   }
@@ -551,20 +581,24 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
   }
 }
 
-template <int K, int S, int T, int ACT, int CC>
+template <int K, int S, int T, int ACT, int CC, bool WG = false>
 int launch_dw_dgrad_tiled(const float* du, const float* z, const float* kabc, const float* w, const float* zin,
                           const float* scale_in, const float* shift_in, const float* mi_in, float* du_in, double* stats, int slots,
-                          int N, int H, int W, int C, int Ho, int Wo, const float* res_pre, const float* res_post, hipStream_t s) {
+                          int N, int H, int W, int C, int Ho, int Wo, const float* res_pre, const float* res_post, hipStream_t s,
+                          float* dw = nullptr) {
   constexpr int OT = (T - 1 + K - 1) / S + 2;
   constexpr int OTP = OT | 1;
+  constexpr int CQN = CC / 4, NSLOT = 256 / CQN;
   size_t lds = (size_t)(OT * OTP * CC + (K > 3 ? K * K * CC : 0)) * sizeof(float);
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);
+  if (WG && lds < (size_t)NSLOT * CQN * K * 4 * sizeof(float)) lds = (size_t)NSLOT * CQN * K * 4 * sizeof(float);
   const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((H + T - 1) / T) * ((W + T - 1) / T);
-  const unsigned bx = xcd_chunk_grid(chunks, ntiles, 8192);
-  hipLaunchKernelGGL((dwconv_dgrad_tiled_kernel<K, S, T, ACT, CC>), dim3(bx), dim3(256), lds, s, du, z, kabc, w, zin,
-                     scale_in, shift_in, mi_in, du_in, stats, slots > 0 ? slots : 1, N, H, W, C, Ho, Wo, res_pre, res_post);
-  return check_launch("mt_dwconv_bwd(data, tiled)");
+  // the fused form keeps K*K tap accumulators per thread across tiles: fewer, longer-lived blocks keep the final atomics rare
+  const unsigned bx = xcd_chunk_grid(chunks, ntiles, WG ? 4096 : 8192);
+  hipLaunchKernelGGL((dwconv_dgrad_tiled_kernel<K, S, T, ACT, CC, WG>), dim3(bx), dim3(256), lds, s, du, z, kabc, w, zin,
+                     scale_in, shift_in, mi_in, du_in, stats, slots > 0 ? slots : 1, N, H, W, C, Ho, Wo, res_pre, res_post, dw);
+  return check_launch(WG ? "mt_dwconv_bwd(data + weight, fused)" : "mt_dwconv_bwd(data, tiled)");
 }
 
 template <int K, int S, int ACT>
@@ -573,6 +607,12 @@ int launch_dw_bwd_tiled_any(const float* du, const float* z, const float* kabc, 
                             int W, int C, int Ho, int Wo, int parts, const float* res_pre, const float* res_post, hipStream_t s) {
   int rc = 0;
   const bool t14o = Ho >= 14, t14i = H >= 14;
+  if (parts == 3) {       // one pass over du / z / the dw input for both gradients
+    if (C % 16 == 0) return t14i ? launch_dw_dgrad_tiled<K, S, 14, ACT, 16, true>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, res_pre, res_post, s, dw)
+                                 : launch_dw_dgrad_tiled<K, S, 7, ACT, 16, true>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, res_pre, res_post, s, dw);
+    return t14i ? launch_dw_dgrad_tiled<K, S, 14, ACT, 8, true>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, res_pre, res_post, s, dw)
+                : launch_dw_dgrad_tiled<K, S, 7, ACT, 8, true>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, res_pre, res_post, s, dw);
+  }
   if (parts & 1) {
     if (C % 16 == 0) rc = t14o ? launch_dw_wgrad_tiled<K, S, 14, ACT, 16>(du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s)
                                : launch_dw_wgrad_tiled<K, S, 7, ACT, 16>(du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s);

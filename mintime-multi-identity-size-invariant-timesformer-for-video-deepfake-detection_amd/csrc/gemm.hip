@@ -144,8 +144,10 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
       // auto: enough blocks to fill 256 CUs several times over (these outputs are skinny: a handful of tiles), but keep
       // >= 256 contraction rows per block so the fp32 atomics of the epilogue stay a small fraction of the work
       const int tiles = m_tiles * n_tiles;
-      splits = (2048 + tiles - 1) / tiles;
-      const int max_splits = d->K / 256 > 0 ? d->K / 256 : 1;
+      static const int target = getenv("MT_WGRAD_BLOCKS_OLD") ? atoi(getenv("MT_WGRAD_BLOCKS_OLD")) : 2048;   // tuning knobs
+      static const int min_rows = getenv("MT_WGRAD_MINROWS_OLD") ? atoi(getenv("MT_WGRAD_MINROWS_OLD")) : 256;
+      splits = (target + tiles - 1) / tiles;
+      const int max_splits = d->K / min_rows > 0 ? d->K / min_rows : 1;
       if (splits > max_splits) splits = max_splits;
       if (splits < 1) splits = 1;
     }

@@ -32,6 +32,10 @@ int pick_variant(const mt_gemm_desc* d) {
     if (d->op == MT_OP_NN) return (d->K >= 4096 && k32) ? V_BIG32 : V_BIG16;
     return V_MID16;
   }
+  if (d->K >= 1024 && d->M >= 4096) {       // tall, skinny, long contraction (FF2, the N = 512 data gradients)
+    static const int v = getenv("MT_DMA_SKINNY_VARIANT") ? atoi(getenv("MT_DMA_SKINNY_VARIANT")) : -1;   // tuning knob
+    if (v >= 0) return v;
+  }
   return k32 ? V_SMALL32 : V_SMALL16;
 }
 

@@ -6,6 +6,9 @@ from . import lib as L
 from .effnet_engine import SLOTS, STREAM_ROWS, _StatsPool
 
 
+FUSED_DW = __import__("os").environ.get("MT_DW_FUSED", "1") != "0"
+
+
 def _new(dev, *shape):
     return torch.empty(*shape, dtype=torch.float32, device=dev)
 
@@ -133,10 +136,14 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                                       L.ptr(_bn.scale), L.ptr(_bn.shift), L.ptr(_bn.mean_invstd), L.ptr(_du_in), L.ptr(_sums), SLOTS,
                                       L.ptr(grads[_ix["d"]]), N, _s.hin, _s.hin, _s.cexp, _s.k, _s.s, parts, 1, None, None, L.stream_ptr()),
                     "mt_dwconv_bwd")
-        side.launch(lambda: dw_part(1), reads=(da, rec["z_d"], kabc_d, rec["dw_in"], in_bn.scale, in_bn.shift))
-        # algorithmic HBM bytes of the data-gradient pass: read da, z_d (M_out x cexp each) and the dw input's pre-activation
-        # (M_in x cexp, for swish'), write du_in (M_in x cexp)
-        L.timed("dwconv_dgrad", lambda: dw_part(2), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
+        # algorithmic HBM bytes of the pass: read da, z_d (M_out x cexp each) and the dw input's pre-activation (M_in x cexp: swish'
+        # for the data gradient, swish for the weight gradient), write du_in (M_in x cexp)
+        if FUSED_DW:
+            # data AND weight gradient in one pass over da / z_d / the dw input (the separate weight-gradient kernel re-read all three)
+            L.timed("dwconv_dgrad", lambda: dw_part(3), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
+        else:
+            side.launch(lambda: dw_part(1), reads=(da, rec["z_d"], kabc_d, rec["dw_in"], in_bn.scale, in_bn.shift))
+            L.timed("dwconv_dgrad", lambda: dw_part(2), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
         del da
         if s.has_expand:
             # (h,i,j) bn0 + expand conv: z_e = y_in . We^T
