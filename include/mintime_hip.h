@@ -206,11 +206,13 @@ int mt_bn_bwd_finalize(const double* stats, int slots, double count, const float
                        float* kabc, float* dgamma, float* dbeta, int C, int training, void* stream);
 
 /* Squeeze-excite adjoint (model.py:104-113): from da = d(gated tensor) computes dgate, the two 1x1-conv weight/bias
- * grads (accumulated) and dpooled [N,C] (the pooling path's contribution to d(activated tensor)). */
+ * grads (accumulated) and dpooled [N,C] (the pooling path's contribution to d(activated tensor)).
+ * parts & 1: the reduction and the per-image adjoint (dgate, dpre2, dhid, dpooled -- what the data path waits for);
+ * parts & 2: the weight / bias gradients from dpre2, dhid (independent of the data path: may run on another stream). */
 int mt_se_bwd(const float* da, const float* z, const float* scale, const float* shift, const float* gate,
               const float* hidden, const float* pooled, const float* w1, const float* w2, float* dgate,
               float* dpre2, float* dhid, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, int N,
-              int HW, int C, int CS, void* stream);
+              int HW, int C, int CS, int parts, void* stream);
 
 /* Depthwise-conv adjoint: dz = ka*du+kb*z+kc (virtual, output side).  parts&1: dw (accumulated, torch layout
  * [C,1,k,k]); parts&2: du_in = d(input pre-activation) = dgrad * swish'(bn_in(zin)), plus the input-side BN sums.

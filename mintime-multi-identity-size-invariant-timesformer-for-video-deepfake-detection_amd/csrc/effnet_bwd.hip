@@ -741,7 +741,7 @@ extern "C" int mt_bn_bwd_finalize(const double* stats, int slots, double count, 
 extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, const float* shift, const float* gate,
                          const float* hidden, const float* pooled, const float* w1, const float* w2, float* dgate,
                          float* dpre2, float* dhid, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, int N,
-                         int HW, int C, int CS, void* stream) {
+                         int HW, int C, int CS, int parts_mask, void* stream) {
   if (!da || !z || !scale || !shift || !gate || !hidden || !pooled || !w1 || !w2 || !dgate || !dpre2 || !dhid || !dpooled ||
       !dw1 || !db1 || !dw2 || !db2)
     return fail(MT_ERR_ARG, "mt_se_bwd: null pointer");
@@ -749,18 +749,22 @@ extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, co
   if (CS > CS_MAX) return fail(MT_ERR_UNSUPPORTED, "mt_se_bwd: squeeze width %d > %d", CS, CS_MAX);
   hipStream_t s = (hipStream_t)stream;
   const int CQ = C / 4, CQB = pick_cqb(CQ), PB = 256 / CQB;
+  int rc = 0;
+  if (parts_mask & 1) {
   int parts = 1;
   while ((int64_t)N * (CQ / CQB) * parts < 2048 && HW / (parts * 2) >= PB * 16) parts *= 2;
   if (parts > 1 && hipMemsetAsync(dgate, 0, (size_t)N * C * sizeof(float), s) != hipSuccess)
     return fail(MT_ERR_LAUNCH, "mt_se_bwd: memset failed");
   hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(N, CQ / CQB, parts), dim3(CQB * PB), (size_t)PB * CQB * 4 * sizeof(float), s, da, z,
                      scale, shift, dgate, HW, C, CQB, PB);
-  int rc = check_launch("mt_se_bwd(reduce)");
+  rc = check_launch("mt_se_bwd(reduce)");
   if (rc) return rc;
   hipLaunchKernelGGL(se_bwd_kernel, dim3(N), dim3(256), (size_t)(C + CS) * sizeof(float), s, dgate, gate, hidden, w1, w2, dpre2, dhid,
                      dpooled, C, CS);
   rc = check_launch("mt_se_bwd(image)");
   if (rc) return rc;
+  }
+  if (!(parts_mask & 2)) return 0;
   const int ipb = 16;      // images per block: 8 / 16 / 32 / 64 measured 56 / 43 / 51 / 86 us (atomics vs parallelism)
   hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 127) / 128, (N + ipb - 1) / ipb), dim3(128), 0, s, dpre2, dhid, hidden, pooled, dw1,
                      db1, dw2, db2, N, C, CS, ipb);

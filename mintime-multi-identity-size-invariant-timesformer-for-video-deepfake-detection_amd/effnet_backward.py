@@ -6,7 +6,9 @@ from . import lib as L
 from .effnet_engine import SLOTS, STREAM_ROWS, _StatsPool
 
 
-FUSED_DW = __import__("os").environ.get("MT_DW_FUSED", "1") != "0"
+# measured in-step: the fused pass (6.9 ms/step on the critical main stream) loses to data gradient (5.0 ms, main) + weight gradient on the
+# side stream, which has slack during the EfficientNet backward: 65.5 vs 64.1 ms/step.  Kept selectable for single-stream use.
+FUSED_DW = __import__("os").environ.get("MT_DW_FUSED", "0") == "1"
 
 
 def _new(dev, *shape):
@@ -120,10 +122,13 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         dgate, dpre2, dpooled = _new(dev, N, s.cexp), _new(dev, N, s.cexp), _new(dev, N, s.cexp)
         dhid = _new(dev, N, s.cse)
         se = ix["se"]
-        L.check(lib.mt_se_bwd(L.ptr(da), L.ptr(rec["z_d"]), L.ptr(bn_d.scale), L.ptr(bn_d.shift), L.ptr(rec["gate"]), L.ptr(rec["hidden"]),
-                              L.ptr(rec["pooled"]), L.ptr(P[se]), L.ptr(P[se + 2]), L.ptr(dgate), L.ptr(dpre2), L.ptr(dhid), L.ptr(dpooled),
-                              L.ptr(grads[se]), L.ptr(grads[se + 1]), L.ptr(grads[se + 2]), L.ptr(grads[se + 3]), N, hw, s.cexp, s.cse,
-                              st), "mt_se_bwd")
+        def se_part(parts, _da=da, _rec=rec, _bn=bn_d, _se=se, _s=s, _dg=dgate, _dp=dpre2, _dh=dhid, _dpo=dpooled, _hw=hw):
+            L.check(lib.mt_se_bwd(L.ptr(_da), L.ptr(_rec["z_d"]), L.ptr(_bn.scale), L.ptr(_bn.shift), L.ptr(_rec["gate"]),
+                                  L.ptr(_rec["hidden"]), L.ptr(_rec["pooled"]), L.ptr(P[_se]), L.ptr(P[_se + 2]), L.ptr(_dg), L.ptr(_dp),
+                                  L.ptr(_dh), L.ptr(_dpo), L.ptr(grads[_se]), L.ptr(grads[_se + 1]), L.ptr(grads[_se + 2]),
+                                  L.ptr(grads[_se + 3]), N, _hw, _s.cexp, _s.cse, parts, L.stream_ptr()), "mt_se_bwd")
+        se_part(1)                                    # dgate -> dpooled: the data path waits for these
+        side.launch(lambda: se_part(2), reads=(dpre2, dhid, rec["hidden"], rec["pooled"]))     # SE weight gradients: off the path
         # (e) through swish + bn1: du_d (in place over da)
         sums = act_bwd(da, rec["z_d"], bn_d, da, M_out, hw, 1, gate=rec["gate"], dpool=dpooled)
         kabc_d = bn_finalize(bn_d, sums, ix["d"] + 1)

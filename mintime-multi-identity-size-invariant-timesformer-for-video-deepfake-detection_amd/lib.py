@@ -76,7 +76,7 @@ PROTOTYPES = {
                     C.c_void_p],
     "mt_bn_act_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_bn_bwd_finalize": [C.c_void_p, C.c_int, C.c_double, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_void_p],
-    "mt_se_bwd": [f32p] * 17 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_se_bwd": [f32p] * 17 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_dwconv_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_int, f32p, f32p, C.c_void_p],
     "mt_conv_weight_pack": [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
