@@ -8,7 +8,7 @@ from .effnet_engine import SLOTS, STREAM_ROWS, _StatsPool
 
 # measured in-step: the fused pass (6.9 ms/step on the critical main stream) loses to data gradient (5.0 ms, main) + weight gradient on the
 # side stream, which has slack during the EfficientNet backward: 65.5 vs 64.1 ms/step.  Kept selectable for single-stream use.
-FUSED_DW = __import__("os").environ.get("MT_DW_FUSED", "0") == "1"
+FUSED_DW = __import__("os").environ.get("MT_DW_FUSED", "0")      # "1": every layer, "3": the 3x3 layers only, "0": off
 
 
 def _new(dev, *shape):
@@ -143,7 +143,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                     "mt_dwconv_bwd")
         # algorithmic HBM bytes of the pass: read da, z_d (M_out x cexp each) and the dw input's pre-activation (M_in x cexp: swish'
         # for the data gradient, swish for the weight gradient), write du_in (M_in x cexp)
-        if FUSED_DW:
+        if FUSED_DW == "1" or (FUSED_DW == "3" and s.k == 3):
             # data AND weight gradient in one pass over da / z_d / the dw input (the separate weight-gradient kernel re-read all three)
             L.timed("dwconv_dgrad", lambda: dw_part(3), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
         else:
