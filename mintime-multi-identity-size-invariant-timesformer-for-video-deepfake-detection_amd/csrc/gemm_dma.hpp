@@ -25,6 +25,9 @@
 #ifndef MT_DMA_LOOP_ALIGN       // log2; 0 = none
 #define MT_DMA_LOOP_ALIGN 0
 #endif
+#ifndef MT_DMA_ISSUE_MID        // 1: issue the next tile's DMA between the MFMA groups instead of right behind the barrier
+#define MT_DMA_ISSUE_MID 0
+#endif
 #ifndef MT_DMA_ABLATE          // tuning lab only (tools/lab): 1 no DMA, 2 no barrier, 4 no LDS fragment reads, 8 no epilogue
 #define MT_DMA_ABLATE 0
 #endif
@@ -221,7 +224,7 @@ void gemm_dma_kernel(const GemmArgs p) {
     else if (later == 1) wait_vmcnt<IPW>();
     else wait_vmcnt<0>();
     if (!(MT_DMA_ABLATE & 2)) __builtin_amdgcn_s_barrier();   // every wave's share of tile kt is visible; slot (kt-1) % STAGES is free
-    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+    if (!MT_DMA_ISSUE_MID && kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
     const float* as = smem_dma + (kt % STAGES) * STAGE;
     const float* bs = as + A_TILE;
     float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
@@ -242,6 +245,11 @@ void gemm_dma_kernel(const GemmArgs p) {
     for (int g = 0; g < NG; g += 2) {
       load_frags(as, bs, g + 1, fa1, fb1);
       mma_group(fa0, fb0);
+      if (MT_DMA_ISSUE_MID && g == 0) {            // the VMEM issue rides under the matrix pipe's backlog of this wave
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (g + 2 < NG) load_frags(as, bs, g + 2, fa0, fb0);
       mma_group(fa1, fb1);
     }

@@ -779,7 +779,8 @@ extern "C" int mt_layernorm_bwd(const float* dy, const float* x, const float* st
   if (dim <= 0 || (dim & 3) || dim > 1024) return fail(MT_ERR_ARG, "mt_layernorm_bwd: dim %d unsupported", dim);
   if (rows <= 0) return 0;
   int blocks = (rows + 3) / 4;
-  if (blocks > 256) blocks = 256;
+  static const int cap = getenv("MT_LN_BWD_BLOCKS") ? atoi(getenv("MT_LN_BWD_BLOCKS")) : 256;     // tuning knob
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dgamma, dbeta,
                      rows, dim, accumulate, dx_colsum, skip_period);
   return check_launch("mt_layernorm_bwd");
