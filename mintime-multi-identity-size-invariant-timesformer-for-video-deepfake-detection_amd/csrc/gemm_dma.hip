@@ -39,21 +39,36 @@ int pick_variant(const mt_gemm_desc* d) {
   return k32 ? V_SMALL32 : V_SMALL16;
 }
 
-template <int WM, int WN, int TM, int TN, int AL, int BL, int EPI, int BK, int ST, int MINW>
+template <int WM, int WN, int TM, int TN, int AL, int BL, int EPI, int BK, int ST, int MINW, int PRO = PRO_NONE>
 int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
-  auto k = gemm_dma_kernel<WM, WN, TM, TN, AL, BL, EPI, BK, ST, MINW>;
+  auto k = gemm_dma_kernel<WM, WN, TM, TN, AL, BL, EPI, BK, ST, MINW, PRO>;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr size_t lds = (size_t)ST * (BM + BN) * BK * 4;
-  if constexpr (lds > 48 * 1024) {
-    static bool raised = false;        // idempotent; a benign race at worst repeats the call
-    if (!raised) {
+  size_t lds = (size_t)ST * (BM * (PRO == PRO_BN_BWD ? 2 : 1) + BN) * BK * 4;
+  if (PRO == PRO_BN_SWISH_GATE) lds += (size_t)(2 + (BM - 1) / a.hw + 2) * a.K * 4;     // scale, shift, gate rows of the images a row tile touches
+  if (PRO == PRO_BN_BWD) lds += (size_t)3 * a.K * 4;                                     // ka, kb, kc
+  if (lds > 160 * 1024) return 1;      // not this way: caller falls back to the register-staged kernel
+  if (lds > 48 * 1024) {
+    static size_t raised = 0;          // idempotent; a benign race at worst repeats the call
+    if (lds > raised) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_gemm(dma): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-      raised = true;
+      raised = lds;
     }
   }
   hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, s, a);
   return check_launch("mt_gemm(dma)");
+}
+
+// prologue problems (the extractor's project convs and 1x1-conv data gradients): 64x64 or 128x64 tiles
+template <int AL, int BL, int EPI, int PRO>
+int launch_pro(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
+  switch (v) {
+    case V_MID16: return launch_one<2, 2, 2, 1, AL, BL, EPI, 16, 2, 3, PRO>(a, grid, s);
+    case V_SMALL32: return launch_one<2, 2, 1, 1, AL, BL, EPI, 32, 2, 4, PRO>(a, grid, s);
+    case V_SMALL16: return launch_one<2, 2, 1, 1, AL, BL, EPI, 16, 3, 4, PRO>(a, grid, s);
+    default: break;
+  }
+  return 1;
 }
 
 template <int AL, int BL, int EPI>
@@ -98,8 +113,37 @@ namespace mt {
 int try_launch_dma(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
   static const bool disabled = getenv("MT_GEMM_DMA") && atoi(getenv("MT_GEMM_DMA")) == 0;
   if (disabled) return 1;
-  if (d->prologue != MT_PRO_NONE || d->b_prologue != MT_BPRO_NONE) return 1;
+  if (d->b_prologue != MT_BPRO_NONE) return 1;
   if (d->M < 64 || d->N < 64) return 1;
+  if (d->prologue != MT_PRO_NONE) {
+    // operand transforms applied at fragment-read time (gemm_dma.hpp PRO): project conv forward and the 1x1-conv data gradients
+    static const int pro_on = getenv("MT_DMA_PRO") ? atoi(getenv("MT_DMA_PRO")) : 1;
+    if (!pro_on || (d->K % 16) || d->M < 4096) return 1;
+    const bool gate_fwd = d->op == MT_OP_NT && d->prologue == MT_PRO_BN_SWISH_GATE && (d->epilogue == MT_EPI_STATS || d->epilogue == MT_EPI_STORE);
+    const bool bn_bwd = d->op == MT_OP_NN && d->prologue == MT_PRO_BN_BWD && (d->epilogue == MT_EPI_STORE || d->epilogue == MT_EPI_BIAS_RES);
+    if (!gate_fwd && !bn_bwd) return 1;
+    static const int vforce = getenv("MT_DMA_PRO_VARIANT") ? atoi(getenv("MT_DMA_PRO_VARIANT")) : -1;
+    int v = vforce >= 0 ? vforce : ((d->K % 32) == 0 ? V_SMALL32 : V_SMALL16);
+    if (kVar[v].bk == 32 && (d->K % 32)) v = V_SMALL16;
+    const Var var = kVar[v];
+    const int m_tiles = (d->M + var.bm - 1) / var.bm, n_tiles = (d->N + var.bn - 1) / var.bn;
+    dim3 grid(m_tiles * n_tiles, 1, 1);
+    a.group_n = 0; a.k_chunk = 0; a.trace = nullptr;
+    if (m_tiles >= 32 && n_tiles >= 2 && !getenv("MT_NO_L2_BLOCKING")) {
+      const int64_t panel = (int64_t)var.bn * d->K * 4;
+      int gn = (int)((2 << 20) / (panel > 0 ? panel : 1));
+      if (gn < 1) gn = 1;
+      if (gn > n_tiles) gn = n_tiles;
+      a.group_n = gn;
+      grid.x = 8 * ((m_tiles + 7) / 8) * n_tiles;
+    }
+    if (gate_fwd) {
+      if (d->epilogue == MT_EPI_STATS) return launch_pro<LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_STATS, PRO_BN_SWISH_GATE>(v, a, grid, s);
+      return launch_pro<LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_STORE, PRO_BN_SWISH_GATE>(v, a, grid, s);
+    }
+    if (d->epilogue == MT_EPI_BIAS_RES) return launch_pro<LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_BIAS_RES, PRO_BN_BWD>(v, a, grid, s);
+    return launch_pro<LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_STORE, PRO_BN_BWD>(v, a, grid, s);
+  }
   if (d->epilogue == MT_EPI_GEGLU && (d->n_half & 63)) return 1;
   int v = pick_variant(d);
   if (v < 0 || v >= V_COUNT) return 1;

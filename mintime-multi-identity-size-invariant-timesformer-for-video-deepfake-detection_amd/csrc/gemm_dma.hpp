@@ -45,19 +45,27 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 #define MT_STR2(x) #x
 #define MT_STR(x) MT_STR2(x)
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int EPI, int BK, int STAGES, int MINW>
+// PRO (k-contiguous A only): the operand transform of the register-staged kernel, applied when the FRAGMENT is read out of LDS
+// (the DMA cannot transform in flight):  PRO_BN_SWISH_GATE  a = swish(z*scale[k]+shift[k]) * gate[(m/hw)*K+k]  (project conv),
+//                                        PRO_BN_BWD         a = ka[k]*A + kb[k]*A2 + kc[k]                  (data gradients; A2's tile
+// rides in the same ring).  The per-k vectors and the gate rows of the images this row tile touches are cached in LDS once per block.
+template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int EPI, int BK, int STAGES, int MINW, int PRO = PRO_NONE>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) __attribute__((aligned(MT_DMA_FN_ALIGN)))
 void gemm_dma_kernel(const GemmArgs p) {
+  static_assert(PRO == PRO_NONE || AL == LAYOUT_KCONTIG, "fragment-time prologues are implemented for k-contiguous A");
+  static_assert(PRO == PRO_NONE || PRO == PRO_BN_SWISH_GATE || PRO == PRO_BN_BWD, "unsupported prologue");
+  constexpr bool TWO_A = PRO == PRO_BN_BWD;         // a second A-shaped tile (A2) per stage
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   constexpr int GPR = BK / 4;                       // 16-byte granules per k-contiguous row
   constexpr int SW_SHIFT = BK == 16 ? 2 : 1;        // swizzle = (row >> SW_SHIFT) & (GPR - 1)
   constexpr int A_TILE = BM * BK, B_TILE = BN * BK; // floats
-  constexpr int STAGE = A_TILE + B_TILE;
+  constexpr int STAGE = A_TILE * (TWO_A ? 2 : 1) + B_TILE;
+  constexpr int A2_OFF = A_TILE + B_TILE;           // A2's tile sits behind B inside a stage
   constexpr int A_INSTR = A_TILE / 256, B_INSTR = B_TILE / 256;   // 1 KiB wave-instructions per tile
   static_assert(A_INSTR % NW == 0 && B_INSTR % NW == 0, "every wavefront must issue the same number of DMA instructions");
-  constexpr int A_IPW = A_INSTR / NW, B_IPW = B_INSTR / NW, IPW = A_IPW + B_IPW;
+  constexpr int A_IPW = A_INSTR / NW, B_IPW = B_INSTR / NW, IPW = A_IPW * (TWO_A ? 2 : 1) + B_IPW;
   static_assert(BK == 16 || BK == 32, "BK must be 16 or 32");
   static_assert(STAGES >= 2 && STAGES <= 4, "2..4 stages");
   constexpr int NG = BK / 8;
@@ -89,6 +97,7 @@ void gemm_dma_kernel(const GemmArgs p) {
   // k-major:      granule gi -> k row gi / (cols/4), column granule gi % (cols/4).
   const float* a_src[A_IPW];
   const float* b_src[B_IPW];
+  int64_t a2_delta = 0;
   int a_k[A_IPW], b_k[B_IPW];                       // k-major: the lane's k offset inside a tile
 #pragma unroll
   for (int j = 0; j < A_IPW; ++j) {
@@ -100,6 +109,7 @@ void gemm_dma_kernel(const GemmArgs p) {
       m = m < p.M ? m : p.M - 1;                    // rows past the end are never stored: any valid row will do
       a_src[j] = p.A + map_row(p.a_map, m) * p.lda + k_begin + kq * 4;
       a_k[j] = 0;
+      if constexpr (TWO_A) a2_delta = p.A2 - p.A;     // A2 has A's layout, leading dimension and row map
     } else {
       constexpr int CPR = BM / 4;
       const int kk = gi / CPR, cq = gi % CPR;
@@ -147,6 +157,7 @@ void gemm_dma_kernel(const GemmArgs p) {
       if constexpr (AL == LAYOUT_KCONTIG) src = a_src[j] + kt * BK;
       else src = a_src[j] + map_row(p.a_map, k0 + a_k[j]) * p.lda;
       lds_dma16(src, st + (unsigned)((wave * A_IPW + j) * 1024));
+      if constexpr (TWO_A) lds_dma16(src + a2_delta, st + (unsigned)(A2_OFF * 4 + (wave * A_IPW + j) * 1024));
     }
 #pragma unroll
     for (int j = 0; j < B_IPW; ++j) {
@@ -177,11 +188,44 @@ void gemm_dma_kernel(const GemmArgs p) {
     if constexpr (BL == LAYOUT_KCONTIG) b_off[g] = b_col * BK + 4 * ((2 * g + khalf) ^ ((b_col >> SW_SHIFT) & (GPR - 1)));
     else b_off[g] = (8 * g + 4 * khalf) * BN + b_col;
   }
+  // ---- prologue vectors in LDS (behind the ring): [scale | shift | gate rows] or [ka | kb | kc], indexed by absolute k
+  float* pv = smem_dma + STAGES * STAGE;
+  int g_off[TM];                                    // PRO_BN_SWISH_GATE: float offset of the lane's rows' gate row inside pv
+  if constexpr (PRO != PRO_NONE) {
+    const int K = p.K;
+    if constexpr (PRO == PRO_BN_SWISH_GATE) {
+      const int img_lo = m0 / p.hw;
+      const int img_hi = min(m0 + BM - 1, p.M - 1) / p.hw;
+      for (int i = tid; i < K; i += NW * 64) { pv[i] = p.scale[i]; pv[K + i] = p.shift[i]; }
+      for (int i = tid; i < (img_hi - img_lo + 1) * K; i += NW * 64) pv[2 * K + i] = p.gate[(int64_t)img_lo * K + i];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) g_off[i] = (2 + min(m0 + a_row + i * 32, p.M - 1) / p.hw - img_lo) * K;
+    } else {
+      for (int i = tid; i < K; i += NW * 64) { pv[i] = p.scale[i]; pv[K + i] = p.shift[i]; pv[2 * K + i] = p.gate[i]; }
+    }
+    __syncthreads();                                // ordinary loads + LDS stores: complete before the counted-vmcnt pipeline starts
+  }
+
+  int kbase = 0;                                    // absolute k of the current tile's first column (prologue vector index)
   auto load_frags = [&](const float* as, const float* bs, int g, float (&af)[TM][4], float (&bf)[TN][4]) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       if constexpr (AL == LAYOUT_KCONTIG) {
-        const float4 v = *reinterpret_cast<const float4*>(as + a_off[g] + i * 32 * BK);      // (row + 32 i) has the same swizzle
+        float4 v = *reinterpret_cast<const float4*>(as + a_off[g] + i * 32 * BK);      // (row + 32 i) has the same swizzle
+        if constexpr (PRO == PRO_BN_SWISH_GATE) {
+          const int k = kbase + 8 * g + 4 * khalf;
+          const float4 sc = *reinterpret_cast<const float4*>(pv + k), sh = *reinterpret_cast<const float4*>(pv + p.K + k);
+          const float4 gt = *reinterpret_cast<const float4*>(pv + g_off[i] + k);
+          v.x = swishf_(fmaf(v.x, sc.x, sh.x)) * gt.x; v.y = swishf_(fmaf(v.y, sc.y, sh.y)) * gt.y;
+          v.z = swishf_(fmaf(v.z, sc.z, sh.z)) * gt.z; v.w = swishf_(fmaf(v.w, sc.w, sh.w)) * gt.w;
+        } else if constexpr (PRO == PRO_BN_BWD) {
+          const int k = kbase + 8 * g + 4 * khalf;
+          const float4 z2 = *reinterpret_cast<const float4*>(as + A2_OFF + a_off[g] + i * 32 * BK);
+          const float4 ka = *reinterpret_cast<const float4*>(pv + k), kb = *reinterpret_cast<const float4*>(pv + p.K + k);
+          const float4 kc = *reinterpret_cast<const float4*>(pv + 2 * p.K + k);
+          v.x = fmaf(ka.x, v.x, fmaf(kb.x, z2.x, kc.x)); v.y = fmaf(ka.y, v.y, fmaf(kb.y, z2.y, kc.y));
+          v.z = fmaf(ka.z, v.z, fmaf(kb.z, z2.z, kc.z)); v.w = fmaf(ka.w, v.w, fmaf(kb.w, z2.w, kc.w));
+        }
         af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
       } else {
 #pragma unroll
@@ -227,6 +271,7 @@ void gemm_dma_kernel(const GemmArgs p) {
     if (!MT_DMA_ISSUE_MID && kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
     const float* as = smem_dma + (kt % STAGES) * STAGE;
     const float* bs = as + A_TILE;
+    kbase = k_begin + kt * BK;
     float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
     if (MT_DMA_ABLATE & 4) {
 #pragma unroll

@@ -327,3 +327,46 @@ def test_dma_wgrad_with_token_rowmap_small(dma_variant):
         dW = torch.zeros(D, Cin, device="cuda")
         L.gemm(L.OP_TN, dx.cuda(), feat.cuda(), dW, D, Cin, B * Fn, D, Cin, Cin, epilogue=L.EPI_ATOMIC, split_k=2, a_map=(Fn, Fn + 1, 1))
         assert_close(dW, _dmm(dx[:, 1:].reshape(B * Fn, D).T, feat), 5e-5, f"DMA v{v} row-mapped wgrad")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Operand prologues on the LDS-DMA pipeline (transform applied when the fragment is read out of LDS): the extractor's project
+# convs (BN + swish + per-image gate) and 1x1-conv data gradients (BatchNorm backward folded in) at M >= 4096.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("M,hw,K,N", [(5000 + 39, 49, 96, 80), (12544, 49, 1152, 192), (4096 + 196 * 3, 196, 480, 112)])
+def test_dma_gate_prologue_with_stats(variant, M, hw, K, N, monkeypatch):
+    monkeypatch.setenv("MT_DMA_PRO_VARIANT", str(variant))
+    n_img = (M + hw - 1) // hw
+    Z, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.2)
+    sc, sh, gate = _rand(K, seed=3).abs() + 0.5, _rand(K, seed=4, scale=0.2), torch.sigmoid(_rand(n_img, K, seed=5))
+    slots = 8
+    stats = torch.zeros(slots, 2, N, dtype=torch.float64, device="cuda")
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    L.gemm(L.OP_NT, Z.cuda(), W.cuda(), Cd, M, N, K, K, K, N, prologue=L.PRO_BN_SWISH_GATE, epilogue=L.EPI_STATS,
+           scale=sc.cuda(), shift=sh.cuda(), gate=gate.cuda(), hw=hw, stats=stats, stats_slots=slots)
+    a = Z.double() * sc.double() + sh.double()
+    a = a * torch.sigmoid(a) * gate.double().repeat_interleave(hw, 0)[:M]
+    ref = a @ W.double().T
+    assert_close(Cd, ref, 5e-5, f"gated project conv (DMA v{variant})")
+    st = stats.sum(0).cpu()
+    assert_close(st[0], ref.sum(0), 1e-4, "column sums")
+    assert_close(st[1], (ref * ref).sum(0), 1e-4, "column sums of squares")
+
+
+@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("M,K,N,with_res", [(5000 + 39, 80, 480, False), (12544, 1152, 192, True), (50176, 480, 80, True)])
+def test_dma_bn_backward_prologue_dgrad(variant, M, K, N, with_res, monkeypatch):
+    monkeypatch.setenv("MT_DMA_PRO_VARIANT", str(variant))
+    du, z, W = _rand(M, K, seed=1), _rand(M, K, seed=2), _rand(K, N, seed=3, scale=0.1)
+    ka, kb, kc = _rand(K, seed=4), _rand(K, seed=5, scale=0.3), _rand(K, seed=6, scale=0.1)
+    res = _rand(M, N, seed=7) if with_res else None
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    kw = dict(epilogue=L.EPI_BIAS_RES, R=res.cuda(), ldr=N) if with_res else {}
+    L.gemm(L.OP_NN, du.cuda(), W.cuda(), Cd, M, N, K, K, N, N, prologue=L.PRO_BN_BWD, A2=z.cuda(), scale=ka.cuda(), shift=kb.cuda(),
+           gate=kc.cuda(), **kw)
+    dz = ka.double() * du.double() + kb.double() * z.double() + kc.double()
+    ref = dz @ W.double()
+    if with_res:
+        ref = ref + res.double()
+    assert_close(Cd, ref, 5e-5, f"BN-backward data gradient (DMA v{variant})")
