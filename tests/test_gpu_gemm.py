@@ -337,6 +337,7 @@ def test_dma_wgrad_with_token_rowmap_small(dma_variant):
 @pytest.mark.parametrize("M,hw,K,N", [(5000 + 39, 49, 96, 80), (12544, 49, 1152, 192), (4096 + 196 * 3, 196, 480, 112)])
 def test_dma_gate_prologue_with_stats(variant, M, hw, K, N, monkeypatch):
     monkeypatch.setenv("MT_DMA_PRO_VARIANT", str(variant))
+    monkeypatch.setenv("MT_DMA_PRO_GATE", "1")          # opt-in form (the register-staged kernel is the default for this prologue)
     n_img = (M + hw - 1) // hw
     Z, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.2)
     sc, sh, gate = _rand(K, seed=3).abs() + 0.5, _rand(K, seed=4, scale=0.2), torch.sigmoid(_rand(n_img, K, seed=5))
