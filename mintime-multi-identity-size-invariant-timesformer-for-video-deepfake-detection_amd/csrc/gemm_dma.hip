@@ -121,11 +121,11 @@ int try_launch_dma(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
     if (!pro_on || (d->K % 16) || d->M < 4096) return 1;
     // the gated forward form is correct (tests) but measured slower than the register-staged kernel (swish evaluated per
     // fragment read, i.e. twice per element and inside each wave's MFMA stream: 115 -> 138 us on 50176x80x480): opt-in only
-    static const bool gate_on = getenv("MT_DMA_PRO_GATE") != nullptr;
+    const bool gate_on = getenv("MT_DMA_PRO_GATE") != nullptr;          // (read per call: tests toggle it)
     const bool gate_fwd = gate_on && d->op == MT_OP_NT && d->prologue == MT_PRO_BN_SWISH_GATE && (d->epilogue == MT_EPI_STATS || d->epilogue == MT_EPI_STORE);
     const bool bn_bwd = d->op == MT_OP_NN && d->prologue == MT_PRO_BN_BWD && (d->epilogue == MT_EPI_STORE || d->epilogue == MT_EPI_BIAS_RES);
     if (!gate_fwd && !bn_bwd) return 1;
-    static const int vforce = getenv("MT_DMA_PRO_VARIANT") ? atoi(getenv("MT_DMA_PRO_VARIANT")) : -1;
+    const int vforce = getenv("MT_DMA_PRO_VARIANT") ? atoi(getenv("MT_DMA_PRO_VARIANT")) : -1;
     int v = vforce >= 0 ? vforce : ((d->K % 32) == 0 ? V_SMALL32 : V_SMALL16);
     if (kVar[v].bk == 32 && (d->K % 32)) v = V_SMALL16;
     const Var var = kVar[v];
