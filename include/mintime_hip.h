@@ -70,6 +70,15 @@ typedef struct {
 
 int mt_gemm(const mt_gemm_desc* d, void* stream);
 
+/* Matrix pipe of the prologue-free contractions (the TimeSformer's Linear layers and their gradients).
+ *   1 (default; MT_GEMM_SPLIT=0 in the environment starts at 0): split-operand fp32 -- every fp32 operand value is split exactly
+ *     into three bf16 pieces and the six leading piece products are accumulated in fp32 on v_mfma_f32_32x32x16_bf16
+ *     (csrc/gemm_split.hpp); error against fp64 equal to the fp32 MFMA pipe's (tests/test_gpu_gemm.py), 6/16 of its matrix time.
+ *   0: v_mfma_f32_32x32x2_f32 everywhere.
+ * Process-wide; returns the previous setting.  Inputs, outputs and accumulators are fp32 either way. */
+int mt_gemm_set_split(int on);
+int mt_gemm_get_split(void);
+
 /* ------------------------------------------------------------------------------------------------
  * Size-Invariant TimeSformer forward, non-GEMM pieces
  * ------------------------------------------------------------------------------------------------ */

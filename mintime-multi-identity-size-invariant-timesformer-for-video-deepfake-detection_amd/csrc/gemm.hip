@@ -58,6 +58,7 @@ int launch(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
 }  // namespace
 
 namespace mt { int try_launch_dma(const mt_gemm_desc* d, GemmArgs a, hipStream_t s); }   // gemm_dma.hip
+namespace mt { int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s); } // gemm_split.hip
 
 static long long* g_trace = nullptr;
 // tuning aid, not part of the ABI header: per-block phase timestamps of the following mt_gemm launches (NULL = off)
@@ -114,7 +115,9 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
 
   // K-contiguous operands need K % 4 == 0 etc. were checked above; plain problems take the LDS-DMA pipeline when it has an instance
   if (!g_trace) {
-    const int rc = try_launch_dma(d, a, s);
+    int rc = try_launch_split(d, a, s);
+    if (rc <= 0) return rc;
+    rc = try_launch_dma(d, a, s);
     if (rc <= 0) return rc;
   }
   const int cfg = pick_cfg(d->op, d->M, d->N, d->prologue, d->epilogue);

@@ -13,9 +13,9 @@ namespace {
 // Variants (tile, BK, ring depth, waves/SIMD the register budget is held to).  Chosen from tools/lab/gemm_lab sweeps over the
 // shapes of a B = 32 training step (profiles/r02_gemm_dma_lab.txt): deeper rings stop paying once 2-3 blocks share a CU, BK = 32
 // halves the barrier count for the long-K problems, 64x64 tiles win whenever 128x128 leaves fewer than ~3 tiles per CU.
-enum { V_BIG32 = 0, V_BIG16 = 1, V_MID16 = 2, V_SMALL32 = 3, V_SMALL16 = 4, V_COUNT };
+enum { V_BIG32 = 0, V_BIG16 = 1, V_MID16 = 2, V_SMALL32 = 3, V_SMALL16 = 4, V_BIG16W8 = 5, V_COUNT };
 struct Var { int bm, bn, bk, stages; };
-constexpr Var kVar[V_COUNT] = {{128, 128, 32, 2}, {128, 128, 16, 3}, {128, 64, 16, 3}, {64, 64, 32, 3}, {64, 64, 16, 3}};
+constexpr Var kVar[V_COUNT] = {{128, 128, 32, 2}, {128, 128, 16, 3}, {128, 64, 16, 3}, {64, 64, 32, 3}, {64, 64, 16, 3}, {128, 128, 16, 2}};
 
 int pick_variant(const mt_gemm_desc* d) {
   if (const char* f = getenv("MT_DMA_VARIANT")) return atoi(f);      // tuning experiments only
@@ -23,7 +23,10 @@ int pick_variant(const mt_gemm_desc* d) {
   if (d->epilogue == MT_EPI_GEGLU) return k32 ? V_BIG32 : V_BIG16;
   if (d->epilogue == MT_EPI_GEGLU_BWD) return V_MID16;
   if (d->op == MT_OP_TN) {
-    if (d->M >= 1024 && d->N >= 512) return V_BIG16;
+    // eight waves of 32 x 64 over the same 128 x 128 tile: the k-major operand reads of a weight gradient hide better behind
+    // twice the waves per SIMD (lab: 1536x512x12576 205 -> 183 us, 4096x512x12576 436 -> 430 us)
+    static const int tn8 = getenv("MT_DMA_TN8") ? atoi(getenv("MT_DMA_TN8")) : 0;   // in-step 63.5 -> 64.5 ms: off
+    if (d->M >= 1024 && d->N >= 512) return tn8 ? V_BIG16W8 : V_BIG16;
     if ((int64_t)d->M * d->N >= (1 << 20)) return V_MID16;
     return k32 ? V_SMALL32 : V_SMALL16;
   }
@@ -92,6 +95,9 @@ int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
     case V_BIG32: return launch_one<2, 2, 2, 2, AL, BL, EPI, 32, 2, 2>(a, grid, s);
     case V_BIG16: return launch_one<2, 2, 2, 2, AL, BL, EPI, 16, 3, 3>(a, grid, s);
     default: break;
+  }
+  if constexpr (EPI == EPI_ATOMIC && AL == LAYOUT_KMAJOR) {
+    if (v == V_BIG16W8) return launch_one<4, 2, 1, 2, AL, BL, EPI, 16, 2, 8>(a, grid, s);
   }
   if constexpr (EPI != EPI_GEGLU) {
     switch (v) {

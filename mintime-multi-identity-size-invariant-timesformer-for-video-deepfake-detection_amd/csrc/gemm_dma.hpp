@@ -49,7 +49,42 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // (the DMA cannot transform in flight):  PRO_BN_SWISH_GATE  a = swish(z*scale[k]+shift[k]) * gate[(m/hw)*K+k]  (project conv),
 //                                        PRO_BN_BWD         a = ka[k]*A + kb[k]*A2 + kc[k]                  (data gradients; A2's tile
 // rides in the same ring).  The per-k vectors and the gate rows of the images this row tile touches are cached in LDS once per block.
-template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int EPI, int BK, int STAGES, int MINW, int PRO = PRO_NONE>
+//
+// MMA selects the matrix instruction stream fed from the same fp32 LDS fragments:
+//   MMA_F32     v_mfma_f32_32x32x2_f32 (64 cycles per 32x32x2: the 157 TF/s pipe)
+//   MMA_BF16X6  every fp32 operand value is split EXACTLY into three bf16 pieces  x = x0 + x1 + x2  (round-to-nearest at each
+//               level: |x1| <= 2^-9 |x|, |x2| <= 2^-18 |x|) when the fragment is read, and the product is accumulated from the six
+//               piece products of weight >= 2^-18:  x0y0 + (x0y1 + x1y0) + (x0y2 + x1y1 + x2y0)  on v_mfma_f32_32x32x16_bf16
+//               (32 cycles per 32x32x16).  bf16 x bf16 products are exact in fp32 and the accumulator is the same fp32 one, so
+//               the only difference from the fp32 pipe is the three dropped terms (<= 2^-26 |x||y| each, below fp32's own
+//               2^-24 rounding of the product sum).  6/16 of the matrix-pipe time of MMA_F32.
+//   MMA_BF16X3  the three leading products only (error ~2^-17 per product): NOT fp32-grade, lab comparisons only.
+enum { MMA_F32 = 0, MMA_BF16X6 = 1, MMA_BF16X3 = 2 };
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// (lo, hi) = the lane's 8 operand values (two 4-float fragments) -> three bf16x8 planes
+template <bool THREE>
+__device__ __forceinline__ void split_bf16(const float (&lo)[4], const float (&hi)[4], bf16x8_t& x0, bf16x8_t& x1, bf16x8_t& x2) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2_t v = q < 2 ? f32x2_t{lo[2 * q], lo[2 * q + 1]} : f32x2_t{hi[2 * q - 4], hi[2 * q - 3]};
+    const bf16x2_t a = __builtin_convertvector(v, bf16x2_t);
+    const f32x2_t r = v - __builtin_convertvector(a, f32x2_t);
+    const bf16x2_t b = __builtin_convertvector(r, bf16x2_t);
+    x0[2 * q] = a[0]; x0[2 * q + 1] = a[1];
+    x1[2 * q] = b[0]; x1[2 * q + 1] = b[1];
+    if constexpr (THREE) {
+      const f32x2_t t = r - __builtin_convertvector(b, f32x2_t);
+      const bf16x2_t c = __builtin_convertvector(t, bf16x2_t);
+      x2[2 * q] = c[0]; x2[2 * q + 1] = c[1];
+    }
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int EPI, int BK, int STAGES, int MINW, int PRO = PRO_NONE,
+          int MMA = MMA_F32>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW) __attribute__((aligned(MT_DMA_FN_ALIGN)))
 void gemm_dma_kernel(const GemmArgs p) {
   static_assert(PRO == PRO_NONE || AL == LAYOUT_KCONTIG, "fragment-time prologues are implemented for k-contiguous A");
@@ -283,6 +318,26 @@ void gemm_dma_kernel(const GemmArgs p) {
       }
 #pragma unroll
       for (int g = 0; g < NG; g += 2) { mma_group(fa0, fb0); mma_group(fa1, fb1); }
+      continue;
+    }
+    if constexpr (MMA != MMA_F32) {
+      constexpr bool X6 = MMA == MMA_BF16X6;
+#pragma unroll
+      for (int g = 0; g < NG; g += 2) {
+        load_frags(as, bs, g, fa0, fb0);
+        load_frags(as, bs, g + 1, fa1, fb1);
+        bf16x8_t a0[TM], a1[TM], a2[TM], b0[TN], b1[TN], b2[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) split_bf16<X6>(fa0[i], fa1[i], a0[i], a1[i], a2[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) split_bf16<X6>(fb0[j], fb1[j], b0[j], b1[j], b2[j]);
+#define MT_TERM(X, Y)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[i], Y[j], acc[i][j], 0, 0, 0);
+        if constexpr (X6) { MT_TERM(a2, b0) MT_TERM(a1, b1) MT_TERM(a0, b2) }
+        MT_TERM(a1, b0) MT_TERM(a0, b1) MT_TERM(a0, b0)
+#undef MT_TERM
+      }
       continue;
     }
     load_frags(as, bs, 0, fa0, fb0);

@@ -1,0 +1,138 @@
+// Dispatch of the split-operand GEMM main loop (gemm_split.hpp): fp32 operands split exactly into three bf16 pieces, six
+// piece products per fp32 product on the bf16 matrix pipe, fp32 accumulators.  mt_gemm (gemm.hip) asks try_launch_split()
+// first; problems it does not take (operand prologues, tiny or K % 16 != 0 shapes) go on to the fp32-MFMA kernels.
+#include "../../include/mintime_hip.h"
+#include "common.hpp"
+#include "gemm_split.hpp"
+#include <stdio.h>
+#include <stdlib.h>
+
+using namespace mt;
+
+namespace {
+
+// 0 = fp32 MFMA everywhere, 1 = split-operand bf16x6 where eligible.  Process-wide; MT_GEMM_SPLIT sets the initial value.
+int g_mode = -1;
+int mode() {
+  if (g_mode < 0) {
+    const char* e = getenv("MT_GEMM_SPLIT");
+    g_mode = e ? (atoi(e) != 0) : 1;
+  }
+  return g_mode;
+}
+
+enum { S_BIG = 0, S_MID = 1, S_COUNT };      // 128 x 128 (4 waves of 64 x 64), 128 x 64 (4 waves of 64 x 32)
+struct Var { int bm, bn; };
+constexpr Var kVar[S_COUNT] = {{128, 128}, {128, 64}};
+
+template <int WM, int WN, int TM, int TN, int AL, int BL, int EPI, int MINW, bool BAL>
+int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
+  auto k = gemm_split_kernel<WM, WN, TM, TN, AL, BL, EPI, MINW, true, 2, BAL>;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t lds = (size_t)2 * 3 * (BM + BN) * 32;
+  if (lds > 48 * 1024) {
+    static bool raised = false;        // idempotent; a benign race at worst repeats the call
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_gemm(split): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, s, a);
+  return check_launch("mt_gemm(split)");
+}
+
+template <int AL, int BL, int EPI>
+int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
+  // balanced accumulators always (gemm_split.hpp: BAL); the single-accumulator form lives on in tools/lab only
+  if (v == S_BIG) return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, true>(a, grid, s);
+  if constexpr (EPI != EPI_GEGLU) {
+    if (v == S_MID) return launch_one<2, 2, 2, 1, AL, BL, EPI, 3, true>(a, grid, s);
+  }
+  return fail(MT_ERR_UNSUPPORTED, "mt_gemm(split): no instance for variant %d", v);
+}
+
+}  // namespace
+
+extern "C" int mt_gemm_set_split(int on) {
+  const int prev = mode();
+  g_mode = on != 0;
+  return prev;
+}
+
+extern "C" int mt_gemm_get_split(void) { return mode(); }
+
+namespace mt {
+
+// Returns 1 when the problem is not eligible (caller falls back), 0 on success, < 0 on error.
+int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
+  if (!mode()) return 1;
+  if (const char* f = getenv("MT_SPLIT_ONLY_EPI")) {                // bisection aid: only this epilogue (and K, if given) takes the split loop
+    if (d->epilogue != atoi(f)) return 1;
+    if (const char* k = getenv("MT_SPLIT_ONLY_K")) if (d->K != atoi(k)) return 1;
+    static int calls = 0;                                           // ... and only calls [MT_SPLIT_FIRST, MT_SPLIT_LAST] of those
+    const int idx = calls++;
+    if (const char* lo = getenv("MT_SPLIT_FIRST")) if (idx < atoi(lo)) return 1;
+    if (const char* hi = getenv("MT_SPLIT_LAST")) if (idx > atoi(hi)) return 1;
+    if (getenv("MT_SPLIT_TRACE")) fprintf(stderr, "[split] call %d: op %d M %d N %d K %d\n", idx, d->op, d->M, d->N, d->K);
+  }
+  if (d->prologue != MT_PRO_NONE || d->b_prologue != MT_BPRO_NONE) return 1;
+  if (d->K % 16 || d->M < 128 || d->N < 64) return 1;
+  // short contractions stay on the fp32 pipe: the matrix time they could save is small next to their epilogue, and the bf16 pipe's
+  // residual rounding bias (gemm_split.hpp) is then kept out of the extractors' long chains of small-K convolutions
+  static const int min_k = getenv("MT_SPLIT_MIN_K") ? atoi(getenv("MT_SPLIT_MIN_K")) : 512;
+  if (d->K < min_k) return 1;
+  if (d->epilogue == MT_EPI_STATS) return 1;                        // fp64 column statistics: register budget of the 64 x 64 epilogue
+  if (d->epilogue == MT_EPI_GEGLU && (d->n_half & 63)) return 1;
+  if ((int64_t)d->M * d->N < (1 << 18)) return 1;                   // a handful of tiles: the fp32 kernels' small tiles fill the chip better
+  int v = S_BIG;
+  if (d->epilogue == MT_EPI_GEGLU_BWD) v = S_MID;
+  else if (d->N < 128) v = S_MID;
+  if (const char* f = getenv("MT_SPLIT_VARIANT")) v = atoi(f);      // tuning experiments only
+  if (v < 0 || v >= S_COUNT) return 1;
+  const Var var = kVar[v];
+  const int m_tiles = (d->M + var.bm - 1) / var.bm, n_tiles = (d->N + var.bn - 1) / var.bn;
+  dim3 grid(m_tiles * n_tiles, 1, 1);
+  a.group_n = 0;
+  a.k_chunk = 0;
+  a.trace = nullptr;
+  if (m_tiles >= 32 && n_tiles >= 2 && !getenv("MT_NO_L2_BLOCKING")) {
+    const int64_t panel = (int64_t)var.bn * d->K * 4;
+    int gn = (int)((2 << 20) / (panel > 0 ? panel : 1));
+    if (gn < 1) gn = 1;
+    if (gn > n_tiles) gn = n_tiles;
+    a.group_n = gn;
+    grid.x = 8 * ((m_tiles + 7) / 8) * n_tiles;
+  }
+  if (d->op == MT_OP_TN || d->epilogue == MT_EPI_ATOMIC) {
+    int splits = d->split_k;
+    if (d->op == MT_OP_TN && splits <= 0) {
+      const int tiles = m_tiles * n_tiles;
+      static const int target = getenv("MT_WGRAD_BLOCKS") ? atoi(getenv("MT_WGRAD_BLOCKS")) : 2048;   // tuning knob
+      splits = (target + tiles - 1) / tiles;
+      const int max_splits = d->K / 256 > 0 ? d->K / 256 : 1;
+      if (splits > max_splits) splits = max_splits;
+    }
+    if (splits < 1) splits = 1;
+    int chunk = (d->K + splits - 1) / splits;
+    chunk = (chunk + 15) / 16 * 16;
+    a.k_chunk = chunk;
+    grid.y = (d->K + chunk - 1) / chunk;
+  }
+
+#define SPLIT_COMBO(OP, AL, BL, EPI)                                 \
+  if (d->op == OP && d->epilogue == EPI) return launch_variant<AL, BL, EPI>(v, a, grid, s);
+  SPLIT_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_STORE)
+  SPLIT_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_BIAS_RES)
+  SPLIT_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_GEGLU)
+  SPLIT_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_ATOMIC)
+  SPLIT_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_STORE)
+  SPLIT_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_ACCUM)
+  SPLIT_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_GEGLU_BWD)
+  SPLIT_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_ATOMIC)
+  SPLIT_COMBO(MT_OP_TN, LAYOUT_KMAJOR, LAYOUT_KMAJOR, EPI_ATOMIC)
+#undef SPLIT_COMBO
+  return 1;
+}
+
+}  // namespace mt

@@ -1,0 +1,350 @@
+// Split-operand GEMM main loop for gfx950:  fp32 in, fp32 out, fp32 accumulate, products on the bf16 matrix pipe.
+//
+// gfx950 has no TF32/xf32 and its fp32 MFMA runs at 1/16 of the bf16 rate (v_mfma_f32_32x32x2_f32: 64 cycles for K = 2;
+// v_mfma_f32_32x32x16_bf16: 32 cycles for K = 16).  This loop keeps fp32 semantics and moves the products to the bf16 pipe:
+// every fp32 operand value is split EXACTLY into three bf16 pieces (round-to-nearest at each level)
+//       x = x0 + x1 + x2,   |x1| <= 2^-9 |x|,  |x2| <= 2^-18 |x|
+// and  x*y  is accumulated from the six piece products of weight >= 2^-18:
+//       x0y0 + (x0y1 + x1y0) + (x0y2 + x1y1 + x2y0)                 (dropped: x1y2 + x2y1 + x2y2 <= 2^-26 |x||y|)
+// bf16 x bf16 products are exact in fp32 and land in the same fp32 accumulator registers the fp32 MFMA uses, so the result
+// differs from the fp32 pipe's by less than that pipe's own rounding (tests/test_gpu_gemm.py compares both with fp64).
+// Six bf16 MFMAs replace sixteen fp32 ones: 6/16 of the matrix-pipe time.
+//
+// BAL (balanced accumulators).  v_mfma_f32_32x32x16_bf16 does not round  C + sum_k a_k b_k  like an fmaf chain: measured on
+// gfx950 (tools/lab/split_probe.py, mfma_round_probe.hip) its result carries a sign-INDEPENDENT bias of about -3e-9 x sum|a||b|
+// per instruction (rms error equal to the fp32 pipe's, but a mean that the fp32 pipe does not have).  Invisible in one GEMM's
+// max error, it adds up coherently over a deep network (Xception's 36 convolutions moved a logit by 1.6e-3 relative).  Because
+// the bias does not depend on the sign of the products it cancels between two accumulators fed with opposite signs: even k-tiles
+// accumulate  +x*y  into acc, odd k-tiles accumulate  (-x0)*y  into nacc (the leading A piece is stored negated), and the
+// result is acc - nacc.  Same MFMA count; 16 x TM x TN more accumulator registers.
+//
+// The split costs ~4.6 VALU instructions per element, so it must run ONCE per element per block, not once per fragment read
+// (gemm_dma.hpp's MMA_BF16X6 does the latter: VALU-bound at 1.3x).  Hence this loop stages through registers:
+//   global fp32 -> VGPRs (8 consecutive k of one tile row/column per thread) -> split -> three bf16 "planes" in LDS
+//   -> ds_read_b128 fragments (8 k of the lane's row: the 32x32x16 operand layout) -> 6 x TM x TN MFMAs per 16 k.
+// k-major operands (dgrad's weight, both wgrad operands) are transposed for free by the load pattern: lane = column, eight
+// strided dword loads (a wave covers 256 contiguous bytes per k row), so the LDS image is the same [rows][16 k] for every layout.
+//
+// LDS per stage: (BM + BN) rows x 16 k x 2 B x 3 planes; two stages (one barrier per 16 k).  Row = 32 B = two 16-byte slots
+// (k 0-7, k 8-15); slot ^= (row >> 3) & 1 makes the 16 rows a ds_read_b128 serves per cycle cover all 64 banks.
+#pragma once
+#include "gemm_dma.hpp"
+#include <type_traits>
+
+#ifndef MT_SPLIT_ABLATE        // tuning lab only: 1 no global loads, 2 no split + LDS writes, 4 no barrier, 8 no fragment reads, 16 no epilogue
+#define MT_SPLIT_ABLATE 0
+#endif
+
+namespace mt {
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int EPI, int MINW, bool X6 = true, int PIPE = 2, bool BAL = false>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW)
+void gemm_split_kernel(const GemmArgs p) {
+  static_assert(!BAL || PIPE == 2, "the balanced accumulators need the stage = tile parity of the two-register-set loop");
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int NT = NW * 64;
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int BK = 16;
+  constexpr int A_PLANE = BM * 32, B_PLANE = BN * 32;           // bytes
+  constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+  constexpr int AG = (BM * 2 + NT - 1) / NT, BG = (BN * 2 + NT - 1) / NT;   // 8-k granules per thread
+  constexpr bool A_ALL = (BM * 2) % NT == 0, B_ALL = (BN * 2) % NT == 0;   // every thread stages AG / BG granules (no predicate)
+  static_assert((BM * 2) % NT == 0 || BM * 2 < NT, "A granules must divide over the block");
+  static_assert((BN * 2) % NT == 0 || BN * 2 < NT, "B granules must divide over the block");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+
+  int mt_, nt_;
+  if (!tile_coords<BM, BN>(p, mt_, nt_)) return;
+  const int m0 = mt_ * BM;
+  const int n0 = nt_ * BN;
+
+  int k_begin = 0, k_end = p.K;
+  if (p.k_chunk > 0) {
+    k_begin = blockIdx.y * p.k_chunk;
+    k_end = min(p.K, k_begin + p.k_chunk);
+    if (k_begin >= k_end) return;
+  }
+  const int nk = (k_end - k_begin) / BK;            // host guarantees (k_end - k_begin) % 16 == 0
+
+  // ---- the granules this thread stages: (tile row, k half) -> global source, LDS byte offset inside a plane
+  const float* a_src[AG];
+  const float* b_src[BG];
+  int a_dst[AG], b_dst[BG];
+  int a_kh[AG], b_kh[BG];                           // k-major: the granule's k half
+  bool a_on[AG], b_on[BG];
+#pragma unroll
+  for (int j = 0; j < AG; ++j) {
+    const int gi = tid + j * NT;
+    a_on[j] = A_ALL || gi < BM * 2;
+    int row, kh;
+    if constexpr (AL == LAYOUT_KCONTIG) { row = gi >> 1; kh = gi & 1; } else { row = gi % BM; kh = gi / BM; }
+    row = a_on[j] ? row : 0; kh = a_on[j] ? kh : 0;
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;                      // rows past the end are never stored: any valid row will do
+    if constexpr (AL == LAYOUT_KCONTIG) a_src[j] = p.A + map_row(p.a_map, m) * p.lda + k_begin + kh * 8;
+    else a_src[j] = p.A + m;
+    a_kh[j] = kh;
+    a_dst[j] = row * 32 + ((kh ^ ((row >> 3) & 1)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < BG; ++j) {
+    const int gi = tid + j * NT;
+    b_on[j] = B_ALL || gi < BN * 2;
+    int row, kh;
+    if constexpr (BL == LAYOUT_KCONTIG) { row = gi >> 1; kh = gi & 1; } else { row = gi % BN; kh = gi / BN; }
+    row = b_on[j] ? row : 0; kh = b_on[j] ? kh : 0;
+    int n;
+    if constexpr (EPI == EPI_GEGLU) {               // tile row -> weight row: 'a' and 'gate' halves interleaved per 32 columns
+      static_assert(EPI != EPI_GEGLU || TN == 2, "GEGLU wants TN == 2");
+      const int w = row / 64, sel = (row >> 5) & 1, c = row & 31;
+      const int jj = (n0 >> 1) + w * 32 + c;
+      n = jj < p.n_half ? sel * p.n_half + jj : 0;
+    } else {
+      n = n0 + row;
+      n = n < p.N ? n : p.N - 1;
+    }
+    if constexpr (BL == LAYOUT_KCONTIG) b_src[j] = p.B + (int64_t)n * p.ldb + k_begin + kh * 8;
+    else b_src[j] = p.B + n;
+    b_kh[j] = kh;
+    b_dst[j] = row * 32 + ((kh ^ ((row >> 3) & 1)) << 4);
+  }
+
+  auto gload = [&](int kt, float (&ga)[AG][8], float (&gb)[BG][8]) {
+    if (MT_SPLIT_ABLATE & 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int j = 0; j < AG; ++j) ga[j][e] = (float)(lane + e + kt);
+#pragma unroll
+        for (int j = 0; j < BG; ++j) gb[j][e] = (float)(lane - e + kt);
+      }
+      return;
+    }
+    const int k0 = k_begin + kt * BK;
+#pragma unroll
+    for (int j = 0; j < AG; ++j) {
+      if (!A_ALL && !a_on[j]) continue;
+      if constexpr (AL == LAYOUT_KCONTIG) {
+        const float4 u = *reinterpret_cast<const float4*>(a_src[j] + kt * BK), v = *reinterpret_cast<const float4*>(a_src[j] + kt * BK + 4);
+        ga[j][0] = u.x; ga[j][1] = u.y; ga[j][2] = u.z; ga[j][3] = u.w; ga[j][4] = v.x; ga[j][5] = v.y; ga[j][6] = v.z; ga[j][7] = v.w;
+      } else {
+        const int kr = k0 + a_kh[j] * 8;
+        if (p.a_map.gin == 0) {
+          const float* s = a_src[j] + (int64_t)kr * p.lda;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ga[j][e] = s[(int64_t)e * p.lda];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ga[j][e] = a_src[j][map_row(p.a_map, kr + e) * p.lda];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+      if (!B_ALL && !b_on[j]) continue;
+      if constexpr (BL == LAYOUT_KCONTIG) {
+        const float4 u = *reinterpret_cast<const float4*>(b_src[j] + kt * BK), v = *reinterpret_cast<const float4*>(b_src[j] + kt * BK + 4);
+        gb[j][0] = u.x; gb[j][1] = u.y; gb[j][2] = u.z; gb[j][3] = u.w; gb[j][4] = v.x; gb[j][5] = v.y; gb[j][6] = v.z; gb[j][7] = v.w;
+      } else {
+        const int kr = k0 + b_kh[j] * 8;
+        if (p.b_map.gin == 0) {
+          const float* s = b_src[j] + (int64_t)kr * p.ldb;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gb[j][e] = s[(int64_t)e * p.ldb];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gb[j][e] = b_src[j][map_row(p.b_map, kr + e) * p.ldb];
+        }
+      }
+    }
+  };
+  auto sstore = [&](int stage, const float (&ga)[AG][8], const float (&gb)[BG][8], bool negate_a0 = false) {
+    if (MT_SPLIT_ABLATE & 2) {
+      float z = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int j = 0; j < AG; ++j) z += ga[j][e];
+#pragma unroll
+        for (int j = 0; j < BG; ++j) z += gb[j][e];
+      }
+      if (z == 123.456f) smem_split[tid] = 1;        // keeps the loads live
+      return;
+    }
+    unsigned char* st = smem_split + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < AG; ++j) {
+      if (!A_ALL && !a_on[j]) continue;
+      bf16x8_t x0, x1, x2;
+      split_bf16<X6>(reinterpret_cast<const float(&)[4]>(ga[j][0]), reinterpret_cast<const float(&)[4]>(ga[j][4]), x0, x1, x2);
+      if (negate_a0) {                                // BAL: the odd tiles' leading A piece goes in negated (see the header comment)
+        uint4 u = *reinterpret_cast<uint4*>(&x0);
+        u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
+        x0 = *reinterpret_cast<bf16x8_t*>(&u);
+      }
+      *reinterpret_cast<bf16x8_t*>(st + a_dst[j]) = x0;
+      *reinterpret_cast<bf16x8_t*>(st + A_PLANE + a_dst[j]) = x1;
+      if constexpr (X6) *reinterpret_cast<bf16x8_t*>(st + 2 * A_PLANE + a_dst[j]) = x2;
+    }
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+      if (!B_ALL && !b_on[j]) continue;
+      bf16x8_t x0, x1, x2;
+      split_bf16<X6>(reinterpret_cast<const float(&)[4]>(gb[j][0]), reinterpret_cast<const float(&)[4]>(gb[j][4]), x0, x1, x2);
+      *reinterpret_cast<bf16x8_t*>(st + 3 * A_PLANE + b_dst[j]) = x0;
+      *reinterpret_cast<bf16x8_t*>(st + 3 * A_PLANE + B_PLANE + b_dst[j]) = x1;
+      if constexpr (X6) *reinterpret_cast<bf16x8_t*>(st + 3 * A_PLANE + 2 * B_PLANE + b_dst[j]) = x2;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+  f32x16 nacc[BAL ? TM : 1][BAL ? TN : 1];           // BAL: minus the sum of the odd tiles' a0-products
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if constexpr (BAL) nacc[i][j][r] = 0.f; }
+
+  // ---- fragment addressing: lane = (row l & 31, k half l >> 5); tile i / j adds 32 rows (same swizzle)
+  const int kh = lane >> 5;
+  const int a_row = wm * TM * 32 + (lane & 31);
+  const int b_row = wn * TN * 32 + (lane & 31);
+  const int a_frag = a_row * 32 + ((kh ^ ((a_row >> 3) & 1)) << 4);
+  const int b_frag = 3 * A_PLANE + b_row * 32 + ((kh ^ ((b_row >> 3) & 1)) << 4);
+
+  auto compute = [&](int stage, int kt, auto odd_c) {
+    constexpr bool ODD = BAL && decltype(odd_c)::value;
+    const unsigned char* st = smem_split + stage * STAGE;
+    bf16x8_t a0[TM], a1[TM], a2[TM], b0[TN], b1[TN], b2[TN];
+    if (MT_SPLIT_ABLATE & 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { a0[i][e] = (__bf16)(float)(lane + e + i); a1[i][e] = (__bf16)(float)(lane - e); a2[i][e] = (__bf16)(float)(lane ^ e); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { b0[j][e] = (__bf16)(float)(lane * 2 + e + j); b1[j][e] = (__bf16)(float)(lane + 3 * e); b2[j][e] = (__bf16)(float)(3 + e); }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        a0[i] = *reinterpret_cast<const bf16x8_t*>(st + a_frag + i * 1024);
+        a1[i] = *reinterpret_cast<const bf16x8_t*>(st + A_PLANE + a_frag + i * 1024);
+        if constexpr (X6) a2[i] = *reinterpret_cast<const bf16x8_t*>(st + 2 * A_PLANE + a_frag + i * 1024);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        b0[j] = *reinterpret_cast<const bf16x8_t*>(st + b_frag + j * 1024);
+        b1[j] = *reinterpret_cast<const bf16x8_t*>(st + B_PLANE + b_frag + j * 1024);
+        if constexpr (X6) b2[j] = *reinterpret_cast<const bf16x8_t*>(st + 2 * B_PLANE + b_frag + j * 1024);
+      }
+    }
+#define MT_TERM(X, Y)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[i], Y[j], acc[i][j], 0, 0, 0);
+#define MT_NTERM(X, Y)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
+      nacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[i], Y[j], nacc[i][j], 0, 0, 0);
+    if constexpr (ODD) {                              // a0 holds -x0 here: its products build the negated sum
+      if constexpr (X6) { MT_TERM(a2, b0) MT_TERM(a1, b1) MT_NTERM(a0, b2) }
+      MT_TERM(a1, b0) MT_NTERM(a0, b1) MT_NTERM(a0, b0)
+    } else {
+      if constexpr (X6) { MT_TERM(a2, b0) MT_TERM(a1, b1) MT_TERM(a0, b2) }
+      MT_TERM(a1, b0) MT_TERM(a0, b1) MT_TERM(a0, b0)
+    }
+#undef MT_TERM
+#undef MT_NTERM
+  };
+  // scheduling directive for the basic block {fragment reads, MFMAs, split, LDS writes}: VALU_PER MFMA-shadow slots of the split
+  // behind every MFMA (an MFMA holds the matrix pipe for 32 cycles; the wave's next 4-5 VALU issues are free in that shadow)
+  auto interleave = [&]() {
+    constexpr int N_MFMA = (X6 ? 6 : 3) * TM * TN;
+    constexpr int N_VALU = (AG + BG) * (X6 ? 36 : 22);
+    constexpr int VALU_PER = (N_VALU + N_MFMA - 1) / N_MFMA;
+    constexpr int N_VMEM = AG * (AL == LAYOUT_KCONTIG ? 2 : 8) + BG * (BL == LAYOUT_KCONTIG ? 2 : 8);
+    (void)N_VMEM;   // pinning the VMEM group first was tried: the compiler then drains the previous step's loads at the top (722 vs 669 us at 4096^3)
+#pragma unroll
+    for (int q = 0; q < N_MFMA; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);   // then VALU
+    }
+  };
+#define MT_SPLIT_SYNC() do { if (!(MT_SPLIT_ABLATE & 4)) __syncthreads(); } while (0)
+
+  if (nk <= 0) return;
+  if constexpr (PIPE == 1) {
+    // one register set: tile kt+1's loads are issued at the top of step kt and consumed (split + LDS write) at its end
+    float ga[AG][8], gb[BG][8];
+    gload(0, ga, gb); sstore(0, ga, gb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) gload(kt + 1, ga, gb);
+      compute(kt & 1, kt, std::false_type{});
+      if (kt + 1 < nk) sstore((kt + 1) & 1, ga, gb);
+      MT_SPLIT_SYNC();
+    }
+  } else {
+    // two register sets: tile kt+2's loads are issued at the top of step kt; tile kt+1 (loaded a full step ago) is split and
+    // written to the other LDS stage in the shadow of tile kt's MFMAs.  Branch-free body (the scheduler interleaves the VALU
+    // split with the MFMA stream inside one basic block): past the end the loads re-read the last tile and the stores fill
+    // a stage nobody reads.
+    float ga0[AG][8], gb0[BG][8], ga1[AG][8], gb1[BG][8];
+    const int last = nk - 1;
+    gload(0, ga0, gb0); sstore(0, ga0, gb0);
+    gload(min(1, last), ga0, gb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      gload(min(kt + 2, last), ga1, gb1);
+      compute(0, kt, std::false_type{});
+      sstore(1, ga0, gb0, BAL);
+      interleave();
+      MT_SPLIT_SYNC();
+      if (kt + 1 >= nk) break;
+      gload(min(kt + 3, last), ga0, gb0);
+      compute(1, kt + 1, std::true_type{});
+      sstore(0, ga1, gb1);
+      interleave();
+      MT_SPLIT_SYNC();
+    }
+  }
+
+  if constexpr (BAL) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] -= nacc[i][j][r];
+    // finish the subtraction here (nacc dead) instead of letting it sink into the epilogue's branches next to their address registers
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
+  }
+  if (MT_SPLIT_ABLATE & 16) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 123.456f) p.C[0] = sacc;
+    return;
+  }
+  // the epilogue's address arithmetic depends only on the tile coordinates: without this fence the compiler computes it before
+  // the main loop and carries it through (60-100 VGPRs: spills in the balanced variants)
+  int m0e = m0, n0e = n0, lane_e = lane;
+  asm volatile("" : "+s"(m0e), "+s"(n0e), "+v"(lane_e));
+  gemm_epilogue<TM, TN, EPI>(p, acc, m0e, n0e, wm, wn, lane_e);
+}
+
+}  // namespace mt

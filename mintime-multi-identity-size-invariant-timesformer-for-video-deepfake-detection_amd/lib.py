@@ -50,6 +50,8 @@ PROTOTYPES = {
     "mt_version": [],
     "mt_last_error": [],
     "mt_gemm": [C.POINTER(GemmDesc), C.c_void_p],
+    "mt_gemm_set_split": [C.c_int],
+    "mt_gemm_get_split": [],
     "mt_layernorm_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "mt_embed_fwd": [f32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                      C.c_void_p],
@@ -134,6 +136,16 @@ def get():
         raise MintimeHipError(f"libmintime_hip.so version {v} != header version 100; rebuild it")
     _lib = lib
     return lib
+
+
+def set_gemm_split(on: bool) -> bool:
+    """Select the matrix pipe of the prologue-free contractions (include/mintime_hip.h, mt_gemm_set_split): True = split-operand
+    fp32 on the bf16 pipe (default), False = fp32 MFMA everywhere.  Returns the previous setting."""
+    return bool(get().mt_gemm_set_split(1 if on else 0))
+
+
+def gemm_split_enabled() -> bool:
+    return bool(get().mt_gemm_get_split())
 
 
 def check(rc, what):

@@ -1,5 +1,7 @@
 """GPU parity of the whole hot path (EfficientNet-B0 -> SizeInvariantTimeSformer, forward + backward) driven exactly
 like the reference call sites (train.py:332-378, test.py:235-247)."""
+import os
+
 import pytest
 import torch
 
@@ -249,6 +251,8 @@ def test_config5_xception_timesformer_step_vs_oracle():
     oloss.backward()
 
     assert_close(feats.reshape(F, 2048, 7, 7), ofeat.detach(), REL_TOL, "Xception features")
+    if os.environ.get("MT_TEST_VERBOSE"):
+        print("[config5] logit", float(out), "oracle", float(ologits))
     assert_close(out, ologits.detach(), REL_TOL, "logits")
     assert abs(float(loss.detach()) - float(oloss.detach())) <= 1e-4 * max(1.0, abs(float(oloss.detach())))
     tsf_named = dict(tsf.named_parameters())

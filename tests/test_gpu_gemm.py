@@ -1,4 +1,5 @@
-"""GPU parity of the fp32-MFMA GEMM family (through the C ABI) against fp64 CPU matmuls."""
+"""GPU parity of the GEMM family (through the C ABI) against fp64 CPU matmuls.  Every test runs on both matrix pipes:
+the split-operand fp32 loop (bf16 pipe, default) and the fp32 MFMA kernels (mt_gemm_set_split)."""
 import numpy as np
 import pytest
 import torch
@@ -8,7 +9,14 @@ from mintime_amd import lib as L
 from tests.util import assert_close
 
 pytestmark = pytest.mark.gpu
-TOL = 2e-5   # exact-fp32 MFMA vs fp64: rounding only
+TOL = 2e-5   # fp32 products and accumulation vs fp64: rounding only (same bound for both pipes)
+
+
+@pytest.fixture(autouse=True, params=["split", "fp32"])
+def matrix_pipe(request):
+    prev = L.set_gemm_split(request.param == "split")
+    yield request.param
+    L.set_gemm_split(prev)
 
 
 def _rand(*shape, seed=0, scale=1.0):
@@ -264,7 +272,9 @@ def test_full_size_wgrad_with_token_rowmap():
 # row maps -- forced through MT_DMA_VARIANT so that the shapes below do not depend on the dispatch heuristics.
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.fixture
-def dma_variant(monkeypatch):
+def dma_variant(monkeypatch, matrix_pipe):
+    if matrix_pipe == "split":
+        pytest.skip("the LDS-DMA loop is the fp32 pipe's")
     def force(v):
         monkeypatch.setenv("MT_DMA_VARIANT", str(v))
     return force
@@ -371,3 +381,91 @@ def test_dma_bn_backward_prologue_dgrad(variant, M, K, N, with_res, monkeypatch)
     if with_res:
         ref = ref + res.double()
     assert_close(Cd, ref, 5e-5, f"BN-backward data gradient (DMA v{variant})")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Split-operand loop (csrc/gemm_split.hpp): fp32 in / fp32 accumulate with the products on the bf16 pipe.  Its claim is
+# "the same error against fp64 as the fp32 MFMA pipe", checked here on well-scaled, wide-dynamic-range and cancelling data.
+# ---------------------------------------------------------------------------------------------------------------------
+def _both_pipes(op, A, B, M, N, K, split_k=1):
+    """(C_split, C_fp32) of the same problem through mt_gemm."""
+    out = []
+    for on in (True, False):
+        prev = L.set_gemm_split(on)
+        try:
+            C = torch.zeros(M, N, device="cuda")
+            if op == "NT":
+                L.gemm(L.OP_NT, A, B, C, M, N, K, K, K, N)
+            elif op == "NN":
+                L.gemm(L.OP_NN, A, B, C, M, N, K, K, N, N, epilogue=L.EPI_ATOMIC, split_k=split_k)
+            else:
+                L.gemm(L.OP_TN, A, B, C, M, N, K, M, N, N, epilogue=L.EPI_ATOMIC, split_k=split_k)
+            torch.cuda.synchronize()
+            out.append(C.cpu().double())
+        finally:
+            L.set_gemm_split(prev)
+    return out
+
+
+def _operands(op, M, N, K, kind):
+    g = torch.Generator().manual_seed(11)
+    a_shape = (K, M) if op == "TN" else (M, K)
+    b_shape = (N, K) if op == "NT" else (K, N)
+    A = torch.randn(*a_shape, generator=g)
+    B = torch.randn(*b_shape, generator=g)
+    if kind == "wide":          # 16 decades of dynamic range inside every dot product
+        A = A * torch.pow(10.0, torch.rand(*a_shape, generator=g) * 8 - 4)
+        B = B * torch.pow(10.0, torch.rand(*b_shape, generator=g) * 8 - 4)
+    if kind == "cancel":        # dot products that cancel to ~1e-4 of their terms
+        A = A.abs() + 1.0
+        sign = torch.ones(K)
+        sign[1::2] = -1.0
+        B = (1.0 + 1e-4 * B)
+        B = B * (sign[None, :] if op == "NT" else sign[:, None])
+    return A.float().contiguous(), B.float().contiguous()
+
+
+@pytest.mark.parametrize("kind", ["normal", "wide", "cancel"])
+@pytest.mark.parametrize("op,M,N,K,split_k", [("NT", 1024, 512, 2048, 1), ("NN", 1024, 512, 1024, 2), ("TN", 1024, 512, 4096, 4)])
+def test_split_pipe_error_equals_fp32_pipe_error(op, M, N, K, split_k, kind):
+    A, B = _operands(op, M, N, K, kind)
+    Cs, Cf = _both_pipes(op, A.cuda(), B.cuda(), M, N, K, split_k)
+    Ad, Bd = A.double(), B.double()
+    Am = Ad.T if op == "TN" else Ad
+    Bm = Bd.T if op == "NT" else Bd
+    ref = Am @ Bm
+    bound = Am.abs() @ Bm.abs()            # sum_k |a||b|: what rounding errors scale with
+    e_split = float(((Cs - ref).abs() / bound).max())
+    e_fp32 = float(((Cf - ref).abs() / bound).max())
+    assert not torch.equal(Cs, Cf), "both settings produced bit-identical results: the split loop did not run"
+    # condition-aware bound: the random-walk growth of K fp32 roundings per unit of sum |a||b|, for either pipe ...
+    walk = 2.0 * K ** 0.5 * 2.0 ** -24
+    assert e_fp32 < walk and e_split < walk, (e_split, e_fp32, walk)
+    # ... and the split pipe within a small factor of the fp32 pipe (measured: 0.85 - 1.2x)
+    assert e_split <= 2.0 * e_fp32 + 2.0 ** -26, (e_split, e_fp32)
+
+
+def test_split_pipe_is_exact_on_bf16_representable_products():
+    """Operands that are exact in bf16 and small integer sums: both pipes must return the exact integers."""
+    M, N, K = 1024, 512, 512
+    g = torch.Generator().manual_seed(5)
+    A = torch.randint(-8, 9, (M, K), generator=g).float()
+    B = torch.randint(-8, 9, (N, K), generator=g).float()
+    Cs, Cf = _both_pipes("NT", A.cuda(), B.cuda(), M, N, K)
+    ref = A.double() @ B.double().T
+    assert torch.equal(Cs, ref) and torch.equal(Cf, ref)
+
+
+def test_split_pipe_handles_fp32_only_values():
+    """Values with all 24 mantissa bits set (nothing bf16 can hold alone) times powers of two: the three-piece split is exact,
+    so a K = 16 dot product of one non-zero term must come back bit-exact."""
+    M, N, K = 1024, 512, 16
+    A = torch.zeros(M, K)
+    B = torch.zeros(N, K)
+    A[:, 3] = torch.tensor([1.0 + (2 ** 23 - 1 - i) * 2.0 ** -23 for i in range(M)], dtype=torch.float64).float()      # 1.111...1b and neighbours
+    B[:, 3] = torch.tensor([2.0 ** (j % 20 - 10) for j in range(N)])
+    Cs, Cf = _both_pipes("NT", A.cuda(), B.cuda(), M, N, K)
+    ref = A.double() @ B.double().T
+    assert L.gemm_split_enabled() in (True, False)
+    assert torch.equal(Cf, ref)
+    assert torch.equal(Cs, ref)

@@ -25,6 +25,8 @@ def rel_err(got, ref):
 
 def assert_close(got, ref, tol=REL_TOL, what=""):
     e = rel_err(got, ref)
+    if os.environ.get("MT_TEST_VERBOSE"):
+        print(f"[assert_close] {what}: rel err {e:.3e} (tol {tol:.1e})")
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
     return e
 

@@ -10,7 +10,8 @@
 // the library exports the same template instances: give the lab's copies their own symbol names, or the runtime resolves a
 // launch by NAME to the library's (non-ablated) kernel
 #define gemm_dma_kernel gemm_dma_kernel_lab
-#include "../../mintime-multi-identity-size-invariant-timesformer-for-video-deepfake-detection_amd/csrc/gemm_dma.hpp"
+#define gemm_split_kernel gemm_split_kernel_lab
+#include "../../mintime-multi-identity-size-invariant-timesformer-for-video-deepfake-detection_amd/csrc/gemm_split.hpp"
 
 using namespace mt;
 
@@ -74,13 +75,41 @@ static GemmArgs make_args(const Problem& pr, int bm, int bn, int bk, int& gx, in
   return a;
 }
 
-template <int WM, int WN, int TM, int TN, int AL, int BL, int EPI, int BK, int ST, int MINW>
+// max |x - fp64 reference| over a sample of outputs, relative to the largest reference magnitude (plain matmul epilogues only)
+static void err64(const Problem& pr, const std::vector<float>& got, const std::vector<float>& base, double& e_got, double& e_base) {
+  e_got = e_base = -1;
+  const Shape& s = pr.s;
+  if (s.epi != EPI_STORE && s.epi != EPI_ATOMIC) return;
+  static std::vector<float> hA, hB, hBias; static const float* cached = nullptr;
+  size_t a_el = (size_t)s.M * s.K, b_el = (size_t)s.N * s.K;
+  if (cached != pr.A) { hA.resize(a_el); hB.resize(b_el); CK(hipMemcpy(hA.data(), pr.A, a_el * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hB.data(), pr.B, b_el * 4, hipMemcpyDeviceToHost)); hBias.resize(s.N); CK(hipMemcpy(hBias.data(), pr.bias, (size_t)s.N * 4, hipMemcpyDeviceToHost)); cached = pr.A; }
+  double mg = 0, mb = 0, mr = 0;
+  uint64_t st = 12345;
+  for (int it = 0; it < 4000; ++it) {
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    const int m = (int)((st >> 33) % s.M);
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    const int n = (int)((st >> 33) % s.N);
+    double acc = 0;
+    for (int k = 0; k < s.K; ++k) {
+      const double av = s.op == MT_OP_TN ? hA[(size_t)k * pr.lda + m] : hA[(size_t)m * pr.lda + k];
+      const double bv = s.op == MT_OP_NT ? hB[(size_t)n * pr.ldb + k] : hB[(size_t)k * pr.ldb + n];
+      acc += av * bv;
+    }
+    acc += hBias[n];                 // both plain epilogues add the bias
+    const size_t ci = (size_t)m * pr.ldc + n;
+    mg = fmax(mg, fabs(got[ci] - acc)); mb = fmax(mb, fabs(base[ci] - acc)); mr = fmax(mr, fabs(acc));
+  }
+  e_got = mg / mr; e_base = mb / mr;
+}
+
+template <int WM, int WN, int TM, int TN, int AL, int BL, int EPI, int BK, int ST, int MINW, int MMA = MMA_F32>
 static float run_variant(const Problem& pr, int reps) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   int gx, gy;
   GemmArgs a = make_args(pr, BM, BN, BK, gx, gy);
   if (pr.s.K % BK || (a.k_chunk && a.k_chunk % BK)) return -1.f;
-  auto k = gemm_dma_kernel<WM, WN, TM, TN, AL, BL, EPI, BK, ST, MINW>;
+  auto k = gemm_dma_kernel<WM, WN, TM, TN, AL, BL, EPI, BK, ST, MINW, PRO_NONE, MMA>;
   const size_t lds = (size_t)ST * (BM + BN) * BK * 4;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   auto f = [&]() {
@@ -97,11 +126,48 @@ static float run_variant(const Problem& pr, int reps) {
   for (size_t i = 0; i < pr.c_elems; ++i) { md = fmax(md, fabs((double)h[i] - r[i])); mr = fmax(mr, fabs((double)r[i])); }
   const float ms = time_ms(f, reps);
   const float memset_ms = EPI == EPI_ATOMIC ? time_ms([&]() { CK(hipMemsetAsync(pr.C, 0, pr.c_elems * 4, 0)); }, reps) : 0.f;
-  printf("    %dx%d bk%d st%d w%d : %8.1f us  %6.1f TF   relerr %.1e%s\n", BM, BN, BK, ST, MINW, (ms - memset_ms) * 1e3,
-         2.0 * pr.s.M * pr.s.N * pr.s.K / ((ms - memset_ms) * 1e-3) / 1e12, md / (mr > 0 ? mr : 1), md / (mr > 0 ? mr : 1) > 1e-4 ? "  <<<<<< MISMATCH" : "");
+  double e_got, e_base;
+  err64(pr, h, r, e_got, e_base);
+  printf("    %dx%d bk%d st%d w%d %s : %8.1f us  %6.1f TF   relerr %.1e%s   err-vs-fp64 %.2e (fp32 pipe %.2e)\n", BM, BN, BK, ST, MINW,
+         MMA == MMA_F32 ? "f32  " : (MMA == MMA_BF16X6 ? "bf16x6" : "bf16x3"), (ms - memset_ms) * 1e3,
+         2.0 * pr.s.M * pr.s.N * pr.s.K / ((ms - memset_ms) * 1e-3) / 1e12, md / (mr > 0 ? mr : 1), md / (mr > 0 ? mr : 1) > 1e-4 ? "  <<<<<< MISMATCH" : "",
+         e_got, e_base);
   fflush(stdout);
   return ms;
 }
+
+template <int WM, int WN, int TM, int TN, int AL, int BL, int EPI, int MINW, bool X6 = true, int PIPE = 2, bool BAL = false>
+static float run_split(const Problem& pr, int reps) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  int gx, gy;
+  GemmArgs a = make_args(pr, BM, BN, 16, gx, gy);
+  if (pr.s.K % 16 || (a.k_chunk && a.k_chunk % 16)) return -1.f;
+  auto k = gemm_split_kernel_lab<WM, WN, TM, TN, AL, BL, EPI, MINW, X6, PIPE, BAL>;
+  const size_t lds = (size_t)2 * 3 * (BM + BN) * 32;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto f = [&]() {
+    if (EPI == EPI_ATOMIC) CK(hipMemsetAsync(pr.C, 0, pr.c_elems * 4, 0));
+    hipLaunchKernelGGL(k, dim3(gx, gy), dim3(WM * WN * 64), lds, 0, a);
+  };
+  f(); CK(hipDeviceSynchronize());
+  CK(hipGetLastError());
+  std::vector<float> h(pr.c_elems), r(pr.c_elems);
+  CK(hipMemcpy(h.data(), pr.C, pr.c_elems * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(r.data(), pr.Cref, pr.c_elems * 4, hipMemcpyDeviceToHost));
+  double md = 0, mr = 0;
+  for (size_t i = 0; i < pr.c_elems; ++i) { md = fmax(md, fabs((double)h[i] - r[i])); mr = fmax(mr, fabs((double)r[i])); }
+  const float ms = time_ms(f, reps);
+  const float memset_ms = EPI == EPI_ATOMIC ? time_ms([&]() { CK(hipMemsetAsync(pr.C, 0, pr.c_elems * 4, 0)); }, reps) : 0.f;
+  double e_got, e_base;
+  err64(pr, h, r, e_got, e_base);
+  printf("    SPLIT p%d%s %dx%d %dw(%dx%d) w%d %s : %8.1f us  %6.1f TF   relerr %.1e%s   err-vs-fp64 %.2e (fp32 pipe %.2e)\n", PIPE, BAL ? " bal" : "", BM, BN, WM * WN, WM, WN, MINW,
+         X6 ? "bf16x6" : "bf16x3", (ms - memset_ms) * 1e3,
+         2.0 * pr.s.M * pr.s.N * pr.s.K / ((ms - memset_ms) * 1e-3) / 1e12, md / (mr > 0 ? mr : 1), md / (mr > 0 ? mr : 1) > 1e-4 ? "  <<<<<< MISMATCH" : "",
+         e_got, e_base);
+  fflush(stdout);
+  return ms;
+}
+#define PIPE_ARG
 
 static float run_baseline(Problem& pr, int reps) {
   const Shape& s = pr.s;
@@ -149,6 +215,76 @@ static void free_problem(Problem& pr) { hipFree(pr.A); hipFree(pr.B); hipFree(pr
 #define KM LAYOUT_KMAJOR
 
 template <int AL, int BL, int EPI> static void sweep(Problem& pr, int reps) {
+#ifdef MT_LAB_SPLIT_BAL
+  run_split<2, 2, 2, 2, AL, BL, EPI, 2, true, 2, false>(pr, reps);
+  run_split<2, 2, 2, 2, AL, BL, EPI, 2, true, 2, true>(pr, reps);
+  run_split<2, 2, 2, 2, AL, BL, EPI, 1, true, 2, true>(pr, reps);
+  run_split<4, 2, 1, 2, AL, BL, EPI, 2, true, 2, true>(pr, reps);
+  run_split<4, 2, 1, 2, AL, BL, EPI, 3, true, 2, true>(pr, reps);
+  run_split<4, 2, 1, 2, AL, BL, EPI, 3, true, 2, false>(pr, reps);
+  run_split<4, 2, 1, 2, AL, BL, EPI, 4, true, 2, true>(pr, reps);
+  if constexpr (EPI != EPI_GEGLU) {
+    run_split<2, 4, 2, 1, AL, BL, EPI, 4, true, 2, true>(pr, reps);
+    run_split<2, 4, 2, 1, AL, BL, EPI, 3, true, 2, true>(pr, reps);
+    run_split<4, 2, 2, 1, AL, BL, EPI, 3, true, 2, true>(pr, reps);     // 256 x 64
+  }
+  return;
+#endif
+#ifdef MT_LAB_SPLIT_AB
+  run_split<2, 2, 2, 2, AL, BL, EPI, 2, true, 1>(pr, reps);
+  run_split<2, 2, 2, 2, AL, BL, EPI, 2, true, 2>(pr, reps);
+  run_split<2, 2, 2, 2, AL, BL, EPI, 1, true, 2>(pr, reps);
+  if constexpr (EPI != EPI_GEGLU) run_split<4, 2, 2, 2, AL, BL, EPI, 2, true, 1>(pr, reps);
+  if constexpr (EPI != EPI_GEGLU) run_split<4, 2, 2, 2, AL, BL, EPI, 2, true, 2>(pr, reps);
+  if constexpr (EPI != EPI_GEGLU) run_split<4, 2, 2, 2, AL, BL, EPI, 1, true, 2>(pr, reps);
+  return;
+#endif
+#ifdef MT_LAB_SPLIT
+  run_variant<2, 2, 2, 2, AL, BL, EPI, 32, 2, 2, MMA_BF16X6>(pr, reps);
+  run_split<2, 2, 2, 2, AL, BL, EPI, 2>(pr, reps);
+  run_split<2, 2, 2, 2, AL, BL, EPI, 3>(pr, reps);
+  run_split<2, 2, 2, 2, AL, BL, EPI, 2, false>(pr, reps);
+  if constexpr (EPI != EPI_GEGLU) {
+    run_split<2, 2, 2, 1, AL, BL, EPI, 3>(pr, reps);
+    run_split<2, 2, 2, 4, AL, BL, EPI, 1>(pr, reps);
+    run_split<4, 2, 2, 2, AL, BL, EPI, 2>(pr, reps);
+    run_split<4, 2, 1, 2, AL, BL, EPI, 4>(pr, reps);
+    run_split<2, 4, 2, 1, AL, BL, EPI, 4>(pr, reps);
+  }
+  return;
+#endif
+#ifdef MT_LAB_BF16
+  run_variant<2, 2, 2, 2, AL, BL, EPI, 32, 2, 2>(pr, reps);
+  run_variant<2, 2, 2, 2, AL, BL, EPI, 32, 2, 2, MMA_BF16X6>(pr, reps);
+  run_variant<2, 2, 2, 2, AL, BL, EPI, 16, 3, 2, MMA_BF16X6>(pr, reps);
+  run_variant<2, 2, 2, 2, AL, BL, EPI, 16, 2, 2, MMA_BF16X6>(pr, reps);
+  run_variant<2, 2, 2, 2, AL, BL, EPI, 32, 2, 2, MMA_BF16X3>(pr, reps);
+  if constexpr (EPI != EPI_GEGLU) {
+    run_variant<2, 2, 2, 1, AL, BL, EPI, 16, 3, 3, MMA_BF16X6>(pr, reps);
+    run_variant<2, 2, 1, 1, AL, BL, EPI, 32, 3, 4, MMA_BF16X6>(pr, reps);
+    run_variant<4, 2, 1, 2, AL, BL, EPI, 16, 2, 4, MMA_BF16X6>(pr, reps);
+    run_variant<4, 2, 2, 2, AL, BL, EPI, 16, 2, 2, MMA_BF16X6>(pr, reps);      // 256 x 128 tile, 8 waves of 64 x 64
+    run_variant<2, 2, 2, 4, AL, BL, EPI, 16, 2, 1, MMA_BF16X6>(pr, reps);      // 128 x 256 tile, 4 waves of 64 x 128
+  }
+  return;
+#endif
+#ifdef MT_LAB_8WAVE
+  run_variant<2, 2, 2, 2, AL, BL, EPI, 16, 2, 3>(pr, reps);
+  run_variant<2, 2, 2, 2, AL, BL, EPI, 16, 2, 4>(pr, reps);
+  run_variant<2, 2, 2, 2, AL, BL, EPI, 32, 2, 2>(pr, reps);
+  if constexpr (EPI != EPI_GEGLU) {
+    run_variant<4, 2, 1, 2, AL, BL, EPI, 16, 2, 6>(pr, reps);
+    run_variant<4, 2, 1, 2, AL, BL, EPI, 16, 2, 8>(pr, reps);
+    run_variant<4, 2, 1, 2, AL, BL, EPI, 16, 3, 6>(pr, reps);
+    run_variant<4, 2, 1, 2, AL, BL, EPI, 32, 2, 6>(pr, reps);
+    run_variant<2, 4, 2, 1, AL, BL, EPI, 16, 2, 6>(pr, reps);
+    run_variant<4, 2, 2, 2, AL, BL, EPI, 16, 2, 4>(pr, reps);      // 256 x 128 tile, 8 waves of 64 x 64
+    run_variant<4, 2, 2, 2, AL, BL, EPI, 32, 2, 4>(pr, reps);
+  } else {
+    run_variant<4, 2, 2, 2, AL, BL, EPI, 16, 2, 4>(pr, reps);
+  }
+  return;
+#endif
 #if MT_DMA_ABLATE
   run_variant<2, 2, 2, 2, AL, BL, EPI, 16, 3, 3>(pr, reps);
   run_variant<2, 2, 2, 2, AL, BL, EPI, 16, 2, 3>(pr, reps);
