@@ -34,6 +34,19 @@ import torch.distributed as dist
 FLOP_PER_CLIP_FWD = 2 * 22097637120          # BASELINE.md §2 (EF 3.076 G MAC + TSF 19.021 G MAC per 8-frame clip)
 FLOP_PER_CLIP_STEP = 3 * FLOP_PER_CLIP_FWD   # backward = 2x forward MACs
 PEAK_FP32_MFMA = 157.3e12                    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
+PEAK_BF16_MFMA = 2500e12                     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+SPLIT_PIPE = ("split-operand fp32 (csrc/gemm_split.hpp): each fp32 operand = 3 exact bf16 pieces, 6 piece products per fp32 product on "
+              "v_mfma_f32_32x32x16_bf16, fp32 accumulators; error vs fp64 equal to the fp32 MFMA pipe's (tests/test_gpu_gemm.py)")
+
+
+def pipe_fields(achieved_flops_s, split_on):
+    """The matrix pipe a GEMM family ran on.  `frac` in the roofline objects stays achieved fp32 FLOP/s over the fp32 dense MFMA
+    peak (the dtype's peak, > 1 is possible on the split pipe); pipe_frac prices the 6 bf16 MFMA flops per fp32 flop against the
+    bf16 dense peak, i.e. how busy the matrix cores actually are."""
+    if not split_on:
+        return {"pipe": "v_mfma_f32_32x32x2_f32"}
+    return {"pipe": SPLIT_PIPE, "pipe_peak": PEAK_BF16_MFMA / 1e12, "pipe_flops_per_flop": 6,
+            "pipe_frac": round(6 * achieved_flops_s / PEAK_BF16_MFMA, 4) if achieved_flops_s else None}
 
 
 def usable_cores():
@@ -322,6 +335,7 @@ def main():
         n_f, t_f, f_f = _probe_summary(p_ff1)
         n_d, t_d, b_d = _probe_summary(p_dw)
         pmc = lambda key: (committed_counters(key) or {}) if headline else {}
+        split_on = lib.gemm_split_enabled()
         out = {
             "metric": "clips/sec (8-frame, 2-identity, 224^2 crops) fwd+bwd" if a.config != 5 else
                       "clips/sec (16-frame, 3-identity, 224^2 crops, Xception extractor) fwd+bwd",
@@ -337,10 +351,14 @@ def main():
                        "global_batch": world * B, "frames": frames, "parallelism": f"dp{world}", "reducer_path": reducer_path,
                        "model_tflops": round(clips_s * flop_step / 1e12, 2),
                        "model_mfma_frac": round(clips_s * flop_step / (world * PEAK_FP32_MFMA), 4),
+                       "matrix_pipe": SPLIT_PIPE + "; convolution GEMMs with operand prologues and K < 512: v_mfma_f32_32x32x2_f32"
+                       if split_on else "v_mfma_f32_32x32x2_f32 (MT_GEMM_SPLIT=0)",
                        "loss": round(float(loss.item()), 5)},
             # the time-dominant kernel family: in-step duration (next to the main stream's data-gradient GEMMs), all launches summed
-            "roofline": {"bound": "mfma", "kernel": "TimeSformer weight-gradient GEMMs: mt::gemm_dma_kernel<..., TN, EPI_ATOMIC> "
+            "roofline": {"bound": "mfma", "kernel": "TimeSformer weight-gradient GEMMs: mt::gemm_" + ("split" if split_on else "dma")
+                                                    + "_kernel<..., TN, EPI_ATOMIC> "
                                                     "(dW = dY^T X over B*393 rows, split-K + fp32 atomics; side stream)",
+                         **pipe_fields(f_w / t_w if t_w else None, split_on),
                          "achieved": round(f_w / t_w / 1e12, 2) if t_w else None, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": round(f_w / t_w / PEAK_FP32_MFMA, 4) if t_w else None,
                          "traffic": pmc("tsf_wgrad").get("bytes_per_launch"), "traffic_unit": "bytes/launch (family mean)",
@@ -349,7 +367,9 @@ def main():
                          "launches_timed": n_w, "launches_per_step": n_w // max(a.steps, 1),
                          "avg_launch_us": round(t_w / max(n_w, 1) * 1e6, 1), "flops_per_launch": f_w / max(n_w, 1),
                          "ms_per_step": round(t_w / max(a.steps, 1) * 1e3, 3)},
-            "roofline_ff1": {"bound": "mfma", "kernel": "mt::gemm_dma_kernel<128x128, NT, EPI_GEGLU> (FF1 512->4096 + GEGLU, M=B*393)",
+            "roofline_ff1": {"bound": "mfma", "kernel": "mt::gemm_" + ("split" if split_on else "dma")
+                                                        + "_kernel<128x128, NT, EPI_GEGLU> (FF1 512->4096 + GEGLU, M=B*393)",
+                             **pipe_fields(f_f / t_f if t_f else None, split_on),
                              "achieved": round(f_f / t_f / 1e12, 2) if t_f else None, "peak": PEAK_FP32_MFMA / 1e12,
                              "unit": "TFLOP/s", "frac": round(f_f / t_f / PEAK_FP32_MFMA, 4) if t_f else None,
                              "traffic": pmc("tsf_ff1").get("bytes_per_launch"), "traffic_unit": "bytes/launch",
@@ -391,6 +411,20 @@ def main():
                 seeds[str(sd)] = round(1e3 * (time.perf_counter() - t1) / n_sd, 3)
             out["seeds"] = {"ms_per_step": seeds, "median_ms": sorted(seeds.values())[1],
                             "median_clips_s": round(B / (sorted(seeds.values())[1] * 1e-3), 2)}
+            if split_on:                     # the same step with every contraction on the fp32 MFMA pipe
+                lib.set_gemm_split(False)
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n_f32 = max(3, a.steps // 2)
+                for _ in range(n_f32):
+                    step()
+                torch.cuda.synchronize()
+                ms_f32 = 1e3 * (time.perf_counter() - t1) / n_f32
+                lib.set_gemm_split(True)
+                out["fp32_mfma_pipe"] = {"ms_per_step": round(ms_f32, 3), "clips_s": round(B / (ms_f32 * 1e-3), 2),
+                                         "note": "mt_gemm_set_split(0): v_mfma_f32_32x32x2_f32 everywhere"}
             if a.config != 5:
                 out["attention_modules"] = attention_modules_leg(dev, B, frames)
         if world == 1 and not a.no_cpu_baseline and a.config != 5:

@@ -6,6 +6,7 @@
 #include "gemm_split.hpp"
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 using namespace mt;
 
@@ -21,9 +22,9 @@ int mode() {
   return g_mode;
 }
 
-enum { S_BIG = 0, S_MID = 1, S_COUNT };      // 128 x 128 (4 waves of 64 x 64), 128 x 64 (4 waves of 64 x 32)
+enum { S_BIG = 0, S_MID = 1, S_SMALL = 2, S_COUNT };      // 128 x 128 (4 waves of 64 x 64), 128 x 64 (64 x 32), 64 x 64 (32 x 32)
 struct Var { int bm, bn; };
-constexpr Var kVar[S_COUNT] = {{128, 128}, {128, 64}};
+constexpr Var kVar[S_COUNT] = {{128, 128}, {128, 64}, {64, 64}};
 
 template <int WM, int WN, int TM, int TN, int AL, int BL, int EPI, int MINW, bool BAL>
 int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
@@ -48,6 +49,7 @@ int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
   if (v == S_BIG) return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, true>(a, grid, s);
   if constexpr (EPI != EPI_GEGLU) {
     if (v == S_MID) return launch_one<2, 2, 2, 1, AL, BL, EPI, 3, true>(a, grid, s);
+    if (v == S_SMALL) return launch_one<2, 2, 1, 1, AL, BL, EPI, 4, true>(a, grid, s);
   }
   return fail(MT_ERR_UNSUPPORTED, "mt_gemm(split): no instance for variant %d", v);
 }
@@ -89,6 +91,13 @@ int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
   if (d->epilogue == MT_EPI_GEGLU_BWD) v = S_MID;
   else if (d->N < 128) v = S_MID;
   if (const char* f = getenv("MT_SPLIT_VARIANT")) v = atoi(f);      // tuning experiments only
+  if (const char* f = getenv("MT_SPLIT_VARIANT_EPI")) {             // "epi:variant[,epi:variant...]"
+    for (const char* q = f; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) {
+      int e = -1, vv = -1;
+      if (sscanf(q, "%d:%d", &e, &vv) == 2 && e == d->epilogue + 10 * d->op) v = vv;
+    }
+  }
+  if (v != S_BIG && d->epilogue == MT_EPI_GEGLU) v = S_BIG;
   if (v < 0 || v >= S_COUNT) return 1;
   const Var var = kVar[v];
   const int m_tiles = (d->M + var.bm - 1) / var.bm, n_tiles = (d->N + var.bn - 1) / var.bn;

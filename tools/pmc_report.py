@@ -104,8 +104,9 @@ if a.json_out:
                                   "write_GB": round(f["wr"] / 1e9, 3)} for k, f in fam.items() if f["us"] > 100}
     else:
         M = 32 * 393
-        tn = family(lambda n: re.match(r"gemm_dma_kernel<\d+, \d+, \d+, \d+, 1, 1, 4,", n) is not None)
-        ff1 = family(lambda n: re.match(r"gemm_dma_kernel<2, 2, 2, 2, 0, 0, 2,", n) is not None)
+        # TN weight gradients / FF1 + GEGLU on whichever main loop ran (gemm_split_kernel by default, gemm_dma_kernel with MT_GEMM_SPLIT=0)
+        tn = family(lambda n: re.match(r"gemm_(dma|split)_kernel<\d+, \d+, \d+, \d+, 1, 1, 4,", n) is not None)
+        ff1 = family(lambda n: re.match(r"gemm_(dma|split)_kernel<2, 2, 2, 2, 0, 0, 2,", n) is not None)
         shapes = [(512, 2048, 9), (4096, 512, 9), (1536, 512, 18), (512, 512, 18)]
         alg = sum(4.0 * (M * (n1 + n2) + n1 * n2) * c for n1, n2, c in shapes) / sum(c for _, _, c in shapes)
         if tn:

@@ -8,6 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("csv")
 ap.add_argument("--start", default="5, 3, 0>")
 ap.add_argument("--steps-from-end", type=int, default=2)
+ap.add_argument("--top", type=int, default=40, help="symbols listed per queue")
 a = ap.parse_args()
 rows = sorted(csv.DictReader(open(a.csv)), key=lambda r: int(r["Start_Timestamp"]))
 
@@ -44,3 +45,13 @@ for r in seg:
 print("in-step kernel time by symbol (us):")
 for k, (n, d) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:28]:
     print(f"  {d / 1e3:7.2f} ms {n:4d}  {k}")
+for q in sorted(qs, key=lambda k: -qs[k]):
+    qf = defaultdict(lambda: [0, 0.0])
+    for r in seg:
+        if r.get("Queue_Id", "?") != q:
+            continue
+        f = qf[short(r["Kernel_Name"])]
+        f[0] += 1; f[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    print(f"queue {q}: {qs[q] / 1e6:.2f} ms of kernel time; by symbol:")
+    for k, (n, d) in sorted(qf.items(), key=lambda kv: -kv[1][1])[:a.top]:
+        print(f"  {d / 1e3:7.2f} ms {n:4d}  {k}")
