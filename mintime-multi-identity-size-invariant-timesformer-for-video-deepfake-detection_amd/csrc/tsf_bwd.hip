@@ -243,45 +243,41 @@ __device__ __forceinline__ float block_reduce(float v, float* red, int wave, int
   return r;
 }
 
+// Lane mapping: 16 lanes per key (lane & 15 = which float4 of the 64-wide head), 16 keys per pass of the block, so every K / V /
+// dK / dV row is one coalesced 256-byte access (one key per lane made each lane walk its own 6 KB-strided row: 105 us per launch).
 __global__ __launch_bounds__(CLS_W * 64) void attn_cls_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                  float* __restrict__ dqkv, const uint8_t* __restrict__ mask,
                                                                  int B, int H, int F, int n, float scale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // p[N], dS[N], CLS_W reduction slots, CLS_W x 64 partial dq
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = tid & 15, grp = tid >> 4;                     // float4 index inside the head, key slot inside a pass
+  constexpr int KPP = CLS_W * 4;                                // keys per pass
   const int bh = blockIdx.x, h = bh % H, b = bh / H;
   const int N = 1 + F * n, inner = H * DH, ld = 3 * inner;
   float* pl_ = lds;
   float* ds_ = lds + N;
   float* red = ds_ + N;
-  float* part = red + CLS_W;
-  const float* base = qkv + (int64_t)b * N * ld + h * DH;
-  float* dbase = dqkv + (int64_t)b * N * ld + h * DH;
-  const float* dob = dout + (int64_t)b * N * inner + h * DH;   // row 0
-  float q[DH], dO[DH];
+  float* part = lds + ((2 * N + CLS_W + 3) & ~3);               // 16-byte aligned (float4 slots)
+  const float* base = qkv + (int64_t)b * N * ld + h * DH + sub * 4;
+  float* dbase = dqkv + (int64_t)b * N * ld + h * DH + sub * 4;
+  float4 q = *reinterpret_cast<const float4*>(base);
+  q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
+  const float4 dO = *reinterpret_cast<const float4*>(dout + (int64_t)b * N * inner + h * DH + sub * 4);   // row 0
+  for (int j = grp; j < N; j += KPP) {
+    const float4 kk = *reinterpret_cast<const float4*>(base + (int64_t)j * ld + inner);
+    const float4 vv = *reinterpret_cast<const float4*>(base + (int64_t)j * ld + 2 * inner);
+    float a = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
+    float dp = fmaf(dO.x, vv.x, fmaf(dO.y, vv.y, fmaf(dO.z, vv.z, dO.w * vv.w)));
 #pragma unroll
-  for (int i = 0; i < DH / 4; ++i) {
-    const float4 v = *reinterpret_cast<const float4*>(base + i * 4);
-    q[4 * i] = v.x * scale; q[4 * i + 1] = v.y * scale; q[4 * i + 2] = v.z * scale; q[4 * i + 3] = v.w * scale;
-    const float4 d = *reinterpret_cast<const float4*>(dob + i * 4);
-    dO[4 * i] = d.x; dO[4 * i + 1] = d.y; dO[4 * i + 2] = d.z; dO[4 * i + 3] = d.w;
-  }
-  float mx = -FLT_MAX;
-  for (int j = tid; j < N; j += CLS_W * 64) {
-    const float* kr = base + (int64_t)j * ld + inner;
-    const float* vr = base + (int64_t)j * ld + 2 * inner;
-    float a = 0.f, dp = 0.f;
-#pragma unroll
-    for (int i = 0; i < DH / 4; ++i) {
-      const float4 kk = *reinterpret_cast<const float4*>(kr + i * 4);
-      const float4 vv = *reinterpret_cast<const float4*>(vr + i * 4);
-      a = fmaf(q[4 * i], kk.x, a); a = fmaf(q[4 * i + 1], kk.y, a); a = fmaf(q[4 * i + 2], kk.z, a); a = fmaf(q[4 * i + 3], kk.w, a);
-      dp = fmaf(dO[4 * i], vv.x, dp); dp = fmaf(dO[4 * i + 1], vv.y, dp);
-      dp = fmaf(dO[4 * i + 2], vv.z, dp); dp = fmaf(dO[4 * i + 3], vv.w, dp);
+    for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o); dp += __shfl_xor(dp, o); }
+    if (sub == 0) {
+      if (j > 0 && mask && !mask[b * F + (j - 1) / n]) a = -FLT_MAX;
+      pl_[j] = a; ds_[j] = dp;
     }
-    if (j > 0 && mask && !mask[b * F + (j - 1) / n]) a = -FLT_MAX;
-    pl_[j] = a; ds_[j] = dp;
-    mx = fmaxf(mx, a);
   }
+  __syncthreads();
+  float mx = -FLT_MAX;
+  for (int j = tid; j < N; j += CLS_W * 64) mx = fmaxf(mx, pl_[j]);
   mx = block_reduce(mx, red, wave, lane, true);
   float sum = 0.f;
   for (int j = tid; j < N; j += CLS_W * 64) { const float e = expf(pl_[j] - mx); pl_[j] = e; sum += e; }
@@ -290,36 +286,32 @@ __global__ __launch_bounds__(CLS_W * 64) void attn_cls_bwd_kernel(const float* _
   float delta = 0.f;
   for (int j = tid; j < N; j += CLS_W * 64) { const float p = pl_[j] * inv; pl_[j] = p; delta += p * ds_[j]; }
   delta = block_reduce(delta, red, wave, lane, false);
-  // per key: dS, write dk_j = dS*q_scaled, dv_j = p*dO
-  for (int j = tid; j < N; j += CLS_W * 64) {
+  __syncthreads();
+  // per key: dS; dk_j = dS * q_scaled, dv_j = p * dO (stores), dq += dS * k_j
+  float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = grp; j < N; j += KPP) {
     const float p = pl_[j];
     const float dS = p * (ds_[j] - delta);
-    ds_[j] = dS;
-    float* dk = dbase + (int64_t)j * ld + inner;
-    float* dv = dbase + (int64_t)j * ld + 2 * inner;
+    const float4 kk = *reinterpret_cast<const float4*>(base + (int64_t)j * ld + inner);
+    *reinterpret_cast<float4*>(dbase + (int64_t)j * ld + inner) = make_float4(dS * q.x, dS * q.y, dS * q.z, dS * q.w);
+    *reinterpret_cast<float4*>(dbase + (int64_t)j * ld + 2 * inner) = make_float4(p * dO.x, p * dO.y, p * dO.z, p * dO.w);
+    dq.x = fmaf(dS, kk.x, dq.x); dq.y = fmaf(dS, kk.y, dq.y); dq.z = fmaf(dS, kk.z, dq.z); dq.w = fmaf(dS, kk.w, dq.w);
+  }
+  // sum over the key slots: the 4 groups of a wavefront, then the wavefronts
 #pragma unroll
-    for (int i = 0; i < DH / 4; ++i) {
-      *reinterpret_cast<float4*>(dk + i * 4) = make_float4(dS * q[4 * i], dS * q[4 * i + 1], dS * q[4 * i + 2], dS * q[4 * i + 3]);
-      *reinterpret_cast<float4*>(dv + i * 4) = make_float4(p * dO[4 * i], p * dO[4 * i + 1], p * dO[4 * i + 2], p * dO[4 * i + 3]);
+  for (int o = 16; o < 64; o <<= 1) {
+    dq.x += __shfl_xor(dq.x, o); dq.y += __shfl_xor(dq.y, o); dq.z += __shfl_xor(dq.z, o); dq.w += __shfl_xor(dq.w, o);
+  }
+  if (lane < 16) *reinterpret_cast<float4*>(part + wave * 64 + sub * 4) = dq;
+  __syncthreads();
+  if (tid < 16) {
+    float4 t = *reinterpret_cast<const float4*>(part + sub * 4);
+#pragma unroll
+    for (int w = 1; w < CLS_W; ++w) {
+      const float4 u = *reinterpret_cast<const float4*>(part + w * 64 + sub * 4);
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
     }
-  }
-  __syncthreads();
-  // dq[d] = scale * sum_j dS_j k_j[d], lane = d, keys strided over the wavefronts
-  const float* kb = base + inner + lane;
-  float a0 = 0.f, a1 = 0.f;
-  int j = wave;
-  for (; j + CLS_W < N; j += 2 * CLS_W) {
-    a0 = fmaf(ds_[j], kb[(int64_t)j * ld], a0);
-    a1 = fmaf(ds_[j + CLS_W], kb[(int64_t)(j + CLS_W) * ld], a1);
-  }
-  if (j < N) a0 = fmaf(ds_[j], kb[(int64_t)j * ld], a0);
-  part[wave * 64 + lane] = a0 + a1;
-  __syncthreads();
-  if (wave == 0) {
-    float t = part[lane];
-#pragma unroll
-    for (int w = 1; w < CLS_W; ++w) t += part[w * 64 + lane];
-    dbase[lane] = scale * t;
+    *reinterpret_cast<float4*>(dbase) = make_float4(scale * t.x, scale * t.y, scale * t.z, scale * t.w);
   }
 }
 
@@ -823,7 +815,7 @@ extern "C" int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, con
   if (n != 49) return fail(MT_ERR_UNSUPPORTED, "mt_attn_bwd: num-patches %d unsupported (49)", n);
   hipStream_t s = (hipStream_t)stream;
   const int N = 1 + F * n;
-  hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(CLS_W * 64), (2 * N + CLS_W + CLS_W * 64) * sizeof(float), s, qkv, dout, dqkv, mask, B, H, F, n, scale);
+  hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(CLS_W * 64), (2 * N + CLS_W + 4 + CLS_W * 64) * sizeof(float), s, qkv, dout, dqkv, mask, B, H, F, n, scale);
   int rc = check_launch("mt_attn_bwd(cls)");
   if (rc) return rc;
   if (mode == 1) {

@@ -384,36 +384,35 @@ __device__ __forceinline__ float block_reduce(float v, float* red, int wave, int
   return r;
 }
 
+// Lane mapping: 16 lanes per key (lane & 15 = which float4 of the 64-wide head), 16 keys per pass: every K / V row is one coalesced
+// 256-byte access.  All reductions have a fixed order (eval stays bit-reproducible).
 __global__ __launch_bounds__(CLS_W * 64) void attn_cls_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  float* __restrict__ att, const uint8_t* __restrict__ mask,
                                                                  int B, int H, int F, int n, float scale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // N probabilities, CLS_W reduction slots, CLS_W x 64 partial outputs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = tid & 15, grp = tid >> 4;
+  constexpr int KPP = CLS_W * 4;
   const int bh = blockIdx.x, h = bh % H, b = bh / H;
   const int N = 1 + F * n, inner = H * DH, ld = 3 * inner;
   float* red = lds + N;
-  float* part = red + CLS_W;
-  const float* base = qkv + (int64_t)b * N * ld + h * DH;
-  float q[DH];
+  float* part = lds + ((N + CLS_W + 3) & ~3);                   // 16-byte aligned (float4 slots)
+  const float* base = qkv + (int64_t)b * N * ld + h * DH + sub * 4;
+  float4 q = *reinterpret_cast<const float4*>(base);
+  q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
+  for (int j = grp; j < N; j += KPP) {
+    const float4 kk = *reinterpret_cast<const float4*>(base + (int64_t)j * ld + inner);
+    float a = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
 #pragma unroll
-  for (int i = 0; i < DH / 4; ++i) {
-    const float4 v = *reinterpret_cast<const float4*>(base + i * 4);
-    q[4 * i] = v.x * scale; q[4 * i + 1] = v.y * scale; q[4 * i + 2] = v.z * scale; q[4 * i + 3] = v.w * scale;
-  }
-  float mx = -FLT_MAX;
-  for (int j = tid; j < N; j += CLS_W * 64) {
-    const float* kr = base + (int64_t)j * ld + inner;
-    float a = 0.f;
-#pragma unroll
-    for (int i = 0; i < DH / 4; ++i) {
-      const float4 kk = *reinterpret_cast<const float4*>(kr + i * 4);
-      a = fmaf(q[4 * i], kk.x, a); a = fmaf(q[4 * i + 1], kk.y, a);
-      a = fmaf(q[4 * i + 2], kk.z, a); a = fmaf(q[4 * i + 3], kk.w, a);
+    for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (sub == 0) {
+      if (j > 0 && mask && !mask[b * F + (j - 1) / n]) a = -FLT_MAX;
+      lds[j] = a;
     }
-    if (j > 0 && mask && !mask[b * F + (j - 1) / n]) a = -FLT_MAX;
-    lds[j] = a;
-    mx = fmaxf(mx, a);
   }
+  __syncthreads();
+  float mx = -FLT_MAX;
+  for (int j = tid; j < N; j += CLS_W * 64) mx = fmaxf(mx, lds[j]);
   mx = block_reduce(mx, red, wave, lane, true);
   float sum = 0.f;
   for (int j = tid; j < N; j += CLS_W * 64) { const float e = expf(lds[j] - mx); lds[j] = e; sum += e; }
@@ -425,22 +424,27 @@ __global__ __launch_bounds__(CLS_W * 64) void attn_cls_fwd_kernel(const float* _
     if (att) att[(int64_t)bh * N + j] = pj;
   }
   __syncthreads();
-  // out[d] = sum_j p_j v_j[d], lane = d, keys strided over the wavefronts
-  const float* vb = base + 2 * inner + lane;
-  float o0 = 0.f, o1 = 0.f;
-  int j = wave;
-  for (; j + CLS_W < N; j += 2 * CLS_W) {
-    o0 = fmaf(lds[j], vb[(int64_t)j * ld], o0);
-    o1 = fmaf(lds[j + CLS_W], vb[(int64_t)(j + CLS_W) * ld], o1);
+  // out = sum_j p_j v_j
+  float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = grp; j < N; j += KPP) {
+    const float pj = lds[j];
+    const float4 vv = *reinterpret_cast<const float4*>(base + (int64_t)j * ld + 2 * inner);
+    o4.x = fmaf(pj, vv.x, o4.x); o4.y = fmaf(pj, vv.y, o4.y); o4.z = fmaf(pj, vv.z, o4.z); o4.w = fmaf(pj, vv.w, o4.w);
   }
-  if (j < N) o0 = fmaf(lds[j], vb[(int64_t)j * ld], o0);
-  part[wave * 64 + lane] = o0 + o1;
-  __syncthreads();
-  if (wave == 0) {
-    float o = part[lane];
 #pragma unroll
-    for (int w = 1; w < CLS_W; ++w) o += part[w * 64 + lane];
-    out[(int64_t)b * N * inner + h * DH + lane] = o;
+  for (int o = 16; o < 64; o <<= 1) {
+    o4.x += __shfl_xor(o4.x, o); o4.y += __shfl_xor(o4.y, o); o4.z += __shfl_xor(o4.z, o); o4.w += __shfl_xor(o4.w, o);
+  }
+  if (lane < 16) *reinterpret_cast<float4*>(part + wave * 64 + sub * 4) = o4;
+  __syncthreads();
+  if (tid < 16) {
+    float4 t = *reinterpret_cast<const float4*>(part + sub * 4);
+#pragma unroll
+    for (int w = 1; w < CLS_W; ++w) {
+      const float4 u = *reinterpret_cast<const float4*>(part + w * 64 + sub * 4);
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)b * N * inner + h * DH + sub * 4) = t;
   }
 }
 
@@ -515,7 +519,7 @@ extern "C" int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const u
   if (n != 49) return fail(MT_ERR_UNSUPPORTED, "mt_attn_fwd: num-patches %d unsupported (49)", n);
   hipStream_t s = (hipStream_t)stream;
   const int N = 1 + F * n;
-  hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(CLS_W * 64), (N + CLS_W + CLS_W * 64) * sizeof(float), s, qkv, out, cls_att, mask, B, H, F, n, scale);
+  hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(CLS_W * 64), (N + CLS_W + 4 + CLS_W * 64) * sizeof(float), s, qkv, out, cls_att, mask, B, H, F, n, scale);
   int rc = check_launch("mt_attn_fwd(cls)");
   if (rc) return rc;
   if (mode == 1) {
