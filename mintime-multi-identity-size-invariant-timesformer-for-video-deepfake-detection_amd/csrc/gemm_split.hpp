@@ -31,7 +31,8 @@
 #include "gemm_dma.hpp"
 #include <type_traits>
 
-#ifndef MT_SPLIT_ABLATE        // tuning lab only: 1 no global loads, 2 no split + LDS writes, 4 no barrier, 8 no fragment reads, 16 no epilogue
+#ifndef MT_SPLIT_ABLATE        // tuning lab only: 1 no global loads, 2 no split + LDS writes, 4 no barrier, 8 no fragment reads, 16 no epilogue,
+                               // 32 B operand neither loaded nor split after the first tile (upper bound of pre-split weight planes)
 #define MT_SPLIT_ABLATE 0
 #endif
 
@@ -147,6 +148,7 @@ void gemm_split_kernel(const GemmArgs p) {
         }
       }
     }
+    if ((MT_SPLIT_ABLATE & 32) && kt > 0) return;
 #pragma unroll
     for (int j = 0; j < BG; ++j) {
       if (!B_ALL && !b_on[j]) continue;
@@ -166,6 +168,7 @@ void gemm_split_kernel(const GemmArgs p) {
       }
     }
   };
+  bool first_store = true;
   auto sstore = [&](int stage, const float (&ga)[AG][8], const float (&gb)[BG][8], bool negate_a0 = false) {
     if (MT_SPLIT_ABLATE & 2) {
       float z = 0.f;
@@ -194,6 +197,7 @@ void gemm_split_kernel(const GemmArgs p) {
       *reinterpret_cast<bf16x8_t*>(st + A_PLANE + a_dst[j]) = x1;
       if constexpr (X6) *reinterpret_cast<bf16x8_t*>(st + 2 * A_PLANE + a_dst[j]) = x2;
     }
+    if ((MT_SPLIT_ABLATE & 32) && !first_store) return;
 #pragma unroll
     for (int j = 0; j < BG; ++j) {
       if (!B_ALL && !b_on[j]) continue;
@@ -299,6 +303,7 @@ void gemm_split_kernel(const GemmArgs p) {
     float ga0[AG][8], gb0[BG][8], ga1[AG][8], gb1[BG][8];
     const int last = nk - 1;
     gload(0, ga0, gb0); sstore(0, ga0, gb0);
+    if (MT_SPLIT_ABLATE & 32) { sstore(1, ga0, gb0); first_store = false; }
     gload(min(1, last), ga0, gb0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {

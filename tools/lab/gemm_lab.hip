@@ -215,6 +215,10 @@ static void free_problem(Problem& pr) { hipFree(pr.A); hipFree(pr.B); hipFree(pr
 #define KM LAYOUT_KMAJOR
 
 template <int AL, int BL, int EPI> static void sweep(Problem& pr, int reps) {
+#ifdef MT_LAB_SPLIT_ONE
+  run_split<2, 2, 2, 2, AL, BL, EPI, 2, true, 2, true>(pr, reps);
+  return;
+#endif
 #ifdef MT_LAB_SPLIT_BAL
   run_split<2, 2, 2, 2, AL, BL, EPI, 2, true, 2, false>(pr, reps);
   run_split<2, 2, 2, 2, AL, BL, EPI, 2, true, 2, true>(pr, reps);
