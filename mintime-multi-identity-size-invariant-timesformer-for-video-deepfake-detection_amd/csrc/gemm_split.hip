@@ -26,17 +26,19 @@ enum { S_BIG = 0, S_MID = 1, S_SMALL = 2, S_COUNT };      // 128 x 128 (4 waves 
 struct Var { int bm, bn; };
 constexpr Var kVar[S_COUNT] = {{128, 128}, {128, 64}, {64, 64}};
 
-template <int WM, int WN, int TM, int TN, int AL, int BL, int EPI, int MINW, bool BAL>
+template <int WM, int WN, int TM, int TN, int AL, int BL, int EPI, int MINW, bool BAL, int PRO = PRO_NONE>
 int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
-  auto k = gemm_split_kernel<WM, WN, TM, TN, AL, BL, EPI, MINW, true, 2, BAL>;
+  auto k = gemm_split_kernel<WM, WN, TM, TN, AL, BL, EPI, MINW, true, 2, BAL, PRO>;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr size_t lds = (size_t)2 * 3 * (BM + BN) * 32;
+  size_t lds = (size_t)2 * 3 * (BM + BN) * 32;
+  if (PRO == PRO_BN_SWISH_GATE) lds += (size_t)(2 + (BM - 1) / a.hw + 2) * a.K * 4;      // scale, shift, gate rows of the images a row tile touches
+  if (lds > 160 * 1024) return 1;      // not this way: the caller falls back to the fp32 kernels
   if (lds > 48 * 1024) {
-    static bool raised = false;        // idempotent; a benign race at worst repeats the call
-    if (!raised) {
+    static size_t raised = 0;          // idempotent; a benign race at worst repeats the call
+    if (lds > raised) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_gemm(split): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-      raised = true;
+      raised = lds;
     }
   }
   hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, s, a);
@@ -78,13 +80,41 @@ int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
     if (const char* hi = getenv("MT_SPLIT_LAST")) if (idx > atoi(hi)) return 1;
     if (getenv("MT_SPLIT_TRACE")) fprintf(stderr, "[split] call %d: op %d M %d N %d K %d\n", idx, d->op, d->M, d->N, d->K);
   }
-  if (d->prologue != MT_PRO_NONE || d->b_prologue != MT_BPRO_NONE) return 1;
+  if (d->b_prologue != MT_BPRO_NONE) return 1;
   if (d->K % 16 || d->M < 128 || d->N < 64) return 1;
+  if (d->prologue == MT_PRO_BN_SWISH_GATE) {
+    // MBConv project convolution (forward): the operand transform rides in the staging registers (gemm_split.hpp PRO)
+    static const int pro_on = getenv("MT_SPLIT_PRO") ? atoi(getenv("MT_SPLIT_PRO")) : 1;
+    if (!pro_on || d->op != MT_OP_NT || d->M < 4096 || d->K < 256) return 1;
+    if (d->epilogue != MT_EPI_STATS && d->epilogue != MT_EPI_STORE) return 1;
+    // tile width by padding waste: 128 columns unless 64-wide tiles waste fewer padded columns
+    const int pad128 = (d->N + 127) / 128 * 128, pad64 = (d->N + 63) / 64 * 64;
+    const int v = pad64 < pad128 ? S_MID : S_BIG;
+    const Var var = kVar[v];
+    const int m_tiles = (d->M + var.bm - 1) / var.bm, n_tiles = (d->N + var.bn - 1) / var.bn;
+    dim3 grid(m_tiles * n_tiles, 1, 1);
+    a.group_n = 0; a.k_chunk = 0; a.trace = nullptr;
+    if (m_tiles >= 32 && n_tiles >= 2 && !getenv("MT_NO_L2_BLOCKING")) {
+      const int64_t panel = (int64_t)var.bn * d->K * 4;
+      int gn = (int)((2 << 20) / (panel > 0 ? panel : 1));
+      if (gn < 1) gn = 1;
+      if (gn > n_tiles) gn = n_tiles;
+      a.group_n = gn;
+      grid.x = 8 * ((m_tiles + 7) / 8) * n_tiles;
+    }
+    constexpr int KC = LAYOUT_KCONTIG;
+    if (d->epilogue == MT_EPI_STATS)
+      return v == S_BIG ? launch_one<2, 2, 2, 2, KC, KC, EPI_STATS, 2, true, PRO_BN_SWISH_GATE>(a, grid, s)
+                        : launch_one<2, 2, 2, 1, KC, KC, EPI_STATS, 3, true, PRO_BN_SWISH_GATE>(a, grid, s);
+    return v == S_BIG ? launch_one<2, 2, 2, 2, KC, KC, EPI_STORE, 2, true, PRO_BN_SWISH_GATE>(a, grid, s)
+                      : launch_one<2, 2, 2, 1, KC, KC, EPI_STORE, 3, true, PRO_BN_SWISH_GATE>(a, grid, s);
+  }
+  if (d->prologue != MT_PRO_NONE) return 1;
   // short contractions stay on the fp32 pipe: the matrix time they could save is small next to their epilogue, and the bf16 pipe's
   // residual rounding bias (gemm_split.hpp) is then kept out of the extractors' long chains of small-K convolutions
   static const int min_k = getenv("MT_SPLIT_MIN_K") ? atoi(getenv("MT_SPLIT_MIN_K")) : 512;
   if (d->K < min_k) return 1;
-  if (d->epilogue == MT_EPI_STATS) return 1;                        // fp64 column statistics: register budget of the 64 x 64 epilogue
+  if (d->epilogue == MT_EPI_STATS && d->M < 4096) return 1;
   if (d->epilogue == MT_EPI_GEGLU && (d->n_half & 63)) return 1;
   if ((int64_t)d->M * d->N < (1 << 18)) return 1;                   // a handful of tiles: the fp32 kernels' small tiles fill the chip better
   int v = S_BIG;
@@ -135,6 +165,7 @@ int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
   SPLIT_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_BIAS_RES)
   SPLIT_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_GEGLU)
   SPLIT_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_ATOMIC)
+  SPLIT_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_STATS)
   SPLIT_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_STORE)
   SPLIT_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_ACCUM)
   SPLIT_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_GEGLU_BWD)

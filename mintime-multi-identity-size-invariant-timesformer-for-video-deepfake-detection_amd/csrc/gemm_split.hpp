@@ -38,10 +38,15 @@
 
 namespace mt {
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int EPI, int MINW, bool X6 = true, int PIPE = 2, bool BAL = false>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int EPI, int MINW, bool X6 = true, int PIPE = 2, bool BAL = false,
+          int PRO = PRO_NONE>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW)
 void gemm_split_kernel(const GemmArgs p) {
   static_assert(!BAL || PIPE == 2, "the balanced accumulators need the stage = tile parity of the two-register-set loop");
+  // PRO_BN_SWISH_GATE (k-contiguous A, two-register-set loop): a = swish(z*scale[k]+shift[k]) * gate[(m/hw)*K+k], applied to the
+  // staged registers right before the split -- VALU work that rides in the MFMA shadow like the split itself.  The per-k vectors
+  // and the gate rows of the images this row tile touches are cached in LDS behind the two plane stages.
+  static_assert(PRO == PRO_NONE || (PRO == PRO_BN_SWISH_GATE && AL == LAYOUT_KCONTIG && PIPE == 2), "unsupported prologue");
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int NT = NW * 64;
   constexpr int BM = WAVES_M * TM * 32;
@@ -118,6 +123,22 @@ void gemm_split_kernel(const GemmArgs p) {
     b_dst[j] = row * 32 + ((kh ^ ((row >> 3) & 1)) << 4);
   }
 
+  float* pv = reinterpret_cast<float*>(smem_split + 2 * STAGE);      // PRO: [scale K | shift K | gate rows of the tile's images]
+  int g_off[AG];
+  if constexpr (PRO == PRO_BN_SWISH_GATE) {
+    const int K = p.K;
+    const int img_lo = m0 / p.hw;
+    const int img_hi = min(m0 + BM - 1, p.M - 1) / p.hw;
+    for (int i = tid; i < K; i += NT) { pv[i] = p.scale[i]; pv[K + i] = p.shift[i]; }
+    for (int i = tid; i < (img_hi - img_lo + 1) * K; i += NT) pv[2 * K + i] = p.gate[(int64_t)img_lo * K + i];
+#pragma unroll
+    for (int j = 0; j < AG; ++j) {
+      const int row = (tid + j * NT) >> 1;
+      g_off[j] = (2 + min(m0 + row, p.M - 1) / p.hw - img_lo) * K;
+    }
+    __syncthreads();
+  }
+
   auto gload = [&](int kt, float (&ga)[AG][8], float (&gb)[BG][8]) {
     if (MT_SPLIT_ABLATE & 1) {
 #pragma unroll
@@ -169,13 +190,13 @@ void gemm_split_kernel(const GemmArgs p) {
     }
   };
   bool first_store = true;
-  auto sstore = [&](int stage, const float (&ga)[AG][8], const float (&gb)[BG][8], bool negate_a0 = false) {
+  auto sstore = [&](int stage, const float (&ga_in)[AG][8], const float (&gb)[BG][8], bool negate_a0 = false, int ktile = 0) {
     if (MT_SPLIT_ABLATE & 2) {
       float z = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
 #pragma unroll
-        for (int j = 0; j < AG; ++j) z += ga[j][e];
+        for (int j = 0; j < AG; ++j) z += ga_in[j][e];
 #pragma unroll
         for (int j = 0; j < BG; ++j) z += gb[j][e];
       }
@@ -186,8 +207,19 @@ void gemm_split_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < AG; ++j) {
       if (!A_ALL && !a_on[j]) continue;
+      float ga[1][8];                                  // (indexed [0] below; keeps the non-prologue path a plain copy)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ga[0][e] = ga_in[j][e];
+      if constexpr (PRO == PRO_BN_SWISH_GATE) {
+        const int k = k_begin + ktile * BK + a_kh[j] * 8;
+        const float* sc = pv + k;
+        const float* sh = pv + p.K + k;
+        const float* gt = pv + g_off[j] + k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ga[0][e] = swishf_(fmaf(ga[0][e], sc[e], sh[e])) * gt[e];
+      }
       bf16x8_t x0, x1, x2;
-      split_bf16<X6>(reinterpret_cast<const float(&)[4]>(ga[j][0]), reinterpret_cast<const float(&)[4]>(ga[j][4]), x0, x1, x2);
+      split_bf16<X6>(reinterpret_cast<const float(&)[4]>(ga[0][0]), reinterpret_cast<const float(&)[4]>(ga[0][4]), x0, x1, x2);
       if (negate_a0) {                                // BAL: the odd tiles' leading A piece goes in negated (see the header comment)
         uint4 u = *reinterpret_cast<uint4*>(&x0);
         u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
@@ -271,7 +303,7 @@ void gemm_split_kernel(const GemmArgs p) {
   // behind every MFMA (an MFMA holds the matrix pipe for 32 cycles; the wave's next 4-5 VALU issues are free in that shadow)
   auto interleave = [&]() {
     constexpr int N_MFMA = (X6 ? 6 : 3) * TM * TN;
-    constexpr int N_VALU = (AG + BG) * (X6 ? 36 : 22);
+    constexpr int N_VALU = (AG + BG) * (X6 ? 36 : 22) + (PRO == PRO_BN_SWISH_GATE ? AG * 8 * 14 : 0);
     constexpr int VALU_PER = (N_VALU + N_MFMA - 1) / N_MFMA;
     constexpr int N_VMEM = AG * (AL == LAYOUT_KCONTIG ? 2 : 8) + BG * (BL == LAYOUT_KCONTIG ? 2 : 8);
     (void)N_VMEM;   // pinning the VMEM group first was tried: the compiler then drains the previous step's loads at the top (722 vs 669 us at 4096^3)
@@ -302,20 +334,20 @@ void gemm_split_kernel(const GemmArgs p) {
     // a stage nobody reads.
     float ga0[AG][8], gb0[BG][8], ga1[AG][8], gb1[BG][8];
     const int last = nk - 1;
-    gload(0, ga0, gb0); sstore(0, ga0, gb0);
+    gload(0, ga0, gb0); sstore(0, ga0, gb0, false, 0);
     if (MT_SPLIT_ABLATE & 32) { sstore(1, ga0, gb0); first_store = false; }
     gload(min(1, last), ga0, gb0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
       gload(min(kt + 2, last), ga1, gb1);
       compute(0, kt, std::false_type{});
-      sstore(1, ga0, gb0, BAL);
+      sstore(1, ga0, gb0, BAL, min(kt + 1, last));
       interleave();
       MT_SPLIT_SYNC();
       if (kt + 1 >= nk) break;
       gload(min(kt + 3, last), ga0, gb0);
       compute(1, kt + 1, std::true_type{});
-      sstore(0, ga1, gb1);
+      sstore(0, ga1, gb1, false, min(kt + 2, last));
       interleave();
       MT_SPLIT_SYNC();
     }

@@ -469,3 +469,45 @@ def test_split_pipe_handles_fp32_only_values():
     assert L.gemm_split_enabled() in (True, False)
     assert torch.equal(Cf, ref)
     assert torch.equal(Cs, ref)
+
+
+@pytest.mark.parametrize("epi", ["stats", "store"])
+@pytest.mark.parametrize("M,hw,K,N", [(12544, 49, 1152, 192), (12544, 49, 1152, 320), (4096 + 196 * 3 + 5, 196, 480, 80),
+                                      (50176, 196, 672, 112), (4100, 49, 256, 64)])
+def test_full_size_gated_project_conv_both_pipes(M, hw, K, N, epi):
+    """MBConv project convolution at the benchmarked sizes (7x7 and 14x14 stages, ragged last row tile, an image boundary inside
+    every row tile): BN + swish + squeeze-excite gate folded into the A operand, BatchNorm statistics in the epilogue.  On the
+    split pipe this is gemm_split.hpp's PRO_BN_SWISH_GATE (transform in the staging registers), on the fp32 pipe the
+    register-staged kernel; the autouse fixture runs both."""
+    n_img = (M + hw - 1) // hw
+    Z, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.2)
+    sc, sh, gate = _rand(K, seed=3).abs() + 0.5, _rand(K, seed=4, scale=0.2), torch.sigmoid(_rand(n_img, K, seed=5))
+    slots = 8
+    stats = torch.zeros(slots, 2, N, dtype=torch.float64, device="cuda")
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    kw = dict(epilogue=L.EPI_STATS, stats=stats, stats_slots=slots) if epi == "stats" else {}
+    L.gemm(L.OP_NT, Z.cuda(), W.cuda(), Cd, M, N, K, K, K, N, prologue=L.PRO_BN_SWISH_GATE, scale=sc.cuda(), shift=sh.cuda(),
+           gate=gate.cuda(), hw=hw, **kw)
+    a = Z.double() * sc.double() + sh.double()
+    a = a * torch.sigmoid(a) * gate.double().repeat_interleave(hw, 0)[:M]
+    ref = a @ W.double().T
+    assert_close(Cd, ref, 5e-5, "gated project conv")
+    if epi == "stats":
+        st = stats.sum(0).cpu()
+        assert_close(st[0], ref.sum(0), 1e-4, "column sums")
+        assert_close(st[1], (ref * ref).sum(0), 1e-4, "column sums of squares")
+
+
+@pytest.mark.parametrize("M,N,K", [(12544, 1152, 192), (50176, 480, 80), (12544, 1280, 320)])
+def test_full_size_expand_conv_stats_both_pipes(M, N, K):
+    """MBConv expand / head convolution shapes: plain operands, BatchNorm statistics in the epilogue."""
+    A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.2)
+    slots = 8
+    stats = torch.zeros(slots, 2, N, dtype=torch.float64, device="cuda")
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), Cd, M, N, K, K, K, N, epilogue=L.EPI_STATS, stats=stats, stats_slots=slots)
+    ref = A.double() @ W.double().T
+    assert_close(Cd, ref, TOL, "expand conv")
+    st = stats.sum(0).cpu()
+    assert_close(st[0], ref.sum(0), 1e-4, "column sums")
+    assert_close(st[1], (ref * ref).sum(0), 1e-4, "column sums of squares")
