@@ -47,7 +47,18 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
 
 template <int AL, int BL, int EPI>
 int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
-  // balanced accumulators always (gemm_split.hpp: BAL); the single-accumulator form lives on in tools/lab only
+  // Balanced accumulators (gemm_split.hpp: BAL) wherever a result feeds further contractions (activations, data gradients): the
+  // bf16 pipe's rounding bias is only a problem when it adds up coherently through depth.  Weight gradients (TN) are leaves --
+  // their error goes no further than lr x bias into the next step's weights -- and take the single-accumulator loop
+  // (max / rms error equal to the fp32 pipe's, 6-8 % faster, 146 instead of 206 VGPRs).  MT_SPLIT_WGRAD_BAL=1 balances them too.
+  if constexpr (AL == LAYOUT_KMAJOR && BL == LAYOUT_KMAJOR) {
+    static const bool wbal = getenv("MT_SPLIT_WGRAD_BAL") && atoi(getenv("MT_SPLIT_WGRAD_BAL")) != 0;
+    if (!wbal) {
+      if (v == S_BIG) return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, false>(a, grid, s);
+      if (v == S_MID) return launch_one<2, 2, 2, 1, AL, BL, EPI, 3, false>(a, grid, s);
+      if (v == S_SMALL) return launch_one<2, 2, 1, 1, AL, BL, EPI, 4, false>(a, grid, s);
+    }
+  }
   if (v == S_BIG) return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, true>(a, grid, s);
   if constexpr (EPI != EPI_GEGLU) {
     if (v == S_MID) return launch_one<2, 2, 2, 1, AL, BL, EPI, 3, true>(a, grid, s);
