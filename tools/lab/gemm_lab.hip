@@ -320,6 +320,10 @@ int main(int argc, char** argv) {
       {"NT ff2 splitk5 12576x512x2048", MT_OP_NT, M, 512, 2048, EPI_ATOMIC, 5},
       {"NN geglu_bwd 12576x2048x512", MT_OP_NN, M, 2048, 512, EPI_GEGLU_BWD, 1},
       {"NN ff1 dgrad sk4 12576x512x4096", MT_OP_NN, M, 512, 4096, EPI_ATOMIC, 4},
+      {"NN ff1 dgrad sk1 12576x512x4096 store", MT_OP_NN, M, 512, 4096, EPI_STORE, 1},
+      {"NT ff1 dgrad-as-NT 12576x512x4096 store", MT_OP_NT, M, 512, 4096, EPI_STORE, 1},
+      {"NN qkv dgrad sk1 12576x512x1536 store", MT_OP_NN, M, 512, 1536, EPI_STORE, 1},
+      {"NT qkv dgrad-as-NT 12576x512x1536 store", MT_OP_NT, M, 512, 1536, EPI_STORE, 1},
       {"NN qkv dgrad sk3 12576x512x1536", MT_OP_NN, M, 512, 1536, EPI_ATOMIC, 3},
       {"NN outproj dgrad 12576x512x512", MT_OP_NN, M, 512, 512, EPI_STORE, 1},
       {"TN ff2 wgrad 512x2048x12576", MT_OP_TN, 512, 2048, M, EPI_ATOMIC, 0},
