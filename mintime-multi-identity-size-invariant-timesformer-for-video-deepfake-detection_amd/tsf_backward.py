@@ -44,6 +44,9 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         return idx
 
     side = L.SideStream(dev)
+    wT = saved.get("wT")                              # transposed weights (tsf_engine.tsf_forward): data gradients in NT form
+    if wT is not None:
+        side.wait(saved["wT_ready"])
 
     def colsum(A, lda, rows, cols, out, amap=(0, 0, 0)):
         L.check(lib.mt_colsum(L.ptr(A), lda, L.RowMap(*amap), rows, cols, L.ptr(out), L.stream_ptr()), "mt_colsum")
@@ -51,7 +54,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
     # share of a long-K data gradient that is handed to the side stream (see dgrad_skinny); tuned in-step
     side_share = float(os.environ.get("MT_DGRAD_SIDE_SHARE", "0.25"))
 
-    def dgrad_skinny(dY, Wm, out, K_):
+    def dgrad_skinny(dY, Wm, out, K_, WmT=None):
         """out[M,D] = dY[M,K_] . Wm[K_,D]: only 396 output tiles -> K-slices + fp32 atomics onto a zeroed output when K is long.
         The step is bound by the main stream's kernel time while the weight-gradient stream has slack (in-step trace: main
         97 % busy, side 80-90 %), and a split-K sum does not care which stream a slice runs on: the last `side_share` of the
@@ -71,7 +74,10 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
                                                 split_k=max(1, round(splits * k_side / K_))), reads=(dY, Wm, out))
             L.gemm(L.OP_NN, dY, Wm, out, M, D, k_main, K_, D, D, epilogue=L.EPI_ATOMIC, split_k=max(1, round(splits * k_main / K_)))
             return ev
-        L.gemm(L.OP_NN, dY, Wm, out, M, D, K_, K_, D, D)
+        if WmT is not None:
+            L.gemm(L.OP_NT, dY, WmT, out, M, D, K_, K_, K_, D)          # WmT = Wm^T [D, K_]
+        else:
+            L.gemm(L.OP_NN, dY, Wm, out, M, D, K_, K_, D, D)
         return None
 
     def wgrad(A, Bm, out, M_, N_, K_, lda, ldb, ldc, bias_out=None, **kw):
@@ -107,10 +113,14 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         side.wait()                                   # du / dx2 readers of the previous sub-block are done
         e_dx = wgrad(dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D,
                      bias_out=grads[i0 + 5] if li == model.depth - 1 else None)
-        L.gemm(L.OP_NN, dx2, w2, du, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D, n_half=4 * D,
-               col_sum=grads[i0 + 3])                 # net.0.bias gradient = column sums of du, taken in the epilogue
+        if wT is not None:
+            L.gemm(L.OP_NT, dx2, wT[(li, 14)], du, M, 4 * D, D, D, D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D,
+                   n_half=4 * D, col_sum=grads[i0 + 3])
+        else:
+            L.gemm(L.OP_NN, dx2, w2, du, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D, n_half=4 * D,
+                   col_sum=grads[i0 + 3])             # net.0.bias gradient = column sums of du, taken in the epilogue
         wgrad(du, r["xn"], grads[i0 + 2], 8 * D, D, M, 8 * D, D, D)
-        e_dg = dgrad_skinny(du, w1, dxn, 8 * D)
+        e_dg = dgrad_skinny(du, w1, dxn, 8 * D, wT[(li, 12)] if wT is not None else None)
         side.wait(e_dx)                               # LayerNorm backward updates dx2 in place
         if e_dg is not None:
             side.wait(e_dg)                           # ... and reads dxn, part of which the side stream summed
@@ -124,11 +134,14 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             r = rec[mode]
             side.wait()                               # dqkv / dx2 readers of the previous sub-block are done
             e_dx = wgrad(dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner)
-            L.gemm(L.OP_NN, dx2, w_o, do, M, inner, D, D, inner, inner)
+            if wT is not None:
+                L.gemm(L.OP_NT, dx2, wT[(li, 8 if mode == 1 else 3)], do, M, inner, D, D, D, inner)
+            else:
+                L.gemm(L.OP_NN, dx2, w_o, do, M, inner, D, D, inner, inner)
             L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
                                     scale, st), "mt_attn_bwd")
             wgrad(dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
-            e_dg = dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner)
+            e_dg = dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner, wT[(li, 7 if mode == 1 else 2)] if wT is not None else None)
             side.wait(e_dx)
             if e_dg is not None:
                 side.wait(e_dg)

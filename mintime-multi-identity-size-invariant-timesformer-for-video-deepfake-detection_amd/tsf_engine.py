@@ -117,6 +117,28 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
     _publish_index_flag(aux.err)
 
     saved = {"layers": []} if save else None
+    if save and M >= 4096 and L.gemm_split_enabled() and os.environ.get("MT_DGRAD_NT", "1") != "0" \
+            and not torch.cuda.is_current_stream_capturing():
+        # Data gradients contract over a weight's ROW index: with the weight as stored that is a k-major B operand (eight strided
+        # dword loads per thread in the split loop); over the transposed weight it is the same k-contiguous NT form as the forward
+        # (two float4 loads): -10 % per launch (profiles/r02_gemm_split_lab.txt).  The 36 transposes (48 M floats) run on the
+        # weight-gradient stream, which is idle through the forward.
+        side = L.SideStream(dev)
+        wts = list(params[5:5 + 16 * model.depth])
+        holder = {}
+        main_stream = torch.cuda.current_stream(dev)
+
+        def transpose_all():
+            for li in range(model.depth):
+                base = 16 * li
+                for off in (2, 3, 7, 8, 12, 14):       # w_qkv, w_o (time); w_qkv, w_o (space); net.0.weight, net.3.weight
+                    w = wts[base + off]
+                    t = w.detach().t().contiguous()
+                    t.record_stream(main_stream)      # allocated on the side stream, read by the main stream's data gradients
+                    holder[(li, off)] = t
+        ev = side.launch(transpose_all, reads=wts)
+        if ev is not None:
+            saved["wT"], saved["wT_ready"] = holder, ev
     want_att = model.require_attention
     s_att = t_att = None
     xn = _new(dev, M, D)
