@@ -66,6 +66,10 @@ typedef struct {
   int conv_src_u8;                  /* im2col source image is uint8 (raw crops, 3 channels) instead of fp32      */
   float* col_sum;                   /* GEGLU_BWD: optional [2*n_half] column sums of the stored gradient (= d bias of the
                                        Linear that produced the pre-activations), atomically accumulated; caller zero-fills */
+  const void* b_planes;             /* NT only, optional: B pre-split by mt_split_planes (three bf16 planes, each [N][K] with B's
+                                       ldb).  The split-operand loop then streams B by DMA instead of splitting it per tile;
+                                       every other path ignores the field and reads B.  B must still be valid.             */
+  int64_t b_plane_stride;           /* elements between planes */
 } mt_gemm_desc;
 
 int mt_gemm(const mt_gemm_desc* d, void* stream);
@@ -78,6 +82,11 @@ int mt_gemm(const mt_gemm_desc* d, void* stream);
  * Process-wide; returns the previous setting.  Inputs, outputs and accumulators are fp32 either way. */
 int mt_gemm_set_split(int on);
 int mt_gemm_get_split(void);
+
+/* planes[p][i], p = 0..2: the exact three-piece bf16 split of src[i] (x = x0 + x1 + x2, round-to-nearest at each level) that the
+ * split-operand loop computes on the fly -- done once for operands that many launches share (weights: once per optimizer step).
+ * planes: 3 * n bf16 values, 16-byte aligned; plane stride n. */
+int mt_split_planes(const float* src, void* planes, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Size-Invariant TimeSformer forward, non-GEMM pieces

@@ -86,6 +86,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   a.n_half = d->n_half; a.k_chunk = 0;
   a.conv = {d->conv_H, d->conv_W, d->conv_C, d->conv_Ho, d->conv_Wo, d->conv_k, d->conv_stride, d->conv_pad, d->conv_act, d->conv_src_u8};
   a.col_sum = d->col_sum;
+  a.b_planes = d->b_planes; a.b_pstride = d->b_plane_stride;
   a.A2 = d->A2; a.b_scale = d->b_scale; a.b_shift = d->b_shift; a.b_gate = d->b_gate; a.b_hw = d->b_hw > 0 ? d->b_hw : 1;
 
   // K-contiguous operands need K % 4 == 0 (float4 along K); k-major operands need M resp. N % 4 == 0

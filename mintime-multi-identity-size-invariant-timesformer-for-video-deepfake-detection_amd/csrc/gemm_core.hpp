@@ -143,6 +143,7 @@ struct GemmArgs {
   int group_n;                          // > 0: L2-blocked tile order with this many tile columns per group
   long long* trace;                     // tuning aid (mt_debug_gemm_trace): per block {t_start, t_prologue, t_loop, t_end, hw_id}
   float* col_sum;                       // GEGLU_BWD: optional column sums of the stored values (bias gradient), fp32 atomics
+  const void* b_planes; int64_t b_pstride;   // split loop: B as three pre-split bf16 planes [N][K] (plane stride in elements), or null
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

@@ -26,11 +26,11 @@ enum { S_BIG = 0, S_MID = 1, S_SMALL = 2, S_COUNT };      // 128 x 128 (4 waves 
 struct Var { int bm, bn; };
 constexpr Var kVar[S_COUNT] = {{128, 128}, {128, 64}, {64, 64}};
 
-template <int WM, int WN, int TM, int TN, int AL, int BL, int EPI, int MINW, bool BAL, int PRO = PRO_NONE>
+template <int WM, int WN, int TM, int TN, int AL, int BL, int EPI, int MINW, bool BAL, int PRO = PRO_NONE, bool BPL = false>
 int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
-  auto k = gemm_split_kernel<WM, WN, TM, TN, AL, BL, EPI, MINW, true, 2, BAL, PRO>;
+  auto k = gemm_split_kernel<WM, WN, TM, TN, AL, BL, EPI, MINW, true, 2, BAL, PRO, BPL>;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  size_t lds = (size_t)2 * 3 * (BM + BN) * 32;
+  size_t lds = BPL ? (size_t)(6 * BM + 9 * BN) * 32 : (size_t)2 * 3 * (BM + BN) * 32;
   if (PRO == PRO_BN_SWISH_GATE) lds += (size_t)(2 + (BM - 1) / a.hw + 2) * a.K * 4;      // scale, shift, gate rows of the images a row tile touches
   if (lds > 160 * 1024) return 1;      // not this way: the caller falls back to the fp32 kernels
   if (lds > 48 * 1024) {
@@ -59,6 +59,15 @@ int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
       if (v == S_SMALL) return launch_one<2, 2, 1, 1, AL, BL, EPI, 4, false>(a, grid, s);
     }
   }
+  if constexpr (AL == LAYOUT_KCONTIG && BL == LAYOUT_KCONTIG && EPI != EPI_STATS) {
+    // weight pre-split into bf16 planes (mt_split_planes): B by DMA, 128 x 128 tiles only.  Bit-identical to the in-kernel split and
+    // 7-12 % SLOWER (tools/lab/planes_probe.py: QKV 148 -> 158 us, FF2 194 -> 215, 4096^3 700 -> 785): hipcc counts only its own
+    // loads, so its vmcnt for the staged A tile also drains the DMA issued in the same step.  Opt-in (MT_SPLIT_PLANES=1) until
+    // the A loads move under manual wait counts as well.
+    const bool planes_on = getenv("MT_SPLIT_PLANES") && atoi(getenv("MT_SPLIT_PLANES")) != 0;
+    if (planes_on && a.b_planes && a.k_chunk == 0 && (a.ldb % 8) == 0 && a.b_map.gin == 0 && (v == S_BIG || EPI == EPI_GEGLU_BWD))
+      return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, true, PRO_NONE, true>(a, grid, s);
+  }
   if (v == S_BIG) return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, true>(a, grid, s);
   if constexpr (EPI != EPI_GEGLU) {
     if (v == S_MID) return launch_one<2, 2, 2, 1, AL, BL, EPI, 3, true>(a, grid, s);
@@ -76,6 +85,31 @@ extern "C" int mt_gemm_set_split(int on) {
 }
 
 extern "C" int mt_gemm_get_split(void) { return mode(); }
+
+namespace {
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, __bf16* __restrict__ planes, int64_t n) {
+  const int64_t n8 = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const float4 u = reinterpret_cast<const float4*>(src)[2 * i], v = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    const float lo[4] = {u.x, u.y, u.z, u.w}, hi[4] = {v.x, v.y, v.z, v.w};
+    bf16x8_t x0, x1, x2;
+    split_bf16<true>(lo, hi, x0, x1, x2);
+    reinterpret_cast<bf16x8_t*>(planes)[i] = x0;
+    reinterpret_cast<bf16x8_t*>(planes + n)[i] = x1;
+    reinterpret_cast<bf16x8_t*>(planes + 2 * n)[i] = x2;
+  }
+}
+}  // namespace
+
+extern "C" int mt_split_planes(const float* src, void* planes, int64_t n, void* stream) {
+  if (!src || !planes) return fail(MT_ERR_ARG, "mt_split_planes: null pointer");
+  if (n <= 0 || (n & 7) || ((uintptr_t)src & 15) || ((uintptr_t)planes & 15))
+    return fail(MT_ERR_ARG, "mt_split_planes: n must be a positive multiple of 8, pointers 16-byte aligned");
+  const int64_t n8 = n >> 3;
+  const unsigned blocks = (unsigned)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, reinterpret_cast<__bf16*>(planes), n);
+  return check_launch("mt_split_planes");
+}
 
 namespace mt {
 

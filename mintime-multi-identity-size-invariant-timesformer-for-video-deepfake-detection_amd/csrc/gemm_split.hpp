@@ -38,10 +38,14 @@
 
 namespace mt {
 
+// BPL (B planes): the B operand arrives already split -- three bf16 planes [N][K] in memory (weights: split once per step by
+// mt_split_planes) -- and goes global -> LDS by DMA (global_load_lds_dwordx4, no staging VGPRs, no VALU, no ds_write) through a
+// ring of three B stages: tile kt+2's planes are issued at the top of step kt, so they have two steps to land.
 template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int EPI, int MINW, bool X6 = true, int PIPE = 2, bool BAL = false,
-          int PRO = PRO_NONE>
+          int PRO = PRO_NONE, bool BPL = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW)
 void gemm_split_kernel(const GemmArgs p) {
+  static_assert(!BPL || (PIPE == 2 && X6 && AL == LAYOUT_KCONTIG && BL == LAYOUT_KCONTIG && PRO == PRO_NONE), "B planes: NT form only");
   static_assert(!BAL || PIPE == 2, "the balanced accumulators need the stage = tile parity of the two-register-set loop");
   // PRO_BN_SWISH_GATE (k-contiguous A, two-register-set loop): a = swish(z*scale[k]+shift[k]) * gate[(m/hw)*K+k], applied to the
   // staged registers right before the split -- VALU work that rides in the MFMA shadow like the split itself.  The per-k vectors
@@ -56,6 +60,13 @@ void gemm_split_kernel(const GemmArgs p) {
   constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
   constexpr int AG = (BM * 2 + NT - 1) / NT, BG = (BN * 2 + NT - 1) / NT;   // 8-k granules per thread
   constexpr bool A_ALL = (BM * 2) % NT == 0, B_ALL = (BN * 2) % NT == 0;   // every thread stages AG / BG granules (no predicate)
+  // LDS map.  Staged B: two stages of {A planes, B planes}.  B planes by DMA: two A stages, then a ring of three B stages.
+  constexpr int A_STAGE = BPL ? 3 * A_PLANE : STAGE;             // byte distance between the two A stages
+  constexpr int B_BASE = BPL ? 6 * A_PLANE : 3 * A_PLANE;        // first B stage
+  constexpr int B_STAGE = BPL ? 3 * B_PLANE : STAGE;
+  constexpr int LDS_END = BPL ? 6 * A_PLANE + 9 * B_PLANE : 2 * STAGE;
+  constexpr int BI = BPL ? (6 * BN / 64) / NW : 1;               // DMA wave-instructions per wave per B tile (3 planes x BN rows x 2 slots)
+  static_assert(!BPL || (6 * BN / 64) % NW == 0, "B plane tile must divide into whole wave-instructions per wave");
   static_assert((BM * 2) % NT == 0 || BM * 2 < NT, "A granules must divide over the block");
   static_assert((BN * 2) % NT == 0 || BN * 2 < NT, "B granules must divide over the block");
 
@@ -123,7 +134,7 @@ void gemm_split_kernel(const GemmArgs p) {
     b_dst[j] = row * 32 + ((kh ^ ((row >> 3) & 1)) << 4);
   }
 
-  float* pv = reinterpret_cast<float*>(smem_split + 2 * STAGE);      // PRO: [scale K | shift K | gate rows of the tile's images]
+  float* pv = reinterpret_cast<float*>(smem_split + LDS_END);      // PRO: [scale K | shift K | gate rows of the tile's images]
   int g_off[AG];
   if constexpr (PRO == PRO_BN_SWISH_GATE) {
     const int K = p.K;
@@ -138,6 +149,36 @@ void gemm_split_kernel(const GemmArgs p) {
     }
     __syncthreads();
   }
+
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_split;
+  const __bf16* bp_src[BI];
+  if constexpr (BPL) {
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+      const int gi = (wave * BI + j) * 64 + lane;                // granule of the stage image: plane, row, slot
+      const int plane = gi / (2 * BN), within = gi % (2 * BN);
+      const int row = within >> 1, slot = within & 1;
+      const int kh = slot ^ ((row >> 3) & 1);
+      int n;
+      if constexpr (EPI == EPI_GEGLU) {
+        const int w = row / 64, sel = (row >> 5) & 1, c = row & 31;
+        const int jj = (n0 >> 1) + w * 32 + c;
+        n = jj < p.n_half ? sel * p.n_half + jj : 0;
+      } else {
+        n = n0 + row;
+        n = n < p.N ? n : p.N - 1;
+      }
+      bp_src[j] = reinterpret_cast<const __bf16*>(p.b_planes) + plane * p.b_pstride + (int64_t)n * p.ldb + k_begin + kh * 8;
+    }
+  }
+  auto dma_b = [&](int kt, int ring) {                           // B planes of k-tile kt -> ring slot
+    if constexpr (BPL) {
+      const unsigned dst = lds_base + (unsigned)(B_BASE + ring * B_STAGE);
+#pragma unroll
+      for (int j = 0; j < BI; ++j)
+        lds_dma16(reinterpret_cast<const float*>(bp_src[j] + kt * BK), dst + (unsigned)((wave * BI + j) * 1024));
+    }
+  };
 
   auto gload = [&](int kt, float (&ga)[AG][8], float (&gb)[BG][8]) {
     if (MT_SPLIT_ABLATE & 1) {
@@ -170,6 +211,7 @@ void gemm_split_kernel(const GemmArgs p) {
       }
     }
     if ((MT_SPLIT_ABLATE & 32) && kt > 0) return;
+    if constexpr (BPL) return;
 #pragma unroll
     for (int j = 0; j < BG; ++j) {
       if (!B_ALL && !b_on[j]) continue;
@@ -203,7 +245,7 @@ void gemm_split_kernel(const GemmArgs p) {
       if (z == 123.456f) smem_split[tid] = 1;        // keeps the loads live
       return;
     }
-    unsigned char* st = smem_split + stage * STAGE;
+    unsigned char* st = smem_split + stage * A_STAGE;
 #pragma unroll
     for (int j = 0; j < AG; ++j) {
       if (!A_ALL && !a_on[j]) continue;
@@ -230,6 +272,7 @@ void gemm_split_kernel(const GemmArgs p) {
       if constexpr (X6) *reinterpret_cast<bf16x8_t*>(st + 2 * A_PLANE + a_dst[j]) = x2;
     }
     if ((MT_SPLIT_ABLATE & 32) && !first_store) return;
+    if constexpr (BPL) return;
 #pragma unroll
     for (int j = 0; j < BG; ++j) {
       if (!B_ALL && !b_on[j]) continue;
@@ -255,11 +298,12 @@ void gemm_split_kernel(const GemmArgs p) {
   const int a_row = wm * TM * 32 + (lane & 31);
   const int b_row = wn * TN * 32 + (lane & 31);
   const int a_frag = a_row * 32 + ((kh ^ ((a_row >> 3) & 1)) << 4);
-  const int b_frag = 3 * A_PLANE + b_row * 32 + ((kh ^ ((b_row >> 3) & 1)) << 4);
+  const int b_frag = b_row * 32 + ((kh ^ ((b_row >> 3) & 1)) << 4);
 
-  auto compute = [&](int stage, int kt, auto odd_c) {
+  auto compute = [&](int stage, int kt, auto odd_c, int b_ring = 0) {
     constexpr bool ODD = BAL && decltype(odd_c)::value;
-    const unsigned char* st = smem_split + stage * STAGE;
+    const unsigned char* st = smem_split + stage * A_STAGE;
+    const unsigned char* sb = smem_split + B_BASE + (BPL ? b_ring : stage) * B_STAGE;
     bf16x8_t a0[TM], a1[TM], a2[TM], b0[TN], b1[TN], b2[TN];
     if (MT_SPLIT_ABLATE & 8) {
 #pragma unroll
@@ -278,9 +322,9 @@ void gemm_split_kernel(const GemmArgs p) {
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        b0[j] = *reinterpret_cast<const bf16x8_t*>(st + b_frag + j * 1024);
-        b1[j] = *reinterpret_cast<const bf16x8_t*>(st + B_PLANE + b_frag + j * 1024);
-        if constexpr (X6) b2[j] = *reinterpret_cast<const bf16x8_t*>(st + 2 * B_PLANE + b_frag + j * 1024);
+        b0[j] = *reinterpret_cast<const bf16x8_t*>(sb + b_frag + j * 1024);
+        b1[j] = *reinterpret_cast<const bf16x8_t*>(sb + B_PLANE + b_frag + j * 1024);
+        if constexpr (X6) b2[j] = *reinterpret_cast<const bf16x8_t*>(sb + 2 * B_PLANE + b_frag + j * 1024);
       }
     }
 #define MT_TERM(X, Y)                                                                                        \
@@ -303,7 +347,7 @@ void gemm_split_kernel(const GemmArgs p) {
   // behind every MFMA (an MFMA holds the matrix pipe for 32 cycles; the wave's next 4-5 VALU issues are free in that shadow)
   auto interleave = [&]() {
     constexpr int N_MFMA = (X6 ? 6 : 3) * TM * TN;
-    constexpr int N_VALU = (AG + BG) * (X6 ? 36 : 22) + (PRO == PRO_BN_SWISH_GATE ? AG * 8 * 14 : 0);
+    constexpr int N_VALU = (AG + (BPL ? 0 : BG)) * (X6 ? 36 : 22) + (PRO == PRO_BN_SWISH_GATE ? AG * 8 * 14 : 0);
     constexpr int VALU_PER = (N_VALU + N_MFMA - 1) / N_MFMA;
     constexpr int N_VMEM = AG * (AL == LAYOUT_KCONTIG ? 2 : 8) + BG * (BL == LAYOUT_KCONTIG ? 2 : 8);
     (void)N_VMEM;   // pinning the VMEM group first was tried: the compiler then drains the previous step's loads at the top (722 vs 669 us at 4096^3)
@@ -326,6 +370,41 @@ void gemm_split_kernel(const GemmArgs p) {
       compute(kt & 1, kt, std::false_type{});
       if (kt + 1 < nk) sstore((kt + 1) & 1, ga, gb);
       MT_SPLIT_SYNC();
+    }
+  } else if constexpr (BPL) {
+    // A as below (two register sets); B planes by DMA two tiles ahead through the three-slot ring.  In-order return of VMEM
+    // operations: once the A loads of tile kt+1 (issued after tile kt+1's DMA) have been waited for by the split, that DMA has
+    // landed too; the explicit counted wait before the barrier states it independently of the compiler's placement.
+    constexpr int YOUNGER = BI + AG * 2;            // VMEM operations issued in a step after the DMA that must have landed
+    float ga0[AG][8], gb0[BG][8], ga1[AG][8], gb1[BG][8];
+    const int last = nk - 1;
+    dma_b(0, 0);
+    dma_b(min(1, last), 1);
+    gload(0, ga0, gb0); sstore(0, ga0, gb0, false, 0);
+    gload(min(1, last), ga0, gb0);
+    wait_vmcnt<AG * 2>();                           // both DMAs done; tile 1's A loads may stay in flight
+    __syncthreads();
+    int ring = 0;                                   // ring slot of tile kt
+    for (int kt = 0; kt < nk; kt += 2) {
+      int r2 = ring + 2; r2 = r2 >= 3 ? r2 - 3 : r2;
+      dma_b(min(kt + 2, last), r2);
+      gload(min(kt + 2, last), ga1, gb1);
+      compute(0, kt, std::false_type{}, ring);
+      sstore(1, ga0, gb0, BAL, min(kt + 1, last));
+      interleave();
+      wait_vmcnt<YOUNGER>();
+      MT_SPLIT_SYNC();
+      if (kt + 1 >= nk) break;
+      ring = ring + 1 >= 3 ? 0 : ring + 1;
+      r2 = ring + 2; r2 = r2 >= 3 ? r2 - 3 : r2;
+      dma_b(min(kt + 3, last), r2);
+      gload(min(kt + 3, last), ga0, gb0);
+      compute(1, kt + 1, std::true_type{}, ring);
+      sstore(0, ga1, gb1, false, min(kt + 2, last));
+      interleave();
+      wait_vmcnt<YOUNGER>();
+      MT_SPLIT_SYNC();
+      ring = ring + 1 >= 3 ? 0 : ring + 1;
     }
   } else {
     // two register sets: tile kt+2's loads are issued at the top of step kt; tile kt+1 (loaded a full step ago) is split and

@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
                 ("b_gate", C.c_void_p), ("b_hw", C.c_int),
                 ("conv_H", C.c_int), ("conv_W", C.c_int), ("conv_C", C.c_int), ("conv_Ho", C.c_int), ("conv_Wo", C.c_int),
                 ("conv_k", C.c_int), ("conv_stride", C.c_int), ("conv_pad", C.c_int), ("conv_act", C.c_int), ("conv_src_u8", C.c_int),
-                ("col_sum", C.c_void_p)]
+                ("col_sum", C.c_void_p), ("b_planes", C.c_void_p), ("b_plane_stride", C.c_int64)]
 
 
 OP_NT, OP_NN, OP_TN = 0, 1, 2
@@ -52,6 +52,7 @@ PROTOTYPES = {
     "mt_gemm": [C.POINTER(GemmDesc), C.c_void_p],
     "mt_gemm_set_split": [C.c_int],
     "mt_gemm_get_split": [],
+    "mt_split_planes": [f32p, C.c_void_p, C.c_int64, C.c_void_p],
     "mt_layernorm_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "mt_embed_fwd": [f32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                      C.c_void_p],
@@ -144,6 +145,16 @@ def set_gemm_split(on: bool) -> bool:
     return bool(get().mt_gemm_set_split(1 if on else 0))
 
 
+def split_planes(w):
+    """The three exact bf16 pieces of an fp32 tensor (w == p[0] + p[1] + p[2]), shape [3, *w.shape], for mt_gemm's b_planes."""
+    w = w.detach()
+    if not w.is_contiguous() or w.numel() % 8:
+        raise MintimeHipError("split_planes: contiguous tensor with numel % 8 == 0 expected")
+    out = torch.empty((3,) + tuple(w.shape), dtype=torch.bfloat16, device=w.device)
+    check(get().mt_split_planes(ptr(w), ptr(out), w.numel(), stream_ptr()), "mt_split_planes")
+    return out
+
+
 def gemm_split_enabled() -> bool:
     return bool(get().mt_gemm_get_split())
 
@@ -192,7 +203,7 @@ def timed(name, fn, work=0.0):
 def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI_STORE, bias=None, R=None, ldr=0,
          scale=None, shift=None, gate=None, hw=1, C2=None, ldc2=0, stats=None, stats_slots=1, n_half=0, split_k=1,
          a_map=(0, 0, 0), b_map=(0, 0, 0), c_map=(0, 0, 0), A2=None, b_prologue=BPRO_NONE, b_scale=None, b_shift=None,
-         b_gate=None, b_hw=1, conv=None, col_sum=None):
+         b_gate=None, b_hw=1, conv=None, col_sum=None, b_planes=None):
     d = GemmDesc()
     d.op, d.prologue, d.epilogue = op, prologue, epilogue
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
@@ -205,6 +216,8 @@ def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI
     d.n_half, d.split_k = n_half, split_k
     d.A2, d.b_prologue, d.b_scale, d.b_shift, d.b_gate, d.b_hw = ptr(A2), b_prologue, ptr(b_scale), ptr(b_shift), ptr(b_gate), b_hw
     d.col_sum = ptr(col_sum)
+    if b_planes is not None:             # bf16 [3, N, K] from split_planes(B)
+        d.b_planes, d.b_plane_stride = ptr(b_planes), b_planes[0].numel()
     if conv is not None:   # (H, W, C, Ho, Wo, k, stride, pad, act[, src_u8])
         (d.conv_H, d.conv_W, d.conv_C, d.conv_Ho, d.conv_Wo, d.conv_k, d.conv_stride, d.conv_pad, d.conv_act) = conv[:9]
         d.conv_src_u8 = conv[9] if len(conv) > 9 else 0

@@ -511,3 +511,27 @@ def test_full_size_expand_conv_stats_both_pipes(M, N, K):
     st = stats.sum(0).cpu()
     assert_close(st[0], ref.sum(0), 1e-4, "column sums")
     assert_close(st[1], (ref * ref).sum(0), 1e-4, "column sums of squares")
+
+
+@pytest.mark.parametrize("epi", ["store", "bias_res"])
+def test_presplit_weight_planes_are_bit_identical_to_the_in_kernel_split(epi, monkeypatch, matrix_pipe):
+    """mt_split_planes + mt_gemm(b_planes=...) (opt-in: MT_SPLIT_PLANES=1): the planes sum back to the weight exactly and the DMA-fed
+    loop returns the same bits as the loop that splits B per tile."""
+    if matrix_pipe != "split":
+        pytest.skip("b_planes is read by the split-operand loop only")
+    M, N, K = 2048 + 37, 512, 1024
+    A, W, b, R = _rand(M, K, seed=1).cuda(), _rand(N, K, seed=2, scale=0.05).cuda(), _rand(N, seed=3).cuda(), _rand(M, N, seed=4).cuda()
+    P = L.split_planes(W)
+    assert torch.equal(P.float().sum(0), W)
+    outs = []
+    for planes, env in ((None, "0"), (P, "1")):
+        monkeypatch.setenv("MT_SPLIT_PLANES", env)
+        C = torch.full((M, N), float("nan"), device="cuda")
+        if epi == "store":
+            L.gemm(L.OP_NT, A, W, C, M, N, K, K, K, N, bias=b, b_planes=planes)
+        else:
+            L.gemm(L.OP_NT, A, W, C, M, N, K, K, K, N, epilogue=L.EPI_BIAS_RES, bias=b, R=R, ldr=N, b_planes=planes)
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    ref = A.double().cpu() @ W.double().cpu().T + b.double().cpu() + (R.double().cpu() if epi == "bias_res" else 0)
+    assert_close(outs[1], ref, TOL, "pre-split planes")
