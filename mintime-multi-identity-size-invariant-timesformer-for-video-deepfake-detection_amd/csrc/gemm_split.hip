@@ -1,6 +1,6 @@
 // Dispatch of the split-operand GEMM main loop (gemm_split.hpp): fp32 operands split exactly into three bf16 pieces, six
 // piece products per fp32 product on the bf16 matrix pipe, fp32 accumulators.  mt_gemm (gemm.hip) asks try_launch_split()
-// first; problems it does not take (operand prologues, tiny or K % 16 != 0 shapes) go on to the fp32-MFMA kernels.
+// first; problems it does not take (most operand prologues, tiny or K % 8 != 0 shapes) go on to the fp32-MFMA kernels.
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
 #include "gemm_split.hpp"
@@ -65,7 +65,7 @@ int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
     // loads, so its vmcnt for the staged A tile also drains the DMA issued in the same step.  Opt-in (MT_SPLIT_PLANES=1) until
     // the A loads move under manual wait counts as well.
     const bool planes_on = getenv("MT_SPLIT_PLANES") && atoi(getenv("MT_SPLIT_PLANES")) != 0;
-    if (planes_on && a.b_planes && a.k_chunk == 0 && (a.ldb % 8) == 0 && a.b_map.gin == 0 && (v == S_BIG || EPI == EPI_GEGLU_BWD))
+    if (planes_on && a.b_planes && (a.K % 16) == 0 && a.k_chunk == 0 && (a.ldb % 8) == 0 && a.b_map.gin == 0 && (v == S_BIG || EPI == EPI_GEGLU_BWD))
       return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, true, PRO_NONE, true>(a, grid, s);
   }
   if (v == S_BIG) return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, true>(a, grid, s);
@@ -126,11 +126,11 @@ int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
     if (getenv("MT_SPLIT_TRACE")) fprintf(stderr, "[split] call %d: op %d M %d N %d K %d\n", idx, d->op, d->M, d->N, d->K);
   }
   if (d->b_prologue != MT_BPRO_NONE) return 1;
-  if (d->K % 16 || d->M < 128 || d->N < 64) return 1;
+  if (d->K % 8 || d->M < 128 || d->N < 64) return 1;     // K % 16 == 8: the last k-tile is half zeros (gemm_split.hpp k_tail)
   if (d->prologue == MT_PRO_BN_SWISH_GATE) {
     // MBConv project convolution (forward): the operand transform rides in the staging registers (gemm_split.hpp PRO)
     static const int pro_on = getenv("MT_SPLIT_PRO") ? atoi(getenv("MT_SPLIT_PRO")) : 1;
-    if (!pro_on || d->op != MT_OP_NT || d->M < 4096 || d->K < 256) return 1;
+    if (!pro_on || d->op != MT_OP_NT || d->M < 4096 || d->K < 256 || (d->K % 16)) return 1;
     if (d->epilogue != MT_EPI_STATS && d->epilogue != MT_EPI_STORE) return 1;
     // tile width by padding waste: 128 columns unless 64-wide tiles waste fewer padded columns
     const int pad128 = (d->N + 127) / 128 * 128, pad64 = (d->N + 63) / 64 * 64;

@@ -89,7 +89,8 @@ void gemm_split_kernel(const GemmArgs p) {
     k_end = min(p.K, k_begin + p.k_chunk);
     if (k_begin >= k_end) return;
   }
-  const int nk = (k_end - k_begin) / BK;            // host guarantees (k_end - k_begin) % 16 == 0
+  const int nk = (k_end - k_begin + BK - 1) / BK;   // host guarantees (k_end - k_begin) % 8 == 0: the last tile may hold one 8-k granule only
+  const bool k_tail = ((k_end - k_begin) & 15) != 0;
 
   // ---- the granules this thread stages: (tile row, k half) -> global source, LDS byte offset inside a plane
   const float* a_src[AG];
@@ -195,6 +196,11 @@ void gemm_split_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < AG; ++j) {
       if (!A_ALL && !a_on[j]) continue;
+      if (k_tail && kt == nk - 1 && a_kh[j]) {         // second granule of a half-filled last tile: zeros
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ga[j][e] = 0.f;
+        continue;
+      }
       if constexpr (AL == LAYOUT_KCONTIG) {
         const float4 u = *reinterpret_cast<const float4*>(a_src[j] + kt * BK), v = *reinterpret_cast<const float4*>(a_src[j] + kt * BK + 4);
         ga[j][0] = u.x; ga[j][1] = u.y; ga[j][2] = u.z; ga[j][3] = u.w; ga[j][4] = v.x; ga[j][5] = v.y; ga[j][6] = v.z; ga[j][7] = v.w;
@@ -215,6 +221,11 @@ void gemm_split_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < BG; ++j) {
       if (!B_ALL && !b_on[j]) continue;
+      if (k_tail && kt == nk - 1 && b_kh[j]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gb[j][e] = 0.f;
+        continue;
+      }
       if constexpr (BL == LAYOUT_KCONTIG) {
         const float4 u = *reinterpret_cast<const float4*>(b_src[j] + kt * BK), v = *reinterpret_cast<const float4*>(b_src[j] + kt * BK + 4);
         gb[j][0] = u.x; gb[j][1] = u.y; gb[j][2] = u.z; gb[j][3] = u.w; gb[j][4] = v.x; gb[j][5] = v.y; gb[j][6] = v.z; gb[j][7] = v.w;

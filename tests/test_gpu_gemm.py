@@ -535,3 +535,25 @@ def test_presplit_weight_planes_are_bit_identical_to_the_in_kernel_split(epi, mo
     assert torch.equal(outs[0], outs[1])
     ref = A.double().cpu() @ W.double().cpu().T + b.double().cpu() + (R.double().cpu() if epi == "bias_res" else 0)
     assert_close(outs[1], ref, TOL, "pre-split planes")
+
+
+@pytest.mark.parametrize("op,M,N,K,split_k", [("NT", 3136, 728, 728, 1), ("NN", 3136, 728, 728, 1), ("NT", 1000, 512, 520, 1),
+                                              ("TN", 1024, 512, 4104, 4), ("NN", 2048, 512, 1544, 3)])
+def test_k_tail_of_eight(op, M, N, K, split_k):
+    """K % 16 == 8 (Xception's 728-channel middle flow): the split loop's last k-tile holds one 8-k granule and zeros."""
+    A, B = _operands(op, M, N, K, "normal")
+    Cs, Cf = _both_pipes(op, A.cuda(), B.cuda(), M, N, K, split_k) if op != "NN" or split_k > 1 else (None, None)
+    Ad, Bd = A.double(), B.double()
+    ref = (Ad.T if op == "TN" else Ad) @ (Bd.T if op == "NT" else Bd)
+    if Cs is None:                                   # NN store form
+        outs = []
+        for on in (True, False):
+            prev = L.set_gemm_split(on)
+            C = torch.full((M, N), float("nan"), device="cuda")
+            L.gemm(L.OP_NN, A.cuda(), B.cuda(), C, M, N, K, K, N, N)
+            L.set_gemm_split(prev)
+            outs.append(C.cpu().double())
+        Cs, Cf = outs
+    assert not torch.equal(Cs, Cf), "the split loop did not take this shape"
+    assert_close(Cs, ref, TOL, "split pipe, K tail")
+    assert_close(Cf, ref, TOL, "fp32 pipe")
