@@ -257,6 +257,28 @@ def grads_ready(model, params, flat):
         hook(params, flat)
 
 
+def _low_priority_stream(device):
+    """The weight-gradient stream at the LOWEST hardware queue priority: its kernels fill the CUs the critical path leaves idle
+    instead of taking CUs from it (in-step trace: with equal priorities the main queue's LayerNorm-backward launches stretched
+    2x next to the three-blocks-per-CU weight-gradient GEMMs).  torch only exposes normal / high, so the stream is created through
+    the HIP runtime and wrapped.  MT_SIDE_PRIORITY=normal keeps torch's default."""
+    if os.environ.get("MT_SIDE_PRIORITY", "low") != "low":
+        return torch.cuda.Stream(device=device)
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        least, greatest = C.c_int(0), C.c_int(0)
+        idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        with torch.cuda.device(idx):
+            if hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) != 0 or least.value <= 0:
+                return torch.cuda.Stream(device=device)
+            handle = C.c_void_p()
+            if hip.hipStreamCreateWithPriority(C.byref(handle), C.c_uint(1), least) != 0:      # 1 = hipStreamNonBlocking
+                return torch.cuda.Stream(device=device)
+        return torch.cuda.ExternalStream(handle.value, device=torch.device("cuda", idx))
+    except (OSError, AttributeError):
+        return torch.cuda.Stream(device=device)
+
+
 class SideStream:
     """Second HIP stream for work that is independent of the critical path (weight-gradient GEMMs, bias sums): their
     blocks fill the CUs a skinny dgrad leaves idle (396 tiles on 256 CUs = 23 % idle slots).  Every launch is fenced by
@@ -271,7 +293,7 @@ class SideStream:
         if self.enabled:
             key = str(device)
             if key not in SideStream._streams:
-                SideStream._streams[key] = torch.cuda.Stream(device=device)
+                SideStream._streams[key] = _low_priority_stream(device)
             self.stream = SideStream._streams[key]
         self.pending = []
 
