@@ -32,6 +32,12 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   size_t lds = BPL ? (size_t)(6 * BM + 9 * BN) * 32 : (size_t)2 * 3 * (BM + BN) * 32;
   if (PRO == PRO_BN_SWISH_GATE) lds += (size_t)(2 + (BM - 1) / a.hw + 2) * a.K * 4;      // scale, shift, gate rows of the images a row tile touches
+  if (!BAL && AL == LAYOUT_KMAJOR) {
+    // experiment knob: extra LDS per weight-gradient block (8192 -> two instead of three blocks per CU, leaving room for a
+    // main-stream GEMM block).  Measured in-step: 55.3 vs 54.4 ms -- the weight gradients lose more than the main stream gains.
+    static const int pad = getenv("MT_WGRAD_LDS_PAD") ? atoi(getenv("MT_WGRAD_LDS_PAD")) : 0;
+    lds += (size_t)pad;
+  }
   if (lds > 160 * 1024) return 1;      // not this way: the caller falls back to the fp32 kernels
   if (lds > 48 * 1024) {
     static size_t raised = 0;          // idempotent; a benign race at worst repeats the call

@@ -109,23 +109,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       }
     }
   }
-  // block reduction over the 4 wavefronts, then one atomic per column per block
-  __shared__ float red[3][4][1024];
+  // block reduction over the 4 wavefronts, then one atomic per column per block.  One 16 KB buffer reused for the three sums:
+  // the former 48 KB kept this kernel's blocks off CUs whose LDS the weight-gradient stream's GEMM blocks had filled (in-step the
+  // launch stretched from 76 to 157 us).
+  __shared__ float red[4][1024];
   const int wv = threadIdx.x >> 6;
+#pragma unroll 1
+  for (int which = 0; which < 3; ++which) {
+    if (which == 2 && !dxsum) break;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = lane + i * 64;
-    if (q < nq) {
-      *reinterpret_cast<float4*>(&red[0][wv][4 * q]) = dg[i];
-      *reinterpret_cast<float4*>(&red[1][wv][4 * q]) = db[i];
-      *reinterpret_cast<float4*>(&red[2][wv][4 * q]) = ds[i];
+    for (int i = 0; i < 4; ++i) {
+      const int q = lane + i * 64;
+      if (q < nq) *reinterpret_cast<float4*>(&red[wv][4 * q]) = which == 0 ? dg[i] : (which == 1 ? db[i] : ds[i]);
     }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < D; c += 256) {
-    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
-    if (dxsum) atomicAdd(dxsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+    __syncthreads();
+    float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+    for (int c = threadIdx.x; c < D; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    __syncthreads();
   }
 }
 
