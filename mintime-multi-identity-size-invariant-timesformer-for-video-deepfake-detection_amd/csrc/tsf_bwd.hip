@@ -31,7 +31,10 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------------------------------- LayerNorm backward
-// one wavefront per row, grid-strided so each wave keeps dgamma/dbeta partials in registers.
+// one wavefront per row, grid-strided so each wave keeps dgamma/dbeta partials in registers.  NI = float4 slots per lane
+// (ceil(D / 256)): sized to the row width, the register arrays cost 100 instead of 200 VGPRs at D = 512, which lets these
+// wavefronts start on SIMDs that the weight-gradient stream's GEMM waves have mostly filled.
+template <int NI>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             float* __restrict__ dx, float* __restrict__ dgamma,
@@ -41,9 +44,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
   const int nq = D >> 2;
-  float4 dg[4], db[4], g[4], ds[4];     // ds: column sums of the UPDATED dx (the bias gradient of whoever consumes dx next)
+  float4 dg[NI], db[NI], g[NI], ds[NI];     // ds: column sums of the UPDATED dx (the bias gradient of whoever consumes dx next)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NI; ++i) {
     dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i]; ds[i] = dg[i];
     const int q = lane + i * 64;
     g[i] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -60,11 +63,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float4* dyr0 = reinterpret_cast<const float4*>(dy + (int64_t)row0 * D);
     const float4* xr1 = reinterpret_cast<const float4*>(x + (int64_t)r1 * D);
     const float4* dyr1 = reinterpret_cast<const float4*>(dy + (int64_t)r1 * D);
-    float4 xh0[4], gy0[4], xh1[4], gy1[4];
+    float4 xh0[NI], gy0[NI], xh1[NI], gy1[NI];
     float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
     const float w1 = has1 ? 1.f : 0.f;          // the duplicated tail row must not count twice in dgamma / dbeta
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int q = lane + i * 64;
       if (q < nq) {
         const float4 xv0 = xr0[q], d0 = dyr0[q], xv1 = xr1[q], d1 = dyr1[q];
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float c0 = (skip_period > 0 && row0 % skip_period == 0) ? 0.f : 1.f;
     const float c1 = (!has1 || (skip_period > 0 && row1 % skip_period == 0)) ? 0.f : 1.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int q = lane + i * 64;
       if (q < nq) {
         float4 o;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int which = 0; which < 3; ++which) {
     if (which == 2 && !dxsum) break;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int q = lane + i * 64;
       if (q < nq) *reinterpret_cast<float4*>(&red[wv][4 * q]) = which == 0 ? dg[i] : (which == 1 ? db[i] : ds[i]);
     }
@@ -773,8 +776,12 @@ extern "C" int mt_layernorm_bwd(const float* dy, const float* x, const float* st
   int blocks = (rows + 3) / 4;
   static const int cap = getenv("MT_LN_BWD_BLOCKS") ? atoi(getenv("MT_LN_BWD_BLOCKS")) : 256;     // tuning knob
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dgamma, dbeta,
-                     rows, dim, accumulate, dx_colsum, skip_period);
+  if (dim <= 512)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dgamma, dbeta,
+                       rows, dim, accumulate, dx_colsum, skip_period);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dgamma, dbeta,
+                       rows, dim, accumulate, dx_colsum, skip_period);
   return check_launch("mt_layernorm_bwd");
 }
 
