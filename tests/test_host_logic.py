@@ -386,3 +386,39 @@ def test_reducer_broadcast_none_slot_accumulation_world_size_2_gloo():
     for g0, g1 in zip(r0["accum"], r1["accum"]):
         assert torch.equal(g0, g1) and torch.allclose(g0, torch.full_like(g0, 49.5))
     assert "no_sync" in r0["double"] and "no_sync" in r1["double"]
+
+
+def test_bench_self_launches_multi_rank_and_prints_one_json_line_last():
+    """`python bench.py --gpus 2` (what the driver's scaling run invokes, no launcher around it) must start its own ranks under
+    torch.distributed.run and leave exactly ONE JSON line, last, on stdout.  The launcher / barrier / max-over-ranks plumbing is
+    exercised here on gloo with a stand-in step (--stub); the product step itself needs GPUs."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["checksum"] == 1024 * 2.0 * (1 + 2)          # both ranks took part in the all-reduce
+
+
+def test_bench_drops_pmc_counters_measured_on_other_sources(tmp_path, monkeypatch):
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f = tmp_path / "pmc.json"
+    monkeypatch.setattr(bench, "PMC_FILE", str(f))
+    f.write_text(json.dumps({"csrc_sha16": bench.csrc_hash(), "tsf_wgrad": {"bytes_per_launch": 1.0}}))
+    assert bench.committed_counters("tsf_wgrad") == {"bytes_per_launch": 1.0}
+    f.write_text(json.dumps({"csrc_sha16": "0" * 16, "tsf_wgrad": {"bytes_per_launch": 1.0}}))
+    assert bench.committed_counters("tsf_wgrad") is None             # stale counters are not reported as current
+    # no roofline object may print a fraction above 1: the split pipe is priced against its own ceiling
+    r = bench.mfma_roofline(170e12, True)
+    assert r["peak"] == 416.7 and r["frac"] < 1 and r["frac_vs_fp32_mfma"] > 1
+    assert bench.mfma_roofline(100e12, False)["peak"] == 157.3

@@ -119,5 +119,14 @@ if a.json_out:
                               "algorithmic_bytes_per_launch": 4.0 * (M * 512 + 4096 * 512 + 4096 + M * 2048 + M * 4096), "source": src}
         doc["tsf_families"] = {k: {"ms": round(f["us"] / 1e3, 3), "n": int(f["n"]), "read_GB": round(f["rd"] / 1e9, 3),
                                    "write_GB": round(f["wr"] / 1e9, 3)} for k, f in fam.items() if f["us"] > 100}
+    # which kernel sources these counters belong to: bench.py refuses them for any other tree (same hash as bench.csrc_hash)
+    import glob as _g, hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "mintime-multi-identity-size-invariant-timesformer-for-video-deepfake-detection_amd", "csrc")
+    for f in sorted(_g.glob(os.path.join(pkg, "*.hip")) + _g.glob(os.path.join(pkg, "*.hpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    doc["csrc_sha16"] = h.hexdigest()[:16]
     json.dump(doc, open(a.json_out, "w"), indent=1)
     print("wrote", a.json_out)
