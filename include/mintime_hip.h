@@ -275,6 +275,12 @@ int mt_conv1x1_rows(const float* x, const float* x2, const float* w, int ldw, in
  * ------------------------------------------------------------------------------------------------ */
 int mt_bce_logits(const float* logits, const float* labels, float pos_weight, float* loss, float* dlogits, int n, void* stream);
 int mt_sgd_multi(const void* items, int count, int64_t total_blocks, float lr, float weight_decay, void* stream);
+/* mt_adam_multi: torch.optim.Adam (decoupled_weight_decay = 0: L2 term added to the gradient) / torch.optim.AdamW
+ *   (decoupled_weight_decay = 1: p *= 1 - lr*wd first) over many tensors in one launch (train.py:187-190, :378; amsgrad off).
+ *   items = device array of {float* p; const float* g; float* m; float* v; int64 n; int64 block0} sorted by block0 (as above).
+ *   step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t) for the step count t of this call. */
+int mt_adam_multi(const void* items, int count, int64_t total_blocks, float lr, float weight_decay, float beta1, float beta2,
+                  float eps, float step_size, float bias_correction2_sqrt, int decoupled_weight_decay, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Xception (config 5 extractor, reference models/xception.py).  Dense convolutions are mt_gemm with the IM2COL

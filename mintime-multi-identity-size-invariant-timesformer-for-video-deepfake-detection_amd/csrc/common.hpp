@@ -19,6 +19,12 @@ inline int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+inline int cur_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d & 15;
+}
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(-2, "%s: launch failed: %s", what, hipGetErrorString(e));

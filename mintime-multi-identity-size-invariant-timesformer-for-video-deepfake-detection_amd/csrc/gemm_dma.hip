@@ -51,7 +51,8 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
   if (PRO == PRO_BN_BWD) lds += (size_t)3 * a.K * 4;                                     // ka, kb, kc
   if (lds > 160 * 1024) return 1;      // not this way: caller falls back to the register-staged kernel
   if (lds > 48 * 1024) {
-    static size_t raised = 0;          // idempotent; a benign race at worst repeats the call
+    static size_t raised_dev[16] = {0};   // per device (the attribute is per device); idempotent, a benign race at worst repeats the call
+    size_t& raised = raised_dev[cur_device()];
     if (lds > raised) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_gemm(dma): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
@@ -198,6 +199,7 @@ int try_launch_dma(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
   DMA_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_GEGLU)
   DMA_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_STATS)
   DMA_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_ATOMIC)
+  DMA_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_GEGLU_BWD)
   DMA_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_STORE)
   DMA_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_ACCUM)
   DMA_COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_GEGLU_BWD)

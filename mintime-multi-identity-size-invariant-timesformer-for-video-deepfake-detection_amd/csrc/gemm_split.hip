@@ -40,7 +40,8 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
   }
   if (lds > 160 * 1024) return 1;      // not this way: the caller falls back to the fp32 kernels
   if (lds > 48 * 1024) {
-    static size_t raised = 0;          // idempotent; a benign race at worst repeats the call
+    static size_t raised_dev[16] = {0};   // per device (the attribute is per device); idempotent, a benign race at worst repeats the call
+    size_t& raised = raised_dev[cur_device()];
     if (lds > raised) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_gemm(split): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));

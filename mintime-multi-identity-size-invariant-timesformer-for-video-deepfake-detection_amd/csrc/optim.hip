@@ -59,7 +59,49 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdItem* __restric
   }
 }
 
+// torch.optim.Adam / AdamW (train.py:187-190; amsgrad off, maximize off), same per-element operation order as torch's
+// single-tensor path: [AdamW: p *= 1 - lr*wd] [Adam: g += wd*p]; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  The bias corrections come in precomputed (host doubles -> float).
+struct AdamItem { float* p; const float* g; float* m; float* v; int64_t n; int64_t block0; };
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamItem* __restrict__ items, int count, float lr, float wd, float b1,
+                                                         float b2, float eps, float step_size, float bc2_sqrt, int decoupled) {
+  int lo = 0, hi = count - 1;
+  const int64_t b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const AdamItem it = items[lo];
+  const int64_t off = (b - it.block0) * SGD_CHUNK;
+  const int64_t left = it.n - off;
+#pragma unroll
+  for (int i = 0; i < SGD_CHUNK / 256; ++i) {
+    const int e = i * 256 + threadIdx.x;          // tensors are not 16-byte aligned in general (flat views): scalar, coalesced
+    if (e < left) {
+      float p = it.p[off + e], g = it.g[off + e], m = it.m[off + e], v = it.v[off + e];
+      if (decoupled) p *= 1.0f - lr * wd;
+      else if (wd != 0.f) g = fmaf(wd, p, g);
+      m = m + (g - m) * (1.0f - b1);              // torch: exp_avg.lerp_(grad, 1 - beta1)
+      v = v * b2 + (1.0f - b2) * g * g;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+      const float denom = sqrtf(v) / bc2_sqrt + eps;
+      p -= step_size * (m / denom);
+      it.p[off + e] = p; it.m[off + e] = m; it.v[off + e] = v;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int mt_adam_multi(const void* items, int count, int64_t total_blocks, float lr, float weight_decay, float beta1, float beta2,
+                             float eps, float step_size, float bias_correction2_sqrt, int decoupled_weight_decay, void* stream) {
+  if (!items || count <= 0 || total_blocks <= 0) return fail(MT_ERR_ARG, "mt_adam_multi: empty table");
+  if (total_blocks > 0x7fffffff) return fail(MT_ERR_ARG, "mt_adam_multi: too many blocks");
+  hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const AdamItem*>(items), count, lr, weight_decay, beta1, beta2, eps, step_size,
+                     bias_correction2_sqrt, decoupled_weight_decay);
+  return check_launch("mt_adam_multi");
+}
 
 extern "C" int mt_bce_logits(const float* logits, const float* labels, float pos_weight, float* loss, float* dlogits, int n,
                              void* stream) {

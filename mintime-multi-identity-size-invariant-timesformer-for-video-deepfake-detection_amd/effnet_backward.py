@@ -19,6 +19,10 @@ def _splits(rows):
     return max(1, min(64, rows // 1024))
 
 
+# what the last backward pass actually launched (tests check that frozen parameters cost nothing: train.py:153-170)
+LAST_RUN = {"blocks_run": 0, "wgrad_launches": 0, "stem_run": False}
+
+
 def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_dparams):
     lib = L.get()
     st = L.stream_ptr()
@@ -41,6 +45,17 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         pos += 10
         bidx.append(d)
     ih = pos
+    # Frozen parameters (train.py:159-167 unfreezes only the last k MBConv blocks; everything else has requires_grad = False):
+    # their weight-gradient launches are skipped, and the reverse walk stops at the lowest block that still owns a trainable
+    # parameter -- nothing below it is touched.
+    need = [bool(x) for x in need_dparams]
+    first_of = [3 if bi == 0 else (bidx[bi]["e"] if "e" in bidx[bi] else bidx[bi]["d"]) for bi in range(len(blocks))]
+    need_below = [any(need[:first_of[bi]]) for bi in range(len(blocks))]        # stem or an earlier block needs a gradient
+    lowest = min((bi for bi in range(len(blocks)) if any(need[first_of[bi]:(first_of[bi + 1] if bi + 1 < len(blocks) else ih)])),
+                 default=len(blocks))
+    if any(need[:3]):
+        lowest = -1                                                             # the stem itself is trainable
+    run = {"blocks_run": 0, "wgrad_launches": 0, "stem_run": False}
     total_c = arch.STEM_COUT + arch.HEAD_COUT + sum((b.spec.cexp if b.spec.has_expand else 0) + b.spec.cexp + b.spec.cout
                                                     for b in blocks)
     pool = _StatsPool(dev, total_c)
@@ -66,13 +81,17 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         if b_pro is not None:
             kw = dict(b_prologue=L.BPRO_BN_SWISH_GATE, b_scale=b_pro[0], b_shift=b_pro[1], b_gate=b_pro[2], b_hw=b_pro[3])
         reads = (du, z, x_in, kabc) + (tuple(b_pro[:3]) if b_pro is not None else ())
-        if rows >= 100000 and lib.mt_conv1x1_wgrad_supported(cout, cin):
+        if not need[gw_idx]:
+            pass                                      # frozen weight: no launch
+        elif rows >= 100000 and lib.mt_conv1x1_wgrad_supported(cout, cin):
+            run["wgrad_launches"] += 1
             # few channels, very many rows: the result stays in MFMA accumulators while the rows stream (skinny_wgrad.hip)
             bp = b_pro if b_pro is not None else (None, None, None, 1)
             side.launch(lambda: L.check(lib.mt_conv1x1_wgrad(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(x_in), L.ptr(bp[0]), L.ptr(bp[1]),
                                                              L.ptr(bp[2]), bp[3], L.ptr(grads[gw_idx]), rows, cout, cin,
                                                              L.stream_ptr()), "mt_conv1x1_wgrad"), reads=reads)
         else:
+            run["wgrad_launches"] += 1
             side.launch(lambda: L.gemm(L.OP_TN, du, x_in, grads[gw_idx], cout, cin, rows, cout, cin, cin, prologue=L.PRO_BN_BWD,
                                        epilogue=L.EPI_ATOMIC, split_k=0, A2=z, scale=kabc[0], shift=kabc[1], gate=kabc[2], **kw),
                         reads=reads)
@@ -99,11 +118,14 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
     du_h = _new(dev, M, arch.HEAD_COUT)
     sums = act_bwd(dfeat, hd["z"], hd["bn"], du_h, M, 1, 1)
     kabc = bn_finalize(hd["bn"], sums, ih + 1)
-    dy = conv1x1_bwd(du_h, hd["z"], kabc, P[ih], hd["y_in"], M, arch.HEAD_COUT, arch.HEAD_CIN, ih, True)
+    dy = conv1x1_bwd(du_h, hd["z"], kabc, P[ih], hd["y_in"], M, arch.HEAD_COUT, arch.HEAD_CIN, ih, lowest < len(blocks))
     del du_h
 
     # ---- blocks, last to first
     for bi in reversed(range(len(blocks))):
+        if bi < lowest:
+            break                                     # every parameter from here down is frozen
+        run["blocks_run"] += 1
         blk, rec, ix = blocks[bi], saved["blocks"][bi], bidx[bi]
         s = rec["spec"]
         M_in, M_out = N * s.hin * s.hin, N * s.hout * s.hout
@@ -128,7 +150,9 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                                   L.ptr(_dh), L.ptr(_dpo), L.ptr(grads[_se]), L.ptr(grads[_se + 1]), L.ptr(grads[_se + 2]),
                                   L.ptr(grads[_se + 3]), N, _hw, _s.cexp, _s.cse, parts, L.stream_ptr()), "mt_se_bwd")
         se_part(1)                                    # dgate -> dpooled: the data path waits for these
-        side.launch(lambda: se_part(2), reads=(dpre2, dhid, rec["hidden"], rec["pooled"]))     # SE weight gradients: off the path
+        if any(need[se:se + 4]):
+            run["wgrad_launches"] += 1
+            side.launch(lambda: se_part(2), reads=(dpre2, dhid, rec["hidden"], rec["pooled"]))     # SE weight gradients: off the path
         # (e) through swish + bn1: du_d (in place over da)
         sums = act_bwd(da, rec["z_d"], bn_d, da, M_out, hw, 1, gate=rec["gate"], dpool=dpooled)
         kabc_d = bn_finalize(bn_d, sums, ix["d"] + 1)
@@ -143,17 +167,29 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                     "mt_dwconv_bwd")
         # algorithmic HBM bytes of the pass: read da, z_d (M_out x cexp each) and the dw input's pre-activation (M_in x cexp: swish'
         # for the data gradient, swish for the weight gradient), write du_in (M_in x cexp)
-        if FUSED_DW == "1" or (FUSED_DW == "3" and s.k == 3):
+        need_du_in = need_below[bi] or (s.has_expand and any(need[ix["e"]:ix["e"] + 3]))
+        if not need_du_in or not need[ix["d"]]:
+            # a frozen neighbour: only the half that something trainable still needs
+            if need[ix["d"]]:
+                run["wgrad_launches"] += 1
+                side.launch(lambda: dw_part(1), reads=(da, rec["z_d"], kabc_d, rec["dw_in"], in_bn.scale, in_bn.shift))
+            if need_du_in:
+                L.timed("dwconv_dgrad", lambda: dw_part(2), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
+        elif FUSED_DW == "1" or (FUSED_DW == "3" and s.k == 3):
+            run["wgrad_launches"] += 1
             # data AND weight gradient in one pass over da / z_d / the dw input (the separate weight-gradient kernel re-read all three)
             L.timed("dwconv_dgrad", lambda: dw_part(3), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
         else:
+            run["wgrad_launches"] += 1
             side.launch(lambda: dw_part(1), reads=(da, rec["z_d"], kabc_d, rec["dw_in"], in_bn.scale, in_bn.shift))
             L.timed("dwconv_dgrad", lambda: dw_part(2), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
         del da
-        if s.has_expand:
+        if not need_du_in:
+            dy = None
+        elif s.has_expand:
             # (h,i,j) bn0 + expand conv: z_e = y_in . We^T
             kabc_e = bn_finalize(in_bn, sums_in, ix["e"] + 1)
-            dy = conv1x1_bwd(du_in, rec["z_e"], kabc_e, P[ix["e"]], rec["y_in"], M_in, s.cexp, s.cin, ix["e"], True,
+            dy = conv1x1_bwd(du_in, rec["z_e"], kabc_e, P[ix["e"]], rec["y_in"], M_in, s.cexp, s.cin, ix["e"], need_below[bi],
                              res=dy if s.skip else None)
         else:
             # block 0: the dw input is the stem's activated output
@@ -161,8 +197,11 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
             stem = saved["stem"]
             # the dedicated kernel (LDS-staged outer products) beats the im2col-gather wgrad GEMM here (1.15 vs 2.5 ms at 256 crops):
             # with 3 input channels the gather is scalar
-            L.check(lib.mt_stem_conv_wgrad(L.ptr(du_in), L.ptr(stem["z"]), L.ptr(kabc0), L.ptr(stem["x"]), 1 if stem["x"].dtype == torch.uint8 else 0, L.ptr(grads[0]), N, H, W, st),
-                    "mt_stem_conv_wgrad")
+            run["stem_run"] = True
+            if need[0]:
+                run["wgrad_launches"] += 1
+                L.check(lib.mt_stem_conv_wgrad(L.ptr(du_in), L.ptr(stem["z"]), L.ptr(kabc0), L.ptr(stem["x"]), 1 if stem["x"].dtype == torch.uint8 else 0, L.ptr(grads[0]), N, H, W, st),
+                        "mt_stem_conv_wgrad")
             dy = None
         del du_in
         rec.clear()
@@ -171,6 +210,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
     if need_dx:
         raise NotImplementedError("gradient w.r.t. the input crops is not part of the MINTIME training path "
                                   "(train.py never sets requires_grad on videos)")
+    LAST_RUN.update(run)
     L.grads_ready(model, params, flat_grads)
-    out = [g if need else None for need, g in zip(need_dparams, grads)]
+    out = [g if nd else None for nd, g in zip(need_dparams, grads)]
     return None, out

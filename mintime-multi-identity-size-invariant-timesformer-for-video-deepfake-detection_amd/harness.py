@@ -38,9 +38,13 @@ def make_optimizer(cfg, ef, tsf):
     """train.py:180-190: optimizer over chain(extractor, model) parameters; SGD(lr, weight_decay) from the YAML."""
     t = cfg["training"]
     params = list(ef.parameters()) + list(tsf.parameters())
-    if params[0].is_cuda:   # one multi-tensor launch per step instead of torch's ~15 foreach kernels (same update rule)
-        return optim.FusedSGD(params, lr=t["lr"], weight_decay=t["weight-decay"])
-    return torch.optim.SGD(params, lr=t["lr"], weight_decay=t["weight-decay"])
+    kind = str(t.get("optimizer", "sgd")).lower()
+    fused = {"sgd": optim.FusedSGD, "adamw": optim.FusedAdamW, "adam": optim.FusedAdam}
+    plain = {"sgd": torch.optim.SGD, "adamw": torch.optim.AdamW, "adam": torch.optim.Adam}
+    if kind not in fused:
+        raise ValueError("Error: Invalid optimizer specified in the config file.")      # train.py:191-193
+    # one multi-tensor launch per step instead of torch's foreach kernels (same update rule)
+    return (fused if params[0].is_cuda else plain)[kind](params, lr=t["lr"], weight_decay=t["weight-decay"])
 
 
 def device_batch(batch, num_frames=8, num_identities=2, seed=0, device="cuda", ragged=False, as_uint8=False):

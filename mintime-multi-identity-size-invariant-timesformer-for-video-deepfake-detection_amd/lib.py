@@ -92,6 +92,7 @@ PROTOTYPES = {
                         C.c_int, C.c_int, C.c_void_p],
     "mt_bce_logits": [f32p, f32p, C.c_float, f32p, f32p, C.c_int, C.c_void_p],
     "mt_sgd_multi": [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_void_p],
+    "mt_adam_multi": [C.c_void_p, C.c_int, C.c_int64] + [C.c_float] * 7 + [C.c_int, C.c_void_p],
     "mt_conv1x1_wgrad_supported": [C.c_int, C.c_int],
     "mt_conv1x1_wgrad": [f32p] * 7 + [C.c_int, f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "mt_stem_conv_wgrad": [f32p] * 4 + [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],

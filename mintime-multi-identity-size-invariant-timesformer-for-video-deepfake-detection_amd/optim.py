@@ -61,6 +61,88 @@ class FusedSGD(torch.optim.Optimizer):
         return loss
 
 
+class _FusedAdamBase(torch.optim.Optimizer):
+    """torch.optim.Adam / AdamW (train.py:187-190 pass only lr and weight_decay: betas (0.9, 0.999), eps 1e-8, amsgrad off) with
+    step() as ONE multi-tensor launch per parameter group.  State ('step', 'exp_avg', 'exp_avg_sq') uses torch's keys, so
+    state_dict() round-trips with the torch optimizers.  The moments of a group live in two flat buffers."""
+
+    _decoupled = False
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=None):
+        if weight_decay is None:
+            weight_decay = 1e-2 if self._decoupled else 0.0        # the torch defaults of AdamW / Adam
+        if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables = {}
+
+    def _table(self, gi, ps):
+        key = (gi,) + tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), p.numel()) for p in ps)
+        hit = self._tables.get(key)
+        if hit is not None:
+            return hit[0], hit[1]
+        rows, block = [], 0
+        for p in ps:
+            st = self.state[p]
+            rows.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), block))
+            block += (p.numel() + _CHUNK - 1) // _CHUNK
+        host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+        table = host.to(ps[0].device, non_blocking=True)
+        if len(self._tables) >= 8:
+            self._tables.pop(next(iter(self._tables)))
+        self._tables[key] = (table, block, host)
+        return table, block
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = L.get()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            fresh = [p for p in ps if "exp_avg" not in self.state[p]]
+            if fresh:
+                flat = torch.zeros(2, sum(p.numel() for p in fresh), dtype=torch.float32, device=fresh[0].device)
+                o = 0
+                for p in fresh:
+                    if p.dtype != torch.float32 or not p.is_contiguous():
+                        raise L.MintimeHipError("FusedAdam needs contiguous fp32 parameters")
+                    L.ptr(p)
+                    self.state[p].update(step=0, exp_avg=flat[0, o:o + p.numel()].view(p.shape),
+                                         exp_avg_sq=flat[1, o:o + p.numel()].view(p.shape))
+                    o += p.numel()
+            steps = {int(self.state[p]["step"]) for p in ps}
+            if len(steps) != 1:
+                raise L.MintimeHipError("FusedAdam: parameters of one group must share their step count")
+            t = steps.pop() + 1
+            for p in ps:
+                if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                    raise L.MintimeHipError("FusedAdam needs contiguous fp32 gradients")
+                self.state[p]["step"] = t
+            b1, b2 = group["betas"]
+            step_size = group["lr"] / (1.0 - b1 ** t)
+            bc2_sqrt = (1.0 - b2 ** t) ** 0.5
+            table, blocks = self._table(gi, ps)
+            L.check(lib.mt_adam_multi(table.data_ptr(), len(ps), blocks, float(group["lr"]), float(group["weight_decay"]), float(b1),
+                                      float(b2), float(group["eps"]), float(step_size), float(bc2_sqrt), 1 if self._decoupled else 0,
+                                      L.stream_ptr()), "mt_adam_multi")
+        return loss
+
+
+class FusedAdam(_FusedAdamBase):
+    """Drop-in for torch.optim.Adam(parameters, lr=..., weight_decay=...) (train.py:189-190): L2 term added to the gradient."""
+    _decoupled = False
+
+
+class FusedAdamW(_FusedAdamBase):
+    """Drop-in for torch.optim.AdamW(parameters, lr=..., weight_decay=...) (train.py:187-188): decoupled weight decay."""
+    _decoupled = True
+
+
 class _BCEWithLogits(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, pos_weight):

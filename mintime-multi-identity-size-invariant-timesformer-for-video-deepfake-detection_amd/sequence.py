@@ -31,7 +31,12 @@ class Identity:
 
     @property
     def mean_side(self):
-        return float(np.mean([f[1] for f in self.faces])) if self.faces else 0.0
+        """Mean crop WIDTH: the reference takes groups()[0] of libmagic's "W x H" string (deepfakes_dataset.py:113); if any
+        file of the identity fails to parse there, the whole identity's mean falls back to 0 (:114-115) -- the caller models
+        that by handing a face with width <= 0, which zeroes the mean here as well."""
+        if not self.faces or any(f[2] <= 0 for f in self.faces):
+            return 0.0
+        return float(np.mean([f[2] for f in self.faces]))
 
 
 @dataclass

@@ -136,9 +136,8 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
                     t = w.detach().t().contiguous()
                     t.record_stream(main_stream)      # allocated on the side stream, read by the main stream's data gradients
                     holder[(li, off)] = t
-        ev = side.launch(transpose_all, reads=wts)
-        if ev is not None:
-            saved["wT"], saved["wT_ready"] = holder, ev
+        if side.enabled:       # with MT_SIDE_STREAM=0 the transposes would sit on the critical path: the NN form is used instead
+            saved["wT"], saved["wT_ready"] = holder, side.launch(transpose_all, reads=wts)
     want_att = model.require_attention
     s_att = t_att = None
     xn = _new(dev, M, D)
@@ -260,7 +259,9 @@ def tsf_apply(model, x, mask, identities_mask, size_embedding, positions):
         raise ValueError(f"expected {model.num_patches} patches per slot, got {h * w}")
     grad_on = torch.is_grad_enabled()
     chains = int(os.environ.get("MT_TSF_CHAINS", "1"))
-    if chains > 1 and b >= 8 * chains and not torch.cuda.is_current_stream_capturing():
+    # single-GPU experiment knob: a data-parallel reducer counts ONE grads_ready call per network and step (ddp.py), which the
+    # chains would fire once each -- with a reducer installed the clips stay in one chain
+    if chains > 1 and b >= 8 * chains and not torch.cuda.is_current_stream_capturing()             and getattr(model, "_grads_ready_hook", None) is None:
         # Clips are independent inside the TimeSformer (no BatchNorm): run `chains` groups of clips as concurrent launch
         # sequences on their own streams.  One sequence leaves the matrix cores idle during its LayerNorm / attention / epilogue
         # phases and the tile tails; a second one fills them (measured in-step: two co-running kernels each stretch ~1.4x, not 2x).

@@ -281,7 +281,10 @@ def tsf_forward(sd: Dict[str, torch.Tensor], cfg: dict, x: torch.Tensor, mask: t
     tok = F.linear(x, sd["to_patch_embedding.weight"], sd["to_patch_embedding.bias"])   # :228
     cls = sd["cls_token"].unsqueeze(0).expand(b, -1, -1)                    # :231
     x = torch.cat((cls, tok), dim=1)                                        # :232
-    x = x + F.embedding(positions, sd["pos_emb.weight"])                    # :235-236
+    if m.get("enable-pos-emb", True):
+        x = x + F.embedding(positions, sd["pos_emb.weight"])                # :235-236
+    else:
+        x = x + F.embedding(torch.arange(x.shape[1]), sd["pos_emb.weight"])  # :237-238 (token index, clips share it)
     if m["enable-size-emb"]:                                                # :241-248
         se = size_embedding.to(x.device).repeat_interleave(n, dim=1)
         se = torch.cat((torch.zeros(b, 1, dtype=se.dtype), se), dim=1).int()

@@ -306,6 +306,35 @@ def test_native_bce_and_fused_sgd_match_torch():
         assert_close(pg.detach(), pr.detach(), 1e-6, "parameters after 3 SGD steps")
 
 
+@pytest.mark.parametrize("kind", ["adam", "adamw"])
+def test_fused_adam_and_adamw_match_torch(kind):
+    """train.py:187-190: the AdamW / Adam branches of the YAML's `optimizer` key as one multi-tensor launch, against torch's own
+    optimizers over awkward tensors (scalar, odd, unaligned), several steps, an lr schedule, and a state_dict round trip."""
+    from mintime_amd import optim
+    g = torch.Generator().manual_seed(11)
+    sizes = [(1,), (3, 5), (4097,), (128, 64), (2, 3, 3, 3), (100003,)]
+    ps_ref = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in sizes]
+    ps_gpu = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ps_ref]
+    T, F_ = (torch.optim.AdamW, optim.FusedAdamW) if kind == "adamw" else (torch.optim.Adam, optim.FusedAdam)
+    o_ref, o_gpu = T(ps_ref, lr=0.01, weight_decay=1e-2), F_(ps_gpu, lr=0.01, weight_decay=1e-2)
+    s_ref = torch.optim.lr_scheduler.StepLR(o_ref, step_size=2, gamma=0.5)
+    for step in range(5):
+        for pr, pg in zip(ps_ref, ps_gpu):
+            gr = torch.randn(pr.shape, generator=g) * (10.0 ** (step - 2))       # gradient scales over 5 decades
+            pr.grad, pg.grad = gr.clone(), gr.clone().cuda()
+        o_ref.step(); o_gpu.step(); s_ref.step()
+        if step == 2:                                                           # checkpoint / resume keeps the moments
+            o_new = F_(ps_gpu, lr=0.01, weight_decay=1e-2)
+            o_new.load_state_dict(o_gpu.state_dict())
+            o_gpu = o_new
+        o_gpu.param_groups[0]["lr"] = o_ref.param_groups[0]["lr"]              # lr is read from the group at every step
+    for pr, pg in zip(ps_ref, ps_gpu):
+        assert_close(pg.detach(), pr.detach(), 2e-6, f"parameters after 5 {kind} steps")
+        assert_close(o_gpu.state[pg]["exp_avg_sq"], o_ref.state[pr]["exp_avg_sq"], 2e-6, "second moment")
+    # the default weight decay differs between the two, like torch's
+    assert F_(ps_gpu).defaults["weight_decay"] == T(ps_ref).defaults["weight_decay"]
+
+
 _DP2_SCRIPT = r"""
 import os, sys, json, torch, torch.distributed as dist
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -410,3 +439,87 @@ def test_nn_dataparallel_wrap_on_one_gpu_is_transparent():
     for k, p in list(tsf1.named_parameters()) + list(ef1.named_parameters()):
         if p.grad is not None and not k.endswith("_bn2.bias"):                      # _bn2.bias: analytically zero, noise only
             assert_close(p.grad, g0[k], 2e-4, "grad through DataParallel " + k)      # atomics order only
+
+
+def _apply_unfreeze_rule(named_params, unfreeze_blocks):
+    """train.py:157-170: with --extractor_unfreeze_blocks k > -1 only MBConv blocks >= 16 - k stay trainable; the stem, the head
+    conv and every other block get requires_grad = False (the extractor itself stays in train() mode)."""
+    for name, p in named_params:
+        if "blocks" in name:
+            p.requires_grad_(int(name.split(".")[1]) >= 16 - unfreeze_blocks)
+        else:
+            p.requires_grad_(False)
+
+
+@pytest.mark.parametrize("unfreeze", [3, 0])
+def test_partially_frozen_extractor_matches_oracle_and_skips_frozen_work(unfreeze):
+    """Frozen parameters get NO gradient (None, like torch autograd), the trainable ones match the oracle, and the reverse
+    walk neither launches a frozen weight gradient nor descends below the lowest trainable block."""
+    from mintime_amd import effnet_backward as EB
+    seed, B, Fr = 5, 1, 8
+    cfg, ef, tsf, ef_sd, tsf_sd = _models(seed, Fr, True, require_attention=False)
+    _apply_unfreeze_rule(ef.named_parameters(), unfreeze)
+    inp = synth.clip_inputs(B, Fr, 2, seed)
+    EB.LAST_RUN.update(blocks_run=-1, wgrad_launches=-1, stem_run=None)
+    _, y = _step(ef, tsf, inp, require_attention=False)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(y.cpu(), inp["labels"].reshape(-1, 1))
+    loss.backward()
+    eo = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in ef_sd.items()}
+    for k, v in eo.items():
+        if v.is_floating_point() and "running_" not in k and not k.startswith("_fc"):
+            v.requires_grad_(True)
+    _apply_unfreeze_rule([(k, v) for k, v in eo.items() if v.is_floating_point() and "running_" not in k and "num_batches" not in k], unfreeze)
+    to = {k: v.double().requires_grad_(True) for k, v in tsf_sd.items()}
+    inp64 = dict(inp)
+    inp64["videos"] = inp["videos"].double()
+    yo = O.clip_forward(eo, to, cfg, inp64, training_extractor=True)
+    O.bce_with_logits(yo, inp["labels"]).backward()
+    assert_close(y, yo, REL_TOL, "logits")
+    n_train = 0
+    for k, p in ef.named_parameters():
+        if k.startswith("_fc"):
+            continue
+        if not p.requires_grad:
+            assert p.grad is None and eo[k].grad is None, k
+            continue
+        n_train += 1
+        if k.endswith("_bn2.bias"):
+            continue                       # analytically zero under train-mode BN (see test_effnet_backward_all_parameters_vs_oracle)
+        assert_close(p.grad, eo[k].grad, 3 * REL_TOL, "grad " + k)
+    for k, p in tsf.named_parameters():
+        if float(to[k].grad.abs().max()) > 0:
+            assert_close(p.grad, to[k].grad, 3 * REL_TOL, "tsf grad " + k)
+    if unfreeze == 0:
+        # nothing in the extractor is trainable: its backward never runs, the TimeSformer skips the feature gradient
+        assert n_train == 0 and EB.LAST_RUN["blocks_run"] == -1
+    else:
+        assert EB.LAST_RUN["blocks_run"] == unfreeze and EB.LAST_RUN["stem_run"] is False
+        # per trainable block: expand, depthwise, squeeze-excite (one launch for its four tensors), project; the frozen head conv: none
+        assert EB.LAST_RUN["wgrad_launches"] == 4 * unfreeze
+
+
+def test_frozen_backbone_step_like_train_py():
+    """--freeze_backbone (train.py:153-155,344-346,180-181): extractor in eval() under no_grad, only the TimeSformer trains."""
+    seed, B, Fr = 6, 2, 8
+    cfg, ef, tsf, ef_sd, tsf_sd = _models(seed, Fr, False, require_attention=False)
+    inp = synth.clip_inputs(B, Fr, 2, seed)
+    videos = inp["videos"].reshape(B * Fr, 224, 224, 3).permute(0, 3, 1, 2).cuda()
+    with torch.no_grad():
+        features = ef(videos)
+    assert not features.requires_grad
+    features = features.reshape(B, Fr, *features.shape[1:])
+    y = tsf(features, mask=inp["mask"].cuda(), size_embedding=inp["size_embedding"], identities_mask=inp["identities_mask"].cuda(),
+            positions=inp["positions"].cuda())
+    torch.nn.functional.binary_cross_entropy_with_logits(y.cpu(), inp["labels"].reshape(-1, 1)).backward()
+    assert all(p.grad is None for p in ef.parameters())
+    eo = {k: v.clone() for k, v in ef_sd.items()}
+    to = {k: v.clone().requires_grad_(True) for k, v in tsf_sd.items()}
+    with torch.no_grad():
+        fo = O.effnet_b0_forward(eo, inp["videos"].reshape(B * Fr, 224, 224, 3).permute(0, 3, 1, 2), training=False)
+    yo = O.tsf_forward(to, cfg, fo.reshape(B, Fr, *fo.shape[1:]), inp["mask"], inp["identities_mask"], inp["size_embedding"], inp["positions"])
+    yo = yo[0] if isinstance(yo, tuple) else yo
+    O.bce_with_logits(yo, inp["labels"]).backward()
+    assert_close(y, yo, REL_TOL, "logits")
+    for k, p in tsf.named_parameters():
+        if float(to[k].grad.abs().max()) > 0:
+            assert_close(p.grad, to[k].grad, 3 * REL_TOL, "tsf grad " + k)

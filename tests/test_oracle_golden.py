@@ -18,6 +18,8 @@ ORACLE_TOL = 2e-5   # oracle vs reference: same fp32 op sequence, only reduction
 def _tsf_run(g, taps=None, grad=False):
     B, Fr, C = int(g["batch"]), int(g["frames"]), int(g["channels"])
     cfg = arch.default_tsf_config(C, Fr)
+    if "pos_emb" in g.files:        # the embedding switches of size_invariant_timesformer.py:235-248
+        cfg["model"]["enable-pos-emb"], cfg["model"]["enable-size-emb"] = bool(g["pos_emb"]), bool(g["size_emb"])
     sd = synth.tsf_state(cfg, int(g["seed"]))
     feats = synth.features(B, Fr, C, int(g["seed"]))
     aux = synth.clip_inputs(B, Fr, int(g["identities"]), int(g["seed"]), ragged=bool(g["ragged"]), with_video=False)
@@ -30,7 +32,7 @@ def _tsf_run(g, taps=None, grad=False):
     return sd, feats, aux, out, att
 
 
-@pytest.mark.parametrize("name", ["tsf_cfg1", "tsf_2id_ragged", "tsf_xs_3id"])
+@pytest.mark.parametrize("name", ["tsf_cfg1", "tsf_2id_ragged", "tsf_xs_3id", "tsf_nopos", "tsf_nosize"])
 def test_tsf_forward_matches_reference(name):
     g = golden(name)
     taps = {}
@@ -51,7 +53,7 @@ def test_tsf_forward_matches_reference(name):
         assert float(torch.as_tensor(g["time_att"])[~cm].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("name", ["tsf_cfg1", "tsf_2id_ragged"])
+@pytest.mark.parametrize("name", ["tsf_cfg1", "tsf_2id_ragged", "tsf_nopos", "tsf_nosize"])
 def test_tsf_backward_matches_reference(name):
     g = golden(name)
     sd, feats, aux, out, _ = _tsf_run(g, grad=True)
@@ -62,9 +64,13 @@ def test_tsf_backward_matches_reference(name):
         if k.startswith("gnorm."):
             key = k[len("gnorm."):]
             assert_close(sd[key].grad.norm(), g[k], 1e-4, k)
-            assert_close(sd[key].grad.reshape(-1)[:256], g["gslice." + key], 1e-4, "gslice." + key)
+            if "gslice." + key in g.files:
+                assert_close(sd[key].grad.reshape(-1)[:256], g["gslice." + key], 1e-4, "gslice." + key)
     assert_close(sd["pos_emb.weight"].grad[:8], g["gslice.pos_emb.rows"], 1e-4, "pos_emb grad rows")
-    assert_close(sd["size_emb.weight"].grad[:21], g["gslice.size_emb.rows"], 1e-4, "size_emb grad rows")
+    if "gslice.size_emb.rows" in g.files:
+        assert_close(sd["size_emb.weight"].grad[:21], g["gslice.size_emb.rows"], 1e-4, "size_emb grad rows")
+    else:
+        assert "size_emb.weight" not in sd                       # enable-size-emb False: the table does not exist (:179-180)
     assert_close(feats.grad.norm(), g["dfeats_norm"], 1e-4, "dfeats norm")
 
 

@@ -128,3 +128,20 @@ def test_built_inputs_drive_the_model():
         yo = O.tsf_forward(sd, cfg, feats, out["mask"].cpu(), out["identities_mask"].cpu(), out["size_embedding"],
                            out["positions"].cpu())
     assert float((y.cpu() - yo).abs().max()) <= 1e-3 * float(yo.abs().max())
+
+
+def test_ordering_by_face_size_uses_the_crop_width_and_the_all_or_nothing_fallback():
+    """identities_ordering = 0 (deepfakes_dataset.py:113,142-143): identities sort by the mean of groups()[0] of libmagic's
+    "W x H" string, i.e. the crop WIDTH, and an identity with any unparsable file counts as 0.  Hand-derived (python-magic is
+    not installed here and may not be faked, so this rule is restated, not pinned): faces are (frame, height, width)."""
+    tall = S.Identity("tall", [(0, 300, 100), (3, 300, 100)])          # mean width 100, mean height 300
+    wide = S.Identity("wide", [(0, 120, 200), (3, 120, 200)])          # mean width 200, mean height 120
+    assert tall.mean_side == 100.0 and wide.mean_side == 200.0
+    plan = S.plan_clip([tall, wide], 8, (1280, 720), max_identities=2, ordering=0)
+    assert [i.name for i in plan.identities] == ["wide", "tall"]      # by width; by height the order would be the opposite
+    plan = S.plan_clip([tall, wide], 8, (1280, 720), max_identities=1, ordering=0)
+    assert [i.name for i in plan.identities] == ["wide"]              # ... and truncation follows that order
+    broken = S.Identity("broken", [(0, 500, 500), (3, 500, -1)])       # one file failed to parse -> the whole identity is 0
+    assert broken.mean_side == 0.0
+    plan = S.plan_clip([broken, tall], 8, (1280, 720), max_identities=2, ordering=0)
+    assert [i.name for i in plan.identities] == ["tall", "broken"]

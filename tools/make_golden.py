@@ -103,8 +103,9 @@ def build_tsf(TSF, cfg, seed, require_attention, dtype=torch.float32):
     return model.to(dtype), sd
 
 
-def tsf_case(TSF, name, batch, frames, channels, identities, ragged, seed):
+def tsf_case(TSF, name, batch, frames, channels, identities, ragged, seed, pos_emb=True, size_emb=True):
     cfg = arch.default_tsf_config(channels=channels, num_frames=frames)
+    cfg["model"]["enable-pos-emb"], cfg["model"]["enable-size-emb"] = pos_emb, size_emb   # size_invariant_timesformer.py:235-248
     model, sd = build_tsf(TSF, cfg, seed, True)
     feats = synth.features(batch, frames, channels, seed)
     aux = synth.clip_inputs(batch, frames, identities, seed, ragged=ragged, with_video=False)
@@ -138,13 +139,16 @@ def tsf_case(TSF, name, batch, frames, channels, identities, ragged, seed):
         grads["gslice." + key] = g.reshape(-1)[:256].clone()
     # live rows of the embedding tables
     grads["gslice.pos_emb.rows"] = named["pos_emb.weight"].grad[:8].clone()
-    grads["gslice.size_emb.rows"] = named["size_emb.weight"].grad[:21].clone()
+    if size_emb:
+        grads["gslice.size_emb.rows"] = named["size_emb.weight"].grad[:21].clone()
+    if not pos_emb:                      # arange positions: every row 0..N-1 of the table is live
+        grads["gnorm.pos_emb.weight"] = named["pos_emb.weight"].grad.norm()
     save(name, logits=logits, logits64=logits64, space_att=s_att, time_att=t_att,
          cls_rows=torch.stack(rows), tokens_head=tok[0][:, :60].clone(), tokens_sum=checksum(tok[0]),
          feats_sum=checksum(feats), loss=loss.detach(), dfeats_norm=feats_g.grad.norm(),
          dfeats_slice=feats_g.grad.permute(0, 1, 3, 4, 2).reshape(-1)[:512].clone(),
          batch=batch, frames=frames, channels=channels, identities=identities, ragged=int(ragged), seed=seed,
-         **grads)
+         pos_emb=int(pos_emb), size_emb=int(size_emb), **grads)
 
 
 GRAD_KEYS_TSF = ["cls_token", "to_patch_embedding.weight", "to_patch_embedding.bias",
@@ -380,7 +384,10 @@ def main():
         agg_case("agg_att")
     if only in ("", "slots"):
         slots_case("slots")
-    if only in ("dc", "agg", "slots"):
+    if only in ("", "switch"):
+        tsf_case(TSF, "tsf_nopos", batch=2, frames=8, channels=1280, identities=2, ragged=True, seed=3, pos_emb=False, size_emb=True)
+        tsf_case(TSF, "tsf_nosize", batch=2, frames=8, channels=1280, identities=2, ragged=True, seed=4, pos_emb=True, size_emb=False)
+    if only in ("dc", "agg", "slots", "switch"):
         return
     from models.xception import xception as _xc
     man["xception"] = [[k, list(v.shape), str(v.dtype)] for k, v in _xc(num_classes=1).state_dict().items()]
