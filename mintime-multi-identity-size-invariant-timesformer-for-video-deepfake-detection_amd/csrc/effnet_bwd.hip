@@ -186,13 +186,18 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ K4: SE adjoint per image
+// W2 [C][CS] is walked by COLUMN here (dh[j] = sum_c dp2[c] W2[c][j]): straight from global that is one cache line per lane and
+// instruction (77 us at C = 1152).  128-channel slabs are copied coalesced into LDS ([128][CS+1], odd pitch) and read from there.
+constexpr int SE_SLAB = 128;
+constexpr int SE_JW = 12;            // CS_MAX / 4 squeeze channels per wavefront
 __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
                                                      const float* __restrict__ hidden, const float* __restrict__ w1,
                                                      const float* __restrict__ w2, float* __restrict__ dpre2,
                                                      float* __restrict__ dhid, float* __restrict__ dpooled, int C, int CS) {
-  extern __shared__ float sm[];     // dp2[C] + dh[CS]
+  extern __shared__ float sm[];     // dp2[C] + dh[CS] + slab[SE_SLAB][CS+1]
   float* dp2 = sm;
   float* dh = sm + C;
+  float* slab = dh + CS;
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = tid; c < C; c += 256) {
     const float g = gate[(int64_t)n * C + c];
@@ -200,13 +205,36 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ d
     dp2[c] = v;
     dpre2[(int64_t)n * C + c] = v;
   }
-  __syncthreads();
-  for (int j = wave; j < CS; j += 4) {
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a = fmaf(dp2[c], w2[(int64_t)c * CS + j], a);
+  const int pitch = CS + 1;
+  const float inv_cs = 1.0f / (float)CS;
+  float aj[SE_JW];
+#pragma unroll
+  for (int q = 0; q < SE_JW; ++q) aj[q] = 0.f;
+  for (int c0 = 0; c0 < C; c0 += SE_SLAB) {
+    const int rows = min(SE_SLAB, C - c0);
+    __syncthreads();                 // dp2 complete (first pass) / previous slab consumed
+    for (int e = tid; e < rows * CS; e += 256) {
+      const int r = (int)(((float)e + 0.5f) * inv_cs);          // e / CS, exact for e < 2^16
+      slab[r * pitch + (e - r * CS)] = w2[(int64_t)c0 * CS + e];
+    }
+    __syncthreads();
+    const float d0 = lane < rows ? dp2[c0 + lane] : 0.f, d1 = lane + 64 < rows ? dp2[c0 + lane + 64] : 0.f;
+#pragma unroll
+    for (int q = 0; q < SE_JW; ++q) {
+      const int j = wave + 4 * q;
+      if (j < CS) {                  // rows past a partial slab hold stale LDS (possibly NaN): select, do not multiply by zero
+        const float w0 = lane < rows ? slab[lane * pitch + j] : 0.f, w1v = lane + 64 < rows ? slab[(lane + 64) * pitch + j] : 0.f;
+        aj[q] = fmaf(d0, w0, fmaf(d1, w1v, aj[q]));
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < SE_JW; ++q) {
+    const int j = wave + 4 * q;
+    float a = aj[q];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    if (lane == 0) {
+    if (lane == 0 && j < CS) {
       const float v = a * dswishf_(hidden[(int64_t)n * CS + j]);
       dh[j] = v;
       dhid[(int64_t)n * CS + j] = v;
@@ -759,7 +787,7 @@ extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, co
                      scale, shift, dgate, HW, C, CQB, PB);
   rc = check_launch("mt_se_bwd(reduce)");
   if (rc) return rc;
-  hipLaunchKernelGGL(se_bwd_kernel, dim3(N), dim3(256), (size_t)(C + CS) * sizeof(float), s, dgate, gate, hidden, w1, w2, dpre2, dhid,
+  hipLaunchKernelGGL(se_bwd_kernel, dim3(N), dim3(256), (size_t)(C + CS + SE_SLAB * (CS + 1)) * sizeof(float), s, dgate, gate, hidden, w1, w2, dpre2, dhid,
                      dpooled, C, CS);
   rc = check_launch("mt_se_bwd(image)");
   if (rc) return rc;

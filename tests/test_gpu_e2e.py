@@ -267,6 +267,70 @@ def test_config5_xception_timesformer_step_vs_oracle():
         assert e <= 2e-2, f"grad {k}: relative L2 error {e:.3e}"      # ReLU/max-pool mask flips: see test_gpu_xception.py
 
 
+def test_config5_train_mode_step_vs_fp64_oracle():
+    """BASELINE config 5 the way bench.py --config 5 times it, at a size the fp64 oracle finishes on the host: 4 clips x 16 slots
+    x 3 identities [7,5,4] (64 crops), TRAIN-mode BatchNorm in the Xception extractor (batch statistics in all 40 BN layers,
+    running stats updated), BCE loss, backward through both networks.  Judged against the oracle in float64."""
+    import time
+    from mintime_amd import xception
+    B, F, seed = 4, 16, 6
+    cfg = arch.default_tsf_config(2048, F)
+    xc_sd, tsf_sd = synth.xception_state(seed), synth.tsf_state(cfg, seed)
+    xc = xception(num_classes=1, pretrain_path=None)
+    xc.load_state_dict(xc_sd)
+    xc.cuda().train()
+    tsf = SizeInvariantTimeSformer(config=cfg, require_attention=False)
+    tsf.load_state_dict(tsf_sd)
+    tsf.cuda().train()
+    inp = synth.clip_inputs(B, F, 3, seed, ragged=False)
+    feats, out = _step(xc, tsf, inp, require_attention=False)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out, inp["labels"].reshape(-1, 1).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+
+    t0 = time.time()
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    vid = inp["videos"].reshape(B * F, 224, 224, 3).permute(0, 3, 1, 2).double()
+    o_xc = {k: (t.double().requires_grad_("running_" not in k) if t.is_floating_point() else t.clone()) for k, t in xc_sd.items()}
+    o_tsf = {k: t.double().requires_grad_(True) for k, t in tsf_sd.items()}
+    ofeat = O.xception_forward(o_xc, vid, training=True)
+    ologits = O.tsf_forward(o_tsf, cfg, ofeat.reshape(B, F, 2048, 7, 7), inp["mask"], inp["identities_mask"], inp["size_embedding"],
+                            inp["positions"])
+    oloss = O.bce_with_logits(ologits, inp["labels"])
+    oloss.backward()
+    print(f"oracle fp64 config-5 step (64 crops) on the host: {time.time() - t0:.1f} s")
+
+    assert_close(feats.reshape(B * F, 2048, 7, 7), ofeat.detach(), REL_TOL, "Xception features (train-mode BN)")
+    assert_close(out, ologits.detach(), REL_TOL, "logits")          # per tensor: max|d| <= 1e-3 max|ref| (north_star)
+    # (no per-element gate here: one logit of this batch is 0.048, and behind 36 ReLU / 5 max-pool layers in train mode a handful of
+    # rounding-level mask flips move it by 1e-4 absolute -- the reference's own fp32 run is as far from its fp64 run)
+    assert abs(float(loss.detach()) - float(oloss.detach())) <= 1e-4 * max(1.0, abs(float(oloss.detach())))
+    worst = 0.0
+    for k, p in tsf.named_parameters():
+        ref = o_tsf[k].grad
+        if float(ref.abs().max()) == 0.0:
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        worst = max(worst, assert_close(p.grad, ref, 3 * REL_TOL, "grad " + k))
+    print("config 5 train step: worst TimeSformer gradient error", worst)
+    xc_named = dict(xc.named_parameters())
+    errs = {}
+    for k in ("conv4.pointwise.weight", "bn4.weight", "conv3.pointwise.weight", "block12.rep.4.pointwise.weight", "block12.skip.weight",
+              "block6.rep.1.conv1.weight", "block6.rep.4.pointwise.weight", "block3.rep.1.pointwise.weight", "block1.skip.weight",
+              "conv2.weight", "conv1.weight"):
+        got, ref = xc_named[k].grad, o_xc[k].grad
+        errs[k] = float((got.cpu().double() - ref).norm() / ref.norm().clamp_min(1e-30))
+    print("config 5 train step: Xception gradient rel-L2 errors", {k: f"{v:.2e}" for k, v in errs.items()})
+    # the tail of the extractor sits behind no ReLU / max-pool decision that fp32 rounding could flip: tight; further up the flips of
+    # test_oracle_golden.py::test_xception_fp32_rounding_flips_relu_and_maxpool_decisions set the floor (the reference's own
+    # fp32 run is this far from its fp64 run)
+    for k in ("conv4.pointwise.weight", "bn4.weight"):
+        assert errs[k] <= 3 * REL_TOL, (k, errs[k])
+    assert max(errs.values()) <= 2e-2, errs
+    # running statistics moved (momentum 0.1, torch defaults of models/xception.py) and the counters were bumped
+    assert int(dict(xc.named_buffers())["bn1.num_batches_tracked"]) == 1
+
+
 def test_native_bce_and_fused_sgd_match_torch():
     """Next-row f4: mt_bce_logits (value + gradient) against torch's BCEWithLogitsLoss(pos_weight) and the one-launch
     multi-tensor SGD against torch.optim.SGD(lr, weight_decay) over tensors of awkward sizes (scalar, odd, unaligned views)."""
