@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 100
+#define MT_VERSION 101
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -44,7 +44,14 @@ enum { MT_PRO_NONE = 0, MT_PRO_BN_SWISH_GATE = 1, MT_PRO_BN_SWISH = 2, MT_PRO_AF
                                 dense k x k / strided 1x1 convolution as a GEMM with M = N*Ho*Wo, K = k*k*C (padded to %4) */  /* A := ka[c]*A + kb[c]*A2 + kc[c]  (BatchNorm backward folded into the load; ka,kb,kc = scale,shift,gate) */
 enum { MT_BPRO_NONE = 0, MT_BPRO_BN_SWISH_GATE = 1, MT_BPRO_IM2COL = 2 };  /* TN only: B := swish(B*b_scale[n]+b_shift[n]) * b_gate[(k/b_hw)*N+n] */
 enum { MT_EPI_STORE = 0, MT_EPI_BIAS_RES = 1, MT_EPI_GEGLU = 2, MT_EPI_STATS = 3, MT_EPI_ATOMIC = 4,
-       MT_EPI_GEGLU_BWD = 5, MT_EPI_ACCUM = 6 };
+       MT_EPI_GEGLU_BWD = 5, MT_EPI_ACCUM = 6,
+       /* MBConv backward around the squeeze-excite stage (autograd of efficientnet_pytorch/model.py:108-117), NN + BN_BWD only.
+          The GEMM result da = dz_p . W_project is consumed in the accumulators and never stored; C2 = the depthwise conv's raw
+          output z_d [M,N], u = z_d*e_scale[n] + e_shift[n], img = m / e_hw:
+            SE_RED:  C[img,n] += sum_rows da * swish(u)                    (d gate, fp32 atomics, C [M/e_hw, N] zero-filled)
+            ACT_BWD: C[m,n] = (da*e_gate[img,n] + e_dpool[img,n]/e_hw) * swish'(u)   and the BatchNorm-backward sums of it:
+                     stats[..][0][n] += C, stats[..][1][n] += C * (z_d - e_mi[n]) * e_mi[N+n]                              */
+       MT_EPI_SE_RED = 7, MT_EPI_ACT_BWD = 8 };
 
 typedef struct {
   int op, prologue, epilogue;
@@ -70,6 +77,9 @@ typedef struct {
                                        ldb).  The split-operand loop then streams B by DMA instead of splitting it per tile;
                                        every other path ignores the field and reads B.  B must still be valid.             */
   int64_t b_plane_stride;           /* elements between planes */
+  const float* e_scale; const float* e_shift;   /* SE_RED / ACT_BWD: BatchNorm affine of z_d [N]                            */
+  const float* e_gate; const float* e_dpool;    /* ACT_BWD: squeeze-excite gate and pooled-gradient rows [M/e_hw, N]         */
+  const float* e_mi; int e_hw;                  /* ACT_BWD: mean | invstd [2][N]; rows per image                             */
 } mt_gemm_desc;
 
 int mt_gemm(const mt_gemm_desc* d, void* stream);

@@ -770,8 +770,10 @@ extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, co
                          const float* hidden, const float* pooled, const float* w1, const float* w2, float* dgate,
                          float* dpre2, float* dhid, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, int N,
                          int HW, int C, int CS, int parts_mask, void* stream) {
-  if (!da || !z || !scale || !shift || !gate || !hidden || !pooled || !w1 || !w2 || !dgate || !dpre2 || !dhid || !dpooled ||
-      !dw1 || !db1 || !dw2 || !db2)
+  // parts_mask: 1 = d-gate reduction over da, z + per-image adjoint; 2 = weight gradients; 4 = per-image adjoint only (dgate was
+  // already reduced by mt_gemm's MT_EPI_SE_RED epilogue; da / z / scale / shift are not read)
+  if (((parts_mask & 1) && (!da || !z || !scale || !shift)) || !gate || !hidden || !pooled || !w1 || !w2 || !dgate || !dpre2 || !dhid ||
+      !dpooled || !dw1 || !db1 || !dw2 || !db2)
     return fail(MT_ERR_ARG, "mt_se_bwd: null pointer");
   if (C & 3) return fail(MT_ERR_ARG, "mt_se_bwd: C %% 4 != 0");
   if (CS > CS_MAX) return fail(MT_ERR_UNSUPPORTED, "mt_se_bwd: squeeze width %d > %d", CS, CS_MAX);
@@ -791,6 +793,12 @@ extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, co
                      dpooled, C, CS);
   rc = check_launch("mt_se_bwd(image)");
   if (rc) return rc;
+  }
+  if (parts_mask & 4) {
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(N), dim3(256), (size_t)(C + CS + SE_SLAB * (CS + 1)) * sizeof(float), s, dgate, gate, hidden, w1, w2, dpre2, dhid,
+                       dpooled, C, CS);
+    rc = check_launch("mt_se_bwd(image)");
+    if (rc) return rc;
   }
   if (!(parts_mask & 2)) return 0;
   const int ipb = 16;      // images per block: 8 / 16 / 32 / 64 measured 56 / 43 / 51 / 86 us (atomics vs parallelism)

@@ -87,6 +87,8 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   a.conv = {d->conv_H, d->conv_W, d->conv_C, d->conv_Ho, d->conv_Wo, d->conv_k, d->conv_stride, d->conv_pad, d->conv_act, d->conv_src_u8};
   a.col_sum = d->col_sum;
   a.b_planes = d->b_planes; a.b_pstride = d->b_plane_stride;
+  a.e_scale = d->e_scale; a.e_shift = d->e_shift; a.e_gate = d->e_gate; a.e_dpool = d->e_dpool; a.e_mi = d->e_mi;
+  a.e_hw = d->e_hw > 0 ? d->e_hw : 1;
   a.A2 = d->A2; a.b_scale = d->b_scale; a.b_shift = d->b_shift; a.b_gate = d->b_gate; a.b_hw = d->b_hw > 0 ? d->b_hw : 1;
 
   // K-contiguous operands need K % 4 == 0 (float4 along K); k-major operands need M resp. N % 4 == 0
@@ -113,6 +115,13 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
     return fail(MT_ERR_ARG, "mt_gemm: B prologue needs op TN and b_scale/b_shift/b_gate");
   if (d->b_prologue == MT_BPRO_IM2COL && d->op != MT_OP_TN) return fail(MT_ERR_ARG, "mt_gemm: im2col B prologue needs op TN");
   if (d->prologue == MT_PRO_BN_SWISH_GATE && !d->gate) return fail(MT_ERR_ARG, "mt_gemm: gate prologue needs gate");
+  if (d->epilogue == MT_EPI_SE_RED || d->epilogue == MT_EPI_ACT_BWD) {
+    if (d->op != MT_OP_NN || d->prologue != MT_PRO_BN_BWD) return fail(MT_ERR_UNSUPPORTED, "mt_gemm: SE_RED / ACT_BWD need op NN with the BN_BWD prologue");
+    if (!d->C2 || !d->e_scale || !d->e_shift || d->e_hw <= 0 || d->c_map.gin != 0)
+      return fail(MT_ERR_ARG, "mt_gemm: SE_RED / ACT_BWD need C2 (z), e_scale, e_shift, e_hw > 0 and identity output rows");
+    if (d->epilogue == MT_EPI_ACT_BWD && (!d->e_gate || !d->e_dpool || !d->e_mi || !d->stats))
+      return fail(MT_ERR_ARG, "mt_gemm: ACT_BWD needs e_gate, e_dpool, e_mi and stats");
+  }
 
   // K-contiguous operands need K % 4 == 0 etc. were checked above; plain problems take the LDS-DMA pipeline when it has an instance
   if (!g_trace) {
@@ -200,6 +209,8 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_GEGLU_BWD)
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_STORE)
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_BIAS_RES)
+  COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_SE_RED)
+  COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_ACT_BWD)
 #undef COMBO
   return fail(MT_ERR_UNSUPPORTED, "mt_gemm: unsupported op/prologue/epilogue %d/%d/%d", d->op, d->prologue, d->epilogue);
 }

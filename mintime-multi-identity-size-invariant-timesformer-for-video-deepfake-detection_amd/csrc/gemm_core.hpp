@@ -58,6 +58,11 @@ enum : int {
   EPI_ATOMIC = 4,       // C += acc (+bias on the first K-slice) via fp32 atomics (split-K); C pre-zeroed or holding the residual
   EPI_GEGLU_BWD = 5,    // acc = dh[m,j]; du[m,j] = dh*gelu(g), du[m,Nh+j] = dh*a*gelu'(g)   (a,g from u)
   EPI_ACCUM = 6,        // C = C + acc (+bias)  -- gradient accumulation into an existing tensor
+  // MBConv backward, squeeze-excite stage, with acc = da (the project conv's data gradient, never written to memory) and
+  // z = C2[m,n] the depthwise conv's raw output, u = z*e_scale[n] + e_shift[n], img = m / e_hw:
+  EPI_SE_RED = 7,       // C[img, n] += sum over the image's rows of acc * swish(u)           (d gate; fp32 atomics, C pre-zeroed)
+  EPI_ACT_BWD = 8,      // C[m,n] = du = (acc*e_gate[img,n] + e_dpool[img,n]/e_hw) * swish'(u);  BatchNorm-backward sums of du:
+                        //   stats[..][0][n] += du, stats[..][1][n] += du * (z - e_mi[n]) * e_mi[N+n]   (fp64 slots like EPI_STATS)
 };
 
 struct RowMap {   // out_row = (r / gin) * gout + off + r % gin   (gin == 0 -> identity)
@@ -144,10 +149,13 @@ struct GemmArgs {
   long long* trace;                     // tuning aid (mt_debug_gemm_trace): per block {t_start, t_prologue, t_loop, t_end, hw_id}
   float* col_sum;                       // GEGLU_BWD: optional column sums of the stored values (bias gradient), fp32 atomics
   const void* b_planes; int64_t b_pstride;   // split loop: B as three pre-split bf16 planes [N][K] (plane stride in elements), or null
+  // EPI_SE_RED / EPI_ACT_BWD (epilogue-side vectors; the prologue's scale/shift/gate are taken by PRO_BN_BWD)
+  const float* e_scale; const float* e_shift; const float* e_gate; const float* e_dpool; const float* e_mi; int e_hw;
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float dswish_gemm_(float u) { const float s = sigmoidf_(u); return s * (1.0f + u * (1.0f - s)); }
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 rounding level) -- libm's erff costs ~3x the VALU slots,
 // and the GEGLU epilogues evaluate it 64x per lane while no MFMA of that wave is in flight.
 __device__ __forceinline__ float erf_fast(float x) {
@@ -236,6 +244,75 @@ __device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&a
           hp[(int64_t)dr * p.ldc] = a * gelu_erf(g);
           // pre-activations interleaved (a_j, g_j): one 8-byte store per lane here, one 8-byte load in GEGLU_BWD
           if (up) *reinterpret_cast<float2*>(up + (int64_t)dr * p.ldc2) = make_float2(a, g);
+        }
+      }
+    }
+    return;
+  } else if constexpr (EPI == EPI_SE_RED || EPI == EPI_ACT_BWD) {
+    // A lane owns one column and 16*TM rows in increasing order, so the image index m / e_hw only ever steps forward: it is
+    // tracked incrementally (one division per lane) and per-image state (running d-gate sum / gate and pooled-gradient values)
+    // is flushed or reloaded when it changes.
+    const float inv_hw = 1.0f / (float)p.e_hw;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+      const bool nok = FAST || n < p.N;
+      const int nn = nok ? n : 0;
+      const float esc = p.e_scale[nn], esh = p.e_shift[nn];
+      float mean = 0.f, istd = 0.f;
+      if constexpr (EPI == EPI_ACT_BWD) { mean = p.e_mi[nn]; istd = p.e_mi[p.N + nn]; }
+      const int mfirst = mw + row_h;
+      int img = mfirst / p.e_hw;
+      int rem = mfirst - img * p.e_hw;
+      float run = 0.f, s1 = 0.f, s2 = 0.f, g = 0.f, dp = 0.f;
+      if constexpr (EPI == EPI_ACT_BWD) {
+        const int64_t gi = (int64_t)min(img, (p.M - 1) / p.e_hw) * p.N + nn;
+        g = p.e_gate[gi]; dp = p.e_dpool[gi] * inv_hw;
+      }
+      const float* zp = p.C2 + (int64_t)mfirst * p.ldc2 + nn;
+      float* cp = p.C + (int64_t)mfirst * p.ldc + nn;
+      int prev = 0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+          rem += dr - prev;
+          prev = dr;
+          if (rem >= p.e_hw) {                                   // next image (rows advance by at most 8 < e_hw ... or more: loop)
+            if constexpr (EPI == EPI_SE_RED) {
+              if (nok && run != 0.f) atomicAdd(p.C + (int64_t)img * p.ldc + n, run);
+              run = 0.f;
+            }
+            do { rem -= p.e_hw; ++img; } while (rem >= p.e_hw);
+            if constexpr (EPI == EPI_ACT_BWD) {
+              const int64_t gi = (int64_t)min(img, (p.M - 1) / p.e_hw) * p.N + nn;
+              g = p.e_gate[gi]; dp = p.e_dpool[gi] * inv_hw;
+            }
+          }
+          if (FAST || (mfirst + dr < p.M && nok)) {
+            const float z = zp[(int64_t)dr * p.ldc2];
+            const float u = fmaf(z, esc, esh);
+            if constexpr (EPI == EPI_SE_RED) {
+              run = fmaf(acc[i][j][r], swishf_(u), run);
+            } else {
+              const float d = fmaf(acc[i][j][r], g, dp) * dswish_gemm_(u);
+              cp[(int64_t)dr * p.ldc] = d;
+              s1 += d;
+              s2 = fmaf(d, (z - mean) * istd, s2);
+            }
+          }
+        }
+      }
+      if constexpr (EPI == EPI_SE_RED) {
+        if (nok && run != 0.f) atomicAdd(p.C + (int64_t)img * p.ldc + n, run);
+      } else {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lane < 32 && nok) {
+          double* st = p.stats + (int64_t)(blockIdx.x % p.stats_slots) * 2 * p.N;
+          atomicAdd(st + n, (double)s1);
+          atomicAdd(st + p.N + n, (double)s2);
         }
       }
     }

@@ -130,7 +130,8 @@ int try_launch_dma(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
     // fragment read, i.e. twice per element and inside each wave's MFMA stream: 115 -> 138 us on 50176x80x480): opt-in only
     const bool gate_on = getenv("MT_DMA_PRO_GATE") != nullptr;          // (read per call: tests toggle it)
     const bool gate_fwd = gate_on && d->op == MT_OP_NT && d->prologue == MT_PRO_BN_SWISH_GATE && (d->epilogue == MT_EPI_STATS || d->epilogue == MT_EPI_STORE);
-    const bool bn_bwd = d->op == MT_OP_NN && d->prologue == MT_PRO_BN_BWD && (d->epilogue == MT_EPI_STORE || d->epilogue == MT_EPI_BIAS_RES);
+    const bool bn_bwd = d->op == MT_OP_NN && d->prologue == MT_PRO_BN_BWD &&
+                        (d->epilogue == MT_EPI_STORE || d->epilogue == MT_EPI_BIAS_RES || d->epilogue == MT_EPI_SE_RED || d->epilogue == MT_EPI_ACT_BWD);
     if (!gate_fwd && !bn_bwd) return 1;
     const int vforce = getenv("MT_DMA_PRO_VARIANT") ? atoi(getenv("MT_DMA_PRO_VARIANT")) : -1;
     int v = vforce >= 0 ? vforce : ((d->K % 32) == 0 ? V_SMALL32 : V_SMALL16);
@@ -152,6 +153,8 @@ int try_launch_dma(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
       return launch_pro<LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_STORE, PRO_BN_SWISH_GATE>(v, a, grid, s);
     }
     if (d->epilogue == MT_EPI_BIAS_RES) return launch_pro<LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_BIAS_RES, PRO_BN_BWD>(v, a, grid, s);
+    if (d->epilogue == MT_EPI_SE_RED) return launch_pro<LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_SE_RED, PRO_BN_BWD>(v, a, grid, s);
+    if (d->epilogue == MT_EPI_ACT_BWD) return launch_pro<LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_ACT_BWD, PRO_BN_BWD>(v, a, grid, s);
     return launch_pro<LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_STORE, PRO_BN_BWD>(v, a, grid, s);
   }
   if (d->epilogue == MT_EPI_GEGLU && (d->n_half & 63)) return 1;

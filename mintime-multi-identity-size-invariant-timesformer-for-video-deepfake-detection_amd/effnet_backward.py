@@ -9,6 +9,13 @@ from .effnet_engine import SLOTS, STREAM_ROWS, _StatsPool
 # measured in-step: the fused pass (6.9 ms/step on the critical main stream) loses to data gradient (5.0 ms, main) + weight gradient on the
 # side stream, which has slack during the EfficientNet backward: 65.5 vs 64.1 ms/step.  Kept selectable for single-stream use.
 FUSED_DW = __import__("os").environ.get("MT_DW_FUSED", "0")      # "1": every layer, "3": the 3x3 layers only, "0": off
+# Squeeze-excite stage of the reverse walk without the project conv's data gradient `da` in memory: the GEMM  dz_p . W_project  is
+# run twice and consumed in its accumulators (MT_EPI_SE_RED: d gate; MT_EPI_ACT_BWD: du of the depthwise BatchNorm + its sums).
+# 3 passes over a block's expanded tensor (read z_d, read z_d, write du_d) instead of 6 (write da | read da, z_d | read da, z_d,
+# write du_d), two launches fewer -- and SLOWER on every block (profiles/r03_se_fused_epilogue_vs_streaming.txt: block 1
+# 406 -> 744 us, the 7x7 blocks 126 -> 193 us, step +1.3 ms): a one-tile-per-block GEMM with a load-z / swish / store epilogue
+# per lane-column runs at 1.3-3.2 TB/s where the float4 streaming kernels it replaces run at 4.5-5.5.  Parity-tested, opt-in.
+SE_FUSED = __import__("os").environ.get("MT_SE_FUSED", "0") != "0"
 
 
 def _new(dev, *shape):
@@ -75,8 +82,9 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                 "mt_bn_act_bwd")
         return sums
 
-    def conv1x1_bwd(du, z, kabc, w, x_in, rows, cout, cin, gw_idx, need_dx_in, res=None, b_pro=None):
-        """z = x_in . w^T with dz = ka*du+kb*z+kc.  Returns dx_in [rows, cin] (+res) or None."""
+    def conv1x1_bwd(du, z, kabc, w, x_in, rows, cout, cin, gw_idx, need_dx_in, res=None, b_pro=None, epi=None):
+        """z = x_in . w^T with dz = ka*du+kb*z+kc.  Returns dx_in [rows, cin] (+res) or None.
+        epi = (kind, out, kwargs): the data gradient is not stored but consumed by mt_gemm's SE_RED / ACT_BWD epilogue."""
         kw = {}
         if b_pro is not None:
             kw = dict(b_prologue=L.BPRO_BN_SWISH_GATE, b_scale=b_pro[0], b_shift=b_pro[1], b_gate=b_pro[2], b_hw=b_pro[3])
@@ -96,6 +104,11 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                                        epilogue=L.EPI_ATOMIC, split_k=0, A2=z, scale=kabc[0], shift=kabc[1], gate=kabc[2], **kw),
                         reads=reads)
         if not need_dx_in:
+            return None
+        if epi is not None:
+            for kind, out, kw2 in epi:
+                L.gemm(L.OP_NN, du, w, out, rows, cin, cout, cout, cin, cin, prologue=L.PRO_BN_BWD, epilogue=kind, A2=z,
+                       scale=kabc[0], shift=kabc[1], gate=kabc[2], **kw2)
             return None
         dx_in = _new(dev, rows, cin)
         if rows >= STREAM_ROWS and lib.mt_conv1x1_rows_supported(cout, cin, 2):
@@ -138,23 +151,41 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         dsrc = dyb if dc is not None else dy
         # (b,c) project conv: z_p = (swish(bn1(z_d))*gate) . Wp^T
         bn_d = rec["bn_d"]
-        da = conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], True,
-                         b_pro=(bn_d.scale, bn_d.shift, rec["gate"], hw))
-        # (d) squeeze-excite adjoint
+        b_pro = (bn_d.scale, bn_d.shift, rec["gate"], hw)
         dgate, dpre2, dpooled = _new(dev, N, s.cexp), _new(dev, N, s.cexp), _new(dev, N, s.cexp)
         dhid = _new(dev, N, s.cse)
         se = ix["se"]
-        def se_part(parts, _da=da, _rec=rec, _bn=bn_d, _se=se, _s=s, _dg=dgate, _dp=dpre2, _dh=dhid, _dpo=dpooled, _hw=hw):
+        def se_part(parts, _da=None, _rec=rec, _bn=bn_d, _se=se, _s=s, _dg=dgate, _dp=dpre2, _dh=dhid, _dpo=dpooled, _hw=hw):
             L.check(lib.mt_se_bwd(L.ptr(_da), L.ptr(_rec["z_d"]), L.ptr(_bn.scale), L.ptr(_bn.shift), L.ptr(_rec["gate"]),
                                   L.ptr(_rec["hidden"]), L.ptr(_rec["pooled"]), L.ptr(P[_se]), L.ptr(P[_se + 2]), L.ptr(_dg), L.ptr(_dp),
                                   L.ptr(_dh), L.ptr(_dpo), L.ptr(grads[_se]), L.ptr(grads[_se + 1]), L.ptr(grads[_se + 2]),
                                   L.ptr(grads[_se + 3]), N, _hw, _s.cexp, _s.cse, parts, L.stream_ptr()), "mt_se_bwd")
-        se_part(1)                                    # dgate -> dpooled: the data path waits for these
-        if any(need[se:se + 4]):
-            run["wgrad_launches"] += 1
-            side.launch(lambda: se_part(2), reads=(dpre2, dhid, rec["hidden"], rec["pooled"]))     # SE weight gradients: off the path
-        # (e) through swish + bn1: du_d (in place over da)
-        sums = act_bwd(da, rec["z_d"], bn_d, da, M_out, hw, 1, gate=rec["gate"], dpool=dpooled)
+        if SE_FUSED:
+            # (c+d) d gate straight from the accumulators of  dz_p . Wp  (da is never written)
+            dgate.zero_()
+            conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], True, b_pro=b_pro,
+                        epi=[(L.EPI_SE_RED, dgate, dict(C2=rec["z_d"], ldc2=s.cexp, epi=(bn_d.scale, bn_d.shift, None, None, None, hw)))])
+            se_part(4)                                # dgate -> dpooled
+            if any(need[se:se + 4]):
+                run["wgrad_launches"] += 1
+                side.launch(lambda: se_part(2), reads=(dpre2, dhid, rec["hidden"], rec["pooled"]))
+            # (c+e) the same product again, through gate / pooled gradient / swish' / bn1 sums: du_d
+            da = _new(dev, M_out, s.cexp)
+            sums = pool.take(s.cexp)
+            need_save, need[ix["p"]] = need[ix["p"]], False        # the weight gradient was launched by the first call
+            conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], True, b_pro=b_pro,
+                        epi=[(L.EPI_ACT_BWD, da, dict(C2=rec["z_d"], ldc2=s.cexp, stats=sums, stats_slots=SLOTS,
+                                                      epi=(bn_d.scale, bn_d.shift, rec["gate"], dpooled, bn_d.mean_invstd, hw)))])
+            need[ix["p"]] = need_save
+        else:
+            da = conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], True, b_pro=b_pro)
+            # (d) squeeze-excite adjoint
+            se_part(1, da)                                # dgate -> dpooled: the data path waits for these
+            if any(need[se:se + 4]):
+                run["wgrad_launches"] += 1
+                side.launch(lambda: se_part(2), reads=(dpre2, dhid, rec["hidden"], rec["pooled"]))     # SE weight gradients: off the path
+            # (e) through swish + bn1: du_d (in place over da)
+            sums = act_bwd(da, rec["z_d"], bn_d, da, M_out, hw, 1, gate=rec["gate"], dpool=dpooled)
         kabc_d = bn_finalize(bn_d, sums, ix["d"] + 1)
         # (f,g) depthwise conv adjoint -> du wrt the dw input's pre-activation (+ its BN sums)
         in_bn = rec["dw_bn"]

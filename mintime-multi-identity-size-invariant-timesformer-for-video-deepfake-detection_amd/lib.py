@@ -37,13 +37,15 @@ class GemmDesc(C.Structure):
                 ("b_gate", C.c_void_p), ("b_hw", C.c_int),
                 ("conv_H", C.c_int), ("conv_W", C.c_int), ("conv_C", C.c_int), ("conv_Ho", C.c_int), ("conv_Wo", C.c_int),
                 ("conv_k", C.c_int), ("conv_stride", C.c_int), ("conv_pad", C.c_int), ("conv_act", C.c_int), ("conv_src_u8", C.c_int),
-                ("col_sum", C.c_void_p), ("b_planes", C.c_void_p), ("b_plane_stride", C.c_int64)]
+                ("col_sum", C.c_void_p), ("b_planes", C.c_void_p), ("b_plane_stride", C.c_int64),
+                ("e_scale", C.c_void_p), ("e_shift", C.c_void_p), ("e_gate", C.c_void_p), ("e_dpool", C.c_void_p),
+                ("e_mi", C.c_void_p), ("e_hw", C.c_int)]
 
 
 OP_NT, OP_NN, OP_TN = 0, 1, 2
 PRO_NONE, PRO_BN_SWISH_GATE, PRO_BN_SWISH, PRO_AFFINE, PRO_BN_BWD, PRO_IM2COL = 0, 1, 2, 3, 4, 5
 BPRO_NONE, BPRO_BN_SWISH_GATE, BPRO_IM2COL = 0, 1, 2
-EPI_STORE, EPI_BIAS_RES, EPI_GEGLU, EPI_STATS, EPI_ATOMIC, EPI_GEGLU_BWD, EPI_ACCUM = 0, 1, 2, 3, 4, 5, 6
+EPI_STORE, EPI_BIAS_RES, EPI_GEGLU, EPI_STATS, EPI_ATOMIC, EPI_GEGLU_BWD, EPI_ACCUM, EPI_SE_RED, EPI_ACT_BWD = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 # name -> argtypes (restype is always int unless listed in _RESTYPES); mirrors include/mintime_hip.h
 PROTOTYPES = {
@@ -134,8 +136,8 @@ def get():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     v = lib.mt_version()
-    if v != 100:
-        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 100; rebuild it")
+    if v != 101:
+        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 101; rebuild it")
     _lib = lib
     return lib
 
@@ -204,7 +206,7 @@ def timed(name, fn, work=0.0):
 def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI_STORE, bias=None, R=None, ldr=0,
          scale=None, shift=None, gate=None, hw=1, C2=None, ldc2=0, stats=None, stats_slots=1, n_half=0, split_k=1,
          a_map=(0, 0, 0), b_map=(0, 0, 0), c_map=(0, 0, 0), A2=None, b_prologue=BPRO_NONE, b_scale=None, b_shift=None,
-         b_gate=None, b_hw=1, conv=None, col_sum=None, b_planes=None):
+         b_gate=None, b_hw=1, conv=None, col_sum=None, b_planes=None, epi=None):
     d = GemmDesc()
     d.op, d.prologue, d.epilogue = op, prologue, epilogue
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
@@ -219,6 +221,9 @@ def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI
     d.col_sum = ptr(col_sum)
     if b_planes is not None:             # bf16 [3, N, K] from split_planes(B)
         d.b_planes, d.b_plane_stride = ptr(b_planes), b_planes[0].numel()
+    if epi is not None:    # SE_RED / ACT_BWD: (e_scale, e_shift, e_gate, e_dpool, e_mi, e_hw)
+        d.e_scale, d.e_shift, d.e_gate, d.e_dpool, d.e_mi, d.e_hw = (ptr(epi[0]), ptr(epi[1]), ptr(epi[2]), ptr(epi[3]),
+                                                                      ptr(epi[4]), epi[5])
     if conv is not None:   # (H, W, C, Ho, Wo, k, stride, pad, act[, src_u8])
         (d.conv_H, d.conv_W, d.conv_C, d.conv_Ho, d.conv_Wo, d.conv_k, d.conv_stride, d.conv_pad, d.conv_act) = conv[:9]
         d.conv_src_u8 = conv[9] if len(conv) > 9 else 0
