@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 101
+#define MT_VERSION 102
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -157,7 +157,7 @@ int mt_se_pool_fwd(const float* z, const float* scale, const float* shift, float
 
 /* excite: pooled = sum of the slices (written to `pooled` [N,C] when not NULL: kept for backward);
  * gate = sigmoid(_se_expand(swish(_se_reduce(pooled)))) (model.py:109-112). w1 [CS,C], w2 [C,CS];
- * hidden (optional) [N,CS] receives the pre-activation of the squeeze layer (kept for backward). */
+ * hidden [N,CS] (required: the hand-over between the kernel pair) receives the pre-activation of the squeeze layer, which backward keeps. */
 int mt_se_gate_fwd(const float* partial, int parts, const float* w1, const float* b1, const float* w2, const float* b2,
                    float* pooled, float* gate, float* hidden, int N, int C, int CS, void* stream);
 
@@ -236,11 +236,14 @@ int mt_bn_bwd_finalize(const double* stats, int slots, double count, const float
 /* Squeeze-excite adjoint (model.py:104-113): from da = d(gated tensor) computes dgate, the two 1x1-conv weight/bias
  * grads (accumulated) and dpooled [N,C] (the pooling path's contribution to d(activated tensor)).
  * parts & 1: the reduction and the per-image adjoint (dgate, dpre2, dhid, dpooled -- what the data path waits for);
- * parts & 2: the weight / bias gradients from dpre2, dhid (independent of the data path: may run on another stream). */
+ * parts & 2: the weight / bias gradients from dpre2, dhid (independent of the data path: may run on another stream);
+ * parts & 4: the per-image adjoint only (dgate given, e.g. reduced by mt_gemm's MT_EPI_SE_RED; da / z / scale / shift unused).
+ * scratch (parts & 5): mt_se_scratch_floats(N, C, CS) floats of workspace (per-slab partial sums of the squeeze gradient). */
+int mt_se_scratch_floats(int N, int C, int CS);
 int mt_se_bwd(const float* da, const float* z, const float* scale, const float* shift, const float* gate,
               const float* hidden, const float* pooled, const float* w1, const float* w2, float* dgate,
               float* dpre2, float* dhid, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, int N,
-              int HW, int C, int CS, int parts, void* stream);
+              int HW, int C, int CS, int parts, float* scratch, void* stream);
 
 /* Depthwise-conv adjoint: dz = ka*du+kb*z+kc (virtual, output side).  parts&1: dw (accumulated, torch layout
  * [C,1,k,k]); parts&2: du_in = d(input pre-activation) = dgrad * swish'(bn_in(zin)), plus the input-side BN sums.
@@ -289,7 +292,7 @@ int mt_sgd_multi(const void* items, int count, int64_t total_blocks, float lr, f
  *   (decoupled_weight_decay = 1: p *= 1 - lr*wd first) over many tensors in one launch (train.py:187-190, :378; amsgrad off).
  *   items = device array of {float* p; const float* g; float* m; float* v; int64 n; int64 block0} sorted by block0 (as above).
  *   step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t) for the step count t of this call. */
-int mt_adam_multi(const void* items, int count, int64_t total_blocks, float lr, float weight_decay, float beta1, float beta2,
+int mt_adam_multi(const void* items, int count, int64_t total_blocks, float lr, float weight_decay, double beta1, double beta2,
                   float eps, float step_size, float bias_correction2_sqrt, int decoupled_weight_decay, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

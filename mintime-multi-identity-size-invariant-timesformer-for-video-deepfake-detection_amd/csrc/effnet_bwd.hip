@@ -185,66 +185,86 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// ------------------------------------------------------------------------------------------------ K4: SE adjoint per image
-// W2 [C][CS] is walked by COLUMN here (dh[j] = sum_c dp2[c] W2[c][j]): straight from global that is one cache line per lane and
-// instruction (77 us at C = 1152).  128-channel slabs are copied coalesced into LDS ([128][CS+1], odd pitch) and read from there.
+// ------------------------------------------------------------------------------------------------ K4: SE adjoint
+// dpre2[n,c] = dgate*g*(1-g);  dh[n,j] = (sum_c dpre2[n,c] W2[c,j]) * swish'(hidden[n,j]);  dpooled[n,c] = sum_j dh[n,j] W1[j,c].
+// One block per image walking W2 by column was latency-bound (77 us at C = 1152, 0.48 ms per step).  Now (1) one block per
+// (image, 128-channel slab): the slab's W2 rows go coalesced into LDS ([128][CS+1]), partial dh per slab -> scratch[n][slab][CS];
+// (2) one block per (image, 256 channels): sums the slab partials, applies swish', and forms dpooled with four load chains.
 constexpr int SE_SLAB = 128;
 constexpr int SE_JW = 12;            // CS_MAX / 4 squeeze channels per wavefront
-__global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
-                                                     const float* __restrict__ hidden, const float* __restrict__ w1,
-                                                     const float* __restrict__ w2, float* __restrict__ dpre2,
-                                                     float* __restrict__ dhid, float* __restrict__ dpooled, int C, int CS) {
-  extern __shared__ float sm[];     // dp2[C] + dh[CS] + slab[SE_SLAB][CS+1]
-  float* dp2 = sm;
-  float* dh = sm + C;
-  float* slab = dh + CS;
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < C; c += 256) {
-    const float g = gate[(int64_t)n * C + c];
-    const float v = dgate[(int64_t)n * C + c] * g * (1.0f - g);
-    dp2[c] = v;
-    dpre2[(int64_t)n * C + c] = v;
-  }
+__device__ __forceinline__ void se_load_slab(float* slab, const float* __restrict__ src, int count, int CS, int tid) {
   const int pitch = CS + 1;
   const float inv_cs = 1.0f / (float)CS;
-  float aj[SE_JW];
+  for (int e0 = tid; e0 < count; e0 += 256 * 8) {                // eight loads in flight per thread, then the LDS writes
+    float v[8];
 #pragma unroll
-  for (int q = 0; q < SE_JW; ++q) aj[q] = 0.f;
-  for (int c0 = 0; c0 < C; c0 += SE_SLAB) {
-    const int rows = min(SE_SLAB, C - c0);
-    __syncthreads();                 // dp2 complete (first pass) / previous slab consumed
-    for (int e = tid; e < rows * CS; e += 256) {
+    for (int u = 0; u < 8; ++u) v[u] = src[min(e0 + 256 * u, count - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u;
       const int r = (int)(((float)e + 0.5f) * inv_cs);          // e / CS, exact for e < 2^16
-      slab[r * pitch + (e - r * CS)] = w2[(int64_t)c0 * CS + e];
-    }
-    __syncthreads();
-    const float d0 = lane < rows ? dp2[c0 + lane] : 0.f, d1 = lane + 64 < rows ? dp2[c0 + lane + 64] : 0.f;
-#pragma unroll
-    for (int q = 0; q < SE_JW; ++q) {
-      const int j = wave + 4 * q;
-      if (j < CS) {                  // rows past a partial slab hold stale LDS (possibly NaN): select, do not multiply by zero
-        const float w0 = lane < rows ? slab[lane * pitch + j] : 0.f, w1v = lane + 64 < rows ? slab[(lane + 64) * pitch + j] : 0.f;
-        aj[q] = fmaf(d0, w0, fmaf(d1, w1v, aj[q]));
-      }
+      if (e < count) slab[r * pitch + (e - r * CS)] = v[u];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void se_bwd_slab_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                          const float* __restrict__ w2, float* __restrict__ dpre2,
+                                                          float* __restrict__ dh_part, int C, int CS) {
+  extern __shared__ float sm[];     // dp2[SE_SLAB] + slab[SE_SLAB][CS+1]
+  float* dp2 = sm;
+  float* slab = sm + SE_SLAB;
+  const int n = blockIdx.x, sl = blockIdx.y, c0 = sl * SE_SLAB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rows = min(SE_SLAB, C - c0), pitch = CS + 1;
+  if (tid < SE_SLAB) {
+    float v = 0.f;
+    if (tid < rows) {
+      const float g = gate[(int64_t)n * C + c0 + tid];
+      v = dgate[(int64_t)n * C + c0 + tid] * g * (1.0f - g);
+      dpre2[(int64_t)n * C + c0 + tid] = v;
+    }
+    dp2[tid] = v;
+  }
+  se_load_slab(slab, w2 + (int64_t)c0 * CS, rows * CS, CS, tid);
+  __syncthreads();
+  const float d0 = dp2[lane], d1 = dp2[lane + 64];
 #pragma unroll
   for (int q = 0; q < SE_JW; ++q) {
     const int j = wave + 4 * q;
-    float a = aj[q];
+    if (j < CS) {                  // rows past a partial slab hold stale LDS (possibly NaN): select, do not multiply by zero
+      const float w0 = lane < rows ? slab[lane * pitch + j] : 0.f, w1v = lane + 64 < rows ? slab[(lane + 64) * pitch + j] : 0.f;
+      float a = fmaf(d0, w0, d1 * w1v);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    if (lane == 0 && j < CS) {
-      const float v = a * dswishf_(hidden[(int64_t)n * CS + j]);
-      dh[j] = v;
-      dhid[(int64_t)n * CS + j] = v;
+      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+      if (lane == 0) dh_part[((int64_t)n * gridDim.y + sl) * CS + j] = a;
     }
   }
-  __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+}
+
+__global__ __launch_bounds__(256) void se_bwd_finish_kernel(const float* __restrict__ dh_part, int slabs, const float* __restrict__ hidden,
+                                                            const float* __restrict__ w1, float* __restrict__ dhid,
+                                                            float* __restrict__ dpooled, int C, int CS) {
+  extern __shared__ float dh[];     // [CS]
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int j = tid; j < CS; j += 256) {
     float a = 0.f;
-    for (int j = 0; j < CS; ++j) a = fmaf(dh[j], w1[(int64_t)j * C + c], a);
-    dpooled[(int64_t)n * C + c] = a;
+    for (int sl = 0; sl < slabs; ++sl) a += dh_part[((int64_t)n * slabs + sl) * CS + j];
+    const float v = a * dswishf_(hidden[(int64_t)n * CS + j]);
+    dh[j] = v;
+    if (blockIdx.y == 0) dhid[(int64_t)n * CS + j] = v;
+  }
+  __syncthreads();
+  const int c = blockIdx.y * 256 + tid;
+  if (c < C) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;    // four chains: the column's CS loads are independent, keep them in flight
+    int j = 0;
+    for (; j + 3 < CS; j += 4) {
+      const float w0 = w1[(int64_t)j * C + c], w1v = w1[(int64_t)(j + 1) * C + c], w2v = w1[(int64_t)(j + 2) * C + c],
+                  w3 = w1[(int64_t)(j + 3) * C + c];
+      a0 = fmaf(dh[j], w0, a0); a1 = fmaf(dh[j + 1], w1v, a1); a2 = fmaf(dh[j + 2], w2v, a2); a3 = fmaf(dh[j + 3], w3, a3);
+    }
+    for (; j < CS; ++j) a0 = fmaf(dh[j], w1[(int64_t)j * C + c], a0);
+    dpooled[(int64_t)n * C + c] = (a0 + a1) + (a2 + a3);
   }
 }
 
@@ -766,14 +786,28 @@ extern "C" int mt_bn_bwd_finalize(const double* stats, int slots, double count, 
   return check_launch("mt_bn_bwd_finalize");
 }
 
+static int se_adjoint(const float* dgate, const float* gate, const float* hidden, const float* w1, const float* w2, float* dpre2,
+                      float* dhid, float* dpooled, float* scratch, int N, int C, int CS, hipStream_t s) {
+  const int slabs = (C + SE_SLAB - 1) / SE_SLAB;
+  hipLaunchKernelGGL(se_bwd_slab_kernel, dim3(N, slabs), dim3(256), (size_t)(SE_SLAB + SE_SLAB * (CS + 1)) * sizeof(float), s, dgate, gate,
+                     w2, dpre2, scratch, C, CS);
+  int rc = check_launch("mt_se_bwd(slab)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(se_bwd_finish_kernel, dim3(N, (C + 255) / 256), dim3(256), (size_t)CS * sizeof(float), s, scratch, slabs, hidden, w1,
+                     dhid, dpooled, C, CS);
+  return check_launch("mt_se_bwd(finish)");
+}
+
+extern "C" int mt_se_scratch_floats(int N, int C, int CS) { return N * ((C + SE_SLAB - 1) / SE_SLAB) * CS; }
+
 extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, const float* shift, const float* gate,
                          const float* hidden, const float* pooled, const float* w1, const float* w2, float* dgate,
                          float* dpre2, float* dhid, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, int N,
-                         int HW, int C, int CS, int parts_mask, void* stream) {
+                         int HW, int C, int CS, int parts_mask, float* scratch, void* stream) {
   // parts_mask: 1 = d-gate reduction over da, z + per-image adjoint; 2 = weight gradients; 4 = per-image adjoint only (dgate was
   // already reduced by mt_gemm's MT_EPI_SE_RED epilogue; da / z / scale / shift are not read)
   if (((parts_mask & 1) && (!da || !z || !scale || !shift)) || !gate || !hidden || !pooled || !w1 || !w2 || !dgate || !dpre2 || !dhid ||
-      !dpooled || !dw1 || !db1 || !dw2 || !db2)
+      !dpooled || !dw1 || !db1 || !dw2 || !db2 || ((parts_mask & 5) && !scratch))
     return fail(MT_ERR_ARG, "mt_se_bwd: null pointer");
   if (C & 3) return fail(MT_ERR_ARG, "mt_se_bwd: C %% 4 != 0");
   if (CS > CS_MAX) return fail(MT_ERR_UNSUPPORTED, "mt_se_bwd: squeeze width %d > %d", CS, CS_MAX);
@@ -789,15 +823,11 @@ extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, co
                      scale, shift, dgate, HW, C, CQB, PB);
   rc = check_launch("mt_se_bwd(reduce)");
   if (rc) return rc;
-  hipLaunchKernelGGL(se_bwd_kernel, dim3(N), dim3(256), (size_t)(C + CS + SE_SLAB * (CS + 1)) * sizeof(float), s, dgate, gate, hidden, w1, w2, dpre2, dhid,
-                     dpooled, C, CS);
-  rc = check_launch("mt_se_bwd(image)");
+  rc = se_adjoint(dgate, gate, hidden, w1, w2, dpre2, dhid, dpooled, scratch, N, C, CS, s);
   if (rc) return rc;
   }
   if (parts_mask & 4) {
-    hipLaunchKernelGGL(se_bwd_kernel, dim3(N), dim3(256), (size_t)(C + CS + SE_SLAB * (CS + 1)) * sizeof(float), s, dgate, gate, hidden, w1, w2, dpre2, dhid,
-                       dpooled, C, CS);
-    rc = check_launch("mt_se_bwd(image)");
+    rc = se_adjoint(dgate, gate, hidden, w1, w2, dpre2, dhid, dpooled, scratch, N, C, CS, s);
     if (rc) return rc;
   }
   if (!(parts_mask & 2)) return 0;

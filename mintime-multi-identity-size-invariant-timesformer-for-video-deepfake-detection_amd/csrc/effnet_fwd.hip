@@ -391,66 +391,84 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ SE: gate
-// gate[n,c] = sigmoid(W2[c,:] . swish(W1 . pooled[n,:] + b1) + b2[c]);  one block per image.
-// W2 is [C][CS] with CS = 4..48: a thread per channel walking its row reads 64 different cache lines per wave-instruction
-// (88 us at C = 1152, 0.57 ms per step).  Rows go through LDS instead: 128-channel slabs are copied with coalesced loads into a
-// [128][CS+1] image (odd pitch: conflict-free column walks) and multiplied from there.
+// gate[n,c] = sigmoid(W2[c,:] . swish(W1 . pooled[n,:] + b1) + b2[c]).
+// Two tiny matrix products per image (C x CS with CS = 4..48).  One block per image doing both was latency-bound at 88 us for
+// C = 1152 (a wavefront walking one W1 row at a time: C/64 dependent round trips per row; a thread per channel walking its W2 row:
+// 64 cache lines per wave-instruction) -- 0.57 ms per step for 30 MFLOP.  Now: (A) hidden pre-activations, a wavefront per four W1
+// rows walked together (independent loads in flight), ceil(CS/16) blocks per image; (B) the gate, one block per (image, 128-channel
+// slab): the slab's W2 rows are copied coalesced into LDS ([128][CS+1], odd pitch) and multiplied from there.
 constexpr int SE_SLAB = 128;
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ partial, int parts, const float* __restrict__ w1,
-                                                      const float* __restrict__ b1, const float* __restrict__ w2,
-                                                      const float* __restrict__ b2, float* __restrict__ pooled,
-                                                      float* __restrict__ gate, float* __restrict__ hidden, int C, int CS) {
-  extern __shared__ float sm[];    // pooled[C] + hid[CS] + slab[SE_SLAB][CS+1]
-  float* pv = sm;
-  float* hid = sm + C;
-  float* slab = hid + CS;
+__global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict__ partial, int parts, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, float* __restrict__ pooled,
+                                                        float* __restrict__ hidden, int C, int CS) {
+  extern __shared__ float pv[];    // pooled[C]
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < C; i += 256) {
     float v = 0.f;
     for (int q = 0; q < parts; ++q) v += partial[((int64_t)n * parts + q) * C + i];
     pv[i] = v;
-    if (pooled) pooled[(int64_t)n * C + i] = v;
+    if (pooled && blockIdx.y == 0) pooled[(int64_t)n * C + i] = v;
   }
   __syncthreads();
-  for (int j = wave; j < CS; j += 4) {
-    float a0 = 0.f, a1 = 0.f;        // two chains: the row's loads pipeline instead of trailing one fma each
-    int i = lane;
-    for (; i + 64 < C; i += 128) {
-      a0 = fmaf(w1[(int64_t)j * C + i], pv[i], a0);
-      a1 = fmaf(w1[(int64_t)j * C + i + 64], pv[i + 64], a1);
-    }
-    if (i < C) a0 = fmaf(w1[(int64_t)j * C + i], pv[i], a0);
-    float a = a0 + a1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    if (lane == 0) {
-      const float pre = a + b1[j];
-      if (hidden) hidden[(int64_t)n * CS + j] = pre;
-      hid[j] = swishf_(pre);
-    }
+  const int j0 = (blockIdx.y * 4 + wave) * 4;
+  if (j0 >= CS) return;
+  const float* r0 = w1 + (int64_t)min(j0 + 0, CS - 1) * C;     // rows past CS alias the last one (results dropped): no branch
+  const float* r1 = w1 + (int64_t)min(j0 + 1, CS - 1) * C;     // around the loads, so all four stay in flight together
+  const float* r2 = w1 + (int64_t)min(j0 + 2, CS - 1) * C;
+  const float* r3 = w1 + (int64_t)min(j0 + 3, CS - 1) * C;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+  for (int i = lane; i < C; i += 64) {
+    const float w0 = r0[i], w1v = r1[i], w2v = r2[i], w3 = r3[i], pvi = pv[i];
+    a0 = fmaf(w0, pvi, a0); a1 = fmaf(w1v, pvi, a1); a2 = fmaf(w2v, pvi, a2); a3 = fmaf(w3, pvi, a3);
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); a3 += __shfl_xor(a3, o);
+  }
+  if (lane < 4 && j0 + lane < CS) {
+    const float a = lane == 0 ? a0 : (lane == 1 ? a1 : (lane == 2 ? a2 : a3));
+    hidden[(int64_t)n * CS + j0 + lane] = a + b1[j0 + lane];
+  }
+}
+
+// loads `count` consecutive floats of src into the [rows][CS+1] slab image, eight loads in flight per thread
+__device__ __forceinline__ void se_load_slab(float* slab, const float* __restrict__ src, int count, int CS, int tid) {
   const int pitch = CS + 1;
   const float inv_cs = 1.0f / (float)CS;
-  for (int c0 = 0; c0 < C; c0 += SE_SLAB) {
-    const int rows = min(SE_SLAB, C - c0);
-    __syncthreads();                 // hid complete (first pass) / previous slab consumed
-    for (int e = tid; e < rows * CS; e += 256) {
+  for (int e0 = tid; e0 < count; e0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[min(e0 + 256 * u, count - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u;
       const int r = (int)(((float)e + 0.5f) * inv_cs);          // e / CS, exact for e < 2^16
-      slab[r * pitch + (e - r * CS)] = w2[(int64_t)c0 * CS + e];
+      if (e < count) slab[r * pitch + (e - r * CS)] = v[u];
     }
-    __syncthreads();
-    // two threads per channel, each half of the CS taps (256 threads on a 128-channel slab)
-    const int r = tid & (SE_SLAB - 1), half = tid >> 7;
-    float a = 0.f;
-    if (r < rows) {
-      const int j0 = half ? (CS + 1) / 2 : 0, j1 = half ? CS : (CS + 1) / 2;
-      for (int j = j0; j < j1; ++j) a = fmaf(slab[r * pitch + j], hid[j], a);
-    }
-    // halves meet through LDS (the slab's padding column is free: pitch = CS + 1)
-    if (half && r < rows) slab[r * pitch + CS] = a;
-    __syncthreads();
-    if (!half && r < rows) gate[(int64_t)n * C + c0 + r] = sigmoidf_(a + slab[r * pitch + CS] + b2[c0 + r]);
   }
+}
+
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ hidden, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, float* __restrict__ gate, int C, int CS) {
+  extern __shared__ float sm[];    // hid[CS] + slab[SE_SLAB][CS+1]
+  float* hid = sm;
+  float* slab = sm + CS;
+  const int n = blockIdx.x, c0 = blockIdx.y * SE_SLAB, tid = threadIdx.x;
+  const int rows = min(SE_SLAB, C - c0), pitch = CS + 1;
+  if (tid < CS) hid[tid] = swishf_(hidden[(int64_t)n * CS + tid]);
+  se_load_slab(slab, w2 + (int64_t)c0 * CS, rows * CS, CS, tid);
+  __syncthreads();
+  // two threads per channel, each half of the CS taps; the halves meet in the slab's padding column
+  const int r = tid & (SE_SLAB - 1), half = tid >> 7;
+  float a = 0.f;
+  if (r < rows) {
+    const int j0 = half ? (CS + 1) / 2 : 0, j1 = half ? CS : (CS + 1) / 2;
+    for (int j = j0; j < j1; ++j) a = fmaf(slab[r * pitch + j], hid[j], a);
+  }
+  if (half && r < rows) slab[r * pitch + CS] = a;
+  __syncthreads();
+  if (!half && r < rows) gate[(int64_t)n * C + c0 + r] = sigmoidf_(a + slab[r * pitch + CS] + b2[c0 + r]);
 }
 
 // ------------------------------------------------------------------------------------------------ BN apply (+swish) (+residual)
@@ -554,9 +572,15 @@ extern "C" int mt_se_pool_fwd(const float* z, const float* scale, const float* s
 
 extern "C" int mt_se_gate_fwd(const float* partial, int parts, const float* w1, const float* b1, const float* w2, const float* b2,
                               float* pooled, float* gate, float* hidden, int N, int C, int CS, void* stream) {
-  if (!partial || !w1 || !b1 || !w2 || !b2 || !gate || parts < 1) return fail(MT_ERR_ARG, "mt_se_gate_fwd: null pointer");
-  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), (size_t)(C + CS + SE_SLAB * (CS + 1)) * sizeof(float), (hipStream_t)stream, partial, parts, w1,
-                     b1, w2, b2, pooled, gate, hidden, C, CS);
+  if (!partial || !w1 || !b1 || !w2 || !b2 || !gate || !hidden || parts < 1) return fail(MT_ERR_ARG, "mt_se_gate_fwd: null pointer");
+  if (CS < 1 || CS > 256) return fail(MT_ERR_UNSUPPORTED, "mt_se_gate_fwd: squeeze width %d", CS);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(se_hidden_kernel, dim3(N, (CS + 15) / 16), dim3(256), (size_t)C * sizeof(float), s, partial, parts, w1, b1, pooled,
+                     hidden, C, CS);
+  int rc = check_launch("mt_se_gate_fwd(hidden)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(se_gate_kernel, dim3(N, (C + SE_SLAB - 1) / SE_SLAB), dim3(256), (size_t)(CS + SE_SLAB * (CS + 1)) * sizeof(float), s,
+                     hidden, w2, b2, gate, C, CS);
   return check_launch("mt_se_gate_fwd");
 }
 

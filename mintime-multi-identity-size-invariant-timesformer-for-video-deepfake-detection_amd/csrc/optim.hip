@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdItem* __restric
 // p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  The bias corrections come in precomputed (host doubles -> float).
 struct AdamItem { float* p; const float* g; float* m; float* v; int64_t n; int64_t block0; };
 
-__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamItem* __restrict__ items, int count, float lr, float wd, float b1,
-                                                         float b2, float eps, float step_size, float bc2_sqrt, int decoupled) {
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamItem* __restrict__ items, int count, float lr, float wd, float omb1,
+                                                         float b2, float omb2, float eps, float step_size, float bc2_sqrt, int decoupled) {
   int lo = 0, hi = count - 1;
   const int64_t b = blockIdx.x;
   while (lo < hi) {
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamItem* __restr
       float p = it.p[off + e], g = it.g[off + e], m = it.m[off + e], v = it.v[off + e];
       if (decoupled) p *= 1.0f - lr * wd;
       else if (wd != 0.f) g = fmaf(wd, p, g);
-      m = m + (g - m) * (1.0f - b1);              // torch: exp_avg.lerp_(grad, 1 - beta1)
-      v = v * b2 + (1.0f - b2) * g * g;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+      m = m + (g - m) * omb1;                     // torch: exp_avg.lerp_(grad, 1 - beta1)   (1 - beta rounded from double, like torch)
+      v = v * b2 + omb2 * g * g;                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
       const float denom = sqrtf(v) / bc2_sqrt + eps;
       p -= step_size * (m / denom);
       it.p[off + e] = p; it.m[off + e] = m; it.v[off + e] = v;
@@ -93,12 +93,13 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamItem* __restr
 
 }  // namespace
 
-extern "C" int mt_adam_multi(const void* items, int count, int64_t total_blocks, float lr, float weight_decay, float beta1, float beta2,
+extern "C" int mt_adam_multi(const void* items, int count, int64_t total_blocks, float lr, float weight_decay, double beta1, double beta2,
                              float eps, float step_size, float bias_correction2_sqrt, int decoupled_weight_decay, void* stream) {
   if (!items || count <= 0 || total_blocks <= 0) return fail(MT_ERR_ARG, "mt_adam_multi: empty table");
   if (total_blocks > 0x7fffffff) return fail(MT_ERR_ARG, "mt_adam_multi: too many blocks");
   hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const AdamItem*>(items), count, lr, weight_decay, beta1, beta2, eps, step_size,
+                     reinterpret_cast<const AdamItem*>(items), count, lr, weight_decay, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), eps, step_size,
                      bias_correction2_sqrt, decoupled_weight_decay);
   return check_launch("mt_adam_multi");
 }

@@ -154,12 +154,13 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         b_pro = (bn_d.scale, bn_d.shift, rec["gate"], hw)
         dgate, dpre2, dpooled = _new(dev, N, s.cexp), _new(dev, N, s.cexp), _new(dev, N, s.cexp)
         dhid = _new(dev, N, s.cse)
+        se_scr = _new(dev, lib.mt_se_scratch_floats(N, s.cexp, s.cse))
         se = ix["se"]
-        def se_part(parts, _da=None, _rec=rec, _bn=bn_d, _se=se, _s=s, _dg=dgate, _dp=dpre2, _dh=dhid, _dpo=dpooled, _hw=hw):
+        def se_part(parts, _da=None, _rec=rec, _bn=bn_d, _se=se, _s=s, _dg=dgate, _dp=dpre2, _dh=dhid, _dpo=dpooled, _hw=hw, _scr=se_scr):
             L.check(lib.mt_se_bwd(L.ptr(_da), L.ptr(_rec["z_d"]), L.ptr(_bn.scale), L.ptr(_bn.shift), L.ptr(_rec["gate"]),
                                   L.ptr(_rec["hidden"]), L.ptr(_rec["pooled"]), L.ptr(P[_se]), L.ptr(P[_se + 2]), L.ptr(_dg), L.ptr(_dp),
                                   L.ptr(_dh), L.ptr(_dpo), L.ptr(grads[_se]), L.ptr(grads[_se + 1]), L.ptr(grads[_se + 2]),
-                                  L.ptr(grads[_se + 3]), N, _hw, _s.cexp, _s.cse, parts, L.stream_ptr()), "mt_se_bwd")
+                                  L.ptr(grads[_se + 3]), N, _hw, _s.cexp, _s.cse, parts, L.ptr(_scr), L.stream_ptr()), "mt_se_bwd")
         if SE_FUSED:
             # (c+d) d gate straight from the accumulators of  dz_p . Wp  (da is never written)
             dgate.zero_()

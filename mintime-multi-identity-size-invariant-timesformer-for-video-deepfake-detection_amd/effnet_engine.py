@@ -153,7 +153,7 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
         _finalize(lib, st, blk._bn1, bn_d, M_out, training, g, b)
         w_r, b_r, w_x, b_x = next(it), next(it), next(it), next(it)
         pooled, gate = _new(dev, N, s.cexp), _new(dev, N, s.cexp)
-        hidden = _new(dev, N, s.cse) if save else None
+        hidden = _new(dev, N, s.cse)          # squeeze pre-activations: the gate kernel reads them (and backward keeps them)
         hw = s.hout * s.hout
         parts = lib.mt_se_pool_parts(N, hw, s.cexp)
         partial = _new(dev, N, parts, s.cexp)

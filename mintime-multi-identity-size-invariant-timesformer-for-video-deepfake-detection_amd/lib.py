@@ -81,7 +81,8 @@ PROTOTYPES = {
                     C.c_void_p],
     "mt_bn_act_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_bn_bwd_finalize": [C.c_void_p, C.c_int, C.c_double, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_void_p],
-    "mt_se_bwd": [f32p] * 17 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_se_bwd": [f32p] * 17 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p],
+    "mt_se_scratch_floats": [C.c_int, C.c_int, C.c_int],
     "mt_dwconv_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_int, f32p, f32p, C.c_void_p],
     "mt_conv_weight_pack": [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
@@ -94,7 +95,8 @@ PROTOTYPES = {
                         C.c_int, C.c_int, C.c_void_p],
     "mt_bce_logits": [f32p, f32p, C.c_float, f32p, f32p, C.c_int, C.c_void_p],
     "mt_sgd_multi": [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_void_p],
-    "mt_adam_multi": [C.c_void_p, C.c_int, C.c_int64] + [C.c_float] * 7 + [C.c_int, C.c_void_p],
+    "mt_adam_multi": [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, C.c_float,
+                      C.c_int, C.c_void_p],
     "mt_conv1x1_wgrad_supported": [C.c_int, C.c_int],
     "mt_conv1x1_wgrad": [f32p] * 7 + [C.c_int, f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "mt_stem_conv_wgrad": [f32p] * 4 + [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
@@ -136,8 +138,8 @@ def get():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     v = lib.mt_version()
-    if v != 101:
-        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 101; rebuild it")
+    if v != 102:
+        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 102; rebuild it")
     _lib = lib
     return lib
 
