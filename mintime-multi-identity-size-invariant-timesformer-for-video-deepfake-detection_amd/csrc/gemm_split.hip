@@ -67,10 +67,12 @@ int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
     }
   }
   if constexpr (AL == LAYOUT_KCONTIG && BL == LAYOUT_KCONTIG && EPI != EPI_STATS) {
-    // weight pre-split into bf16 planes (mt_split_planes): B by DMA, 128 x 128 tiles only.  Bit-identical to the in-kernel split and
-    // 7-12 % SLOWER (tools/lab/planes_probe.py: QKV 148 -> 158 us, FF2 194 -> 215, 4096^3 700 -> 785): hipcc counts only its own
-    // loads, so its vmcnt for the staged A tile also drains the DMA issued in the same step.  Opt-in (MT_SPLIT_PLANES=1) until
-    // the A loads move under manual wait counts as well.
+    // weight pre-split into bf16 planes (mt_split_planes): B by DMA, 128 x 128 tiles only.  Bit-identical to the in-kernel split.
+    // Round 2: 7-12 % slower (hipcc's vmcnt for the staged A tile also drained the DMA of the same step).  Round 3: the A loads are
+    // inline asm under one counted wait per step (no compiler-inserted vmcnt left in the loop, checked in the ISA) -- and the variant
+    // now runs EQUAL to the in-kernel split, not faster (tools/lab/planes_probe.py, profiles/r03_split_planes_manual_waits.txt:
+    // QKV 154.7 / 153.6 us, FF2 203.8 / 201.2, FF1 data gradient 353.5 / 352.0, 4096^3 747 / 780), with two or with three A register
+    // sets in flight: the loop is limited by its matrix + LDS issue, not by operand delivery.  Stays opt-in (MT_SPLIT_PLANES=1).
     const bool planes_on = getenv("MT_SPLIT_PLANES") && atoi(getenv("MT_SPLIT_PLANES")) != 0;
     if (planes_on && a.b_planes && (a.K % 16) == 0 && a.k_chunk == 0 && (a.ldb % 8) == 0 && a.b_map.gin == 0 && (v == S_BIG || EPI == EPI_GEGLU_BWD))
       return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, true, PRO_NONE, true>(a, grid, s);

@@ -31,12 +31,17 @@
 #include "gemm_dma.hpp"
 #include <type_traits>
 
+#ifndef MT_SPLIT_A_DEPTH       // B-planes loop: A register sets in flight (2 = one k-step of prefetch distance, 3 = two).  Measured equal
+#define MT_SPLIT_A_DEPTH 2     // (profiles/r03_split_planes_manual_waits.txt): the loop is not waiting for its operands.
+#endif
 #ifndef MT_SPLIT_ABLATE        // tuning lab only: 1 no global loads, 2 no split + LDS writes, 4 no barrier, 8 no fragment reads, 16 no epilogue,
                                // 32 B operand neither loaded nor split after the first tile (upper bound of pre-split weight planes)
 #define MT_SPLIT_ABLATE 0
 #endif
 
 namespace mt {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // BPL (B planes): the B operand arrives already split -- three bf16 planes [N][K] in memory (weights: split once per step by
 // mt_split_planes) -- and goes global -> LDS by DMA (global_load_lds_dwordx4, no staging VGPRs, no VALU, no ds_write) through a
@@ -383,40 +388,107 @@ void gemm_split_kernel(const GemmArgs p) {
       MT_SPLIT_SYNC();
     }
   } else if constexpr (BPL) {
-    // A as below (two register sets); B planes by DMA two tiles ahead through the three-slot ring.  In-order return of VMEM
-    // operations: once the A loads of tile kt+1 (issued after tile kt+1's DMA) have been waited for by the split, that DMA has
-    // landed too; the explicit counted wait before the barrier states it independently of the compiler's placement.
-    constexpr int YOUNGER = BI + AG * 2;            // VMEM operations issued in a step after the DMA that must have landed
-    float ga0[AG][8], gb0[BG][8], ga1[AG][8], gb1[BG][8];
+    // A through two register sets as below, B planes by DMA two tiles ahead through the three-slot ring -- and NO compiler-visible
+    // VMEM operation in the loop: the A loads are inline asm too (aload), so the only wait is the counted one written here.
+    // (With the A loads as ordinary C++ loads hipcc inserted its own vmcnt for them, counting only its own loads: that wait also
+    // drained the younger DMA of the same step and the variant measured 7-12 % SLOWER than splitting B in the kernel.)
+    // VMEM queue at the wait of step kt, oldest first: DMA(kt+1) | A(kt+1) | DMA(kt+2) | A(kt+2); memory operations retire in
+    // order, so vmcnt <= BI + 2 AG means tile kt+1's planes are in LDS and its A granules in their registers.
+    constexpr int YOUNGER = BI + AG * 2;
+    static_assert(A_ALL && AL == LAYOUT_KCONTIG, "asm A loads: every thread stages AG full granules");
+    f32x4_t ra0[AG][2], ra1[AG][2];
+    float gb_none[BG][8];                           // sstore's B argument is not read with B planes
+    auto aload = [&](int kt, f32x4_t (&r)[AG][2]) {
+#pragma unroll
+      for (int j = 0; j < AG; ++j) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[j][0]) : "v"(a_src[j] + kt * BK));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r[j][1]) : "v"(a_src[j] + kt * BK));
+      }
+    };
+    auto astore = [&](int stage, f32x4_t (&r)[AG][2], bool negate_a0, int ktile) {
+      float ga[AG][8];
+#pragma unroll
+      for (int j = 0; j < AG; ++j) {
+        asm volatile("" : "+v"(r[j][0]), "+v"(r[j][1]));       // uses of r stay behind the counted wait that precedes this call
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ga[j][e] = r[j][0][e]; ga[j][4 + e] = r[j][1][e]; }
+      }
+      sstore(stage, ga, gb_none, negate_a0, ktile);
+    };
+    const int last = nk - 1;
+#if MT_SPLIT_A_DEPTH == 3
+    // Three A register sets: tile t lives in set t % 3 and is loaded THREE half-steps before it is split (a k-step of this tile
+    // is ~0.35 us of matrix time, an L2 / HBM round trip 0.5-1.5 us: one step of prefetch distance is not enough).  The phase of
+    // (stage parity, ring slot, register set) repeats every 6 tiles: the loop body is six half-steps with constant indices.
+    f32x4_t ra2[AG][2];
+    auto rset = [&](auto idx) -> f32x4_t (&)[AG][2] {
+      if constexpr (decltype(idx)::value == 0) return ra0; else if constexpr (decltype(idx)::value == 1) return ra1; else return ra2;
+    };
+    constexpr int YOUNGER3 = BI + AG * 4;          // A(kt+2), DMA(kt+2), A(kt+3) may still be in flight at the wait of step kt
+    dma_b(0, 0);
+    dma_b(min(1, last), 1);
+    aload(0, ra0);
+    wait_vmcnt<0>();
+    astore(0, ra0, false, 0);
+    aload(min(1, last), ra1);
+    aload(min(2, last), ra2);
+    __syncthreads();
+    auto half = [&](int kt, auto ph) {
+      constexpr int PH = decltype(ph)::value;                    // kt % 6
+      dma_b(min(kt + 2, last), (PH + 2) % 3);
+      aload(min(kt + 3, last), rset(std::integral_constant<int, PH % 3>{}));        // (kt + 3) % 3 == kt % 3: the set tile kt was split from
+      compute(PH & 1, kt, std::integral_constant<bool, (PH & 1) != 0>{}, PH % 3);
+      wait_vmcnt<YOUNGER3>();
+      astore((PH + 1) & 1, rset(std::integral_constant<int, (PH + 1) % 3>{}), BAL && ((PH + 1) & 1), min(kt + 1, last));
+      interleave();
+      MT_SPLIT_SYNC();
+    };
+    for (int kt = 0; kt < nk; kt += 6) {
+      half(kt, std::integral_constant<int, 0>{});
+      if (kt + 1 >= nk) break;
+      half(kt + 1, std::integral_constant<int, 1>{});
+      if (kt + 2 >= nk) break;
+      half(kt + 2, std::integral_constant<int, 2>{});
+      if (kt + 3 >= nk) break;
+      half(kt + 3, std::integral_constant<int, 3>{});
+      if (kt + 4 >= nk) break;
+      half(kt + 4, std::integral_constant<int, 4>{});
+      if (kt + 5 >= nk) break;
+      half(kt + 5, std::integral_constant<int, 5>{});
+    }
+#else
     const int last = nk - 1;
     dma_b(0, 0);
     dma_b(min(1, last), 1);
-    gload(0, ga0, gb0); sstore(0, ga0, gb0, false, 0);
-    gload(min(1, last), ga0, gb0);
-    wait_vmcnt<AG * 2>();                           // both DMAs done; tile 1's A loads may stay in flight
+    aload(0, ra0);
+    wait_vmcnt<0>();
+    astore(0, ra0, false, 0);
+    aload(min(1, last), ra0);                       // stays in flight across the barrier
     __syncthreads();
     int ring = 0;                                   // ring slot of tile kt
     for (int kt = 0; kt < nk; kt += 2) {
       int r2 = ring + 2; r2 = r2 >= 3 ? r2 - 3 : r2;
       dma_b(min(kt + 2, last), r2);
-      gload(min(kt + 2, last), ga1, gb1);
+      aload(min(kt + 2, last), ra1);
       compute(0, kt, std::false_type{}, ring);
-      sstore(1, ga0, gb0, BAL, min(kt + 1, last));
-      interleave();
       wait_vmcnt<YOUNGER>();
+      astore(1, ra0, BAL, min(kt + 1, last));
+      interleave();
       MT_SPLIT_SYNC();
       if (kt + 1 >= nk) break;
       ring = ring + 1 >= 3 ? 0 : ring + 1;
       r2 = ring + 2; r2 = r2 >= 3 ? r2 - 3 : r2;
       dma_b(min(kt + 3, last), r2);
-      gload(min(kt + 3, last), ga0, gb0);
+      aload(min(kt + 3, last), ra0);
       compute(1, kt + 1, std::true_type{}, ring);
-      sstore(0, ga1, gb1, false, min(kt + 2, last));
-      interleave();
       wait_vmcnt<YOUNGER>();
+      astore(0, ra1, false, min(kt + 2, last));
+      interleave();
       MT_SPLIT_SYNC();
       ring = ring + 1 >= 3 ? 0 : ring + 1;
     }
+#endif
+    wait_vmcnt<0>();                                // the clamped re-loads of the last tile must not outlive their registers
   } else {
     // two register sets: tile kt+2's loads are issued at the top of step kt; tile kt+1 (loaded a full step ago) is split and
     // written to the other LDS stage in the shadow of tile kt's MFMAs.  Branch-free body (the scheduler interleaves the VALU
