@@ -457,7 +457,6 @@ void gemm_split_kernel(const GemmArgs p) {
       half(kt + 5, std::integral_constant<int, 5>{});
     }
 #else
-    const int last = nk - 1;
     dma_b(0, 0);
     dma_b(min(1, last), 1);
     aload(0, ra0);
