@@ -394,6 +394,8 @@ def main():
     import mintime_amd
     from mintime_amd import harness, lib, ddp
     lib.get()
+    if os.environ.get("MT_BENCH_STREAM"):        # experiment: run the step on a non-default (non-blocking) stream
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     B, frames = wl["B"], wl["frames"]
     if wl["extractor"] == "xception":
         cfg, ef, tsf = harness.build_models_xs(frames, seed=0, device=dev)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 102
+#define MT_VERSION 103
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -196,10 +196,12 @@ int mt_build_clip_inputs(const int* slots, const int* valid, const int* frames, 
  * dx_colsum (optional, [dim], atomically accumulated): column sums of the UPDATED dx rows -- the bias gradient of the Linear
  * whose output gradient dx is next (to_out.0.bias / net.3.bias / to_patch_embedding.bias), which the reference gets from
  * autograd's sum over rows; rows with row % skip_period == 0 are left out when skip_period > 0 (the cls rows, which the patch
- * embedding does not produce, :231-232). */
+ * embedding does not produce, :231-232).
+ * dx_in (optional): with accumulate != 0 the sum is dx = LN'(dy) + dx_in instead of in place (NULL = dx itself), so that the
+ * previous value of the residual-stream gradient stays readable (deferred weight gradients, tsf_backward.py). */
 int mt_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
                      float* dgamma, float* dbeta, int rows, int dim, int accumulate, float* dx_colsum, int skip_period,
-                     void* stream);
+                     const float* dx_in, void* stream);
 
 /* out[n] += sum_m A[map(m)*lda + n]   (bias gradients). */
 int mt_colsum(const float* A, int64_t lda, mt_rowmap map, int M, int N, float* out, void* stream);

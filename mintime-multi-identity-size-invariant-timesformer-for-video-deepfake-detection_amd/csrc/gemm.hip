@@ -89,6 +89,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   a.b_planes = d->b_planes; a.b_pstride = d->b_plane_stride;
   a.e_scale = d->e_scale; a.e_shift = d->e_shift; a.e_gate = d->e_gate; a.e_dpool = d->e_dpool; a.e_mi = d->e_mi;
   a.e_hw = d->e_hw > 0 ? d->e_hw : 1;
+  a.xcd_k = 0;
   a.A2 = d->A2; a.b_scale = d->b_scale; a.b_shift = d->b_shift; a.b_gate = d->b_gate; a.b_hw = d->b_hw > 0 ? d->b_hw : 1;
 
   // K-contiguous operands need K % 4 == 0 (float4 along K); k-major operands need M resp. N % 4 == 0

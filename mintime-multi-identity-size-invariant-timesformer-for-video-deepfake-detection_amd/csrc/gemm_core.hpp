@@ -151,6 +151,7 @@ struct GemmArgs {
   const void* b_planes; int64_t b_pstride;   // split loop: B as three pre-split bf16 planes [N][K] (plane stride in elements), or null
   // EPI_SE_RED / EPI_ACT_BWD (epilogue-side vectors; the prologue's scale/shift/gate are taken by PRO_BN_BWD)
   const float* e_scale; const float* e_shift; const float* e_gate; const float* e_dpool; const float* e_mi; int e_hw;
+  int xcd_k;                            // split-K weight gradients: every XCD owns whole K-ranges (gemm_split.hpp), grid = (tiles, splits % 8 == 0)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

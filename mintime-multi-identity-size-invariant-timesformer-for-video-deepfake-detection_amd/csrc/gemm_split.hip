@@ -207,10 +207,23 @@ int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
       if (splits > max_splits) splits = max_splits;
     }
     if (splits < 1) splits = 1;
-    int chunk = (d->K + splits - 1) / splits;
-    chunk = (chunk + 15) / 16 * 16;
-    a.k_chunk = chunk;
-    grid.y = (d->K + chunk - 1) / chunk;
+    static const int xcd_k_on = getenv("MT_WGRAD_XCD_K") ? atoi(getenv("MT_WGRAD_XCD_K")) : 1;
+    if (d->op == MT_OP_TN && xcd_k_on && splits >= 8 && d->a_map.gin == 0 && d->b_map.gin == 0) {
+      // K-range-major over the XCDs (gemm_split.hpp): a multiple of 8 ranges, exactly m_tiles * n_tiles blocks per range
+      splits = (splits + 4) / 8 * 8;
+      int chunk = (d->K + splits - 1) / splits;
+      chunk = (chunk + 15) / 16 * 16;
+      a.k_chunk = chunk;
+      a.xcd_k = 1;
+      a.group_n = 0;
+      grid.x = m_tiles * n_tiles;
+      grid.y = splits;
+    } else {
+      int chunk = (d->K + splits - 1) / splits;
+      chunk = (chunk + 15) / 16 * 16;
+      a.k_chunk = chunk;
+      grid.y = (d->K + chunk - 1) / chunk;
+    }
   }
 
 #define SPLIT_COMBO(OP, AL, BL, EPI)                                 \

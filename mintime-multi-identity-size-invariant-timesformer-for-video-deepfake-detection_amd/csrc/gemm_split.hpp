@@ -84,16 +84,32 @@ void gemm_split_kernel(const GemmArgs p) {
   const int wn = wave % WAVES_N;
 
   int mt_, nt_;
-  if (!tile_coords<BM, BN>(p, mt_, nt_)) return;
-  const int m0 = mt_ * BM;
-  const int n0 = nt_ * BN;
-
   int k_begin = 0, k_end = p.K;
-  if (p.k_chunk > 0) {
-    k_begin = blockIdx.y * p.k_chunk;
+  if (p.xcd_k) {
+    // Split-K weight gradient, K-range-major over the XCDs.  Workgroups are dealt round-robin to the 8 XCDs in flattened
+    // (y, x) order; with the split index on blockIdx.y every XCD ran a slice of the TILES for ALL K-ranges, so each XCD's L2
+    // fetched the whole second operand (and most of the first) for itself: 3.5x the algorithmic bytes per launch.  Here XCD c owns
+    // the K-ranges c, c + 8, ...: inside one range the operand panels are shared by tiles that run back to back on the SAME L2
+    // (the larger operand's panel index is the slow one), and nothing is read by two XCDs.
+    const int tiles = gridDim.x, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = lin & 7, idx = lin >> 3;
+    const int split = xcd + 8 * (idx / tiles), t = idx % tiles;
+    const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + BM - 1) / BM;
+    if (m_tiles >= n_tiles) { mt_ = t / n_tiles; nt_ = t - mt_ * n_tiles; }
+    else { nt_ = t / m_tiles; mt_ = t - nt_ * m_tiles; }
+    k_begin = split * p.k_chunk;
     k_end = min(p.K, k_begin + p.k_chunk);
     if (k_begin >= k_end) return;
+  } else {
+    if (!tile_coords<BM, BN>(p, mt_, nt_)) return;
+    if (p.k_chunk > 0) {
+      k_begin = blockIdx.y * p.k_chunk;
+      k_end = min(p.K, k_begin + p.k_chunk);
+      if (k_begin >= k_end) return;
+    }
   }
+  const int m0 = mt_ * BM;
+  const int n0 = nt_ * BN;
   const int nk = (k_end - k_begin + BK - 1) / BK;   // host guarantees (k_end - k_begin) % 8 == 0: the last tile may hold one 8-k granule only
   const bool k_tail = ((k_end - k_begin) & 15) != 0;
 

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             float* __restrict__ dx, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int rows, int D, int accumulate,
-                                                            float* __restrict__ dxsum, int skip_period) {
+                                                            float* __restrict__ dxsum, int skip_period, const float* dx_in) {
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
@@ -88,6 +88,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     b1 = wave_sum(b1) / (float)D; b2 = wave_sum(b2) / (float)D;
     float4* dxr0 = reinterpret_cast<float4*>(dx + (int64_t)row0 * D);
     float4* dxr1 = reinterpret_cast<float4*>(dx + (int64_t)r1 * D);
+    const float4* pin0 = reinterpret_cast<const float4*>(dx_in + (int64_t)row0 * D);     // == dx when accumulating in place
+    const float4* pin1 = reinterpret_cast<const float4*>(dx_in + (int64_t)r1 * D);
     // rows with row % skip_period == 0 (the cls rows of the token matrix) are left out of dxsum when skip_period > 0
     const float c0 = (skip_period > 0 && row0 % skip_period == 0) ? 0.f : 1.f;
     const float c1 = (!has1 || (skip_period > 0 && row1 % skip_period == 0)) ? 0.f : 1.f;
@@ -98,14 +100,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         float4 o;
         o.x = rstd0 * (gy0[i].x - a1 - xh0[i].x * a2); o.y = rstd0 * (gy0[i].y - a1 - xh0[i].y * a2);
         o.z = rstd0 * (gy0[i].z - a1 - xh0[i].z * a2); o.w = rstd0 * (gy0[i].w - a1 - xh0[i].w * a2);
-        if (accumulate) { const float4 p = dxr0[q]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+        if (accumulate) { const float4 p = pin0[q]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
         dxr0[q] = o;
         ds[i].x += c0 * o.x; ds[i].y += c0 * o.y; ds[i].z += c0 * o.z; ds[i].w += c0 * o.w;
         if (has1) {
           float4 t;
           t.x = rstd1 * (gy1[i].x - b1 - xh1[i].x * b2); t.y = rstd1 * (gy1[i].y - b1 - xh1[i].y * b2);
           t.z = rstd1 * (gy1[i].z - b1 - xh1[i].z * b2); t.w = rstd1 * (gy1[i].w - b1 - xh1[i].w * b2);
-          if (accumulate) { const float4 p = dxr1[q]; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }
+          if (accumulate) { const float4 p = pin1[q]; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }
           dxr1[q] = t;
           ds[i].x += c1 * t.x; ds[i].y += c1 * t.y; ds[i].z += c1 * t.z; ds[i].w += c1 * t.w;
         }
@@ -769,7 +771,7 @@ int launch_patch_bwd(const float* qkv, const float* dout, float* dqkv, const uin
 
 extern "C" int mt_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
                                 float* dgamma, float* dbeta, int rows, int dim, int accumulate, float* dx_colsum, int skip_period,
-                                void* stream) {
+                                const float* dx_in, void* stream) {
   if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta) return fail(MT_ERR_ARG, "mt_layernorm_bwd: null pointer");
   if (dim <= 0 || (dim & 3) || dim > 1024) return fail(MT_ERR_ARG, "mt_layernorm_bwd: dim %d unsupported", dim);
   if (rows <= 0) return 0;
@@ -778,10 +780,10 @@ extern "C" int mt_layernorm_bwd(const float* dy, const float* x, const float* st
   if (blocks > cap) blocks = cap;
   if (dim <= 512)
     hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dgamma, dbeta,
-                       rows, dim, accumulate, dx_colsum, skip_period);
+                       rows, dim, accumulate, dx_colsum, skip_period, dx_in ? dx_in : dx);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dgamma, dbeta,
-                       rows, dim, accumulate, dx_colsum, skip_period);
+                       rows, dim, accumulate, dx_colsum, skip_period, dx_in ? dx_in : dx);
   return check_launch("mt_layernorm_bwd");
 }
 

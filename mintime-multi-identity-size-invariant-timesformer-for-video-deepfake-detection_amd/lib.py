@@ -72,7 +72,7 @@ PROTOTYPES = {
     "mt_bn_act_fwd": [f32p, f32p, f32p, f32p, f32p, i64, C.c_int, C.c_int, f32p, C.c_int, C.c_void_p],
     "mt_attn_aggregate": [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "mt_build_clip_inputs": [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_void_p],
-    "mt_layernorm_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_void_p],
+    "mt_layernorm_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_void_p],
     "mt_colsum": [f32p, i64, RowMap, C.c_int, C.c_int, f32p, C.c_void_p],
     "mt_head_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                     C.c_void_p],
@@ -138,8 +138,8 @@ def get():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     v = lib.mt_version()
-    if v != 102:
-        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 102; rebuild it")
+    if v != 103:
+        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 103; rebuild it")
     _lib = lib
     return lib
 
@@ -265,13 +265,26 @@ def grads_ready(model, params, flat):
         hook(params, flat)
 
 
-def _low_priority_stream(device):
+def _low_priority_stream(device, cu_mask_words=None):
     """The weight-gradient stream at the LOWEST hardware queue priority: its kernels fill the CUs the critical path leaves idle
     instead of taking CUs from it (in-step trace: with equal priorities the main queue's LayerNorm-backward launches stretched
     2x next to the three-blocks-per-CU weight-gradient GEMMs).  torch only exposes normal / high, so the stream is created through
     the HIP runtime and wrapped.  MT_SIDE_PRIORITY=normal keeps torch's default."""
     if os.environ.get("MT_SIDE_PRIORITY", "low") != "low":
         return torch.cuda.Stream(device=device)
+    if cu_mask_words:
+        # experiment: confine the stream's kernels to a subset of the CUs (hipExtStreamCreateWithCUMask; 32 CUs per word)
+        try:
+            hip = C.CDLL("libamdhip64.so")
+            idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+            arr = (C.c_uint32 * len(cu_mask_words))(*cu_mask_words)
+            handle = C.c_void_p()
+            with torch.cuda.device(idx):
+                rc = hip.hipExtStreamCreateWithCUMask(C.byref(handle), C.c_uint32(len(cu_mask_words)), arr)
+            if rc == 0:
+                return torch.cuda.ExternalStream(handle.value, device=torch.device("cuda", idx))
+        except (OSError, AttributeError):
+            pass
     try:
         hip = C.CDLL("libamdhip64.so")
         least, greatest = C.c_int(0), C.c_int(0)
@@ -295,13 +308,14 @@ class SideStream:
 
     _streams = {}
 
-    def __init__(self, device, enabled=True):
+    def __init__(self, device, enabled=True, name=""):
         self.enabled = enabled and os.environ.get("MT_SIDE_STREAM", "1") != "0"
         self.device = device
         if self.enabled:
-            key = str(device)
+            key = str(device) + name                 # name: a further low-priority stream (deferred weight gradients)
             if key not in SideStream._streams:
-                SideStream._streams[key] = _low_priority_stream(device)
+                mask = os.environ.get("MT_LATE_CU_MASK") if name else None      # "ffffffff,ffffffff,0,0,..." (hex words, 32 CUs each)
+                SideStream._streams[key] = _low_priority_stream(device, [int(w, 16) for w in mask.split(",")] if mask else None)
             self.stream = SideStream._streams[key]
         self.pending = []
 

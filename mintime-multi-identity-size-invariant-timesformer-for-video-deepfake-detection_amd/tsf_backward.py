@@ -44,6 +44,20 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         return idx
 
     side = L.SideStream(dev)
+    # Deferred weight gradients (MT_WGRAD_DEFER=1, off by default).  Inside the TimeSformer's reverse walk the weight-gradient GEMMs
+    # (9 ms of matrix work on the side stream) compete with the data-gradient GEMMs of the critical path for the same matrix cores;
+    # the EfficientNet backward that follows is HBM-bound and leaves those cores idle.  With the switch on the 55 launches are only
+    # RECORDED here (their operands kept: per-layer du / dqkv buffers and out-of-place residual-stream gradients instead of buffers
+    # reused in place, ~4 GB of the 288) and issued after the walk on their own low-priority stream, under the extractor's
+    # backward; the main stream joins that stream when the whole autograd pass has finished (engine callback).
+    # MEASURED (profiles/r03_wgrad_schedule_experiments.txt): the TimeSformer backward phase drops 20.5 -> 12.9 ms and the extractor
+    # backward phase grows 17.3 -> 23.6 ms -- the step is unchanged (54.4 ms), also with the late stream confined to half of the
+    # CUs (hipExtStreamCreateWithCUMask) and with its HBM traffic cut by 45 %.  Concurrency only re-distributes a fixed amount of
+    # work; the GPU runs the step at ~1250 W with the shader clock throttled to ~2245 of 2400 MHz.  Hence off: it would only delay
+    # the TimeSformer gradient bucket of a data-parallel run.
+    defer = (os.environ.get("MT_WGRAD_DEFER", "0") != "0" and need_dfeat and side.enabled and M >= 4096
+             and getattr(model, "_grads_ready_hook", None) is None and not torch.cuda.is_current_stream_capturing())
+    deferred = []
     wT = saved.get("wT")                              # transposed weights (tsf_engine.tsf_forward): data gradients in NT form
     if wT is not None:
         side.wait(saved["wT_ready"])
@@ -86,7 +100,19 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             L.gemm(L.OP_TN, A, Bm, out, M_, N_, K_, lda, ldb, ldc, epilogue=L.EPI_ATOMIC, split_k=0, **kw)
             if bias_out is not None:
                 colsum(A, lda, K_, M_, bias_out, kw.get("a_map", (0, 0, 0)))
+        if defer:
+            deferred.append((run, (A, Bm)))
+            return None
         return side.launch(run, reads=(A, Bm))
+
+    def ln_bwd(dxn_, r_, g_, dx_cur, i_g, tgt, skip):
+        """dx = LN'(dxn) + dx_cur (+ gamma / beta gradients, + column sums for the bias below).  In place, or -- when weight
+        gradients that read dx_cur are still to come -- into a fresh buffer."""
+        dx_new = torch.empty_like(dx_cur) if defer else dx_cur
+        L.check(lib.mt_layernorm_bwd(L.ptr(dxn_), L.ptr(r_["x"]), L.ptr(r_["stats"]), L.ptr(g_), L.ptr(dx_new), L.ptr(grads[i_g]),
+                                     L.ptr(grads[i_g + 1]), M, D, 1, L.ptr(tgt), skip, L.ptr(dx_cur) if defer else None, st),
+                "mt_layernorm_bwd")
+        return dx_new
 
     # ---- head
     i0 = take(4)
@@ -111,6 +137,8 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         g, b_, w1, b1, w2, b2 = P[i0:i0 + 6]
         r = rec[2]
         side.wait()                                   # du / dx2 readers of the previous sub-block are done
+        if defer:
+            du = torch.empty(M, 8 * D, dtype=torch.float32, device=dev)       # kept for the deferred net.0 weight gradient
         e_dx = wgrad(dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D,
                      bias_out=grads[i0 + 5] if li == model.depth - 1 else None)
         if wT is not None:
@@ -121,11 +149,11 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
                    col_sum=grads[i0 + 3])             # net.0.bias gradient = column sums of du, taken in the epilogue
         wgrad(du, r["xn"], grads[i0 + 2], 8 * D, D, M, 8 * D, D, D)
         e_dg = dgrad_skinny(du, w1, dxn, 8 * D, wT[(li, 12)] if wT is not None else None)
-        side.wait(e_dx)                               # LayerNorm backward updates dx2 in place
+        if e_dx is not None:
+            side.wait(e_dx)                           # LayerNorm backward updates dx2 in place
         if e_dg is not None:
             side.wait(e_dg)                           # ... and reads dxn, part of which the side stream summed
-        L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
-                                     L.ptr(grads[i0 + 1]), M, D, 1, L.ptr(grads[i0 - 1]), 0, st), "mt_layernorm_bwd")   # -> space to_out.0.bias
+        dx2 = ln_bwd(dxn, r, g, dx2, i0, grads[i0 - 1], 0)                     # column sums -> space to_out.0.bias
         r.clear()
         # ---- attention blocks: x_out = o Wo^T + bo + x ; o = attn(qkv) ; qkv = LN(x) Wqkv^T
         for mode in (1, 0):
@@ -133,6 +161,8 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             g, b_, w_qkv, w_o, b_o = P[i0:i0 + 5]
             r = rec[mode]
             side.wait()                               # dqkv / dx2 readers of the previous sub-block are done
+            if defer:
+                dqkv = torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)
             e_dx = wgrad(dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner)
             if wT is not None:
                 L.gemm(L.OP_NT, dx2, wT[(li, 8 if mode == 1 else 3)], do, M, inner, D, D, D, inner)
@@ -142,7 +172,8 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
                                     scale, st), "mt_attn_bwd")
             wgrad(dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
             e_dg = dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner, wT[(li, 7 if mode == 1 else 2)] if wT is not None else None)
-            side.wait(e_dx)
+            if e_dx is not None:
+                side.wait(e_dx)
             if e_dg is not None:
                 side.wait(e_dg)
             # the updated dx2 feeds the sub-block below: time attention's to_out.0.bias (index i0 - 1), the previous layer's
@@ -152,13 +183,13 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
                 tgt, skip = grads[1], N
             else:
                 tgt, skip = grads[i0 - 1], 0
-            L.check(lib.mt_layernorm_bwd(L.ptr(dxn), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
-                                         L.ptr(grads[i0 + 1]), M, D, 1, L.ptr(tgt), skip, st), "mt_layernorm_bwd")
+            dx2 = ln_bwd(dxn, r, g, dx2, i0, tgt, skip)
             r.clear()
 
     # ---- embeddings + patch embedding
     i0 = take(5)
     w_pe, b_pe, cls, pos_w, size_w = P[i0:i0 + 5]
+    dx = dx2.view(B, N, D)                            # (a fresh buffer per sub-block when the weight gradients are deferred)
     L.check(lib.mt_embed_bwd(L.ptr(dx), L.ptr(grads[i0 + 2]), L.ptr(grads[i0 + 3]), L.ptr(grads[i0 + 4]), L.ptr(aux.positions),
                              L.ptr(aux.sizes), B, F, n, D, pos_w.shape[0], size_w.shape[0] if size_w is not None else 0, st),
             "mt_embed_bwd")
@@ -172,6 +203,25 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         L.gemm(L.OP_NN, dx2, w_pe, dfeat, Mt, C_in, D, D, C_in, C_in, a_map=tok_map)
     side.wait()
     assert idx == 0
+    if deferred:
+        late = L.SideStream(dev, name=":deferred-wgrad")
+        main = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(main)                            # every operand of the recorded launches has been produced by now
+        late.stream.wait_event(ready)
+        with torch.cuda.stream(late.stream):
+            for run, reads in deferred:
+                for t in reads:
+                    t.record_stream(late.stream)      # freed by this function's return: the allocator must not hand them out early
+                run()
+        for g_ in grads:
+            if g_ is not None:
+                g_.record_stream(late.stream)
+                break                                 # (all views of one flat buffer)
+        done = torch.cuda.Event()
+        done.record(late.stream)
+        # end of the WHOLE backward pass (after the extractor's walk): the stream autograd ran on waits for the late launches
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_event(done))
     L.grads_ready(model, params, flat_grads)
     out = []
     for gneed, gr in zip(need_dparams, grads):

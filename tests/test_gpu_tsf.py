@@ -292,7 +292,13 @@ def test_layernorm_backward_emits_column_sums_of_updated_dx(rows, skip):
     dxd, dg, db, cs = dx0.cuda().clone(), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
     dy_d, x_d, gamma_d = dy.cuda(), x.cuda(), gamma.cuda()          # keep the device copies alive across the raw-pointer call
     L.check(L.get().mt_layernorm_bwd(L.ptr(dy_d), L.ptr(x_d), L.ptr(stats), L.ptr(gamma_d), L.ptr(dxd), L.ptr(dg), L.ptr(db),
-                                     rows, D, 1, L.ptr(cs), skip, L.stream_ptr()), "ln bwd")
+                                     rows, D, 1, L.ptr(cs), skip, None, L.stream_ptr()), "ln bwd")
     assert_close(dxd, dx_ref, 1e-5, "dx")
+    # out-of-place form (dx = LN'(dy) + dx_in): same numbers, the input gradient untouched
+    dx_in, dx_out = dx0.cuda().clone(), torch.full((rows, D), float("nan"), device="cuda")
+    dg2, db2, cs2 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    L.check(L.get().mt_layernorm_bwd(L.ptr(dy_d), L.ptr(x_d), L.ptr(stats), L.ptr(gamma_d), L.ptr(dx_out), L.ptr(dg2), L.ptr(db2),
+                                     rows, D, 1, L.ptr(cs2), skip, L.ptr(dx_in), L.stream_ptr()), "ln bwd (out of place)")
+    assert torch.equal(dx_out, dxd) and torch.equal(dx_in, dx0.cuda())
     assert_close(cs, dx_ref[keep].sum(0), 1e-4, "column sums of the updated dx")
     assert_close(db, dy.double().sum(0), 1e-4, "dbeta")
