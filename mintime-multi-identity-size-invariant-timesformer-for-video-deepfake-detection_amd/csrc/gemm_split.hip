@@ -201,16 +201,20 @@ int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
     int splits = d->split_k;
     if (d->op == MT_OP_TN && splits <= 0) {
       const int tiles = m_tiles * n_tiles;
-      static const int target = getenv("MT_WGRAD_BLOCKS") ? atoi(getenv("MT_WGRAD_BLOCKS")) : 2048;   // tuning knob
+      // blocks per launch.  Round 2: 2048 (16-49 K-ranges, whose fp32-atomic partial sums were as much HBM-side traffic as the
+      // operands).  With the K-range-major XCD mapping the step time is flat from 384 to 2048 (53.7-54.2 ms); 640 keeps 8-40
+      // ranges: partial-sum traffic 104 -> ~48 MB per launch (family total ~1.45x the algorithmic bytes).
+      static const int target = getenv("MT_WGRAD_BLOCKS") ? atoi(getenv("MT_WGRAD_BLOCKS")) : 640;   // tuning knob
       splits = (target + tiles - 1) / tiles;
       const int max_splits = d->K / 256 > 0 ? d->K / 256 : 1;
       if (splits > max_splits) splits = max_splits;
     }
     if (splits < 1) splits = 1;
     static const int xcd_k_on = getenv("MT_WGRAD_XCD_K") ? atoi(getenv("MT_WGRAD_XCD_K")) : 1;
-    if (d->op == MT_OP_TN && xcd_k_on && splits >= 8 && d->a_map.gin == 0 && d->b_map.gin == 0) {
+    if (d->op == MT_OP_TN && xcd_k_on && d->split_k <= 0 && d->K >= 8 * 256 && d->a_map.gin == 0 && d->b_map.gin == 0) {
       // K-range-major over the XCDs (gemm_split.hpp): a multiple of 8 ranges, exactly m_tiles * n_tiles blocks per range
       splits = (splits + 4) / 8 * 8;
+      if (splits < 8) splits = 8;
       int chunk = (d->K + splits - 1) / splits;
       chunk = (chunk + 15) / 16 * 16;
       a.k_chunk = chunk;
