@@ -268,16 +268,28 @@ __global__ __launch_bounds__(CLS_W * 64) void attn_cls_bwd_kernel(const float* _
   float4 q = *reinterpret_cast<const float4*>(base);
   q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
   const float4 dO = *reinterpret_cast<const float4*>(dout + (int64_t)b * N * inner + h * DH + sub * 4);   // row 0
-  for (int j = grp; j < N; j += KPP) {
-    const float4 kk = *reinterpret_cast<const float4*>(base + (int64_t)j * ld + inner);
-    const float4 vv = *reinterpret_cast<const float4*>(base + (int64_t)j * ld + 2 * inner);
-    float a = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
-    float dp = fmaf(dO.x, vv.x, fmaf(dO.y, vv.y, fmaf(dO.z, vv.z, dO.w * vv.w)));
+  // CLS_U passes per trip with all their K / V rows requested up front: one block per (b, h) means one wave per SIMD, so a pass that
+  // loads, reduces and stores before the next pass's loads are issued is a chain of N / 16 exposed round trips (46 us per launch).
+  constexpr int CLS_U = 4;
+  for (int j0 = grp; j0 < N; j0 += KPP * CLS_U) {
+    float4 kk[CLS_U], vv[CLS_U];
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o); dp += __shfl_xor(dp, o); }
-    if (sub == 0) {
-      if (j > 0 && mask && !mask[b * F + (j - 1) / n]) a = -FLT_MAX;
-      pl_[j] = a; ds_[j] = dp;
+    for (int u = 0; u < CLS_U; ++u) {
+      const int j = min(j0 + u * KPP, N - 1);
+      kk[u] = *reinterpret_cast<const float4*>(base + (int64_t)j * ld + inner);
+      vv[u] = *reinterpret_cast<const float4*>(base + (int64_t)j * ld + 2 * inner);
+    }
+#pragma unroll
+    for (int u = 0; u < CLS_U; ++u) {
+      const int j = j0 + u * KPP;
+      float a = fmaf(q.x, kk[u].x, fmaf(q.y, kk[u].y, fmaf(q.z, kk[u].z, q.w * kk[u].w)));
+      float dp = fmaf(dO.x, vv[u].x, fmaf(dO.y, vv[u].y, fmaf(dO.z, vv[u].z, dO.w * vv[u].w)));
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o); dp += __shfl_xor(dp, o); }
+      if (sub == 0 && j < N) {
+        if (j > 0 && mask && !mask[b * F + (j - 1) / n]) a = -FLT_MAX;
+        pl_[j] = a; ds_[j] = dp;
+      }
     }
   }
   __syncthreads();
@@ -294,13 +306,22 @@ __global__ __launch_bounds__(CLS_W * 64) void attn_cls_bwd_kernel(const float* _
   __syncthreads();
   // per key: dS; dk_j = dS * q_scaled, dv_j = p * dO (stores), dq += dS * k_j
   float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j = grp; j < N; j += KPP) {
-    const float p = pl_[j];
-    const float dS = p * (ds_[j] - delta);
-    const float4 kk = *reinterpret_cast<const float4*>(base + (int64_t)j * ld + inner);
-    *reinterpret_cast<float4*>(dbase + (int64_t)j * ld + inner) = make_float4(dS * q.x, dS * q.y, dS * q.z, dS * q.w);
-    *reinterpret_cast<float4*>(dbase + (int64_t)j * ld + 2 * inner) = make_float4(p * dO.x, p * dO.y, p * dO.z, p * dO.w);
-    dq.x = fmaf(dS, kk.x, dq.x); dq.y = fmaf(dS, kk.y, dq.y); dq.z = fmaf(dS, kk.z, dq.z); dq.w = fmaf(dS, kk.w, dq.w);
+  for (int j0 = grp; j0 < N; j0 += KPP * CLS_U) {
+    float4 kk[CLS_U];
+#pragma unroll
+    for (int u = 0; u < CLS_U; ++u)
+      kk[u] = *reinterpret_cast<const float4*>(base + (int64_t)min(j0 + u * KPP, N - 1) * ld + inner);
+#pragma unroll
+    for (int u = 0; u < CLS_U; ++u) {
+      const int j = j0 + u * KPP;
+      if (j < N) {
+        const float p = pl_[j];
+        const float dS = p * (ds_[j] - delta);
+        *reinterpret_cast<float4*>(dbase + (int64_t)j * ld + inner) = make_float4(dS * q.x, dS * q.y, dS * q.z, dS * q.w);
+        *reinterpret_cast<float4*>(dbase + (int64_t)j * ld + 2 * inner) = make_float4(p * dO.x, p * dO.y, p * dO.z, p * dO.w);
+        dq.x = fmaf(dS, kk[u].x, dq.x); dq.y = fmaf(dS, kk[u].y, dq.y); dq.z = fmaf(dS, kk[u].z, dq.z); dq.w = fmaf(dS, kk[u].w, dq.w);
+      }
+    }
   }
   // sum over the key slots: the 4 groups of a wavefront, then the wavefronts
 #pragma unroll

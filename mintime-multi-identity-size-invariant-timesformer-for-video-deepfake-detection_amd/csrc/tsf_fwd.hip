@@ -400,14 +400,23 @@ __global__ __launch_bounds__(CLS_W * 64) void attn_cls_fwd_kernel(const float* _
   const float* base = qkv + (int64_t)b * N * ld + h * DH + sub * 4;
   float4 q = *reinterpret_cast<const float4*>(base);
   q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
-  for (int j = grp; j < N; j += KPP) {
-    const float4 kk = *reinterpret_cast<const float4*>(base + (int64_t)j * ld + inner);
-    float a = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
+  // CLS_U passes per trip, their K rows requested up front (one wave per SIMD: nothing else hides a pass's round trip)
+  constexpr int CLS_U = 4;
+  for (int j0 = grp; j0 < N; j0 += KPP * CLS_U) {
+    float4 kk[CLS_U];
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    if (sub == 0) {
-      if (j > 0 && mask && !mask[b * F + (j - 1) / n]) a = -FLT_MAX;
-      lds[j] = a;
+    for (int u = 0; u < CLS_U; ++u)
+      kk[u] = *reinterpret_cast<const float4*>(base + (int64_t)min(j0 + u * KPP, N - 1) * ld + inner);
+#pragma unroll
+    for (int u = 0; u < CLS_U; ++u) {
+      const int j = j0 + u * KPP;
+      float a = fmaf(q.x, kk[u].x, fmaf(q.y, kk[u].y, fmaf(q.z, kk[u].z, q.w * kk[u].w)));
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o);
+      if (sub == 0 && j < N) {
+        if (j > 0 && mask && !mask[b * F + (j - 1) / n]) a = -FLT_MAX;
+        lds[j] = a;
+      }
     }
   }
   __syncthreads();
@@ -426,10 +435,19 @@ __global__ __launch_bounds__(CLS_W * 64) void attn_cls_fwd_kernel(const float* _
   __syncthreads();
   // out = sum_j p_j v_j
   float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j = grp; j < N; j += KPP) {
-    const float pj = lds[j];
-    const float4 vv = *reinterpret_cast<const float4*>(base + (int64_t)j * ld + 2 * inner);
-    o4.x = fmaf(pj, vv.x, o4.x); o4.y = fmaf(pj, vv.y, o4.y); o4.z = fmaf(pj, vv.z, o4.z); o4.w = fmaf(pj, vv.w, o4.w);
+  for (int j0 = grp; j0 < N; j0 += KPP * CLS_U) {
+    float4 vv[CLS_U];
+#pragma unroll
+    for (int u = 0; u < CLS_U; ++u)
+      vv[u] = *reinterpret_cast<const float4*>(base + (int64_t)min(j0 + u * KPP, N - 1) * ld + 2 * inner);
+#pragma unroll
+    for (int u = 0; u < CLS_U; ++u) {
+      const int j = j0 + u * KPP;
+      if (j < N) {                                      // same order of additions as the one-pass loop: bit-identical outputs
+        const float pj = lds[j];
+        o4.x = fmaf(pj, vv[u].x, o4.x); o4.y = fmaf(pj, vv[u].y, o4.y); o4.z = fmaf(pj, vv[u].z, o4.z); o4.w = fmaf(pj, vv[u].w, o4.w);
+      }
+    }
   }
 #pragma unroll
   for (int o = 16; o < 64; o <<= 1) {
