@@ -32,6 +32,7 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   size_t lds = BPL ? (size_t)(6 * BM + 9 * BN) * 32 : (size_t)2 * 3 * (BM + BN) * 32;
   if (PRO == PRO_BN_SWISH_GATE) lds += (size_t)(2 + (BM - 1) / a.hw + 2) * a.K * 4;      // scale, shift, gate rows of the images a row tile touches
+  if (PRO == PRO_BN_BWD && AL == LAYOUT_KCONTIG) lds += (size_t)3 * a.K * 4;             // ka, kb, kc
   if (!BAL && AL == LAYOUT_KMAJOR) {
     // experiment knob: extra LDS per weight-gradient block (8192 -> two instead of three blocks per CU, leaving room for a
     // main-stream GEMM block).  Measured in-step: 55.3 vs 54.4 ms -- the weight gradients lose more than the main stream gains.
@@ -52,7 +53,7 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
   return check_launch("mt_gemm(split)");
 }
 
-template <int AL, int BL, int EPI>
+template <int AL, int BL, int EPI, int PRO = PRO_NONE>
 int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
   // Balanced accumulators (gemm_split.hpp: BAL) wherever a result feeds further contractions (activations, data gradients): the
   // bf16 pipe's rounding bias is only a problem when it adds up coherently through depth.  Weight gradients (TN) are leaves --
@@ -61,12 +62,12 @@ int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
   if constexpr (AL == LAYOUT_KMAJOR && BL == LAYOUT_KMAJOR) {
     static const bool wbal = getenv("MT_SPLIT_WGRAD_BAL") && atoi(getenv("MT_SPLIT_WGRAD_BAL")) != 0;
     if (!wbal) {
-      if (v == S_BIG) return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, false>(a, grid, s);
-      if (v == S_MID) return launch_one<2, 2, 2, 1, AL, BL, EPI, 3, false>(a, grid, s);
-      if (v == S_SMALL) return launch_one<2, 2, 1, 1, AL, BL, EPI, 4, false>(a, grid, s);
+      if (v == S_BIG) return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, false, PRO>(a, grid, s);
+      if (v == S_MID) return launch_one<2, 2, 2, 1, AL, BL, EPI, 3, false, PRO>(a, grid, s);
+      if (v == S_SMALL) return launch_one<2, 2, 1, 1, AL, BL, EPI, 4, false, PRO>(a, grid, s);
     }
   }
-  if constexpr (AL == LAYOUT_KCONTIG && BL == LAYOUT_KCONTIG && EPI != EPI_STATS) {
+  if constexpr (AL == LAYOUT_KCONTIG && BL == LAYOUT_KCONTIG && EPI != EPI_STATS && PRO == PRO_NONE) {
     // weight pre-split into bf16 planes (mt_split_planes): B by DMA, 128 x 128 tiles only.  Bit-identical to the in-kernel split.
     // Round 2: 7-12 % slower (hipcc's vmcnt for the staged A tile also drained the DMA of the same step).  Round 3: the A loads are
     // inline asm under one counted wait per step (no compiler-inserted vmcnt left in the loop, checked in the ISA) -- and the variant
@@ -77,10 +78,10 @@ int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
     if (planes_on && a.b_planes && (a.K % 16) == 0 && a.k_chunk == 0 && (a.ldb % 8) == 0 && a.b_map.gin == 0 && (v == S_BIG || EPI == EPI_GEGLU_BWD))
       return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, true, PRO_NONE, true>(a, grid, s);
   }
-  if (v == S_BIG) return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, true>(a, grid, s);
+  if (v == S_BIG) return launch_one<2, 2, 2, 2, AL, BL, EPI, 2, true, PRO>(a, grid, s);
   if constexpr (EPI != EPI_GEGLU) {
-    if (v == S_MID) return launch_one<2, 2, 2, 1, AL, BL, EPI, 3, true>(a, grid, s);
-    if (v == S_SMALL) return launch_one<2, 2, 1, 1, AL, BL, EPI, 4, true>(a, grid, s);
+    if (v == S_MID) return launch_one<2, 2, 2, 1, AL, BL, EPI, 3, true, PRO>(a, grid, s);
+    if (v == S_SMALL) return launch_one<2, 2, 1, 1, AL, BL, EPI, 4, true, PRO>(a, grid, s);
   }
   return fail(MT_ERR_UNSUPPORTED, "mt_gemm(split): no instance for variant %d", v);
 }
@@ -163,14 +164,26 @@ int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
     return v == S_BIG ? launch_one<2, 2, 2, 2, KC, KC, EPI_STORE, 2, true, PRO_BN_SWISH_GATE>(a, grid, s)
                       : launch_one<2, 2, 2, 1, KC, KC, EPI_STORE, 3, true, PRO_BN_SWISH_GATE>(a, grid, s);
   }
-  if (d->prologue != MT_PRO_NONE) return 1;
+  // BatchNorm-backward operand prologue (data gradients NN, weight gradients TN with a plain second operand): VALU work in the
+  // staging registers like the split itself.  Long contractions only (the Xception pointwise convolutions, EfficientNet's
+  // expand convolutions from stage 5 on and its head; the weight gradients' K is the row count).
+  const bool bn_bwd = d->prologue == MT_PRO_BN_BWD;
+  if (bn_bwd) {
+    static const int on = getenv("MT_SPLIT_BN_BWD") ? atoi(getenv("MT_SPLIT_BN_BWD")) : 1;
+    if (!on || d->a_map.gin != 0) return 1;
+    const bool nn = d->op == MT_OP_NN && (d->epilogue == MT_EPI_STORE || d->epilogue == MT_EPI_BIAS_RES);
+    const bool tn = d->op == MT_OP_TN && d->epilogue == MT_EPI_ATOMIC;
+    if (!nn && !tn) return 1;
+  } else if (d->prologue != MT_PRO_NONE) return 1;
   // short contractions stay on the fp32 pipe: the matrix time they could save is small next to their epilogue, and the bf16 pipe's
   // residual rounding bias (gemm_split.hpp) is then kept out of the extractors' long chains of small-K convolutions
   static const int min_k = getenv("MT_SPLIT_MIN_K") ? atoi(getenv("MT_SPLIT_MIN_K")) : 512;
   if (d->K < min_k) return 1;
   if (d->epilogue == MT_EPI_STATS && d->M < 4096) return 1;
   if (d->epilogue == MT_EPI_GEGLU && (d->n_half & 63)) return 1;
-  if ((int64_t)d->M * d->N < (1 << 18)) return 1;                   // a handful of tiles: the fp32 kernels' small tiles fill the chip better
+  // a handful of tiles: the fp32 kernels' small tiles fill the chip better -- unless it is a weight gradient over very many rows,
+  // whose K-ranges supply the blocks
+  if ((int64_t)d->M * d->N < (1 << 18) && !(d->op == MT_OP_TN && d->K >= 8192 && (int64_t)d->M * d->N >= (1 << 15))) return 1;
   int v = S_BIG;
   if (d->epilogue == MT_EPI_GEGLU_BWD) v = S_MID;
   else if (d->N < 128) v = S_MID;
@@ -230,6 +243,11 @@ int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
     }
   }
 
+  if (bn_bwd) {
+    if (d->op == MT_OP_TN) return launch_variant<LAYOUT_KMAJOR, LAYOUT_KMAJOR, EPI_ATOMIC, PRO_BN_BWD>(v, a, grid, s);
+    if (d->epilogue == MT_EPI_BIAS_RES) return launch_variant<LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_BIAS_RES, PRO_BN_BWD>(v, a, grid, s);
+    return launch_variant<LAYOUT_KCONTIG, LAYOUT_KMAJOR, EPI_STORE, PRO_BN_BWD>(v, a, grid, s);
+  }
 #define SPLIT_COMBO(OP, AL, BL, EPI)                                 \
   if (d->op == OP && d->epilogue == EPI) return launch_variant<AL, BL, EPI>(v, a, grid, s);
   SPLIT_COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, EPI_STORE)

@@ -55,7 +55,12 @@ void gemm_split_kernel(const GemmArgs p) {
   // PRO_BN_SWISH_GATE (k-contiguous A, two-register-set loop): a = swish(z*scale[k]+shift[k]) * gate[(m/hw)*K+k], applied to the
   // staged registers right before the split -- VALU work that rides in the MFMA shadow like the split itself.  The per-k vectors
   // and the gate rows of the images this row tile touches are cached in LDS behind the two plane stages.
-  static_assert(PRO == PRO_NONE || (PRO == PRO_BN_SWISH_GATE && AL == LAYOUT_KCONTIG && PIPE == 2), "unsupported prologue");
+  // PRO_BN_BWD (either A layout, two-register-set loop): a = ka[c]*A + kb[c]*A2 + kc[c], c = the operand's channel index (k for a
+  // k-contiguous A: data gradients; the output row m for a k-major A: weight gradients).  A2's granules ride in a second half of
+  // the staging registers; the coefficient vectors are cached in LDS (k-contiguous) or held per granule (k-major).
+  static_assert(PRO == PRO_NONE || (PRO == PRO_BN_SWISH_GATE && AL == LAYOUT_KCONTIG && PIPE == 2) || (PRO == PRO_BN_BWD && PIPE == 2 && !BPL),
+                "unsupported prologue");
+  constexpr bool BNB = PRO == PRO_BN_BWD;
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int NT = NW * 64;
   constexpr int BM = WAVES_M * TM * 32;
@@ -65,6 +70,7 @@ void gemm_split_kernel(const GemmArgs p) {
   constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
   constexpr int AG = (BM * 2 + NT - 1) / NT, BG = (BN * 2 + NT - 1) / NT;   // 8-k granules per thread
   constexpr bool A_ALL = (BM * 2) % NT == 0, B_ALL = (BN * 2) % NT == 0;   // every thread stages AG / BG granules (no predicate)
+  constexpr int AG2 = BNB ? 2 * AG : AG;            // staging granules for A (+ A2)
   // LDS map.  Staged B: two stages of {A planes, B planes}.  B planes by DMA: two A stages, then a ring of three B stages.
   constexpr int A_STAGE = BPL ? 3 * A_PLANE : STAGE;             // byte distance between the two A stages
   constexpr int B_BASE = BPL ? 6 * A_PLANE : 3 * A_PLANE;        // first B stage
@@ -115,6 +121,8 @@ void gemm_split_kernel(const GemmArgs p) {
 
   // ---- the granules this thread stages: (tile row, k half) -> global source, LDS byte offset inside a plane
   const float* a_src[AG];
+  const float* a2_src[BNB ? AG : 1];
+  float bn_ka[BNB && AL == LAYOUT_KMAJOR ? AG : 1], bn_kb[BNB && AL == LAYOUT_KMAJOR ? AG : 1], bn_kc[BNB && AL == LAYOUT_KMAJOR ? AG : 1];
   const float* b_src[BG];
   int a_dst[AG], b_dst[BG];
   int a_kh[AG], b_kh[BG];                           // k-major: the granule's k half
@@ -130,6 +138,10 @@ void gemm_split_kernel(const GemmArgs p) {
     m = m < p.M ? m : p.M - 1;                      // rows past the end are never stored: any valid row will do
     if constexpr (AL == LAYOUT_KCONTIG) a_src[j] = p.A + map_row(p.a_map, m) * p.lda + k_begin + kh * 8;
     else a_src[j] = p.A + m;
+    if constexpr (BNB) {
+      a2_src[j] = p.A2 + (a_src[j] - p.A);
+      if constexpr (AL == LAYOUT_KMAJOR) { bn_ka[j] = p.scale[m]; bn_kb[j] = p.shift[m]; bn_kc[j] = p.gate[m]; }
+    }
     a_kh[j] = kh;
     a_dst[j] = row * 32 + ((kh ^ ((row >> 3) & 1)) << 4);
   }
@@ -172,6 +184,11 @@ void gemm_split_kernel(const GemmArgs p) {
     __syncthreads();
   }
 
+  if constexpr (BNB && AL == LAYOUT_KCONTIG) {
+    const int K = p.K;
+    for (int i = tid; i < K; i += NT) { pv[i] = p.scale[i]; pv[K + i] = p.shift[i]; pv[2 * K + i] = p.gate[i]; }
+    __syncthreads();
+  }
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_split;
   const __bf16* bp_src[BI];
   if constexpr (BPL) {
@@ -202,7 +219,7 @@ void gemm_split_kernel(const GemmArgs p) {
     }
   };
 
-  auto gload = [&](int kt, float (&ga)[AG][8], float (&gb)[BG][8]) {
+  auto gload = [&](int kt, float (&ga)[AG2][8], float (&gb)[BG][8]) {
     if (MT_SPLIT_ABLATE & 1) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -217,23 +234,37 @@ void gemm_split_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < AG; ++j) {
       if (!A_ALL && !a_on[j]) continue;
-      if (k_tail && kt == nk - 1 && a_kh[j]) {         // second granule of a half-filled last tile: zeros
+      if (k_tail && kt == nk - 1 && a_kh[j]) {         // second granule of a half-filled last tile: zeros (sstore skips the prologue there)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ga[j][e] = 0.f;
+        for (int e = 0; e < 8; ++e) { ga[j][e] = 0.f; if constexpr (BNB) ga[AG + j][e] = 0.f; }
         continue;
       }
       if constexpr (AL == LAYOUT_KCONTIG) {
         const float4 u = *reinterpret_cast<const float4*>(a_src[j] + kt * BK), v = *reinterpret_cast<const float4*>(a_src[j] + kt * BK + 4);
         ga[j][0] = u.x; ga[j][1] = u.y; ga[j][2] = u.z; ga[j][3] = u.w; ga[j][4] = v.x; ga[j][5] = v.y; ga[j][6] = v.z; ga[j][7] = v.w;
+        if constexpr (BNB) {
+          const float4 u2 = *reinterpret_cast<const float4*>(a2_src[j] + kt * BK), v2 = *reinterpret_cast<const float4*>(a2_src[j] + kt * BK + 4);
+          ga[AG + j][0] = u2.x; ga[AG + j][1] = u2.y; ga[AG + j][2] = u2.z; ga[AG + j][3] = u2.w;
+          ga[AG + j][4] = v2.x; ga[AG + j][5] = v2.y; ga[AG + j][6] = v2.z; ga[AG + j][7] = v2.w;
+        }
       } else {
         const int kr = k0 + a_kh[j] * 8;
         if (p.a_map.gin == 0) {
           const float* s = a_src[j] + (int64_t)kr * p.lda;
 #pragma unroll
           for (int e = 0; e < 8; ++e) ga[j][e] = s[(int64_t)e * p.lda];
+          if constexpr (BNB) {
+            const float* s2 = a2_src[j] + (int64_t)kr * p.lda;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ga[AG + j][e] = s2[(int64_t)e * p.lda];
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) ga[j][e] = a_src[j][map_row(p.a_map, kr + e) * p.lda];
+          if constexpr (BNB) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ga[AG + j][e] = a2_src[j][map_row(p.a_map, kr + e) * p.lda];
+          }
         }
       }
     }
@@ -264,7 +295,7 @@ void gemm_split_kernel(const GemmArgs p) {
     }
   };
   bool first_store = true;
-  auto sstore = [&](int stage, const float (&ga_in)[AG][8], const float (&gb)[BG][8], bool negate_a0 = false, int ktile = 0) {
+  auto sstore = [&](int stage, const float (&ga_in)[AG2][8], const float (&gb)[BG][8], bool negate_a0 = false, int ktile = 0) {
     if (MT_SPLIT_ABLATE & 2) {
       float z = 0.f;
 #pragma unroll
@@ -291,6 +322,21 @@ void gemm_split_kernel(const GemmArgs p) {
         const float* gt = pv + g_off[j] + k;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ga[0][e] = swishf_(fmaf(ga[0][e], sc[e], sh[e])) * gt[e];
+      }
+      if constexpr (BNB) {
+        if (!(k_tail && ktile == nk - 1 && a_kh[j])) {            // (the zero granule of a half-filled last tile stays zero)
+          if constexpr (AL == LAYOUT_KCONTIG) {
+            const int k = k_begin + ktile * BK + a_kh[j] * 8;
+            const float* ka = pv + k;
+            const float* kb = pv + p.K + k;
+            const float* kc = pv + 2 * p.K + k;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ga[0][e] = fmaf(ka[e], ga[0][e], fmaf(kb[e], ga_in[AG + j][e], kc[e]));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ga[0][e] = fmaf(bn_ka[j], ga[0][e], fmaf(bn_kb[j], ga_in[AG + j][e], bn_kc[j]));
+          }
+        }
       }
       bf16x8_t x0, x1, x2;
       split_bf16<X6>(reinterpret_cast<const float(&)[4]>(ga[0][0]), reinterpret_cast<const float(&)[4]>(ga[0][4]), x0, x1, x2);
@@ -379,7 +425,7 @@ void gemm_split_kernel(const GemmArgs p) {
   // behind every MFMA (an MFMA holds the matrix pipe for 32 cycles; the wave's next 4-5 VALU issues are free in that shadow)
   auto interleave = [&]() {
     constexpr int N_MFMA = (X6 ? 6 : 3) * TM * TN;
-    constexpr int N_VALU = (AG + (BPL ? 0 : BG)) * (X6 ? 36 : 22) + (PRO == PRO_BN_SWISH_GATE ? AG * 8 * 14 : 0);
+    constexpr int N_VALU = (AG + (BPL ? 0 : BG)) * (X6 ? 36 : 22) + (PRO == PRO_BN_SWISH_GATE ? AG * 8 * 14 : 0) + (BNB ? AG * 8 * 2 : 0);
     constexpr int VALU_PER = (N_VALU + N_MFMA - 1) / N_MFMA;
     constexpr int N_VMEM = AG * (AL == LAYOUT_KCONTIG ? 2 : 8) + BG * (BL == LAYOUT_KCONTIG ? 2 : 8);
     (void)N_VMEM;   // pinning the VMEM group first was tried: the compiler then drains the previous step's loads at the top (722 vs 669 us at 4096^3)
@@ -394,7 +440,7 @@ void gemm_split_kernel(const GemmArgs p) {
   if (nk <= 0) return;
   if constexpr (PIPE == 1) {
     // one register set: tile kt+1's loads are issued at the top of step kt and consumed (split + LDS write) at its end
-    float ga[AG][8], gb[BG][8];
+    float ga[AG2][8], gb[BG][8];
     gload(0, ga, gb); sstore(0, ga, gb);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -509,7 +555,7 @@ void gemm_split_kernel(const GemmArgs p) {
     // written to the other LDS stage in the shadow of tile kt's MFMAs.  Branch-free body (the scheduler interleaves the VALU
     // split with the MFMA stream inside one basic block): past the end the loads re-read the last tile and the stores fill
     // a stage nobody reads.
-    float ga0[AG][8], gb0[BG][8], ga1[AG][8], gb1[BG][8];
+    float ga0[AG2][8], gb0[BG][8], ga1[AG2][8], gb1[BG][8];
     const int last = nk - 1;
     gload(0, ga0, gb0); sstore(0, ga0, gb0, false, 0);
     if (MT_SPLIT_ABLATE & 32) { sstore(1, ga0, gb0); first_store = false; }

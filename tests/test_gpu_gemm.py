@@ -383,6 +383,36 @@ def test_dma_bn_backward_prologue_dgrad(variant, M, K, N, with_res, monkeypatch)
     assert_close(Cd, ref, 5e-5, f"BN-backward data gradient (DMA v{variant})")
 
 
+@pytest.mark.parametrize("rows,cout,cin", [(12544, 1152, 192), (50176 + 24, 480, 80), (12544, 728, 728), (9000, 672, 112)])
+def test_bn_backward_prologue_wgrad_both_pipes(rows, cout, cin, matrix_pipe):
+    """dW[co,ci] = sum_r (ka*du + kb*z + kc)[r,co] * x[r,ci]: the expand-conv / pointwise-conv weight gradient with BatchNorm
+    backward folded into the operand load (TN + PRO_BN_BWD), on the fp32 MFMA kernels and -- for long contractions -- on the
+    split-operand loop (K-range-major split-K, fp32 atomics)."""
+    du, z, x = _rand(rows, cout, seed=1), _rand(rows, cout, seed=2), _rand(rows, cin, seed=3)
+    ka, kb, kc = _rand(cout, seed=4), _rand(cout, seed=5, scale=0.3), _rand(cout, seed=6, scale=0.1)
+    dW = torch.zeros(cout, cin, device="cuda")
+    L.gemm(L.OP_TN, du.cuda(), x.cuda(), dW, cout, cin, rows, cout, cin, cin, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC, split_k=0,
+           A2=z.cuda(), scale=ka.cuda(), shift=kb.cuda(), gate=kc.cuda())
+    dz = ka.double() * du.double() + kb.double() * z.double() + kc.double()
+    assert_close(dW, dz.T @ x.double(), 5e-5, f"BN-backward weight gradient ({matrix_pipe} pipe)")
+
+
+@pytest.mark.parametrize("M,K,N,with_res", [(12544, 728, 728, False), (3000 + 17, 1288, 320, True), (12544, 672, 112, True)])
+def test_bn_backward_prologue_dgrad_both_pipes_k_tail(M, K, N, with_res, matrix_pipe):
+    """NN + PRO_BN_BWD with K % 16 == 8 (Xception's 728 channels: the half-filled last k-tile must stay zero THROUGH the prologue,
+    whose constant term kc would otherwise leak into it) and K % 16 == 0, with and without the residual epilogue."""
+    du, z, W = _rand(M, K, seed=1), _rand(M, K, seed=2), _rand(K, N, seed=3, scale=0.1)
+    ka, kb, kc = _rand(K, seed=4), _rand(K, seed=5, scale=0.3), _rand(K, seed=6, scale=0.1)
+    res = _rand(M, N, seed=7) if with_res else None
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    kw = dict(epilogue=L.EPI_BIAS_RES, R=res.cuda(), ldr=N) if with_res else {}
+    L.gemm(L.OP_NN, du.cuda(), W.cuda(), Cd, M, N, K, K, N, N, prologue=L.PRO_BN_BWD, A2=z.cuda(), scale=ka.cuda(), shift=kb.cuda(),
+           gate=kc.cuda(), **kw)
+    dz = ka.double() * du.double() + kb.double() * z.double() + kc.double()
+    ref = dz @ W.double() + (res.double() if with_res else 0)
+    assert_close(Cd, ref, 5e-5, f"BN-backward data gradient ({matrix_pipe} pipe)")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Split-operand loop (csrc/gemm_split.hpp): fp32 in / fp32 accumulate with the products on the bf16 pipe.  Its claim is
 # "the same error against fp64 as the fp32 MFMA pipe", checked here on well-scaled, wide-dynamic-range and cancelling data.
