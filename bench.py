@@ -444,6 +444,16 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     lib.PROFILE = None
+    # launch-side cost: wall time the host needs to ENQUEUE one step (~790 launches through ctypes) onto an idle device, i.e. without
+    # back-pressure from a full queue.  The step is device-bound as long as this stays below ms_per_step.
+    t_enq = 0.0
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        t_enq += time.perf_counter() - t1
+    torch.cuda.synchronize()
+    t_enq /= 3
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -476,7 +486,8 @@ def main():
                        "model_frac_vs_fp32_mfma": round(clips_s * flop_step / (world * PEAK_FP32_MFMA), 4),
                        "matrix_pipe": SPLIT_PIPE + "; convolution GEMMs with operand prologues and K < 512: v_mfma_f32_32x32x2_f32"
                        if split_on else "v_mfma_f32_32x32x2_f32 (MT_GEMM_SPLIT=0)",
-                       "loss": round(float(loss.item()), 5)},
+                       "loss": round(float(loss.item()), 5),
+                       "host_enqueue_ms_per_step": round(1e3 * t_enq, 3)},
             # the time-dominant kernel family: in-step duration (next to the main stream's data-gradient GEMMs), all launches summed
             "roofline": {"bound": "mfma", "kernel": WGRAD_KERNEL[split_on],
                          **mfma_roofline(f_w / t_w if t_w else None, split_on),
