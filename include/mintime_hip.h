@@ -116,7 +116,9 @@ int mt_embed_fwd(float* x, const float* cls, const float* pos_emb, const float* 
  * (positions) / bit 1 (size_embedding) set, which the host checks at its next synchronisation point. */
 
 /* Divided attention core (:80-87 attn(), :112-141 of Attention.forward) on the QKV GEMM output
- * qkv [B, 1+F*n, 3*H*64] -> out [B, 1+F*n, H*64] (merged heads).  mode 0 = time (identity-masked), 1 = space.
+ * qkv [B, 1+F*n, 3*H*64] -> out [B, 1+F*n, H*64] (merged heads).  mode 0 = time (identity-masked), 1 = space,
+ * 2 = the cls query only (out row 0 of each clip; what the LAST layer's space attention needs when only the cls token is read
+ * afterwards -- the optional dead-row pruning of tsf_engine.py; mt_attn_bwd mode 2 is its adjoint: dk / dv of all keys, dq of row 0).
  * mask uint8 [B,F], ident uint8 [B,F,F]; cls_att (optional) [(B*H), 1+F*n] = the cls query's probabilities. */
 int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const uint8_t* mask, const uint8_t* ident,
                 int B, int H, int F, int n, int mode, float scale, void* stream);

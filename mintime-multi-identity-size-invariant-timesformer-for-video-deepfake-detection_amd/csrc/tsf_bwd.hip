@@ -847,7 +847,7 @@ extern "C" int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, con
   const int N = 1 + F * n;
   hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(CLS_W * 64), (2 * N + CLS_W + 4 + CLS_W * 64) * sizeof(float), s, qkv, dout, dqkv, mask, B, H, F, n, scale);
   int rc = check_launch("mt_attn_bwd(cls)");
-  if (rc) return rc;
+  if (rc || mode == 2) return rc;                 // mode 2: the cls query's adjoint only (dk / dv of every key, dq of the cls row)
   if (mode == 1) {
     static const bool valu = getenv("MT_ATTN_VALU") != nullptr;     // A/B aid: the one-lane-per-query kernel
     if (valu) return launch_patch_bwd<1, 50, 1, 64, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);

@@ -539,7 +539,7 @@ extern "C" int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const u
   const int N = 1 + F * n;
   hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(CLS_W * 64), (N + CLS_W + 4 + CLS_W * 64) * sizeof(float), s, qkv, out, cls_att, mask, B, H, F, n, scale);
   int rc = check_launch("mt_attn_fwd(cls)");
-  if (rc) return rc;
+  if (rc || mode == 2) return rc;                 // mode 2: the cls query only (out row 0 of every clip; the patch rows are not written)
   if (mode == 1) {
     static const bool valu = getenv("MT_ATTN_VALU") != nullptr;     // A/B aid: the one-lane-per-query kernel
     if (valu) return launch_patch<1, 50, 1, 64, 2>(qkv, out, mask, ident, B, H, F, n, scale, s);

@@ -117,11 +117,13 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
     # ---- head
     i0 = take(4)
     g, b_, w_h, b_h = P[i0:i0 + 4]
-    dx = torch.zeros(B, N, D, dtype=torch.float32, device=dev)
+    pruned = bool(saved.get("pruned_last"))           # tsf_engine: the last layer ran its tail on the cls rows only
+    Nh = 1 if pruned else N
+    dx = torch.zeros(B, Nh, D, dtype=torch.float32, device=dev)
     L.check(lib.mt_head_bwd(L.ptr(dlogits), L.ptr(saved["x_final"]), L.ptr(g), L.ptr(b_), L.ptr(w_h), L.ptr(dx), L.ptr(grads[i0]),
-                            L.ptr(grads[i0 + 1]), L.ptr(grads[i0 + 2]), L.ptr(grads[i0 + 3]), B, N, D, model.num_classes, eps,
+                            L.ptr(grads[i0 + 1]), L.ptr(grads[i0 + 2]), L.ptr(grads[i0 + 3]), B, Nh, D, model.num_classes, eps,
                             st), "mt_head_bwd")
-    dx2 = dx.view(M, D)
+    dx2 = dx.view(B * Nh, D)
     # Bias gradients of the Linears whose output gradient is the residual stream's (net.3 / to_out.0 / patch embedding) are the
     # column sums of dx2 at that point.  The first one (last layer's net.3.bias) takes a column-sum launch over the head's dx;
     # every later one is emitted by the LayerNorm backward that produced that dx2 (dx_colsum), so no pass re-reads dx2 for it.
@@ -132,6 +134,64 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
 
     for li in reversed(range(model.depth)):
         rec = saved["layers"][li]
+        if pruned and li == model.depth - 1:
+            # ---- last layer, dead rows pruned: feed-forward and the space attention's tail on the B cls rows (dx2 is [B, D])
+            i0 = take(6)
+            g, b_, w1, b1, w2, b2 = P[i0:i0 + 6]
+            r = rec[2]
+            du_c = torch.empty(B, 8 * D, dtype=torch.float32, device=dev)
+            dxn_c = torch.empty(B, D, dtype=torch.float32, device=dev)
+            wgrad(dx2, r["h"], grads[i0 + 4], D, 4 * D, B, D, 4 * D, 4 * D, bias_out=grads[i0 + 5])
+            L.gemm(L.OP_NN, dx2, w2, du_c, B, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D, n_half=4 * D,
+                   col_sum=grads[i0 + 3])
+            wgrad(du_c, r["xn"], grads[i0 + 2], 8 * D, D, B, 8 * D, D, D)
+            L.gemm(L.OP_NN, du_c, w1, dxn_c, B, D, 8 * D, 8 * D, D, D)
+            side.wait()
+            L.check(lib.mt_layernorm_bwd(L.ptr(dxn_c), L.ptr(r["x"]), L.ptr(r["stats"]), L.ptr(g), L.ptr(dx2), L.ptr(grads[i0]),
+                                         L.ptr(grads[i0 + 1]), B, D, 1, L.ptr(grads[i0 - 1]), 0, None, st), "mt_layernorm_bwd")
+            r.clear()
+            # space attention: out-projection on the cls rows (row stride N), the cls query's adjoint, then the full QKV tail
+            i0 = take(5)
+            g, b_, w_qkv, w_o, b_o = P[i0:i0 + 5]
+            r = rec[1]
+            wgrad(dx2, r["o"], grads[i0 + 3], D, inner, B, D, N * inner, inner)             # o's cls rows: ldb = N * inner
+            L.gemm(L.OP_NN, dx2, w_o, do, B, inner, D, D, inner, N * inner)                 # row 0 of each clip's do; the rest is not read
+            dqkv.zero_()                                                                    # the patch queries' gradients are zero
+            L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, 2, scale, st),
+                    "mt_attn_bwd")
+            wgrad(dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
+            e_dg = dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner, wT[(li, 7)] if wT is not None else None)
+            dx_full = torch.zeros(B, N, D, dtype=torch.float32, device=dev)
+            dx_full[:, 0, :] = dx2                                                          # the residual path: cls rows only
+            dx2 = dx_full.view(M, D)
+            if e_dg is not None:
+                side.wait(e_dg)
+            dx2 = ln_bwd(dxn, r, g, dx2, i0, grads[i0 - 1], 0)
+            r.clear()
+            # time attention: unchanged
+            i0 = take(5)
+            g, b_, w_qkv, w_o, b_o = P[i0:i0 + 5]
+            r = rec[0]
+            side.wait()
+            if defer:
+                dqkv = torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)
+            e_dx = wgrad(dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner)
+            if wT is not None:
+                L.gemm(L.OP_NT, dx2, wT[(li, 3)], do, M, inner, D, D, D, inner)
+            else:
+                L.gemm(L.OP_NN, dx2, w_o, do, M, inner, D, D, inner, inner)
+            L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, 0, scale, st),
+                    "mt_attn_bwd")
+            wgrad(dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
+            e_dg = dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner, wT[(li, 2)] if wT is not None else None)
+            if e_dx is not None:
+                side.wait(e_dx)
+            if e_dg is not None:
+                side.wait(e_dg)
+            tgt, skip = (grads[1], N) if li == 0 else (grads[i0 - 1], 0)
+            dx2 = ln_bwd(dxn, r, g, dx2, i0, tgt, skip)
+            r.clear()
+            continue
         # ---- feed-forward: x_out = h W2^T + b2 + x ; h = a*gelu(g) ; [a|g] = LN(x) W1^T + b1
         i0 = take(6)
         g, b_, w1, b1, w2, b2 = P[i0:i0 + 6]

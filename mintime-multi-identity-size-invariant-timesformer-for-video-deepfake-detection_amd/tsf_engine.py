@@ -138,6 +138,13 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
                     holder[(li, off)] = t
         if side.enabled:       # with MT_SIDE_STREAM=0 the transposes would sit on the critical path: the NN form is used instead
             saved["wT"], saved["wT_ready"] = holder, side.launch(transpose_all, reads=wts)
+    # Optional (MT_TSF_PRUNE_LAST=1, off by default): dead-row pruning of the LAST layer.  The classification head reads the cls
+    # token only (size_invariant_timesformer.py:270-276), so everything the last layer computes for the 392 patch rows AFTER its
+    # time attention is never read: the space attention's patch queries and out-projection rows and the whole feed-forward block
+    # (the reference computes them and throws them away; their gradients are exactly zero).  With the switch on those rows are not
+    # computed: the cls query attends to all keys as before, out-projection / LayerNorm / FF1 / FF2 run on the B cls rows.  Logits,
+    # attentions and every gradient are the same numbers (tests/test_gpu_tsf.py); 7 % of the TimeSformer's FLOPs disappear.
+    prune_last = os.environ.get("MT_TSF_PRUNE_LAST", "0") != "0"
     want_att = model.require_attention
     s_att = t_att = None
     xn = _new(dev, M, D)
@@ -163,6 +170,16 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
                     t_att = att
                 else:
                     s_att = att
+            if last and mode == 1 and prune_last:
+                # cls query only; out-projection + residual on the B cls rows (row stride N: no gather needed)
+                L.check(lib.mt_attn_fwd(L.ptr(qkv), L.ptr(o), L.ptr(att), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, 2,
+                                        scale, st), "mt_attn_fwd")
+                x_cls = _new(dev, B, D)
+                L.gemm(L.OP_NT, o, w_o, x_cls, B, D, inner, N * inner, inner, D, epilogue=L.EPI_BIAS_RES, bias=b_o, R=x, ldr=N * D)
+                if save:
+                    rec[mode] = dict(x=x, xn=xn, stats=stats, qkv=qkv, o=o)
+                x = x_cls
+                continue
             L.check(lib.mt_attn_fwd(L.ptr(qkv), L.ptr(o), L.ptr(att), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
                                     scale, st), "mt_attn_fwd")
             x_new = _new(dev, B, N, D) if save else x
@@ -171,6 +188,20 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
                 rec[mode] = dict(x=x, xn=xn, stats=stats, qkv=qkv, o=o)
             x = x_new
         g, b_, w1, b1, w2, b2 = next(it), next(it), next(it), next(it), next(it), next(it)
+        if last and prune_last:
+            # feed-forward block on the cls rows only (x is [B, D] here)
+            xn_c, h_c, stats_c = _new(dev, B, D), _new(dev, B, 4 * D), (_new(dev, B, 2) if save else None)
+            u_c = _new(dev, B, 8 * D) if save else None
+            L.check(lib.mt_layernorm_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(xn_c), L.ptr(stats_c), B, D, eps, st), "mt_layernorm_fwd")
+            L.gemm(L.OP_NT, xn_c, w1, h_c, B, 8 * D, D, D, D, 4 * D, epilogue=L.EPI_GEGLU, bias=b1, C2=u_c, ldc2=8 * D, n_half=4 * D)
+            x_out = _new(dev, B, 1, D)
+            L.gemm(L.OP_NT, h_c, w2, x_out, B, D, 4 * D, 4 * D, 4 * D, D, epilogue=L.EPI_BIAS_RES, bias=b2, R=x, ldr=D)
+            if save:
+                rec[2] = dict(x=x, xn=xn_c, stats=stats_c, u=u_c, h=h_c)
+                saved["layers"].append(rec)
+                saved["pruned_last"] = True
+            x = x_out
+            continue
         if save:
             xn, hbuf, stats = _new(dev, M, D), _new(dev, M, 4 * D), _new(dev, M, 2)
             u = _new(dev, M, 8 * D)
@@ -193,8 +224,8 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
         x = x_new
     g, b_, w_h, b_h = next(it), next(it), next(it), next(it)
     logits = _new(dev, B, model.num_classes)
-    L.check(lib.mt_head_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(w_h), L.ptr(b_h), L.ptr(logits), B, N, D, model.num_classes,
-                            eps, st), "mt_head_fwd")
+    L.check(lib.mt_head_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(w_h), L.ptr(b_h), L.ptr(logits), B, x.shape[1], D, model.num_classes,
+                            eps, st), "mt_head_fwd")        # x: [B, N, D], or [B, 1, D] after dead-row pruning
     if save:
         saved["x_final"] = x
     return logits, s_att, t_att, saved

@@ -302,3 +302,39 @@ def test_layernorm_backward_emits_column_sums_of_updated_dx(rows, skip):
     assert torch.equal(dx_out, dxd) and torch.equal(dx_in, dx0.cuda())
     assert_close(cs, dx_ref[keep].sum(0), 1e-4, "column sums of the updated dx")
     assert_close(db, dy.double().sum(0), 1e-4, "dbeta")
+
+
+@pytest.mark.parametrize("B,Fr,ids,ragged", [(2, 8, 2, True), (3, 16, 3, False)])
+def test_last_layer_dead_row_pruning_is_exact(B, Fr, ids, ragged, monkeypatch):
+    """MT_TSF_PRUNE_LAST=1: the last layer's space-attention tail and feed-forward block run on the cls rows only (the head reads
+    nothing else, size_invariant_timesformer.py:270-276).  Logits, both attention maps and EVERY parameter / feature gradient must
+    be the numbers of the full computation (whose dead rows carry exact zeros) -- and match the oracle."""
+    C, seed = 1280, 9
+    cfg = arch.default_tsf_config(C, Fr)
+    feats = synth.features(B, Fr, C, seed)
+    aux = synth.clip_inputs(B, Fr, ids, seed, ragged=ragged, with_video=False)
+    runs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MT_TSF_PRUNE_LAST", flag)
+        model, sd = _build(cfg, seed)
+        x = feats.cuda().requires_grad_(True)
+        logits, (s_att, t_att) = model(x, mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(),
+                                       size_embedding=aux["size_embedding"], positions=aux["positions"].cuda())
+        torch.nn.functional.binary_cross_entropy_with_logits(logits, aux["labels"].reshape(-1, 1).cuda()).backward()
+        runs[flag] = (logits.detach(), s_att, t_att, x.grad, {k: p.grad for k, p in model.named_parameters()})
+    full, pruned = runs["0"], runs["1"]
+    assert_close(pruned[0], full[0], 1e-5, "logits")
+    assert torch.equal(pruned[1], full[1]) and torch.equal(pruned[2], full[2])          # same cls kernels, same inputs
+    assert_close(pruned[3], full[3], 2e-5, "feature gradient")
+    for k, g in full[4].items():
+        if float(g.abs().max()) == 0.0:
+            assert float(pruned[4][k].abs().max()) == 0.0, k
+        else:
+            assert_close(pruned[4][k], g, 5e-5, "grad " + k)
+    o_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o_logits = O.tsf_forward(o_sd, cfg, feats, aux["mask"], aux["identities_mask"], aux["size_embedding"], aux["positions"])
+    O.bce_with_logits(o_logits, aux["labels"]).backward()
+    assert_close(pruned[0], o_logits, REL_TOL, "logits vs oracle")
+    for k in ("layers.8.2.fn.net.0.weight", "layers.8.2.fn.net.3.bias", "layers.8.1.fn.to_out.0.weight", "layers.8.1.fn.to_qkv.weight",
+              "layers.8.0.fn.to_qkv.weight", "layers.0.0.fn.to_qkv.weight", "to_patch_embedding.weight"):
+        assert_close(pruned[4][k], o_sd[k].grad, 3 * REL_TOL, "grad vs oracle " + k)
