@@ -210,7 +210,8 @@ def attention_modules_leg(dev, B, F=8, reps=3):
     return out
 
 
-WGRAD_KERNEL = {True: "TimeSformer weight-gradient GEMMs: mt::gemm_split_kernel<..., TN> (dW = dY^T X over B*393 rows; side stream)",
+WGRAD_KERNEL = {True: "TimeSformer weight-gradient GEMMs: mt::gemm_split_kernel<..., TN, EPI_ATOMIC> (dW = dY^T X over B*393 rows, K-range-major "
+                      "split-K over the XCDs; side stream, next to the main stream's data-gradient GEMMs)",
                 False: "TimeSformer weight-gradient GEMMs: mt::gemm_dma_kernel<..., TN> (dW = dY^T X over B*393 rows; side stream)"}
 
 WORKLOADS = {   # BASELINE.json configs that fit one GPU: (clips/GPU, frames, identities, extractor, fwd GFLOP/clip)
@@ -558,6 +559,26 @@ def main():
                                          "note": "mt_gemm_set_split(0): v_mfma_f32_32x32x2_f32 everywhere"}
             if a.config != 5:
                 out["attention_modules"] = attention_modules_leg(dev, B, frames)
+            # optional exact optimisation, NOT part of `value`: the last layer's dead rows pruned (tsf_engine.py, MT_TSF_PRUNE_LAST)
+            prev = os.environ.get("MT_TSF_PRUNE_LAST")
+            os.environ["MT_TSF_PRUNE_LAST"] = "1"
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_pr = max(3, a.steps // 2)
+            for _ in range(n_pr):
+                step()
+            torch.cuda.synchronize()
+            ms_pr = 1e3 * (time.perf_counter() - t1) / n_pr
+            if prev is None:
+                os.environ.pop("MT_TSF_PRUNE_LAST")
+            else:
+                os.environ["MT_TSF_PRUNE_LAST"] = prev
+            out["last_layer_dead_rows_pruned"] = {"ms_per_step": round(ms_pr, 3), "clips_s": round(B / (ms_pr * 1e-3), 2),
+                                                  "note": "MT_TSF_PRUNE_LAST=1 (off in `value`): the head reads the cls token only, so the last layer's "
+                                                          "space-attention tail and feed-forward run on the cls rows; same logits and gradients "
+                                                          "(tests/test_gpu_tsf.py::test_last_layer_dead_row_pruning_is_exact)"}
         if world == 1 and not a.no_cpu_baseline and a.config != 5:
             out["cpu_baseline"] = cpu_baseline_subprocess(frames)
     line = json.dumps(out) if rank == 0 else None

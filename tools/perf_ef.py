@@ -24,6 +24,8 @@ x = torch.randint(0, 256, (a.crops, 224, 224, 3), device="cuda").float().permute
 
 def step():
     if a.bwd:
+        for p in m.parameters():
+            p.grad = None       # like optimizer.zero_grad(set_to_none=True): the engines' gradient views are adopted, not accumulated
         m(x).sum().backward()
     else:
         with torch.no_grad():

@@ -29,6 +29,8 @@ kw = dict(mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda()
 
 def step():
     if a.bwd:
+        for p in model.parameters():
+            p.grad = None       # like optimizer.zero_grad(set_to_none=True): the engines' gradient views are adopted, not accumulated
         out = model(feats, **kw)
         out.sum().backward()
     else:
