@@ -16,6 +16,7 @@ FUSED_DW = __import__("os").environ.get("MT_DW_FUSED", "0")      # "1": every la
 # 406 -> 744 us, the 7x7 blocks 126 -> 193 us, step +1.3 ms): a one-tile-per-block GEMM with a load-z / swish / store epilogue
 # per lane-column runs at 1.3-3.2 TB/s where the float4 streaming kernels it replaces run at 4.5-5.5.  Parity-tested, opt-in.
 SE_FUSED = __import__("os").environ.get("MT_SE_FUSED", "0") != "0"
+EXPAND_FUSED = __import__("os").environ.get("MT_EXPAND_FUSED", "1") != "0"     # expand-conv data + weight gradient in one pass (stages 1-3)
 
 
 def _new(dev, *shape):
@@ -89,6 +90,15 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         if b_pro is not None:
             kw = dict(b_prologue=L.BPRO_BN_SWISH_GATE, b_scale=b_pro[0], b_shift=b_pro[1], b_gate=b_pro[2], b_hw=b_pro[3])
         reads = (du, z, x_in, kabc) + (tuple(b_pro[:3]) if b_pro is not None else ())
+        if (EXPAND_FUSED and b_pro is None and epi is None and need[gw_idx] and need_dx_in and rows >= 100000
+                and lib.mt_conv1x1_bwd_fused_supported(cout, cin)):
+            # expand convs of stages 1-3: data AND weight gradient in one streaming pass over du / z (2 instead of 4 passes over the
+            # widest tensors of the step; skinny_bwd.hip).  Runs on the main stream: it is the data gradient's critical path.
+            run["wgrad_launches"] += 1
+            dx_in = _new(dev, rows, cin)
+            L.check(lib.mt_conv1x1_bwd_fused(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(x_in), L.ptr(w), L.ptr(res), L.ptr(dx_in),
+                                             L.ptr(grads[gw_idx]), rows, cout, cin, st), "mt_conv1x1_bwd_fused")
+            return dx_in
         if not need[gw_idx]:
             pass                                      # frozen weight: no launch
         elif rows >= 100000 and lib.mt_conv1x1_wgrad_supported(cout, cin):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GEMM micro-benchmark on the TimeSformer shapes; optional alternative .so for A/B runs (MT_LIB=path)."""
 import ctypes, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import mintime_amd
 from mintime_amd import lib as L

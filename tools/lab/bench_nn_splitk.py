@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Split-K sweep of the skinny NN dgrad GEMMs (N = 512): out[M,512] = dY[M,K] . W[K,512] with fp32 atomics onto a zeroed output."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import mintime_amd
 from mintime_amd import lib as L

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Split-K sweep of the TN weight-gradient GEMM (BN-backward prologue, atomic epilogue) on EfficientNet-B0's late-layer shapes."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import mintime_amd
 from mintime_amd import lib as L

@@ -4,7 +4,7 @@ the algorithmic bytes rows*(2*Cout+Cin)*4.  Env MT_WGRAD_BPC / MT_WGRAD_DIAG are
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import mintime_amd
 from mintime_amd import lib as L

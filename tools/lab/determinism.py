@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which op makes two identical eval forwards differ?  Runs every GEMM form twice and compares bits."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 import mintime_amd
 from mintime_amd import lib as L, arch, synth, SizeInvariantTimeSformer

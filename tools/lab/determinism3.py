@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 import mintime_amd
 from mintime_amd import lib as L, arch, synth, tsf_engine, SizeInvariantTimeSformer

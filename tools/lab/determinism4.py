@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-model bisect: the eval launch sequence of tsf_engine.tsf_forward with a bit-hash of every op's output, three runs."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 import mintime_amd
 from mintime_amd import lib as L, arch, synth, tsf_engine, SizeInvariantTimeSformer

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-block phase timestamps of one mt_gemm launch (tuning aid mt_debug_gemm_trace): where does a tile's time go?"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import mintime_amd

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host-side enqueue time of one training step (no device sync inside the timed region) vs the device time per step."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import mintime_amd
 from mintime_amd import harness

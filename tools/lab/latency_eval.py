@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small-batch eval latency: eager launch sequence vs HIP-graph replay."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import mintime_amd
 from mintime_amd import harness

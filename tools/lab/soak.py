@@ -2,7 +2,7 @@
 """Stability soak: N training steps at B=32 with fresh inputs every step; reports loss trend, step-time drift and allocator growth."""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import mintime_amd
 from mintime_amd import harness

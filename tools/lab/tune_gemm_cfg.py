@@ -2,7 +2,7 @@
 """Replays every distinct mt_gemm call of one B=32 training step under each tile configuration (MT_FORCE_CFG) and prints
 the time per configuration next to the dispatcher's own choice -- the evidence behind pick_cfg's rules in csrc/gemm.hip."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import mintime_amd
 from mintime_amd import harness, lib as L
