@@ -71,7 +71,7 @@ def effnet_b0_state(seed: int = 0, include_top: bool = True, calibrate: bool = T
 
 def _calibration_tools():
     """The BatchNorm-buffer calibration walks the network once with plain torch ops on the host.  That is weight SYNTHESIS for
-    tests and benchmarks, not a forward path of the product, so it lives outside the package (tools/lab/calibrate_bn.py)."""
+    tests and benchmarks, not a forward path of the product, so it lives outside the package (tools/calibrate_bn.py)."""
     import importlib
     import os
     import sys
