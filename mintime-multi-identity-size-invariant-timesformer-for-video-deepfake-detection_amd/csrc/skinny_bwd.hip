@@ -10,8 +10,8 @@
 // two widest tensors of the backward pass (1.2 GB each for block 1 of a 256-crop batch) -- once: 4 passes over the expanded
 // tensor.  Here a block streams 64-row chunks (loads of chunk i+1 in flight while chunk i is multiplied) and its four wavefronts
 // split the work by ROLE: waves 0, 1 own a 32-row tile each and produce dx (M = rows, K = Cout, W resident in LDS), waves 2, 3
-// each accumulate the weight gradient of 32 of the rows (K = rows, the result resident in MFMA accumulators for the whole
-// launch).  Both roles cost (Cout / 2) * 32-row MFMA steps per chunk, so the waves stay balanced.  2 passes instead of 4;
+// each accumulate the weight gradient of half of the Cout tiles over the chunk's rows (K = rows, the result resident in MFMA
+// accumulators for the whole launch).  Both roles cost about Cout MFMA steps per chunk, so the waves stay balanced.  2 passes instead of 4;
 // algorithmic bytes = rows * (2*Cout + 2*Cin [+ Cin for the residual]) * 4.
 #include "common.hpp"
 #include <stdint.h>
@@ -32,49 +32,53 @@ struct FusedArgs {
 };
 
 // MT = 32-wide tiles of Cout (3: 96 channels, 5: 144 channels); Cin <= 32 (one tile)
-template <int MT>
-__global__ __launch_bounds__(256) void conv1x1_bwd_fused_kernel(FusedArgs p) {
+// NTHR = 256, or 512 for MT = 5: waves 4-7 only load and stage (the 10 float4 prefetch slots per thread of a 256-thread block
+// put the kernel at 296 VGPRs = one wave per SIMD; with 512 threads it is 5 slots and two waves per SIMD)
+// ROWSPLIT: the two weight-gradient waves split the chunk's ROWS (all MT tiles each, partial results meet in LDS at the end) instead
+// of the Cout tiles.  Measured on block 1 (96 -> 16, 3.2 M rows): 683 us against 1151 us for the tile split; at MT = 5 the tile split is
+// what brings the kernel under 256 VGPRs.
+template <int MT, int NTHR, bool ROWSPLIT>
+__global__ __launch_bounds__(NTHR) void conv1x1_bwd_fused_kernel(FusedArgs p) {
   constexpr int R = 64;
   constexpr int LDZ = MT * 32 + 1;         // odd pitch: the data gradient reads dz by ROW (32 lanes = 32 rows -> 32 banks), the weight
                                            // gradient by column (consecutive lanes = consecutive floats): both conflict-free
   constexpr int LDX = 32;                  // x tile [R][32] (read by column only)
   constexpr int LDW = 33;                  // W tile [MT*32][33]: read as b[k = co][n = ci] with lanes over ci, k uniform per half-wave
-  constexpr int VZ = R * MT * 32 / 4 / 256;            // float4 slots per thread covering [R, MT*32]  (6 or 10)
-  static_assert(R * MT * 32 / 4 % 256 == 0, "chunk must divide over the block");
+  constexpr int VZ = R * MT * 32 / 4 / NTHR;           // float4 slots per thread covering [R, MT*32]
+  static_assert(R * MT * 32 / 4 % NTHR == 0, "chunk must divide over the block");
   extern __shared__ float smem[];
   float* dzs = smem;                       // [R][LDZ]
   float* xs = dzs + R * LDZ;               // [R][LDX]
   float* wt = xs + R * LDX;                // [MT*32][LDW]
-  float* red = dzs;                        // after the last chunk: [2][MT*32][32] partial dW of the two weight-gradient waves
-  static_assert(2 * MT * 32 * 32 <= R * LDZ, "the reduction buffer reuses the dz tile");
+  float* kab = wt + MT * 32 * LDW;         // [3][MT*32]  ka | kb | kc (in registers they cost 12 VGPRs per float4 slot: occupancy 1)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cq = p.Cout >> 2, aq = p.Cin >> 2;
 
-  for (int i = tid; i < R * LDZ + R * LDX + MT * 32 * LDW; i += 256) smem[i] = 0.f;     // padding columns stay zero
+  for (int i = tid; i < R * LDZ + R * LDX + MT * 32 * LDW; i += NTHR) smem[i] = 0.f;     // padding columns stay zero
   __syncthreads();
-  for (int i = tid; i < p.Cout * p.Cin; i += 256) {
+  for (int i = tid; i < p.Cout * p.Cin; i += NTHR) {
     const int co = i / p.Cin, ci = i - co * p.Cin;
     wt[co * LDW + ci] = p.w[i];
+  }
+  for (int i = tid; i < 3 * MT * 32; i += NTHR) {
+    const int which = i / (MT * 32), c = i - which * MT * 32;
+    kab[i] = c < p.Cout ? p.kabc[which * p.Cout + c] : 0.f;
   }
 
   // loop-invariant placement of this thread's slots: dz [R, Cout] as float4 along Cout, x [R, Cin] as float4 along Cin
   int zr[VZ], zc[VZ];
-  float4 kar[VZ], kbr[VZ], kcr[VZ];
 #pragma unroll
   for (int i = 0; i < VZ; ++i) {
-    const int idx = tid + 256 * i;
+    const int idx = tid + NTHR * i;
     zr[i] = idx / cq;
     zc[i] = (idx - zr[i] * cq) * 4;
     if (zr[i] >= R) { zr[i] = -1; zc[i] = 0; }
-    kar[i] = *reinterpret_cast<const float4*>(p.kabc + zc[i]);
-    kbr[i] = *reinterpret_cast<const float4*>(p.kabc + p.Cout + zc[i]);
-    kcr[i] = *reinterpret_cast<const float4*>(p.kabc + 2 * p.Cout + zc[i]);
   }
   int xr_[2], xc_[2];                       // two float4 slots per thread cover [R, Cin <= 32]
   bool x_on[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int idx = tid + 256 * i;
+    const int idx = tid + NTHR * i;
     xr_[i] = idx / aq;
     xc_[i] = (idx - xr_[i] * aq) * 4;
     x_on[i] = xr_[i] < R;
@@ -83,6 +87,8 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_fused_kernel(FusedArgs p) {
 
   const int64_t nchunks = (p.rows + R - 1) / R;
   float4 rdu[VZ], rz[VZ], rx[2];
+  float rcur[16];                           // data-gradient waves: the residual values of their 16 output rows
+  const int kh_ = lane >> 5, cl_ = min(lane & 31, p.Cin - 1);
 
   auto fetch = [&](int64_t chunk) {          // unconditional loads on clamped rows (a predicated load de-pipelines: skinny_wgrad.hip)
     const int64_t r0 = chunk * R;
@@ -101,15 +107,19 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_fused_kernel(FusedArgs p) {
   auto stage = [&](int64_t chunk) {
     const int64_t r0 = chunk * R;
     const int left = (int)((p.rows - r0) < R ? (p.rows - r0) : R);
+
 #pragma unroll
     for (int i = 0; i < VZ; ++i) {
       if (zr[i] >= 0) {
         const bool ok = zr[i] < left;
         float* dst = dzs + zr[i] * LDZ + zc[i];
-        dst[0] = ok ? fmaf(kar[i].x, rdu[i].x, fmaf(kbr[i].x, rz[i].x, kcr[i].x)) : 0.f;
-        dst[1] = ok ? fmaf(kar[i].y, rdu[i].y, fmaf(kbr[i].y, rz[i].y, kcr[i].y)) : 0.f;
-        dst[2] = ok ? fmaf(kar[i].z, rdu[i].z, fmaf(kbr[i].z, rz[i].z, kcr[i].z)) : 0.f;
-        dst[3] = ok ? fmaf(kar[i].w, rdu[i].w, fmaf(kbr[i].w, rz[i].w, kcr[i].w)) : 0.f;
+        const float4 ka = *reinterpret_cast<const float4*>(kab + zc[i]);
+        const float4 kb = *reinterpret_cast<const float4*>(kab + MT * 32 + zc[i]);
+        const float4 kc = *reinterpret_cast<const float4*>(kab + 2 * MT * 32 + zc[i]);
+        dst[0] = ok ? fmaf(ka.x, rdu[i].x, fmaf(kb.x, rz[i].x, kc.x)) : 0.f;
+        dst[1] = ok ? fmaf(ka.y, rdu[i].y, fmaf(kb.y, rz[i].y, kc.y)) : 0.f;
+        dst[2] = ok ? fmaf(ka.z, rdu[i].z, fmaf(kb.z, rz[i].z, kc.z)) : 0.f;
+        dst[3] = ok ? fmaf(ka.w, rdu[i].w, fmaf(kb.w, rz[i].w, kc.w)) : 0.f;
       }
     }
 #pragma unroll
@@ -122,11 +132,17 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_fused_kernel(FusedArgs p) {
   };
 
   const int kh = lane >> 5, cl = lane & 31;
-  f32x16 wacc[MT];                          // weight-gradient waves: dW tiles [32 co][32 ci], resident for the whole launch
+  // weight-gradient waves: wave 2 owns the Cout tiles [0, MTA), wave 3 the tiles [MTA, MT), each over all 64 rows of a chunk:
+  // dW tiles [32 co][32 ci] resident in accumulators for the whole launch, MTA of them per wave (splitting the ROWS instead
+  // kept MT tiles live in every wave: 344 VGPRs at MT = 5, one wave per SIMD)
+  constexpr int MTA = ROWSPLIT ? MT : (MT + 1) / 2;
+  static_assert(!ROWSPLIT || 2 * MT * 32 * 32 <= R * LDZ, "the row-split reduction buffer reuses the dz tile");
+  f32x16 wacc[MTA];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < MTA; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) wacc[i][r] = 0.f;
+  const int t0 = (!ROWSPLIT && wave == 3) ? MTA : 0;       // first tile of this wave (weight-gradient role)
 
   int64_t chunk = blockIdx.x;
   if (chunk < nchunks) fetch(chunk);
@@ -134,6 +150,15 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_fused_kernel(FusedArgs p) {
   for (; chunk < nchunks; chunk += gridDim.x) {
     stage(chunk);
     __syncthreads();
+    if (p.res && wave < 2) {
+      // requested BEFORE the next chunk's prefetch: memory operations retire in order, so the epilogue's wait for these 16 values
+      // leaves the prefetch in flight (issued after it, or in the epilogue itself, that wait would drain the prefetch too)
+      const int64_t r0 = chunk * R;
+      const int last = (int)((p.rows - r0) < R ? (p.rows - r0) : R) - 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        rcur[r] = p.res[(r0 + min(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh_, last)) * p.Cin + cl_];
+    }
     const int64_t nxt = chunk + gridDim.x;
     if (nxt < nchunks) fetch(nxt);          // in flight while this chunk is multiplied
     if (wave < 2) {
@@ -143,7 +168,7 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_fused_kernel(FusedArgs p) {
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const float* a_w = dzs + (wave * 32 + cl) * LDZ + kh;
       const float* b_w = wt + kh * LDW + cl;
-#pragma unroll 4
+#pragma unroll 8
       for (int ks = 0; ks < MT * 16; ++ks)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_w[2 * ks], b_w[2 * ks * LDW], acc, 0, 0, 0);
       const int64_t rbase = chunk * R + wave * 32;
@@ -153,56 +178,83 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_fused_kernel(FusedArgs p) {
           const int64_t row = rbase + (r & 3) + 8 * (r >> 2) + 4 * kh;
           if (row < p.rows) {
             float v = acc[r];
-            if (p.res) v += p.res[row * p.Cin + cl];
+            if (p.res) v += rcur[r];
             p.dx[row * p.Cin + cl] = v;
           }
         }
       }
-    } else {
-      // ---- weight gradient over rows [(wave - 2) * 32, +32) of the chunk: dW[co][ci] += dz[r][co] * x[r][ci], k = rows
-      const int rb = (wave - 2) * 32;
-      const float* dz_w = dzs + rb * LDZ + cl;
-      const float* x_w = xs + rb * LDX + cl;
+    } else if (wave < 4) {
+      if constexpr (ROWSPLIT) {
+        // ---- weight gradient over rows [(wave - 2) * 32, +32) of the chunk, all Cout tiles: dW[co][ci] += dz[r][co] * x[r][ci], k = rows
+        const int rb = (wave - 2) * 32;
+        const float* dz_w = dzs + rb * LDZ + cl;
+        const float* x_w = xs + rb * LDX + cl;
 #pragma unroll 2
-      for (int ks = 0; ks < 16; ++ks) {
-        const int r = 2 * ks + kh;
-        const float bf = x_w[r * LDX];
+        for (int ks = 0; ks < 16; ++ks) {
+          const int r = 2 * ks + kh;
+          const float bf = x_w[r * LDX];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) wacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz_w[r * LDZ + i * 32], bf, wacc[i], 0, 0, 0);
+          for (int i = 0; i < MT; ++i) wacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz_w[r * LDZ + i * 32], bf, wacc[i], 0, 0, 0);
+        }
+      } else {
+        // ---- weight gradient of this wave's Cout tiles over the chunk's 64 rows: dW[co][ci] += dz[r][co] * x[r][ci], k = rows
+        const float* dz_w = dzs + t0 * 32 + cl;
+        const float* x_w = xs + cl;
+#pragma unroll 4
+        for (int ks = 0; ks < R / 2; ++ks) {
+          const int r = 2 * ks + kh;
+          const float bf = x_w[r * LDX];
+#pragma unroll
+          for (int i = 0; i < MTA; ++i)
+            if (MT % 2 == 0 || i < MTA - 1 || wave == 2)          // the second wave has one tile less when MT is odd
+              wacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz_w[r * LDZ + i * 32], bf, wacc[i], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
   }
 
-  // the two weight-gradient waves meet in LDS, then one global atomic per weight and block
-  if (wave >= 2) {
+  if constexpr (ROWSPLIT) {
+    // the two weight-gradient waves meet in LDS (the dz tile is free now), then one global atomic per weight and block
+    float* red = dzs;                       // [2][MT*32][32]
+    if (wave >= 2 && wave < 4) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          red[((wave - 2) * MT * 32 + m) * 32 + cl] = wacc[i][r];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < p.Cout * p.Cin; i += NTHR) {
+      const int co = i / p.Cin, ci = i - co * p.Cin;
+      atomicAdd(p.dw + i, red[co * 32 + ci] + red[(MT * 32 + co) * 32 + ci]);
+    }
+  } else if (wave >= 2 && wave < 4) {
+    // every weight-gradient tile has one owner per block: straight to the global accumulation
+#pragma unroll
+    for (int i = 0; i < MTA; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        red[((wave - 2) * MT * 32 + m) * 32 + cl] = wacc[i][r];
+        const int m = (t0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (t0 + i < MT && m < p.Cout && cl < p.Cin) atomicAdd(p.dw + m * p.Cin + cl, wacc[i][r]);
       }
-  }
-  __syncthreads();
-  for (int i = tid; i < p.Cout * p.Cin; i += 256) {
-    const int co = i / p.Cin, ci = i - co * p.Cin;
-    atomicAdd(p.dw + i, red[co * 32 + ci] + red[(MT * 32 + co) * 32 + ci]);
   }
 }
 
-template <int MT>
+template <int MT, int NTHR, bool ROWSPLIT>
 int launch_fused(const FusedArgs& a, hipStream_t st) {
   constexpr int R = 64, LDZ = MT * 32 + 1;
-  const size_t smem = ((size_t)R * LDZ + R * 32 + MT * 32 * 33) * 4;
+  const size_t smem = ((size_t)R * LDZ + R * 32 + MT * 32 * 33 + 3 * MT * 32) * 4;
   const int64_t nchunks = (a.rows + R - 1) / R;
   const int blocks = (int)(nchunks < 512 ? nchunks : 512);
-  auto k = conv1x1_bwd_fused_kernel<MT>;
+  auto k = conv1x1_bwd_fused_kernel<MT, NTHR, ROWSPLIT>;
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_conv1x1_bwd_fused: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(NTHR), smem, st, a);
   return check_launch("mt_conv1x1_bwd_fused");
 }
 
@@ -222,5 +274,5 @@ extern "C" int mt_conv1x1_bwd_fused(const float* du, const float* z, const float
   if (((uintptr_t)du | (uintptr_t)z | (uintptr_t)x | (uintptr_t)kabc) & 15) return fail(MT_ERR_ARG, "mt_conv1x1_bwd_fused: 16-byte alignment");
   FusedArgs a{du, z, kabc, x, w, res, dx, dw, rows, Cout, Cin};
   hipStream_t st = (hipStream_t)stream;
-  return (Cout + 31) / 32 == 3 ? launch_fused<3>(a, st) : launch_fused<5>(a, st);
+  return (Cout + 31) / 32 == 3 ? launch_fused<3, 256, true>(a, st) : launch_fused<5, 512, false>(a, st);
 }
