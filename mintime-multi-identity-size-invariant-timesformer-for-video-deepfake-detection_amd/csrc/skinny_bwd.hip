@@ -10,8 +10,9 @@
 // two widest tensors of the backward pass (1.2 GB each for block 1 of a 256-crop batch) -- once: 4 passes over the expanded
 // tensor.  Here a block streams 64-row chunks (loads of chunk i+1 in flight while chunk i is multiplied) and its four wavefronts
 // split the work by ROLE: waves 0, 1 own a 32-row tile each and produce dx (M = rows, K = Cout, W resident in LDS), waves 2, 3
-// each accumulate the weight gradient of half of the Cout tiles over the chunk's rows (K = rows, the result resident in MFMA
-// accumulators for the whole launch).  Both roles cost about Cout MFMA steps per chunk, so the waves stay balanced.  2 passes instead of 4;
+// each accumulate the weight gradient of 32 of the chunk's rows (K = rows, the result resident in MFMA accumulators for the whole
+// launch).  Both roles cost (Cout / 2) 32-row MFMA steps per chunk, so the waves stay balanced.  2 passes instead of 4.  Measured on
+// the 256-crop batch: 2.09 ms (three data-gradient + three weight-gradient launches) -> 1.32 ms (three fused launches);
 // algorithmic bytes = rows * (2*Cout + 2*Cin [+ Cin for the residual]) * 4.
 #include "common.hpp"
 #include <stdint.h>
@@ -35,8 +36,9 @@ struct FusedArgs {
 // NTHR = 256, or 512 for MT = 5: waves 4-7 only load and stage (the 10 float4 prefetch slots per thread of a 256-thread block
 // put the kernel at 296 VGPRs = one wave per SIMD; with 512 threads it is 5 slots and two waves per SIMD)
 // ROWSPLIT: the two weight-gradient waves split the chunk's ROWS (all MT tiles each, partial results meet in LDS at the end) instead
-// of the Cout tiles.  Measured on block 1 (96 -> 16, 3.2 M rows): 683 us against 1151 us for the tile split; at MT = 5 the tile split is
-// what brings the kernel under 256 VGPRs.
+// of the Cout tiles.  Measured (256-crop batch, us per launch, row split / tile split): block 1 (96 -> 16, 3.2 M rows) 675 / 1151;
+// blocks 2, 3 (144 -> 24, 0.8 M rows, 512 threads) 309-346 / 343-365.  Both instances use the row split; the tile split stays
+// compilable (it is what fits 144 channels into 256 VGPRs with a 256-thread block).
 template <int MT, int NTHR, bool ROWSPLIT>
 __global__ __launch_bounds__(NTHR) void conv1x1_bwd_fused_kernel(FusedArgs p) {
   constexpr int R = 64;
@@ -274,5 +276,5 @@ extern "C" int mt_conv1x1_bwd_fused(const float* du, const float* z, const float
   if (((uintptr_t)du | (uintptr_t)z | (uintptr_t)x | (uintptr_t)kabc) & 15) return fail(MT_ERR_ARG, "mt_conv1x1_bwd_fused: 16-byte alignment");
   FusedArgs a{du, z, kabc, x, w, res, dx, dw, rows, Cout, Cin};
   hipStream_t st = (hipStream_t)stream;
-  return (Cout + 31) / 32 == 3 ? launch_fused<3, 256, true>(a, st) : launch_fused<5, 512, false>(a, st);
+  return (Cout + 31) / 32 == 3 ? launch_fused<3, 256, true>(a, st) : launch_fused<5, 512, true>(a, st);
 }
