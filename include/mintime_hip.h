@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 104
+#define MT_VERSION 105
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -272,6 +272,18 @@ int mt_conv1x1_wgrad_supported(int Cout, int Cin);
  * (skinny_bwd.hip): dz = ka*du + kb*z + kc is formed once per 64-row chunk; dx[rows, Cin] = dz . W (+ res), dw[Cout, Cin] += dz^T . x.
  * Replaces mt_conv1x1_rows (mode 2) + mt_conv1x1_wgrad on the same tensors: 2 instead of 4 passes over the expanded activations. */
 int mt_conv1x1_bwd_fused_supported(int Cout, int Cin);
+/* Squeeze-excite stage of the MBConv reverse walk for the early blocks without the project conv's data gradient in memory
+ * (skinny_se.hip): da = (ka*du_p + kb*z_p + kc) . W_p is rebuilt from the NARROW gradient inside two streaming passes over z_d:
+ *   mode 0: dgate[rows / hw, C] += sum_rows da * swish(z_d*scale + shift)                     (zero-filled by the caller)
+ *   mode 1: du_d = (da*gate + dpooled/hw) * swish'(z_d*scale + shift), plus its BatchNorm-backward sums (stats like MT_EPI_STATS,
+ *           second sum = du_d * (z_d - mean) * invstd)
+ * Replaces mt_conv1x1_rows (mode 2) + the reduction of mt_se_bwd + mt_bn_act_bwd: 3 instead of 6 passes over the expanded tensor.
+ * w_p [Co, C] (Co <= 32; C = 32 / 96 / 144), hw % 64 == 0, rows % hw == 0. */
+int mt_se_stage_fused_supported(int Co, int C, int hw);
+int mt_se_stage_fused(const float* du_p, const float* z_p, const float* kabc_p, const float* w_p, const float* z_d,
+                      const float* scale_d, const float* shift_d, int mode, float* dgate, const float* gate, const float* dpooled,
+                      const float* mean_invstd_d, float* du_d, double* stats, int slots, int64_t rows, int Co, int C, int hw,
+                      void* stream);
 int mt_conv1x1_bwd_fused(const float* du, const float* z, const float* kabc, const float* x, const float* w, const float* res,
                          float* dx, float* dw, int64_t rows, int Cout, int Cin, void* stream);
 int mt_conv1x1_wgrad(const float* du, const float* z, const float* kabc, const float* x, const float* sc, const float* sh,

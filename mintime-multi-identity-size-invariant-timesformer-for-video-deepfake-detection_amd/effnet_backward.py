@@ -16,7 +16,10 @@ FUSED_DW = __import__("os").environ.get("MT_DW_FUSED", "0")      # "1": every la
 # 406 -> 744 us, the 7x7 blocks 126 -> 193 us, step +1.3 ms): a one-tile-per-block GEMM with a load-z / swish / store epilogue
 # per lane-column runs at 1.3-3.2 TB/s where the float4 streaming kernels it replaces run at 4.5-5.5.  Parity-tested, opt-in.
 SE_FUSED = __import__("os").environ.get("MT_SE_FUSED", "0") != "0"
-EXPAND_FUSED = __import__("os").environ.get("MT_EXPAND_FUSED", "1") != "0"     # expand-conv data + weight gradient in one pass (stages 1-3)
+EXPAND_FUSED = __import__("os").environ.get("MT_EXPAND_FUSED", "1") != "0"
+# squeeze-excite reverse stage of the early blocks (stages 0-2) as two STREAMING passes that rebuild the project conv's data gradient
+# from the narrow gradient (skinny_se.hip): 3 instead of 6 passes over the expanded tensor, no da tensor
+SE_STREAM = __import__("os").environ.get("MT_SE_STREAM", "1") != "0"     # expand-conv data + weight gradient in one pass (stages 1-3)
 
 
 def _new(dev, *shape):
@@ -171,7 +174,23 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                                   L.ptr(_rec["hidden"]), L.ptr(_rec["pooled"]), L.ptr(P[_se]), L.ptr(P[_se + 2]), L.ptr(_dg), L.ptr(_dp),
                                   L.ptr(_dh), L.ptr(_dpo), L.ptr(grads[_se]), L.ptr(grads[_se + 1]), L.ptr(grads[_se + 2]),
                                   L.ptr(grads[_se + 3]), N, _hw, _s.cexp, _s.cse, parts, L.ptr(_scr), L.stream_ptr()), "mt_se_bwd")
-        if SE_FUSED:
+        if (SE_STREAM and not SE_FUSED and M_out >= 100000 and need_below[bi] is not None
+                and lib.mt_se_stage_fused_supported(s.cout, s.cexp, hw)):
+            conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], False, b_pro=b_pro)   # weight gradient only
+            def stage(mode, dg, g_, dpo, mi, out, st_):
+                L.check(lib.mt_se_stage_fused(L.ptr(dsrc), L.ptr(rec["z_p"]), L.ptr(kabc_p), L.ptr(P[ix["p"]]), L.ptr(rec["z_d"]),
+                                              L.ptr(bn_d.scale), L.ptr(bn_d.shift), mode, L.ptr(dg), L.ptr(g_), L.ptr(dpo), L.ptr(mi),
+                                              L.ptr(out), L.ptr(st_), SLOTS, M_out, s.cout, s.cexp, hw, st), "mt_se_stage_fused")
+            dgate.zero_()
+            stage(0, dgate, None, None, None, None, None)                       # (c+d) d gate
+            se_part(4)                                                            # dgate -> dpooled
+            if any(need[se:se + 4]):
+                run["wgrad_launches"] += 1
+                side.launch(lambda: se_part(2), reads=(dpre2, dhid, rec["hidden"], rec["pooled"]))
+            da = _new(dev, M_out, s.cexp)                                         # (c+e) du_d and the bn1 sums
+            sums = pool.take(s.cexp)
+            stage(1, None, rec["gate"], dpooled, bn_d.mean_invstd, da, sums)
+        elif SE_FUSED:
             # (c+d) d gate straight from the accumulators of  dz_p . Wp  (da is never written)
             dgate.zero_()
             conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], True, b_pro=b_pro,

@@ -100,6 +100,8 @@ PROTOTYPES = {
     "mt_conv1x1_wgrad_supported": [C.c_int, C.c_int],
     "mt_conv1x1_wgrad": [f32p] * 7 + [C.c_int, f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "mt_conv1x1_bwd_fused_supported": [C.c_int, C.c_int],
+    "mt_se_stage_fused_supported": [C.c_int, C.c_int, C.c_int],
+    "mt_se_stage_fused": [f32p] * 7 + [C.c_int] + [f32p] * 5 + [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_conv1x1_bwd_fused": [f32p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "mt_stem_conv_wgrad": [f32p] * 4 + [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
 }
@@ -140,8 +142,8 @@ def get():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     v = lib.mt_version()
-    if v != 104:
-        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 104; rebuild it")
+    if v != 105:
+        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 105; rebuild it")
     _lib = lib
     return lib
 

@@ -277,3 +277,42 @@ def test_fused_expand_conv_backward_matches_fp64(rows, cout, cin, with_res):
     assert_close(dx, ref_dx, 2e-5, "fused data gradient")
     assert_close(dW, dz.T @ x.double(), 5e-5, "fused weight gradient")
     assert L.get().mt_conv1x1_bwd_fused_supported(240, 40) == 0 and L.get().mt_conv1x1_bwd_fused_supported(96, 40) == 0
+
+
+@pytest.mark.parametrize("n_img,hw,co,c", [(9, 3136, 24, 96), (3, 12544, 16, 32), (5, 3136, 24, 144)])
+def test_streaming_se_stage_matches_fp64(n_img, hw, co, c):
+    """mt_se_stage_fused: the project conv's data gradient rebuilt from the narrow gradient inside the squeeze-excite reduction
+    (mode 0) and inside the activation / BatchNorm backward (mode 1), against float64 on the host."""
+    from mintime_amd import lib as L
+    g = torch.Generator().manual_seed(8)
+    rows = n_img * hw
+    du, zp = torch.randn(rows, co, generator=g), torch.randn(rows, co, generator=g)
+    kabc = torch.stack([torch.randn(co, generator=g), torch.randn(co, generator=g) * 0.3, torch.randn(co, generator=g) * 0.1])
+    W = torch.randn(co, c, generator=g) * 0.2
+    zd = torch.randn(rows, c, generator=g)
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    gate, dpool = torch.rand(n_img, c, generator=g), torch.randn(n_img, c, generator=g)
+    mi = torch.stack([torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5])
+    d = {k: v.cuda() for k, v in dict(du=du, zp=zp, kabc=kabc, W=W, zd=zd, scale=scale, shift=shift, gate=gate, dpool=dpool, mi=mi).items()}
+    lib = L.get()
+    assert lib.mt_se_stage_fused_supported(co, c, hw) == 1 and lib.mt_se_stage_fused_supported(40, 240, 784) == 0
+    dgate = torch.zeros(n_img, c, device="cuda")
+    L.check(lib.mt_se_stage_fused(L.ptr(d["du"]), L.ptr(d["zp"]), L.ptr(d["kabc"]), L.ptr(d["W"]), L.ptr(d["zd"]), L.ptr(d["scale"]),
+                                  L.ptr(d["shift"]), 0, L.ptr(dgate), None, None, None, None, None, 1, rows, co, c, hw, L.stream_ptr()), "red")
+    slots = 8
+    dud = torch.full((rows, c), float("nan"), device="cuda")
+    stats = torch.zeros(slots, 2, c, dtype=torch.float64, device="cuda")
+    L.check(lib.mt_se_stage_fused(L.ptr(d["du"]), L.ptr(d["zp"]), L.ptr(d["kabc"]), L.ptr(d["W"]), L.ptr(d["zd"]), L.ptr(d["scale"]),
+                                  L.ptr(d["shift"]), 1, None, L.ptr(d["gate"]), L.ptr(d["dpool"]), L.ptr(d["mi"]), L.ptr(dud), L.ptr(stats),
+                                  slots, rows, co, c, hw, L.stream_ptr()), "act")
+    dz = kabc[0].double() * du.double() + kabc[1].double() * zp.double() + kabc[2].double()
+    da = dz @ W.double()
+    u = zd.double() * scale.double() + shift.double()
+    sg = torch.sigmoid(u)
+    ref_dgate = (da * u * sg).reshape(n_img, hw, c).sum(1)
+    assert_close(dgate, ref_dgate, 5e-5, "d gate")
+    ref_du = (da * gate.double().repeat_interleave(hw, 0) + dpool.double().repeat_interleave(hw, 0) / hw) * (sg * (1 + u * (1 - sg)))
+    assert_close(dud, ref_du, 2e-5, "du_d")
+    st = stats.sum(0).cpu()
+    assert_close(st[0], ref_du.sum(0), 1e-4, "sum du")
+    assert_close(st[1], (ref_du * (zd.double() - mi[0].double()) * mi[1].double()).sum(0), 1e-4, "sum du * xhat")
