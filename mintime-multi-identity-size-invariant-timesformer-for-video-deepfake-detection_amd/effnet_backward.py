@@ -174,7 +174,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                                   L.ptr(_rec["hidden"]), L.ptr(_rec["pooled"]), L.ptr(P[_se]), L.ptr(P[_se + 2]), L.ptr(_dg), L.ptr(_dp),
                                   L.ptr(_dh), L.ptr(_dpo), L.ptr(grads[_se]), L.ptr(grads[_se + 1]), L.ptr(grads[_se + 2]),
                                   L.ptr(grads[_se + 3]), N, _hw, _s.cexp, _s.cse, parts, L.ptr(_scr), L.stream_ptr()), "mt_se_bwd")
-        if (SE_STREAM and not SE_FUSED and M_out >= 100000 and need_below[bi] is not None
+        if (SE_STREAM and not SE_FUSED and M_out >= 100000
                 and lib.mt_se_stage_fused_supported(s.cout, s.cexp, hw)):
             conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], False, b_pro=b_pro)   # weight gradient only
             def stage(mode, dg, g_, dpo, mi, out, st_):
