@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 105
+#define MT_VERSION 106
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -268,9 +268,10 @@ int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const
  * a = x, or (gate != NULL) swish(sc*x+sh)*gate[r/hw].  The whole (32-padded) result stays in MFMA accumulators while the rows
  * stream through; mt_conv1x1_wgrad_supported says whether a shape has an instance (otherwise use mt_gemm, MT_OP_TN). */
 int mt_conv1x1_wgrad_supported(int Cout, int Cin);
-/* Data AND weight gradient of an expand conv (z = x . W^T, W [Cout, Cin], Cin <= 32) in one streaming pass over du / z
- * (skinny_bwd.hip): dz = ka*du + kb*z + kc is formed once per 64-row chunk; dx[rows, Cin] = dz . W (+ res), dw[Cout, Cin] += dz^T . x.
- * Replaces mt_conv1x1_rows (mode 2) + mt_conv1x1_wgrad on the same tensors: 2 instead of 4 passes over the expanded activations. */
+/* Data AND weight gradient of an expand conv (z = x . W^T, W [Cout, Cin], Cin <= 32) in ONE streaming pass over du (skinny_bwd.hip):
+ * with dz = ka*du + kb*z + kc (BatchNorm backward of _bn0): dx[rows, Cin] = dz . W (+ res), dw[Cout, Cin] += dz^T . x.  z is not an
+ * argument: it is linear in x, so its share is folded into two Cin x Cin matrices (W^T diag(kb) W and x^T x) inside the kernel.
+ * Replaces mt_conv1x1_rows (mode 2) + mt_conv1x1_wgrad on the same tensors: 1 instead of 4 passes over the expanded activations. */
 int mt_conv1x1_bwd_fused_supported(int Cout, int Cin);
 /* Squeeze-excite stage of the MBConv reverse walk for the early blocks without the project conv's data gradient in memory
  * (skinny_se.hip): da = (ka*du_p + kb*z_p + kc) . W_p is rebuilt from the NARROW gradient inside two streaming passes over z_d:
@@ -284,8 +285,8 @@ int mt_se_stage_fused(const float* du_p, const float* z_p, const float* kabc_p, 
                       const float* scale_d, const float* shift_d, int mode, float* dgate, const float* gate, const float* dpooled,
                       const float* mean_invstd_d, float* du_d, double* stats, int slots, int64_t rows, int Co, int C, int hw,
                       void* stream);
-int mt_conv1x1_bwd_fused(const float* du, const float* z, const float* kabc, const float* x, const float* w, const float* res,
-                         float* dx, float* dw, int64_t rows, int Cout, int Cin, void* stream);
+int mt_conv1x1_bwd_fused(const float* du, const float* kabc, const float* x, const float* w, const float* res, float* dx,
+                         float* dw, int64_t rows, int Cout, int Cin, void* stream);
 int mt_conv1x1_wgrad(const float* du, const float* z, const float* kabc, const float* x, const float* sc, const float* sh,
                      const float* gate, int hw, float* dw, int64_t rows, int Cout, int Cin, void* stream);
 

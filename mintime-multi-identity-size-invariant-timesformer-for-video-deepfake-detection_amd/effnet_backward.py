@@ -95,11 +95,11 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         reads = (du, z, x_in, kabc) + (tuple(b_pro[:3]) if b_pro is not None else ())
         if (EXPAND_FUSED and b_pro is None and epi is None and need[gw_idx] and need_dx_in and rows >= 100000
                 and lib.mt_conv1x1_bwd_fused_supported(cout, cin)):
-            # expand convs of stages 1-3: data AND weight gradient in one streaming pass over du / z (2 instead of 4 passes over the
-            # widest tensors of the step; skinny_bwd.hip).  Runs on the main stream: it is the data gradient's critical path.
+            # expand convs of stages 1-3: data AND weight gradient in one streaming pass over du (z is folded: 1 instead of 4 passes
+            # over the widest tensors of the step; skinny_bwd.hip).  Runs on the main stream: it is the data gradient's critical path.
             run["wgrad_launches"] += 1
             dx_in = _new(dev, rows, cin)
-            L.check(lib.mt_conv1x1_bwd_fused(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(x_in), L.ptr(w), L.ptr(res), L.ptr(dx_in),
+            L.check(lib.mt_conv1x1_bwd_fused(L.ptr(du), L.ptr(kabc), L.ptr(x_in), L.ptr(w), L.ptr(res), L.ptr(dx_in),
                                              L.ptr(grads[gw_idx]), rows, cout, cin, st), "mt_conv1x1_bwd_fused")
             return dx_in
         if not need[gw_idx]:

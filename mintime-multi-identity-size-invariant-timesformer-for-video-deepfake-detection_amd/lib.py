@@ -102,7 +102,7 @@ PROTOTYPES = {
     "mt_conv1x1_bwd_fused_supported": [C.c_int, C.c_int],
     "mt_se_stage_fused_supported": [C.c_int, C.c_int, C.c_int],
     "mt_se_stage_fused": [f32p] * 7 + [C.c_int] + [f32p] * 5 + [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p],
-    "mt_conv1x1_bwd_fused": [f32p] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_void_p],
+    "mt_conv1x1_bwd_fused": [f32p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "mt_stem_conv_wgrad": [f32p] * 4 + [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
 }
 _RESTYPES = {"mt_last_error": C.c_char_p}
@@ -142,8 +142,8 @@ def get():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     v = lib.mt_version()
-    if v != 105:
-        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 105; rebuild it")
+    if v != 106:
+        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 106; rebuild it")
     _lib = lib
     return lib
 

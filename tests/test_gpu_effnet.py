@@ -255,24 +255,27 @@ def test_streaming_conv1x1_kernel(cin, cout, rows, mode):
         assert_close(s[1].float(), (want * want).sum(0).float(), 1e-4, "column sums of squares")
 
 
-@pytest.mark.parametrize("rows,cout,cin,with_res", [(100000 + 37, 96, 16, False), (200704, 144, 24, True), (4096 + 5, 96, 24, True)])
+@pytest.mark.parametrize("rows,cout,cin,with_res", [(100000 + 37, 96, 16, False), (200704, 144, 24, True), (4096 + 5, 96, 24, True), (130, 96, 16, True),
+                                                    (64 * 256 * 3, 144, 24, False)])
 def test_fused_expand_conv_backward_matches_fp64(rows, cout, cin, with_res):
     """mt_conv1x1_bwd_fused: dx = (ka*du + kb*z + kc) . W (+ res) and dW += (ka*du + kb*z + kc)^T . x in one streaming pass
-    (autograd of efficientnet_pytorch/model.py:96-99 through _bn0), against float64 on the host; ragged last chunk included."""
+    (autograd of efficientnet_pytorch/model.py:96-99 through _bn0), against float64 on the host; ragged last chunk included.
+    z = x . W^T is not an argument: the kernel folds it into W^T diag(kb) W and x^T x."""
     from mintime_amd import lib as L
     g = torch.Generator().manual_seed(5)
-    du, z, x = torch.randn(rows, cout, generator=g), torch.randn(rows, cout, generator=g), torch.randn(rows, cin, generator=g)
+    du, x = torch.randn(rows, cout, generator=g), torch.randn(rows, cin, generator=g)
     W = torch.randn(cout, cin, generator=g) * 0.2
+    z = x.double() @ W.double().T
     kabc = torch.stack([torch.randn(cout, generator=g), torch.randn(cout, generator=g) * 0.3, torch.randn(cout, generator=g) * 0.1])
     res = torch.randn(rows, cin, generator=g) if with_res else None
-    d = {k: v.cuda() for k, v in dict(du=du, z=z, x=x, W=W, kabc=kabc).items()}
+    d = {k: v.cuda() for k, v in dict(du=du, x=x, W=W, kabc=kabc).items()}
     res_d = res.cuda() if with_res else None
     dx = torch.full((rows, cin), float("nan"), device="cuda")
     dW = torch.zeros(cout, cin, device="cuda")
     assert L.get().mt_conv1x1_bwd_fused_supported(cout, cin) == 1
-    L.check(L.get().mt_conv1x1_bwd_fused(L.ptr(d["du"]), L.ptr(d["z"]), L.ptr(d["kabc"]), L.ptr(d["x"]), L.ptr(d["W"]), L.ptr(res_d),
+    L.check(L.get().mt_conv1x1_bwd_fused(L.ptr(d["du"]), L.ptr(d["kabc"]), L.ptr(d["x"]), L.ptr(d["W"]), L.ptr(res_d),
                                          L.ptr(dx), L.ptr(dW), rows, cout, cin, L.stream_ptr()), "mt_conv1x1_bwd_fused")
-    dz = kabc[0].double() * du.double() + kabc[1].double() * z.double() + kabc[2].double()
+    dz = kabc[0].double() * du.double() + kabc[1].double() * z + kabc[2].double()
     ref_dx = dz @ W.double() + (res.double() if with_res else 0)
     assert_close(dx, ref_dx, 2e-5, "fused data gradient")
     assert_close(dW, dz.T @ x.double(), 5e-5, "fused weight gradient")
