@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 106
+#define MT_VERSION 107
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -289,6 +289,13 @@ int mt_conv1x1_bwd_fused(const float* du, const float* kabc, const float* x, con
                          float* dw, int64_t rows, int Cout, int Cin, void* stream);
 int mt_conv1x1_wgrad(const float* du, const float* z, const float* kabc, const float* x, const float* sc, const float* sh,
                      const float* gate, int hw, float* dw, int64_t rows, int Cout, int Cin, void* stream);
+/* The same weight gradient for the WIDE project convolutions of the late stages (65-320 output x 224-2048 expanded channels, the gate
+ * form only: sc, sh, gate required; hw >= 32): the result is cut into 128-column slabs, one block per (slab, row range), load / transform
+ * wavefronts feeding MFMA wavefronts through double-buffered LDS (wide_wgrad.hip).  Replaces mt_gemm (MT_OP_TN with both operand
+ * prologues), which re-applied the transforms per fragment read. */
+int mt_conv1x1_wgrad_wide_supported(int Cout, int Cin);
+int mt_conv1x1_wgrad_wide(const float* du, const float* z, const float* kabc, const float* x, const float* sc, const float* sh,
+                          const float* gate, int hw, float* dw, int64_t rows, int Cout, int Cin, void* stream);
 
 /* 1x1 convolution with few channels and very many rows as a streaming kernel (MBConv expand / project convs of stages 1-4 and
  * their data gradients, efficientnet_pytorch/model.py:93-118): out[rows,Cout] = a[rows,Cin] . W^T (+ res), with

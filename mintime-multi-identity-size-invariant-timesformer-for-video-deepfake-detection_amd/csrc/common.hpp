@@ -56,4 +56,11 @@ inline unsigned xcd_chunk_grid(int chunks, int64_t ntiles, int target_blocks) {
   return (unsigned)(8 * chunks * per_xcd);
 }
 
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is preceded by s_waitcnt vmcnt(0): every global load in flight
+// -- i.e. the next chunks' prefetch of a streaming kernel -- is drained at each barrier.  Here only the LDS counter is waited for
+// (ds_writes visible to the other wavefronts), the loads stay in flight across the barrier and the compiler's own counted waits
+// guard their first use.  Global STORES the other wavefronts must see still need __syncthreads().
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 }  // namespace mt

@@ -196,12 +196,12 @@ __global__ __launch_bounds__(NTHR) void conv1x1_bwd_fused_kernel(FusedArgs p) {
       if (j >= 2) MT_DRAIN(chunk_of(j - 2), 0);
       MT_STAGE(0, chunk_of(j), 0);
       if (j + 2 < n_it) MT_FETCH(0, chunk_of(j + 2));
-      __syncthreads();
+      lds_barrier();
       if (j + 1 < n_it) {
         if (j >= 2) MT_DRAIN(chunk_of(j - 1), 1);
         MT_STAGE(1, chunk_of(j + 1), 1);
         if (j + 3 < n_it) MT_FETCH(1, chunk_of(j + 3));
-        __syncthreads();
+        lds_barrier();
       }
     }
     __syncthreads();                        // every consumer is past its last chunk (pairs with their barrier before the reduction)
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(NTHR) void conv1x1_bwd_fused_kernel(FusedArgs p) {
       const float* dzb = dzs + (j & 1) * S::DZ;
       const float* xb = xs + (j & 1) * S::XS;
       float* ob = outs + (j & 1) * S::OUT;
-      __syncthreads();                      // buffer j & 1 staged
+      lds_barrier();                        // buffer j & 1 staged
       if (wave < 2) {
         if constexpr (N16) {
           // ---- data gradient of rows [wave*32, +32): two 16x16 tiles (two independent chains), k = Cout in steps of 4

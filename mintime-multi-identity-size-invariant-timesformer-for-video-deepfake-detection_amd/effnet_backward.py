@@ -17,6 +17,7 @@ FUSED_DW = __import__("os").environ.get("MT_DW_FUSED", "0")      # "1": every la
 # per lane-column runs at 1.3-3.2 TB/s where the float4 streaming kernels it replaces run at 4.5-5.5.  Parity-tested, opt-in.
 SE_FUSED = __import__("os").environ.get("MT_SE_FUSED", "0") != "0"
 EXPAND_FUSED = __import__("os").environ.get("MT_EXPAND_FUSED", "1") != "0"
+WIDE_WGRAD = __import__("os").environ.get("MT_WIDE_WGRAD", "1") != "0"      # late-stage project-conv weight gradients: wide_wgrad.hip
 # squeeze-excite reverse stage of the early blocks (stages 0-2) as two STREAMING passes that rebuild the project conv's data gradient
 # from the narrow gradient (skinny_se.hip): 3 instead of 6 passes over the expanded tensor, no da tensor
 SE_STREAM = __import__("os").environ.get("MT_SE_STREAM", "1") != "0"     # expand-conv data + weight gradient in one pass (stages 1-3)
@@ -111,6 +112,12 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
             side.launch(lambda: L.check(lib.mt_conv1x1_wgrad(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(x_in), L.ptr(bp[0]), L.ptr(bp[1]),
                                                              L.ptr(bp[2]), bp[3], L.ptr(grads[gw_idx]), rows, cout, cin,
                                                              L.stream_ptr()), "mt_conv1x1_wgrad"), reads=reads)
+        elif WIDE_WGRAD and b_pro is not None and lib.mt_conv1x1_wgrad_wide_supported(cout, cin):
+            run["wgrad_launches"] += 1
+            # project convs of the late stages: 128-column slabs of the result, both operand transforms applied once (wide_wgrad.hip)
+            side.launch(lambda: L.check(lib.mt_conv1x1_wgrad_wide(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(x_in), L.ptr(b_pro[0]),
+                                                                  L.ptr(b_pro[1]), L.ptr(b_pro[2]), b_pro[3], L.ptr(grads[gw_idx]), rows,
+                                                                  cout, cin, L.stream_ptr()), "mt_conv1x1_wgrad_wide"), reads=reads)
         else:
             run["wgrad_launches"] += 1
             side.launch(lambda: L.gemm(L.OP_TN, du, x_in, grads[gw_idx], cout, cin, rows, cout, cin, cin, prologue=L.PRO_BN_BWD,

@@ -99,6 +99,8 @@ PROTOTYPES = {
                       C.c_int, C.c_void_p],
     "mt_conv1x1_wgrad_supported": [C.c_int, C.c_int],
     "mt_conv1x1_wgrad": [f32p] * 7 + [C.c_int, f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p],
+    "mt_conv1x1_wgrad_wide_supported": [C.c_int, C.c_int],
+    "mt_conv1x1_wgrad_wide": [f32p] * 7 + [C.c_int, f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "mt_conv1x1_bwd_fused_supported": [C.c_int, C.c_int],
     "mt_se_stage_fused_supported": [C.c_int, C.c_int, C.c_int],
     "mt_se_stage_fused": [f32p] * 7 + [C.c_int] + [f32p] * 5 + [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p],
@@ -142,8 +144,8 @@ def get():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     v = lib.mt_version()
-    if v != 106:
-        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 106; rebuild it")
+    if v != 107:
+        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 107; rebuild it")
     _lib = lib
     return lib
 

@@ -218,6 +218,32 @@ def test_skinny_conv1x1_wgrad_kernel(cout, cin, rows, gated):
     assert_close(dw, want.float(), 1e-4, f"dW {cout}x{cin}")
 
 
+@pytest.mark.parametrize("cout,cin,rows,hw", [(192, 1152, 12544, 49), (80, 240, 50176 // 4, 196), (112, 672, 9973, 196),
+                                              (320, 1152, 4999, 49), (192, 672, 31, 49), (112, 480, 50176 // 2, 196)])
+def test_wide_project_conv_wgrad_kernel(cout, cin, rows, hw):
+    """mt_conv1x1_wgrad_wide (late-stage project-conv weight gradient: 128-column slabs, producer / consumer wavefronts) against
+    fp64 torch; partial last slab (240, 672, 480 columns), ragged last chunk, rows straddling images, fewer chunks than row ranges."""
+    from mintime_amd import lib as L
+    lib = L.get()
+    g = torch.Generator(device="cuda").manual_seed(cout * 1000 + cin)
+    du = torch.randn(rows, cout, device="cuda", generator=g)
+    z = torch.randn(rows, cout, device="cuda", generator=g)
+    kabc = torch.randn(3, cout, device="cuda", generator=g)
+    x = torch.randn(rows, cin, device="cuda", generator=g)
+    sc, sh = torch.randn(cin, device="cuda", generator=g), torch.randn(cin, device="cuda", generator=g)
+    n_img = (rows + hw - 1) // hw
+    gate = torch.rand(n_img, cin, device="cuda", generator=g)
+    dw = torch.full((cout, cin), 0.5, device="cuda")
+    assert lib.mt_conv1x1_wgrad_wide_supported(cout, cin) == 1
+    assert lib.mt_conv1x1_wgrad_wide_supported(40, 240) == 0 and lib.mt_conv1x1_wgrad_wide_supported(192, 96) == 0
+    L.check(lib.mt_conv1x1_wgrad_wide(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(x), L.ptr(sc), L.ptr(sh), L.ptr(gate), hw, L.ptr(dw), rows,
+                                      cout, cin, L.stream_ptr()), "mt_conv1x1_wgrad_wide")
+    dz = (kabc[0] * du + kabc[1] * z + kabc[2]).double()
+    a = torch.nn.functional.silu(sc.double() * x.double() + sh.double()) * gate.double().repeat_interleave(hw, 0)[:rows]
+    want = dz.t() @ a + 0.5
+    assert_close(dw, want.float(), 1e-4, f"dW {cout}x{cin}")
+
+
 @pytest.mark.parametrize("cin,cout,rows,mode", [(16, 96, 100003, 0), (32, 16, 70001, 1), (96, 24, 50000, 1), (24, 144, 10007, 0),
                                                 (96, 16, 40001, 2), (16, 32, 30000, 2), (24, 96, 30001, 2), (24, 144, 20000, 2)])
 def test_streaming_conv1x1_kernel(cin, cout, rows, mode):
