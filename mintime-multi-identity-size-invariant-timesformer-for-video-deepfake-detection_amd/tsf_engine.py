@@ -126,16 +126,20 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
         side = L.SideStream(dev)
         wts = list(params[5:5 + 16 * model.depth])
         holder = {}
-        main_stream = torch.cuda.current_stream(dev)
+
+        # allocated HERE, i.e. from the MAIN stream's pool: they are read by the main stream's data gradients and die at the end of
+        # the backward pass, after which only later main-stream work can reuse the memory.  (Allocated under the side stream they
+        # needed record_stream(main), and the caching allocator then records one event per block on the main queue when they are
+        # freed: 36 back-to-back event records = 0.3 ms of idle device between the TimeSformer's and the extractor's backward,
+        # tools/lab/host_lag.py.)
+        for li in range(model.depth):
+            for off in (2, 3, 7, 8, 12, 14):           # w_qkv, w_o (time); w_qkv, w_o (space); net.0.weight, net.3.weight
+                w = wts[16 * li + off]
+                holder[(li, off)] = torch.empty(w.shape[1], w.shape[0], dtype=w.dtype, device=w.device)
 
         def transpose_all():
-            for li in range(model.depth):
-                base = 16 * li
-                for off in (2, 3, 7, 8, 12, 14):       # w_qkv, w_o (time); w_qkv, w_o (space); net.0.weight, net.3.weight
-                    w = wts[base + off]
-                    t = w.detach().t().contiguous()
-                    t.record_stream(main_stream)      # allocated on the side stream, read by the main stream's data gradients
-                    holder[(li, off)] = t
+            for key, t in holder.items():
+                t.copy_(wts[16 * key[0] + key[1]].detach().t())
         if side.enabled:       # with MT_SIDE_STREAM=0 the transposes would sit on the critical path: the NN form is used instead
             saved["wT"], saved["wT_ready"] = holder, side.launch(transpose_all, reads=wts)
     # Optional (MT_TSF_PRUNE_LAST=1, off by default): dead-row pruning of the LAST layer.  The classification head reads the cls
