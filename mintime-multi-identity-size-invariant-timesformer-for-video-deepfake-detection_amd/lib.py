@@ -352,6 +352,6 @@ class SideStream:
         if event is not None:
             main.wait_event(event)
             return
-        for e in self.pending:
-            main.wait_event(e)
+        if self.pending:
+            main.wait_event(self.pending[-1])        # the side stream is in order: its last launch implies all earlier ones
         self.pending = []

@@ -131,6 +131,13 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
     du = torch.empty(M, 8 * D, dtype=torch.float32, device=dev)
     do = torch.empty(M, inner, dtype=torch.float32, device=dev)
     dqkv = torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)
+    # Joins with the weight-gradient stream.  The side stream is in order and every sub-block already waits for ITS first weight
+    # gradient before the LayerNorm backward overwrites dx2, so by the time a buffer written three sub-blocks ago (du: the
+    # feed-forward blocks; dqkv: space / dqkv_t: time attention) is written again, its side reader has long been waited for.  A
+    # full join at every sub-block start (MT_TSF_JOIN=1, the first version) only adds a cross-queue barrier whose resolution costs
+    # 17-19 us of idle device each time (27 per step in the in-step trace).
+    join_each = os.environ.get("MT_TSF_JOIN", "0") == "1" or defer
+    dqkv_t = dqkv if join_each else torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)
 
     for li in reversed(range(model.depth)):
         rec = saved["layers"][li]
@@ -196,7 +203,8 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         i0 = take(6)
         g, b_, w1, b1, w2, b2 = P[i0:i0 + 6]
         r = rec[2]
-        side.wait()                                   # du / dx2 readers of the previous sub-block are done
+        if join_each:
+            side.wait()                               # du / dx2 readers of the previous sub-block are done
         if defer:
             du = torch.empty(M, 8 * D, dtype=torch.float32, device=dev)       # kept for the deferred net.0 weight gradient
         e_dx = wgrad(dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D,
@@ -220,18 +228,20 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             i0 = take(5)
             g, b_, w_qkv, w_o, b_o = P[i0:i0 + 5]
             r = rec[mode]
-            side.wait()                               # dqkv / dx2 readers of the previous sub-block are done
+            if join_each:
+                side.wait()                           # dqkv / dx2 readers of the previous sub-block are done
             if defer:
                 dqkv = torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)
+            dq = dqkv if (mode == 1 or join_each) else dqkv_t      # one buffer per attention kind
             e_dx = wgrad(dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner)
             if wT is not None:
                 L.gemm(L.OP_NT, dx2, wT[(li, 8 if mode == 1 else 3)], do, M, inner, D, D, D, inner)
             else:
                 L.gemm(L.OP_NN, dx2, w_o, do, M, inner, D, D, inner, inner)
-            L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
+            L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dq), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
                                     scale, st), "mt_attn_bwd")
-            wgrad(dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
-            e_dg = dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner, wT[(li, 7 if mode == 1 else 2)] if wT is not None else None)
+            wgrad(dq, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
+            e_dg = dgrad_skinny(dq, w_qkv, dxn, 3 * inner, wT[(li, 7 if mode == 1 else 2)] if wT is not None else None)
             if e_dx is not None:
                 side.wait(e_dx)
             if e_dg is not None:
