@@ -108,9 +108,9 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
     def ln_bwd(dxn_, r_, g_, dx_cur, i_g, tgt, skip):
         """dx = LN'(dxn) + dx_cur (+ gamma / beta gradients, + column sums for the bias below).  In place, or -- when weight
         gradients that read dx_cur are still to come -- into a fresh buffer."""
-        dx_new = torch.empty_like(dx_cur) if defer else dx_cur
+        dx_new = torch.empty_like(dx_cur) if ln_oop else dx_cur
         L.check(lib.mt_layernorm_bwd(L.ptr(dxn_), L.ptr(r_["x"]), L.ptr(r_["stats"]), L.ptr(g_), L.ptr(dx_new), L.ptr(grads[i_g]),
-                                     L.ptr(grads[i_g + 1]), M, D, 1, L.ptr(tgt), skip, L.ptr(dx_cur) if defer else None, st),
+                                     L.ptr(grads[i_g + 1]), M, D, 1, L.ptr(tgt), skip, L.ptr(dx_cur) if ln_oop else None, st),
                 "mt_layernorm_bwd")
         return dx_new
 
@@ -131,13 +131,14 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
     du = torch.empty(M, 8 * D, dtype=torch.float32, device=dev)
     do = torch.empty(M, inner, dtype=torch.float32, device=dev)
     dqkv = torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)
-    # Joins with the weight-gradient stream.  The side stream is in order and every sub-block already waits for ITS first weight
-    # gradient before the LayerNorm backward overwrites dx2, so by the time a buffer written three sub-blocks ago (du: the
-    # feed-forward blocks; dqkv: space / dqkv_t: time attention) is written again, its side reader has long been waited for.  A
-    # full join at every sub-block start (MT_TSF_JOIN=1, the first version) only adds a cross-queue barrier whose resolution costs
-    # 17-19 us of idle device each time (27 per step in the in-step trace).
-    join_each = os.environ.get("MT_TSF_JOIN", "0") == "1" or defer
-    dqkv_t = dqkv if join_each else torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)
+    # Joins with the weight-gradient stream.  The first version joined the two streams at every sub-block start (its du / dqkv
+    # buffers are reused) and waited for the sub-block's first weight gradient before the LayerNorm backward overwrote dx2 in
+    # place (MT_TSF_JOIN=1 restores that).  Every cross-queue wait costs the main queue 13-19 us even when the event is long
+    # complete (tools/lab/queue_sync_cost.py), and a join stalls it until the side stream has caught up: 54 of them per step.
+    # Now each sub-block writes du / dqkv / dx2 into FRESH buffers (the side launches that read the old ones pin them with
+    # record_stream), so the main stream waits for nothing inside the layer loop.
+    join_each = os.environ.get("MT_TSF_JOIN", "0") == "1" and not defer
+    ln_oop = (defer or not join_each) and side.enabled
 
     for li in reversed(range(model.depth)):
         rec = saved["layers"][li]
@@ -191,7 +192,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
                     "mt_attn_bwd")
             wgrad(dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
             e_dg = dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner, wT[(li, 2)] if wT is not None else None)
-            if e_dx is not None:
+            if e_dx is not None and not ln_oop:
                 side.wait(e_dx)
             if e_dg is not None:
                 side.wait(e_dg)
@@ -203,10 +204,10 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         i0 = take(6)
         g, b_, w1, b1, w2, b2 = P[i0:i0 + 6]
         r = rec[2]
-        if join_each:
+        if join_each or not ln_oop:
             side.wait()                               # du / dx2 readers of the previous sub-block are done
-        if defer:
-            du = torch.empty(M, 8 * D, dtype=torch.float32, device=dev)       # kept for the deferred net.0 weight gradient
+        if ln_oop:
+            du = torch.empty(M, 8 * D, dtype=torch.float32, device=dev)       # the previous one may still be read by a weight gradient
         e_dx = wgrad(dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D,
                      bias_out=grads[i0 + 5] if li == model.depth - 1 else None)
         if wT is not None:
@@ -217,7 +218,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
                    col_sum=grads[i0 + 3])             # net.0.bias gradient = column sums of du, taken in the epilogue
         wgrad(du, r["xn"], grads[i0 + 2], 8 * D, D, M, 8 * D, D, D)
         e_dg = dgrad_skinny(du, w1, dxn, 8 * D, wT[(li, 12)] if wT is not None else None)
-        if e_dx is not None:
+        if e_dx is not None and not ln_oop:
             side.wait(e_dx)                           # LayerNorm backward updates dx2 in place
         if e_dg is not None:
             side.wait(e_dg)                           # ... and reads dxn, part of which the side stream summed
@@ -228,11 +229,11 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             i0 = take(5)
             g, b_, w_qkv, w_o, b_o = P[i0:i0 + 5]
             r = rec[mode]
-            if join_each:
+            if join_each or not ln_oop:
                 side.wait()                           # dqkv / dx2 readers of the previous sub-block are done
-            if defer:
-                dqkv = torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)
-            dq = dqkv if (mode == 1 or join_each) else dqkv_t      # one buffer per attention kind
+            if ln_oop:
+                dqkv = torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)    # (the old one is pinned by the launch reading it)
+            dq = dqkv
             e_dx = wgrad(dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner)
             if wT is not None:
                 L.gemm(L.OP_NT, dx2, wT[(li, 8 if mode == 1 else 3)], do, M, inner, D, D, D, inner)
@@ -242,7 +243,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
                                     scale, st), "mt_attn_bwd")
             wgrad(dq, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
             e_dg = dgrad_skinny(dq, w_qkv, dxn, 3 * inner, wT[(li, 7 if mode == 1 else 2)] if wT is not None else None)
-            if e_dx is not None:
+            if e_dx is not None and not ln_oop:
                 side.wait(e_dx)
             if e_dg is not None:
                 side.wait(e_dg)
