@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 107
+#define MT_VERSION 108
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -308,6 +308,10 @@ int mt_conv1x1_rows(const float* x, const float* x2, const float* w, int ldw, in
                     const float* c2, int hw, int amode, const float* res, float* out, double* stats, int slots, int64_t rows,
                     int Cin, int Cout, void* stream);
 
+/* dst_i [cols_i, rows_i] = src_i [rows_i, cols_i]^T for `count` matrices in one launch (the TimeSformer's transposed Linear weights,
+ * tsf_engine.py: data gradients in the k-contiguous NT form; replaces 54 torch copy kernels per step).  items: device array of
+ * { const float* src; float* dst; int64 rows; int64 cols; int64 tile0 } with tile0 = running count of 32 x 32 tiles. */
+int mt_transpose_multi(const void* items, int count, int64_t total_tiles, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * Training-step ends (next-row f4).
  * mt_bce_logits: torch.nn.BCEWithLogitsLoss(pos_weight)(logits, labels) with mean reduction (train.py:261,367-368) and its

@@ -59,6 +59,36 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdItem* __restric
   }
 }
 
+// Transposes of many small matrices in ONE launch (the TimeSformer's 54 Linear weights, once per step: their data gradients run in
+// the k-contiguous NT form over W^T, tsf_engine.py).  One 32 x 32 tile per block through LDS; the table maps blocks to matrices
+// like sgd_multi's.  (As 54 torch copy kernels this cost the host ~2 ms per step and the side queue 0.6 ms of launch gaps.)
+struct TransposeItem { const float* src; float* dst; int64_t rows; int64_t cols; int64_t tile0; };    // dst [cols, rows] = src [rows, cols]^T
+
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const TransposeItem* __restrict__ items, int count) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = count - 1;
+  const int64_t b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const TransposeItem it = items[lo];
+  const int64_t tcols = (it.cols + 31) / 32, t = b - it.tile0;
+  const int64_t r0 = (t / tcols) * 32, c0 = (t % tcols) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t r = r0 + ty + 8 * i, c = c0 + tx;
+    if (r < it.rows && c < it.cols) tile[ty + 8 * i][tx] = it.src[r * it.cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < it.rows && c < it.cols) it.dst[c * it.rows + r] = tile[tx][ty + 8 * i];
+  }
+}
+
 // torch.optim.Adam / AdamW (train.py:187-190; amsgrad off, maximize off), same per-element operation order as torch's
 // single-tensor path: [AdamW: p *= 1 - lr*wd] [Adam: g += wd*p]; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  The bias corrections come in precomputed (host doubles -> float).
@@ -109,6 +139,13 @@ extern "C" int mt_bce_logits(const float* logits, const float* labels, float pos
   if (!logits || !labels || !loss || n <= 0) return fail(MT_ERR_ARG, "mt_bce_logits: null pointer / empty batch");
   hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, pos_weight, loss, dlogits, n);
   return check_launch("mt_bce_logits");
+}
+
+extern "C" int mt_transpose_multi(const void* items, int count, int64_t total_tiles, void* stream) {
+  if (!items || count <= 0 || total_tiles <= 0) return fail(MT_ERR_ARG, "mt_transpose_multi: empty table");
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     (const TransposeItem*)items, count);
+  return check_launch("mt_transpose_multi");
 }
 
 extern "C" int mt_sgd_multi(const void* items, int count, int64_t total_blocks, float lr, float weight_decay, void* stream) {

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "mt_conv1x1_rows": [f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p, C.c_void_p, C.c_int, C.c_int64,
                         C.c_int, C.c_int, C.c_void_p],
     "mt_bce_logits": [f32p, f32p, C.c_float, f32p, f32p, C.c_int, C.c_void_p],
+    "mt_transpose_multi": [C.c_void_p, C.c_int, C.c_int64, C.c_void_p],
     "mt_sgd_multi": [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_void_p],
     "mt_adam_multi": [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, C.c_float,
                       C.c_int, C.c_void_p],
@@ -144,8 +145,8 @@ def get():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     v = lib.mt_version()
-    if v != 107:
-        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 107; rebuild it")
+    if v != 108:
+        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 108; rebuild it")
     _lib = lib
     return lib
 

@@ -125,23 +125,33 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
         # weight-gradient stream, which is idle through the forward.
         side = L.SideStream(dev)
         wts = list(params[5:5 + 16 * model.depth])
-        holder = {}
-
-        # allocated HERE, i.e. from the MAIN stream's pool: they are read by the main stream's data gradients and die at the end of
-        # the backward pass, after which only later main-stream work can reuse the memory.  (Allocated under the side stream they
-        # needed record_stream(main), and the caching allocator then records one event per block on the main queue when they are
-        # freed: 36 back-to-back event records = 0.3 ms of idle device between the TimeSformer's and the extractor's backward,
-        # tools/lab/host_lag.py.)
-        for li in range(model.depth):
-            for off in (2, 3, 7, 8, 12, 14):           # w_qkv, w_o (time); w_qkv, w_o (space); net.0.weight, net.3.weight
+        sel = [(li, off) for li in range(model.depth) for off in (2, 3, 7, 8, 12, 14)]   # w_qkv, w_o (time); w_qkv, w_o (space); net.0 / net.3
+        key = tuple(wts[16 * li + off].data_ptr() for li, off in sel)
+        cache = getattr(model, "_wT_cache", None)
+        if cache is None or cache["key"] != key:
+            # PERSISTENT transposed copies (192 MB at depth 9) and one device table for mt_transpose_multi: no allocation and one
+            # launch per step.  (Per-step buffers under the side stream needed record_stream(main), and the caching allocator then
+            # queued one event record per buffer on the main queue when they died: 0.3 ms of idle device before the extractor's
+            # backward; 54 torch copy kernels cost the host ~2 ms per step.)  Rewritten at the start of every training forward: the
+            # side stream waits for everything the main stream has enqueued, i.e. for the previous step's data gradients.
+            holder, rows, tiles = {}, [], 0
+            for li, off in sel:
                 w = wts[16 * li + off]
-                holder[(li, off)] = torch.empty(w.shape[1], w.shape[0], dtype=w.dtype, device=w.device)
+                if w.dtype != torch.float32 or not w.is_contiguous():
+                    raise L.MintimeHipError("transposed-weight cache needs contiguous fp32 Linear weights")
+                t = torch.empty(w.shape[1], w.shape[0], dtype=torch.float32, device=dev)
+                holder[(li, off)] = t
+                rows.append((w.data_ptr(), t.data_ptr(), w.shape[0], w.shape[1], tiles))
+                tiles += ((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32)
+            host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+            cache = dict(key=key, holder=holder, table=host.to(dev, non_blocking=True), host=host, tiles=tiles, count=len(rows))
+            model._wT_cache = cache
 
         def transpose_all():
-            for key, t in holder.items():
-                t.copy_(wts[16 * key[0] + key[1]].detach().t())
+            L.check(lib.mt_transpose_multi(cache["table"].data_ptr(), cache["count"], cache["tiles"], L.stream_ptr()),
+                    "mt_transpose_multi")
         if side.enabled:       # with MT_SIDE_STREAM=0 the transposes would sit on the critical path: the NN form is used instead
-            saved["wT"], saved["wT_ready"] = holder, side.launch(transpose_all, reads=wts)
+            saved["wT"], saved["wT_ready"] = cache["holder"], side.launch(transpose_all, reads=wts)
     # Optional (MT_TSF_PRUNE_LAST=1, off by default): dead-row pruning of the LAST layer.  The classification head reads the cls
     # token only (size_invariant_timesformer.py:270-276), so everything the last layer computes for the 392 patch rows AFTER its
     # time attention is never read: the space attention's patch queries and out-projection rows and the whole feed-forward block
