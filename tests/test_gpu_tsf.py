@@ -338,3 +338,21 @@ def test_last_layer_dead_row_pruning_is_exact(B, Fr, ids, ragged, monkeypatch):
     for k in ("layers.8.2.fn.net.0.weight", "layers.8.2.fn.net.3.bias", "layers.8.1.fn.to_out.0.weight", "layers.8.1.fn.to_qkv.weight",
               "layers.8.0.fn.to_qkv.weight", "layers.0.0.fn.to_qkv.weight", "to_patch_embedding.weight"):
         assert_close(pruned[4][k], o_sd[k].grad, 3 * REL_TOL, "grad vs oracle " + k)
+
+
+@pytest.mark.gpu
+def test_transpose_multi_is_exact():
+    """mt_transpose_multi (the TimeSformer's transposed Linear weights, one launch per step): bit-exact against torch, ragged tiles."""
+    from mintime_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(512, 1536), (37, 65), (2048, 512), (1, 33), (64, 64)]
+    src = [torch.randn(r, c, device="cuda", generator=g) for r, c in shapes]
+    dst = [torch.full((c, r), float("nan"), device="cuda") for r, c in shapes]
+    rows, tiles = [], 0
+    for s, d in zip(src, dst):
+        rows.append((s.data_ptr(), d.data_ptr(), s.shape[0], s.shape[1], tiles))
+        tiles += ((s.shape[0] + 31) // 32) * ((s.shape[1] + 31) // 32)
+    table = torch.tensor(rows, dtype=torch.int64).cuda()
+    L.check(L.get().mt_transpose_multi(table.data_ptr(), len(rows), tiles, L.stream_ptr()), "mt_transpose_multi")
+    for s, d in zip(src, dst):
+        assert torch.equal(d, s.t().contiguous())
