@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 108
+#define MT_VERSION 109
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -134,9 +134,11 @@ int mt_head_fwd(const float* x, const float* gamma, const float* beta, const flo
  * zeroed by the caller; pass NULL when batch statistics are not needed (eval).
  * ------------------------------------------------------------------------------------------------ */
 
-/* _conv_stem: 3x3 stride-2 TF-SAME conv 3->32 (model.py:173,276; utils.py:248-276). x [N,H,W,3] -> z [N,H/2,W/2,32];
- * w in torch layout [32,3,3,3]. */
-int mt_stem_conv_fwd(const float* x, const float* w, float* z, double* stats, int slots, int N, int H, int W, void* stream);
+/* _conv_stem: 3x3 stride-2 TF-SAME conv 3->32 (model.py:173,276; utils.py:248-276) + the BatchNorm batch statistics of its output
+ * (stats [slots][2][32] fp64, accumulated; NULL = none).  x [N,H,W,3] fp32 or (x_is_u8) uint8 -> z [N,ceil(H/2),ceil(W/2),32];
+ * w in torch layout [32,3,3,3]; W <= 512.  Streaming MFMA kernel (stem_fwd.hip): one output row per block and pass. */
+int mt_stem_conv_fwd(const void* x, int x_is_u8, const float* w, float* z, double* stats, int slots, int N, int H, int W,
+                     void* stream);
 
 /* Depthwise conv (k 3|5, stride 1|2, TF-SAME padding; for k3 s1 that is pad 1) applied to act(zin*scale+shift);
  * act 1 = swish: EfficientNet _depthwise_conv on swish(bn(z)) (model.py:98-103);

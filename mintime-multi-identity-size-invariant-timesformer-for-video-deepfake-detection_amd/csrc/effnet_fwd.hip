@@ -38,93 +38,6 @@ __device__ __forceinline__ float4 bn_swish4(float4 z, float4 sc, float4 sh) {
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { atomicAdd(p, v); }
 
-// ------------------------------------------------------------------------------------------------ stem
-// x [N, H, W, 3] (raw 0..255) -> z [N, Ho, Wo, 32], 3x3 stride 2, TF-SAME pad (0,1,0,1) for H=224.
-// One thread per output pixel, all 32 output channels in registers; weights broadcast from LDS.
-constexpr int STEM_CO = 32;
-
-__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        float* __restrict__ z, double* __restrict__ stats, int slots,
-                                                        int N, int H, int W, int Ho, int Wo, int pad0) {
-  __shared__ float ws[27 * STEM_CO];            // [tap = (kh*3+kw)*3+ci][co]
-  __shared__ float red[4][2][STEM_CO];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 27 * STEM_CO; i += 256) {
-    // torch layout [co][ci][kh][kw] -> [kh][kw][ci][co]
-    const int co = i % STEM_CO, t = i / STEM_CO;
-    const int ci = t % 3, kk = t / 3, kw = kk % 3, kh = kk / 3;
-    ws[i] = w[((co * 3 + ci) * 3 + kh) * 3 + kw];
-  }
-  __syncthreads();
-  const int64_t total = (int64_t)N * Ho * Wo;
-  const int64_t pix = (int64_t)blockIdx.x * 256 + tid;
-  float acc[STEM_CO];
-#pragma unroll
-  for (int c = 0; c < STEM_CO; ++c) acc[c] = 0.f;
-  const bool live = pix < total;
-  if (live) {
-    const int ow = (int)(pix % Wo);
-    const int64_t t = pix / Wo;
-    const int oh = (int)(t % Ho);
-    const int n = (int)(t / Ho);
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int ih = oh * 2 + kh - pad0;
-      if (ih < 0 || ih >= H) continue;
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int iw = ow * 2 + kw - pad0;
-        if (iw < 0 || iw >= W) continue;
-        const float* px = x + (((int64_t)n * H + ih) * W + iw) * 3;
-        const float v0 = px[0], v1 = px[1], v2 = px[2];
-        const float* wt = ws + ((kh * 3 + kw) * 3) * STEM_CO;
-#pragma unroll
-        for (int c = 0; c < STEM_CO; ++c)
-          acc[c] = fmaf(v2, wt[2 * STEM_CO + c], fmaf(v1, wt[STEM_CO + c], fmaf(v0, wt[c], acc[c])));
-      }
-    }
-    float4* zo = reinterpret_cast<float4*>(z + pix * STEM_CO);
-#pragma unroll
-    for (int c = 0; c < STEM_CO / 4; ++c) zo[c] = make_float4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
-  }
-  if (stats) {
-    // butterfly transpose-reduce: after 5 exchange steps lane l holds channel (l & 31)'s sum over its 32-lane half
-    const int lane = tid & 63, wave = tid >> 6;
-    float s1[STEM_CO], s2[STEM_CO];
-#pragma unroll
-    for (int c = 0; c < STEM_CO; ++c) { s1[c] = acc[c]; s2[c] = acc[c] * acc[c]; }
-#pragma unroll
-    for (int step = 0; step < 5; ++step) {
-      const int half = STEM_CO >> (step + 1);     // values kept after this step
-      const int bit = 16 >> step;                 // lane bit that selects which half I keep
-      const bool up = (lane & bit) != 0;
-#pragma unroll
-      for (int i = 0; i < half; ++i) {
-        const float send1 = up ? s1[i] : s1[i + half];
-        const float send2 = up ? s2[i] : s2[i + half];
-        const float r1 = __shfl_xor(send1, bit);
-        const float r2 = __shfl_xor(send2, bit);
-        s1[i] = (up ? s1[i + half] : s1[i]) + r1;
-        s2[i] = (up ? s2[i + half] : s2[i]) + r2;
-      }
-    }
-    // lane's channel: bits of lane (16,8,4,2,1) chose upper halves successively
-    float a = s1[0] + __shfl_xor(s1[0], 32);
-    float b = s2[0] + __shfl_xor(s2[0], 32);
-    if (lane < 32) {
-      const int ch = ((lane & 16) ? 16 : 0) + ((lane & 8) ? 8 : 0) + ((lane & 4) ? 4 : 0) + ((lane & 2) ? 2 : 0) + (lane & 1);
-      red[wave][0][ch] = a;
-      red[wave][1][ch] = b;
-    }
-    __syncthreads();
-    if (tid < 2 * STEM_CO) {
-      const int which = tid / STEM_CO, ch = tid % STEM_CO;
-      const float v = red[0][which][ch] + red[1][which][ch] + red[2][which][ch] + red[3][which][ch];
-      atomic_add_f64(stats + ((int64_t)(blockIdx.x % slots) * 2 + which) * STEM_CO + ch, (double)v);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ depthwise, LDS-tiled
 // One block = one 16-channel chunk, grid-strided over T x T output tiles.  The activated input tile (with halo) is built
 // once in LDS (swish evaluated once per element, not once per tap); thread (cq = tid&3, slot = tid>>2) then produces the
@@ -501,17 +414,6 @@ int pick_cqb(int CQ) {
 }
 
 }  // namespace
-
-extern "C" int mt_stem_conv_fwd(const float* x, const float* w, float* z, double* stats, int slots, int N, int H, int W,
-                                void* stream) {
-  if (!x || !w || !z) return fail(MT_ERR_ARG, "mt_stem_conv_fwd: null pointer");
-  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-  const int padt = max((Ho - 1) * 2 + 3 - H, 0);
-  const int64_t total = (int64_t)N * Ho * Wo;
-  hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, z, stats,
-                     slots > 0 ? slots : 1, N, H, W, Ho, Wo, padt / 2);
-  return check_launch("mt_stem_conv_fwd");
-}
 
 namespace {
 template <int K, int S>

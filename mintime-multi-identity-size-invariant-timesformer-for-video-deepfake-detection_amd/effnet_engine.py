@@ -8,6 +8,7 @@ from . import arch
 from . import lib as L
 
 SLOTS = 32   # replicated fp64 BatchNorm accumulators (spreads atomic traffic)
+STEM_DIRECT = __import__("os").environ.get("MT_STEM_DIRECT", "1") != "0"    # 0 = the im2col-prologue GEMM
 STREAM_ROWS = int(__import__("os").environ.get("MT_STREAM_ROWS", "100000"))   # 1x1 convs with at least this many rows use the streaming kernels
 
 
@@ -96,12 +97,16 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
     Hc, Wc = (H + 1) // 2, (W + 1) // 2
     bn = _BNCtx(dev, arch.STEM_COUT, training, pool)
     z = _new(dev, N * Hc * Wc, arch.STEM_COUT)
-    # stem = dense 3x3 s2 conv as an im2col GEMM on the fp32 MFMA path (K = 27 taps padded to 28); TF-SAME pad (0,1) is the
-    # gather's bounds check.  (mt_stem_conv_fwd, the direct kernel, is kept in the ABI but is LDS-read bound: 1.15 ms vs 0.2.)
-    wp = _new(dev, arch.STEM_COUT, 28)
-    L.check(lib.mt_conv_weight_pack(L.ptr(w_stem), L.ptr(wp), arch.STEM_COUT, 3, 3, 28, 0, st), "mt_conv_weight_pack")
-    L.gemm(L.OP_NT, x_nhwc, wp, z, N * Hc * Wc, arch.STEM_COUT, 28, 28, 28, arch.STEM_COUT, prologue=L.PRO_IM2COL, epilogue=epi,
-           stats=bn.stats, stats_slots=SLOTS, conv=(H, W, 3, Hc, Wc, 3, 2, 0, 0, 1 if x_nhwc.dtype == torch.uint8 else 0))
+    # stem: streaming MFMA kernel (stem_fwd.hip; uint8 crops converted on the fly, BatchNorm statistics in the same pass).  The
+    # im2col-prologue GEMM it replaced (K = 27 taps padded to 28) stays the path for crops wider than the kernel's LDS row tile.
+    if W <= 512 and H == W and STEM_DIRECT:
+        L.check(lib.mt_stem_conv_fwd(L.ptr(x_nhwc), 1 if x_nhwc.dtype == torch.uint8 else 0, L.ptr(w_stem), L.ptr(z),
+                                     L.ptr(bn.stats) if training else None, SLOTS, N, H, W, st), "mt_stem_conv_fwd")
+    else:
+        wp = _new(dev, arch.STEM_COUT, 28)
+        L.check(lib.mt_conv_weight_pack(L.ptr(w_stem), L.ptr(wp), arch.STEM_COUT, 3, 3, 28, 0, st), "mt_conv_weight_pack")
+        L.gemm(L.OP_NT, x_nhwc, wp, z, N * Hc * Wc, arch.STEM_COUT, 28, 28, 28, arch.STEM_COUT, prologue=L.PRO_IM2COL, epilogue=epi,
+               stats=bn.stats, stats_slots=SLOTS, conv=(H, W, 3, Hc, Wc, 3, 2, 0, 0, 1 if x_nhwc.dtype == torch.uint8 else 0))
     _finalize(lib, st, model._bn0, bn, N * Hc * Wc, training, g0, b0)
     if save:
         saved["stem"] = dict(x=x_nhwc, z=z, bn=bn)

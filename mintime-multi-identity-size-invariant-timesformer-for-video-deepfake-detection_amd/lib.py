@@ -61,7 +61,7 @@ PROTOTYPES = {
     "mt_attn_fwd": [f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                     C.c_void_p],
     "mt_head_fwd": [f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
-    "mt_stem_conv_fwd": [f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_stem_conv_fwd": [C.c_void_p, C.c_int, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_dwconv_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_int, C.c_void_p],
     "mt_bn_finalize": [C.c_void_p, C.c_int, C.c_double, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_float,
@@ -145,8 +145,8 @@ def get():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     v = lib.mt_version()
-    if v != 108:
-        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 108; rebuild it")
+    if v != 109:
+        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 109; rebuild it")
     _lib = lib
     return lib
 

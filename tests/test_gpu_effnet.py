@@ -70,24 +70,28 @@ def test_nchw_contiguous_input_is_accepted():
     assert_close(feats, g["features"], REL_TOL, "NCHW-contiguous input")
 
 
-def test_direct_stem_kernel_agrees_with_the_im2col_gemm_path():
-    """mt_stem_conv_fwd (direct kernel, kept in the ABI) and the im2col-prologue GEMM the engine uses compute the same stem."""
+@pytest.mark.parametrize("n,H,u8", [(2, 224, False), (3, 224, True), (2, 225, False), (1, 96, True)])
+def test_direct_stem_kernel_agrees_with_the_im2col_gemm_path(n, H, u8):
+    """mt_stem_conv_fwd (streaming MFMA kernel, what the engine runs) and the im2col-prologue GEMM compute the same stem: values
+    against fp64 torch (TF-SAME padding: (0,1) at 224, (1,1) at 225), BatchNorm sums against each other; fp32 and uint8 crops."""
     from mintime_amd import lib as L
     lib = L.get()
-    n, H = 2, 224
-    x = torch.randint(0, 256, (n, H, H, 3)).float().cuda()
+    Ho = (H + 1) // 2
+    pad = max((Ho - 1) * 2 + 3 - H, 0)
+    x8 = torch.randint(0, 256, (n, H, H, 3), dtype=torch.uint8)
+    x = (x8 if u8 else x8.float()).cuda()
     w = (torch.randn(32, 3, 3, 3) * 0.01).cuda()
-    z_direct = torch.empty(n * 112 * 112, 32, device="cuda")
+    z_direct = torch.full((n * Ho * Ho, 32), float("nan"), device="cuda")
     st_direct = torch.zeros(4, 2, 32, dtype=torch.float64, device="cuda")
-    L.check(lib.mt_stem_conv_fwd(L.ptr(x), L.ptr(w), L.ptr(z_direct), L.ptr(st_direct), 4, n, H, H, L.stream_ptr()), "stem")
+    L.check(lib.mt_stem_conv_fwd(L.ptr(x), 1 if u8 else 0, L.ptr(w), L.ptr(z_direct), L.ptr(st_direct), 4, n, H, H, L.stream_ptr()), "stem")
     wp = torch.empty(32, 28, device="cuda")
     L.check(lib.mt_conv_weight_pack(L.ptr(w), L.ptr(wp), 32, 3, 3, 28, 0, L.stream_ptr()), "pack")
     z_gemm = torch.empty_like(z_direct)
     st_gemm = torch.zeros(4, 2, 32, dtype=torch.float64, device="cuda")
-    L.gemm(L.OP_NT, x, wp, z_gemm, n * 112 * 112, 32, 28, 28, 28, 32, prologue=L.PRO_IM2COL, epilogue=L.EPI_STATS, stats=st_gemm,
-           stats_slots=4, conv=(H, H, 3, 112, 112, 3, 2, 0, 0))
-    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x.cpu().permute(0, 3, 1, 2).double(), [0, 1, 0, 1]), w.cpu().double(),
-                                     None, 2).permute(0, 2, 3, 1).reshape(-1, 32)
+    L.gemm(L.OP_NT, x, wp, z_gemm, n * Ho * Ho, 32, 28, 28, 28, 32, prologue=L.PRO_IM2COL, epilogue=L.EPI_STATS, stats=st_gemm,
+           stats_slots=4, conv=(H, H, 3, Ho, Ho, 3, 2, pad // 2, 0, 1 if u8 else 0))
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x8.permute(0, 3, 1, 2).double(), [pad // 2, pad - pad // 2] * 2),
+                                     w.cpu().double(), None, 2).permute(0, 2, 3, 1).reshape(-1, 32)
     assert_close(z_direct, ref, 2e-5, "direct stem")
     assert_close(z_gemm, ref, 2e-5, "im2col GEMM stem")
     assert_close(st_direct.sum(0), st_gemm.sum(0), 1e-6, "BatchNorm sums")
