@@ -19,7 +19,7 @@ def short(n):
 
 
 names = [short(r["Kernel_Name"]) for r in rows]
-stem = [i for i, n in enumerate(names) if "5, 3, 0>" in n and "gemm" in n]      # IM2COL-prologue stem GEMM starts a step
+stem = [i for i, n in enumerate(names) if "stem_mfma_kernel" in n]               # the stem kernel starts a step
 seg = rows[stem[-1]:]
 t0 = int(seg[0]["Start_Timestamp"])
 fam = defaultdict(lambda: [0, 0.0])

@@ -2,7 +2,7 @@
 """Idle gaps of the last full step in a rocprofv3 kernel trace of bench.py: where the whole device waits, and between which kernels."""
 import csv, re, sys, collections
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "5, 3, 0>" in r["Kernel_Name"] and "gemm_kernel" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "stem_mfma_kernel" in r["Kernel_Name"]]
 seg = rows[starts[-2]:starts[-1]]
 t0 = int(seg[0]["Start_Timestamp"])
 short = lambda n: re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("void ", "").replace("mt::", ""))[:44]

@@ -11,7 +11,7 @@ from collections import defaultdict
 ap = argparse.ArgumentParser()
 ap.add_argument("dir")
 ap.add_argument("--min", type=float, default=1e9)
-ap.add_argument("--start", default="5, 3, 0>", help="substring of the kernel that starts a step (EfficientNet: the im2col stem GEMM)")
+ap.add_argument("--start", default="stem_mfma_kernel", help="substring of the kernel that starts a step (EfficientNet: the stem kernel)")
 ap.add_argument("--fetch-scale", type=float, default=2.0)
 ap.add_argument("--json-out", default=None, help="merge family totals into this JSON file (profiles/r02_pmc_families.json)")
 ap.add_argument("--kind", default="ef", choices=["ef", "tsf"])

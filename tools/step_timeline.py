@@ -6,7 +6,7 @@ from collections import defaultdict
 
 ap = argparse.ArgumentParser()
 ap.add_argument("csv")
-ap.add_argument("--start", default="5, 3, 0>")
+ap.add_argument("--start", default="stem_mfma_kernel", help="substring of the kernel that starts a step (the stem kernel)")
 ap.add_argument("--steps-from-end", type=int, default=2)
 ap.add_argument("--top", type=int, default=40, help="symbols listed per queue")
 a = ap.parse_args()
@@ -18,7 +18,7 @@ def short(n):
     return re.sub(r"\(.*", "", n)[:60]
 
 
-starts = [i for i, r in enumerate(rows) if a.start in r["Kernel_Name"] and "gemm" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if a.start in r["Kernel_Name"]]
 lo, hi = starts[-a.steps_from_end], starts[-a.steps_from_end + 1]
 seg = rows[lo:hi]
 t0 = int(seg[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in seg)
