@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 109
+#define MT_VERSION 110
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -206,6 +206,14 @@ int mt_build_clip_inputs(const int* slots, const int* valid, const int* frames, 
 int mt_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
                      float* dgamma, float* dbeta, int rows, int dim, int accumulate, float* dx_colsum, int skip_period,
                      const float* dx_in, void* stream);
+/* The same LayerNorm backward split by queue: mt_layernorm_bwd_rows writes only dx = LN'(dy) + dx_in (few registers, no LDS: it
+ * co-resides with the weight-gradient GEMMs instead of waiting for their blocks to end) and mt_layernorm_bwd_cols accumulates the
+ * parameter gradients (dgamma, dbeta, and dx_colsum = column sums of dx_new, rows with r % skip_period == 0 left out when
+ * skip_period > 0) -- meant for the weight-gradient stream. */
+int mt_layernorm_bwd_rows(const float* dy, const float* x, const float* stats, const float* gamma, float* dx, const float* dx_in,
+                          int rows, int dim, void* stream);
+int mt_layernorm_bwd_cols(const float* dy, const float* x, const float* stats, const float* dx_new, float* dgamma, float* dbeta,
+                          float* dx_colsum, int skip_period, int rows, int dim, void* stream);
 
 /* out[n] += sum_m A[map(m)*lda + n]   (bias gradients). */
 int mt_colsum(const float* A, int64_t lda, mt_rowmap map, int M, int N, float* out, void* stream);

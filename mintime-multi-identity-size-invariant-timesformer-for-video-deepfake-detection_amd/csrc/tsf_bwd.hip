@@ -134,6 +134,112 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------- LayerNorm backward, split by queue
+// The fused kernel above keeps three [D] column sums per wavefront (100+ VGPRs) and meets in LDS: in-step it is the most stretched
+// kernel of the main queue (35 us serialised, ~120 us next to a weight-gradient GEMM whose three blocks per CU leave 74 VGPRs per
+// SIMD lane).  Only dx is on the critical path; the column sums are PARAMETER gradients (gamma, beta, the next Linear's bias).  So:
+//   rows kernel (main stream): dx_out = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)) + dx_in, one row per
+//     wavefront and trip, no LDS, few registers -- its wavefronts fit next to the weight-gradient blocks;
+//   cols kernel (weight-gradient stream): dgamma += sum_r dy*xhat, dbeta += sum_r dy, dxsum += sum_r dx_out (rows with
+//     r % skip_period == 0 left out) -- re-reads dy, x, dx_out (75 MB at B = 32) off the critical path.
+template <int NI>
+__device__ __forceinline__ void layernorm_bwd_rows_body(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                        float* __restrict__ dx, const float* __restrict__ dx_in, int rows, int D) {
+  // register diet (56 VGPRs are what three weight-gradient waves leave on a SIMD lane): pass 1 keeps only the two row sums, pass 2
+  // re-reads x / dy / gamma (the row is 2 x 2 KB and still in L1 / L2) one quad at a time
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * 4;
+  const int nq = D >> 2;
+  const float inv_d = 1.0f / (float)D;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nwaves) {
+    const float mean = stats[2 * (int64_t)row], rstd = stats[2 * (int64_t)row + 1];
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+    const float4* dyr = reinterpret_cast<const float4*>(dy + (int64_t)row * D);
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < NI; ++i) {
+      const int q = min(lane + i * 64, nq - 1);             // clamped: every lane loads (D = 512: all 128 quads are live)
+      const float w = lane + i * 64 < nq ? 1.f : 0.f;
+      const float4 xv = xr[q], d = dyr[q], g = reinterpret_cast<const float4*>(gamma)[q];
+      const float gx = d.x * g.x, gy_ = d.y * g.y, gz = d.z * g.z, gw = d.w * g.w;
+      a1 += w * (gx + gy_ + gz + gw);
+      a2 += w * rstd * (gx * (xv.x - mean) + gy_ * (xv.y - mean) + gz * (xv.z - mean) + gw * (xv.w - mean));
+    }
+    a1 = wave_sum(a1) * inv_d; a2 = wave_sum(a2) * inv_d;
+    float4* dxr = reinterpret_cast<float4*>(dx + (int64_t)row * D);
+    const float4* pin = reinterpret_cast<const float4*>(dx_in + (int64_t)row * D);
+#pragma unroll 1
+    for (int i = 0; i < NI; ++i) {
+      const int q = lane + i * 64;
+      if (q < nq) {
+        const float4 xv = xr[q], d = dyr[q], g = reinterpret_cast<const float4*>(gamma)[q], p = pin[q];
+        float4 o;
+        o.x = rstd * (d.x * g.x - a1 - (xv.x - mean) * rstd * a2) + p.x; o.y = rstd * (d.y * g.y - a1 - (xv.y - mean) * rstd * a2) + p.y;
+        o.z = rstd * (d.z * g.z - a1 - (xv.z - mean) * rstd * a2) + p.z; o.w = rstd * (d.w * g.w - a1 - (xv.w - mean) * rstd * a2) + p.w;
+        dxr[q] = o;
+      }
+    }
+  }
+}
+
+// D <= 512: capped at the 56 VGPRs that are free next to three weight-gradient waves (the allocator rounds their 146 up to 152)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56))) void layernorm_bwd_rows_kernel2(
+    const float* dy, const float* x, const float* stats, const float* gamma, float* dx, const float* dx_in, int rows, int D) {
+  layernorm_bwd_rows_body<2>(dy, x, stats, gamma, dx, dx_in, rows, D);
+}
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel4(const float* dy, const float* x, const float* stats, const float* gamma,
+                                                                   float* dx, const float* dx_in, int rows, int D) {
+  layernorm_bwd_rows_body<4>(dy, x, stats, gamma, dx, dx_in, rows, D);
+}
+
+template <int NI>
+__global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ stats, const float* __restrict__ dxn,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 float* __restrict__ dxsum, int skip_period, int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * 4;
+  const int nq = D >> 2;
+  float4 dg[NI], db[NI], ds[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) { dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i]; ds[i] = dg[i]; }
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nwaves) {
+    const float mean = stats[2 * (int64_t)row], rstd = stats[2 * (int64_t)row + 1];
+    const float c = (skip_period > 0 && row % skip_period == 0) ? 0.f : 1.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int q = lane + i * 64;
+      if (q < nq) {
+        const float4 xv = reinterpret_cast<const float4*>(x + (int64_t)row * D)[q];
+        const float4 d = reinterpret_cast<const float4*>(dy + (int64_t)row * D)[q];
+        dg[i].x += d.x * ((xv.x - mean) * rstd); dg[i].y += d.y * ((xv.y - mean) * rstd);
+        dg[i].z += d.z * ((xv.z - mean) * rstd); dg[i].w += d.w * ((xv.w - mean) * rstd);
+        db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+        if (dxsum) {
+          const float4 o = reinterpret_cast<const float4*>(dxn + (int64_t)row * D)[q];
+          ds[i].x += c * o.x; ds[i].y += c * o.y; ds[i].z += c * o.z; ds[i].w += c * o.w;
+        }
+      }
+    }
+  }
+  __shared__ float red[4][1024];
+  const int wv = threadIdx.x >> 6;
+#pragma unroll 1
+  for (int which = 0; which < 3; ++which) {
+    if (which == 2 && !dxsum) break;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int q = lane + i * 64;
+      if (q < nq) *reinterpret_cast<float4*>(&red[wv][4 * q]) = which == 0 ? dg[i] : (which == 1 ? db[i] : ds[i]);
+    }
+    __syncthreads();
+    float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+    for (int cidx = threadIdx.x; cidx < D; cidx += 256) atomicAdd(dst + cidx, red[0][cidx] + red[1][cidx] + red[2][cidx] + red[3][cidx]);
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------- column sums (bias grads)
 // out[n] += sum_m A[map(m)*lda + n];  block = 64 columns x 4 row-lanes, grid (ceil(N/64), row chunks)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t lda, int gin, int gout, int off,
@@ -806,6 +912,37 @@ extern "C" int mt_layernorm_bwd(const float* dy, const float* x, const float* st
     hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dgamma, dbeta,
                        rows, dim, accumulate, dx_colsum, skip_period, dx_in ? dx_in : dx);
   return check_launch("mt_layernorm_bwd");
+}
+
+extern "C" int mt_layernorm_bwd_rows(const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
+                                     const float* dx_in, int rows, int dim, void* stream) {
+  if (!dy || !x || !stats || !gamma || !dx || !dx_in) return fail(MT_ERR_ARG, "mt_layernorm_bwd_rows: null pointer");
+  if (dim <= 0 || (dim & 3) || dim > 1024) return fail(MT_ERR_ARG, "mt_layernorm_bwd_rows: dim %d unsupported", dim);
+  if (rows <= 0) return 0;
+  int blocks = (rows + 3) / 4;
+  static const int cap = getenv("MT_LN_ROWS_BLOCKS") ? atoi(getenv("MT_LN_ROWS_BLOCKS")) : 1024;    // tuning knob
+  if (blocks > cap) blocks = cap;
+  if (dim <= 512)
+    hipLaunchKernelGGL(layernorm_bwd_rows_kernel2, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dx_in, rows, dim);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_rows_kernel4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dx_in, rows, dim);
+  return check_launch("mt_layernorm_bwd_rows");
+}
+
+extern "C" int mt_layernorm_bwd_cols(const float* dy, const float* x, const float* stats, const float* dx_new, float* dgamma,
+                                     float* dbeta, float* dx_colsum, int skip_period, int rows, int dim, void* stream) {
+  if (!dy || !x || !stats || !dgamma || !dbeta || (dx_colsum && !dx_new)) return fail(MT_ERR_ARG, "mt_layernorm_bwd_cols: null pointer");
+  if (dim <= 0 || (dim & 3) || dim > 1024) return fail(MT_ERR_ARG, "mt_layernorm_bwd_cols: dim %d unsupported", dim);
+  if (rows <= 0) return 0;
+  int blocks = (rows + 3) / 4;
+  if (blocks > 256) blocks = 256;
+  if (dim <= 512)
+    hipLaunchKernelGGL(layernorm_bwd_cols_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, dx_new, dgamma, dbeta,
+                       dx_colsum, skip_period, rows, dim);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_cols_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, dx_new, dgamma, dbeta,
+                       dx_colsum, skip_period, rows, dim);
+  return check_launch("mt_layernorm_bwd_cols");
 }
 
 extern "C" int mt_colsum(const float* A, int64_t lda, mt_rowmap map, int M, int N, float* out, void* stream) {

@@ -73,6 +73,8 @@ PROTOTYPES = {
     "mt_attn_aggregate": [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "mt_build_clip_inputs": [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_void_p],
     "mt_layernorm_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_void_p],
+    "mt_layernorm_bwd_rows": [f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_void_p],
+    "mt_layernorm_bwd_cols": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_colsum": [f32p, i64, RowMap, C.c_int, C.c_int, f32p, C.c_void_p],
     "mt_head_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                     C.c_void_p],
@@ -145,8 +147,8 @@ def get():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     v = lib.mt_version()
-    if v != 109:
-        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 109; rebuild it")
+    if v != 110:
+        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 110; rebuild it")
     _lib = lib
     return lib
 

@@ -107,8 +107,18 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
 
     def ln_bwd(dxn_, r_, g_, dx_cur, i_g, tgt, skip):
         """dx = LN'(dxn) + dx_cur (+ gamma / beta gradients, + column sums for the bias below).  In place, or -- when weight
-        gradients that read dx_cur are still to come -- into a fresh buffer."""
+        gradients that read dx_cur are still to come -- into a fresh buffer.  With the weight-gradient stream on, only dx is
+        computed on the main stream (mt_layernorm_bwd_rows: 48 VGPRs, no LDS -- it co-resides with the weight-gradient GEMMs
+        instead of waiting for their blocks to end); the three column sums are parameter gradients and go to the side stream."""
         dx_new = torch.empty_like(dx_cur) if ln_oop else dx_cur
+        if ln_split:
+            x_, st_ = r_["x"], r_["stats"]
+            L.check(lib.mt_layernorm_bwd_rows(L.ptr(dxn_), L.ptr(x_), L.ptr(st_), L.ptr(g_), L.ptr(dx_new), L.ptr(dx_cur), M, D, st),
+                    "mt_layernorm_bwd_rows")
+            side.launch(lambda: L.check(lib.mt_layernorm_bwd_cols(L.ptr(dxn_), L.ptr(x_), L.ptr(st_), L.ptr(dx_new), L.ptr(grads[i_g]),
+                                                                  L.ptr(grads[i_g + 1]), L.ptr(tgt), skip, M, D, L.stream_ptr()),
+                                        "mt_layernorm_bwd_cols"), reads=(dxn_, x_, st_, dx_new))
+            return dx_new
         L.check(lib.mt_layernorm_bwd(L.ptr(dxn_), L.ptr(r_["x"]), L.ptr(r_["stats"]), L.ptr(g_), L.ptr(dx_new), L.ptr(grads[i_g]),
                                      L.ptr(grads[i_g + 1]), M, D, 1, L.ptr(tgt), skip, L.ptr(dx_cur) if ln_oop else None, st),
                 "mt_layernorm_bwd")
@@ -139,6 +149,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
     # record_stream), so the main stream waits for nothing inside the layer loop.
     join_each = os.environ.get("MT_TSF_JOIN", "0") == "1" and not defer
     ln_oop = (defer or not join_each) and side.enabled
+    ln_split = ln_oop and not defer and os.environ.get("MT_LN_SPLIT", "1") != "0"     # dxn is then read on the side stream too: fresh per sub-block
 
     for li in reversed(range(model.depth)):
         rec = saved["layers"][li]
@@ -208,6 +219,8 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             side.wait()                               # du / dx2 readers of the previous sub-block are done
         if ln_oop:
             du = torch.empty(M, 8 * D, dtype=torch.float32, device=dev)       # the previous one may still be read by a weight gradient
+        if ln_split:
+            dxn = torch.empty(M, D, dtype=torch.float32, device=dev)
         e_dx = wgrad(dx2, r["h"], grads[i0 + 4], D, 4 * D, M, D, 4 * D, 4 * D,
                      bias_out=grads[i0 + 5] if li == model.depth - 1 else None)
         if wT is not None:
@@ -233,6 +246,8 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
                 side.wait()                           # dqkv / dx2 readers of the previous sub-block are done
             if ln_oop:
                 dqkv = torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)    # (the old one is pinned by the launch reading it)
+            if ln_split:
+                dxn = torch.empty(M, D, dtype=torch.float32, device=dev)
             dq = dqkv
             e_dx = wgrad(dx2, r["o"], grads[i0 + 3], D, inner, M, D, inner, inner)
             if wT is not None:

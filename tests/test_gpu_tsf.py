@@ -302,6 +302,19 @@ def test_layernorm_backward_emits_column_sums_of_updated_dx(rows, skip):
     assert torch.equal(dx_out, dxd) and torch.equal(dx_in, dx0.cuda())
     assert_close(cs, dx_ref[keep].sum(0), 1e-4, "column sums of the updated dx")
     assert_close(db, dy.double().sum(0), 1e-4, "dbeta")
+    # the same backward split by queue: rows kernel (dx only) + cols kernel (the three parameter-gradient sums)
+    dx_rows = torch.full((rows, D), float("nan"), device="cuda")
+    dg3, db3, cs3 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    L.check(L.get().mt_layernorm_bwd_rows(L.ptr(dy_d), L.ptr(x_d), L.ptr(stats), L.ptr(gamma_d), L.ptr(dx_rows), L.ptr(dx_in), rows, D,
+                                          L.stream_ptr()), "ln bwd rows")
+    L.check(L.get().mt_layernorm_bwd_cols(L.ptr(dy_d), L.ptr(x_d), L.ptr(stats), L.ptr(dx_rows), L.ptr(dg3), L.ptr(db3), L.ptr(cs3), skip,
+                                          rows, D, L.stream_ptr()), "ln bwd cols")
+    assert_close(dx_rows, dx_ref, 1e-5, "dx (rows kernel)")
+    xh = (x.double() - mean[:, None]) * (1.0 / torch.sqrt(var + 1e-5))[:, None]
+    assert_close(dg3, (dy.double() * xh).sum(0), 1e-4, "dgamma (cols kernel)")
+    assert_close(dg, (dy.double() * xh).sum(0), 1e-4, "dgamma (fused kernel)")
+    assert_close(db3, dy.double().sum(0), 1e-4, "dbeta (cols kernel)")
+    assert_close(cs3, dx_ref[keep].sum(0), 1e-4, "column sums (cols kernel)")
 
 
 @pytest.mark.parametrize("B,Fr,ids,ragged", [(2, 8, 2, True), (3, 16, 3, False)])
