@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 110
+#define MT_VERSION 111
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -99,12 +99,54 @@ int mt_gemm_get_split(void);
 int mt_split_planes(const float* src, void* planes, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Plane-operand contractions (csrc/gemm_planes.hpp): the TimeSformer's Linear layers and their gradients
+ * (size_invariant_timesformer.py:60-76, 111, 144 and their autograd) with BOTH operands pre-split.
+ *
+ * A "plane tensor" of an fp32 matrix X [rows][cols] is its exact three-piece bf16 split X = P0 + P1 + P2 (round-to-nearest at each
+ * level -- the pieces mt_gemm's split-operand loop computes on the fly) stored as
+ *     planes[3][Rp/32][Cp/16][32][16] bf16,   Rp = rows rounded up to 32, Cp = cols rounded up to 16, padding = zeros,
+ * i.e. 1 KB blocks of 32 rows x 16 columns; mt_planes_elems(rows, cols) = Rp * Cp is the plane stride in elements.  The producer
+ * of a tensor writes its planes once (mt_layernorm_fwd / mt_layernorm_bwd_rows / mt_attn_fwd / mt_attn_bwd / the GEGLU epilogues
+ * below / mt_split_planes_blk); forward, data-gradient and weight-gradient GEMMs all read the same planes by LDS-DMA, the first
+ * along the columns, the other two along the rows (LDS transpose-reads).  fp32 in, fp32 out, fp32 accumulation:
+ * NT / NN results are bit-identical to mt_gemm's split-operand loop on the same fp32 operands.
+ * ------------------------------------------------------------------------------------------------ */
+int64_t mt_planes_elems(int rows, int cols);
+
+/* planes of src [rows][cols] (row-major, leading dimension ld). */
+int mt_split_planes_blk(const float* src, int64_t ld, int rows, int cols, void* planes, void* stream);
+
+/* Many contiguous matrices in one launch (the Linear weights, once per optimizer step).  items: device array of
+ * { const float* src; void* planes; int64_t rows, cols, first; } with first = running sum of (Rp/32)*(Cp/16) over the items before;
+ * total_blocks = that sum over all items. */
+int mt_split_planes_blk_multi(const void* items, int count, int64_t total_blocks, void* stream);
+
+typedef struct {
+  int op;                           /* MT_OP_NT: C = A[M,K] B[N,K]^T ; MT_OP_NN: C = A[M,K] B[K,N] ; MT_OP_TN: C += A[K,M]^T B[K,N]        */
+  int epilogue;                     /* NT: STORE, BIAS_RES, GEGLU ; NN: STORE, GEGLU_BWD ; TN: ATOMIC (C pre-zeroed, split-K)              */
+  int M, N, K;                      /* GEGLU: N = 2 * n_half ; GEGLU_BWD: N = n_half                                                       */
+  const void* a_planes;             /* plane tensor of A as stored ([M][K], TN: [K][M])                                                    */
+  const void* b_planes;             /* plane tensor of B as stored (NT: [N][K], NN / TN: [K][N])                                           */
+  float* C; int64_t ldc;            /* fp32 result (may be NULL for the GEGLU pair when c_planes is given)                                 */
+  const float* bias;
+  const float* R; int64_t ldr;      /* BIAS_RES residual                                                                                   */
+  float* C2; int64_t ldc2;          /* GEGLU: optional pre-activation store (a_0,g_0,a_1,g_1,...); GEGLU_BWD: those pre-activations        */
+  int n_half;
+  float* col_sum;                   /* GEGLU_BWD: optional [2*n_half] column sums of the gradient (bias gradient), caller zero-fills       */
+  void* c_planes;                   /* GEGLU: plane tensor of h [M][n_half]; GEGLU_BWD: of du [M][2*n_half]; NULL: fp32 output only        */
+  int split_k;                      /* TN: number of K ranges; <= 0 picks one                                                               */
+} mt_gemm_planes_desc;
+
+int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Size-Invariant TimeSformer forward, non-GEMM pieces
  * ------------------------------------------------------------------------------------------------ */
 
-/* nn.LayerNorm over the last dim (size_invariant_timesformer.py:18-26).  stats (optional) [rows,2] = mean, rstd. */
+/* nn.LayerNorm over the last dim (size_invariant_timesformer.py:18-26).  stats (optional) [rows,2] = mean, rstd.
+ * y (fp32) and / or y_planes (plane tensor of y [rows][dim], dim % 16 == 0; see mt_gemm_planes) -- at least one. */
 int mt_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
-                     int rows, int dim, float eps, void* stream);
+                     int rows, int dim, float eps, void* y_planes, void* stream);
 
 /* cls token + positional + size embeddings (:231-248), in place on x [B, 1+F*n, dim] whose rows 1.. hold the
  * patch-embedding output.  positions int64 [B,1+F*n]; sizes int32 [B,F] (NULL size_emb: enable-size-emb False). */
@@ -211,7 +253,7 @@ int mt_layernorm_bwd(const float* dy, const float* x, const float* stats, const 
  * parameter gradients (dgamma, dbeta, and dx_colsum = column sums of dx_new, rows with r % skip_period == 0 left out when
  * skip_period > 0) -- meant for the weight-gradient stream. */
 int mt_layernorm_bwd_rows(const float* dy, const float* x, const float* stats, const float* gamma, float* dx, const float* dx_in,
-                          int rows, int dim, void* stream);
+                          int rows, int dim, void* dx_planes, void* stream);   /* dx_planes (optional): plane tensor of the new dx */
 int mt_layernorm_bwd_cols(const float* dy, const float* x, const float* stats, const float* dx_new, float* dgamma, float* dbeta,
                           float* dx_colsum, int skip_period, int rows, int dim, void* stream);
 

@@ -149,6 +149,8 @@ struct GemmArgs {
   long long* trace;                     // tuning aid (mt_debug_gemm_trace): per block {t_start, t_prologue, t_loop, t_end, hw_id}
   float* col_sum;                       // GEGLU_BWD: optional column sums of the stored values (bias gradient), fp32 atomics
   const void* b_planes; int64_t b_pstride;   // split loop: B as three pre-split bf16 planes [N][K] (plane stride in elements), or null
+  const void* a_planes; int64_t a_pstride;   // plane loop (gemm_planes.hpp): A as three bf16 planes with A's shape and leading dimension
+  void* c_planes; int64_t c_pstride; int64_t ldcp;   // plane loop: optional bf16 planes of the stored result (row-major, leading dimension ldcp)
   // EPI_SE_RED / EPI_ACT_BWD (epilogue-side vectors; the prologue's scale/shift/gate are taken by PRO_BN_BWD)
   const float* e_scale; const float* e_shift; const float* e_gate; const float* e_dpool; const float* e_mi; int e_hw;
   int xcd_k;                            // split-K weight gradients: every XCD owns whole K-ranges (gemm_split.hpp), grid = (tiles, splits % 8 == 0)

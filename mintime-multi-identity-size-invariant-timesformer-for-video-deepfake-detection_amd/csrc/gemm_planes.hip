@@ -1,0 +1,164 @@
+// Plane-operand GEMM (gemm_planes.hpp) behind the C ABI: mt_gemm_planes, and the fp32 -> blocked-plane converters
+// (mt_split_planes_blk, mt_split_planes_blk_multi) for tensors that no producer kernel emits as planes (the Linear weights once per
+// step, the head's gradient of the residual stream).
+#include "../../include/mintime_hip.h"
+#include "common.hpp"
+#include "gemm_planes.hpp"
+#include <stdlib.h>
+#include <string.h>
+
+using namespace mt;
+
+namespace {
+
+// fp32 row-major [R][C] (leading dimension ld) -> blocked planes, zero padded.  One wavefront per 32 x 16 block: lane = (row, half),
+// its 16-byte stores make whole 1 KB blocks; a 256-thread workgroup takes four adjacent column blocks (256 B of every row).
+__device__ __forceinline__ void to_blk_block(const float* __restrict__ src, int64_t ld, int R, int C, const PlaneRef& o, int rb, int cb, int lane) {
+  const int r = rb * 32 + (lane >> 1), c = cb * 16 + (lane & 1) * 8;
+  float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (r < R) {
+    const float* s = src + (int64_t)r * ld + c;
+    if (c + 8 <= C && ((ld & 3) == 0) && (((uintptr_t)src & 15) == 0)) {
+      const float4 u = *reinterpret_cast<const float4*>(s), v = *reinterpret_cast<const float4*>(s + 4);
+      x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (c + e < C) x[e] = s[e];
+    }
+  }
+  planes_store8(o, r, c, x);
+}
+
+__global__ __launch_bounds__(256) void split_planes_blk_kernel(const float* __restrict__ src, int64_t ld, int R, int C, PlaneRef o) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rb = blockIdx.y, cb = blockIdx.x * 4 + wave;
+  if (cb >= o.cb16) return;
+  to_blk_block(src, ld, R, C, o, rb, cb, lane);
+}
+
+struct SplitItem { const float* src; __bf16* planes; int64_t rows, cols, first; };   // first = index of the item's first wave-block
+
+__global__ __launch_bounds__(256) void split_planes_blk_multi_kernel(const SplitItem* __restrict__ items, int count, int64_t total) {
+  const int64_t wb = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wb >= total) return;
+  int lo = 0, hi = count - 1;                        // the item whose block range holds wb
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].first <= wb) lo = mid; else hi = mid - 1; }
+  const SplitItem it = items[lo];
+  const int R = (int)it.rows, Cc = (int)it.cols;
+  const int cb16 = (Cc + 15) >> 4, rp = (R + 31) & ~31;
+  const int64_t loc = wb - it.first;
+  const PlaneRef o{it.planes, (int64_t)rp * cb16 * 16, cb16, rp};
+  to_blk_block(it.src, Cc, R, Cc, o, (int)(loc / cb16), (int)(loc % cb16), threadIdx.x & 63);
+}
+
+template <bool AKM, bool BKM, int EPI, int BAL, bool CPL>
+int launch_planes(const GemmArgs& a, dim3 grid, hipStream_t s) {
+  constexpr int ST = 2;
+  auto k = gemm_planes_kernel<2, 2, 2, 2, AKM, BKM, EPI, ST, BAL == BAL_PAIR ? 2 : 3, BAL, CPL>;
+  constexpr size_t lds = (size_t)ST * 3 * (128 + 128) * 32;
+  static bool raised_dev[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (lds > 48 * 1024 && !raised_dev[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_gemm_planes: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    raised_dev[dev & 63] = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  return check_launch("mt_gemm_planes");
+}
+
+}  // namespace
+
+extern "C" int64_t mt_planes_elems(int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  return (int64_t)((rows + 31) & ~31) * ((cols + 15) & ~15);
+}
+
+extern "C" int mt_split_planes_blk(const float* src, int64_t ld, int rows, int cols, void* planes, void* stream) {
+  if (!src || !planes) return fail(MT_ERR_ARG, "mt_split_planes_blk: null pointer");
+  if (rows <= 0 || cols <= 0 || ld < cols) return fail(MT_ERR_ARG, "mt_split_planes_blk: bad shape %d x %d (ld %lld)", rows, cols, (long long)ld);
+  if ((uintptr_t)planes & 15) return fail(MT_ERR_ARG, "mt_split_planes_blk: planes must be 16-byte aligned");
+  const int cb16 = (cols + 15) >> 4, rp = (rows + 31) & ~31;
+  const PlaneRef o{reinterpret_cast<__bf16*>(planes), (int64_t)rp * cb16 * 16, cb16, rp};
+  hipLaunchKernelGGL(split_planes_blk_kernel, dim3((cb16 + 3) / 4, rp / 32), dim3(256), 0, (hipStream_t)stream, src, ld, rows, cols, o);
+  return check_launch("mt_split_planes_blk");
+}
+
+extern "C" int mt_split_planes_blk_multi(const void* items, int count, int64_t total_blocks, void* stream) {
+  if (!items || count <= 0 || total_blocks <= 0) return fail(MT_ERR_ARG, "mt_split_planes_blk_multi: bad arguments");
+  hipLaunchKernelGGL(split_planes_blk_multi_kernel, dim3((unsigned)((total_blocks + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const SplitItem*>(items), count, total_blocks);
+  return check_launch("mt_split_planes_blk_multi");
+}
+
+extern "C" int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream) {
+  if (!d || !d->a_planes || !d->b_planes) return fail(MT_ERR_ARG, "mt_gemm_planes: null operand planes");
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0) return fail(MT_ERR_ARG, "mt_gemm_planes: bad shape %d %d %d", d->M, d->N, d->K);
+  if (((uintptr_t)d->a_planes & 15) || ((uintptr_t)d->b_planes & 15) || ((uintptr_t)d->c_planes & 15))
+    return fail(MT_ERR_ARG, "mt_gemm_planes: planes must be 16-byte aligned");
+  const int op = d->op, epi = d->epilogue;
+  const bool cpl = d->c_planes != nullptr;
+  if (!d->C && !cpl) return fail(MT_ERR_ARG, "mt_gemm_planes: no output");
+  if (cpl && epi != MT_EPI_GEGLU && epi != MT_EPI_GEGLU_BWD) return fail(MT_ERR_UNSUPPORTED, "mt_gemm_planes: plane output only from the GEGLU pair");
+  if (!cpl && !d->C) return fail(MT_ERR_ARG, "mt_gemm_planes: C is null");
+  if (epi == MT_EPI_BIAS_RES && !d->R) return fail(MT_ERR_ARG, "mt_gemm_planes: BIAS_RES needs R");
+  if (epi == MT_EPI_GEGLU && (d->n_half * 2 != d->N || (d->n_half & 63))) return fail(MT_ERR_ARG, "mt_gemm_planes GEGLU: N must be 2*n_half, n_half %% 64 == 0");
+  if (epi == MT_EPI_GEGLU_BWD && (!d->C2 || d->n_half != d->N)) return fail(MT_ERR_ARG, "mt_gemm_planes GEGLU_BWD: needs C2 and n_half == N");
+  hipStream_t s = (hipStream_t)stream;
+
+  // operand geometry as stored: A is [M][K] (NT, NN) or [K][M] (TN); B is [N][K] (NT) or [K][N] (NN, TN)
+  const int a_rows = op == MT_OP_TN ? d->K : d->M, a_cols = op == MT_OP_TN ? d->M : d->K;
+  const int b_rows = op == MT_OP_NT ? d->N : d->K, b_cols = op == MT_OP_NT ? d->K : d->N;
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.C = d->C; a.M = d->M; a.N = d->N; a.K = d->K; a.ldc = d->ldc;
+  a.a_planes = d->a_planes; a.a_pstride = mt_planes_elems(a_rows, a_cols); a.lda = (a_cols + 15) >> 4;
+  a.b_planes = d->b_planes; a.b_pstride = mt_planes_elems(b_rows, b_cols); a.ldb = (b_cols + 15) >> 4;
+  a.bias = d->bias; a.R = d->R; a.ldr = d->ldr; a.C2 = d->C2; a.ldc2 = d->ldc2; a.n_half = d->n_half; a.col_sum = d->col_sum;
+  a.hw = 1; a.stats_slots = 1; a.b_hw = 1; a.e_hw = 1;
+  if (cpl) {
+    const int c_cols = epi == MT_EPI_GEGLU ? d->n_half : 2 * d->n_half;
+    a.c_planes = d->c_planes; a.c_pstride = mt_planes_elems(d->M, c_cols); a.ldcp = (c_cols + 15) >> 4;
+  }
+
+  const int m_tiles = (d->M + 127) / 128, n_tiles = (d->N + 127) / 128;
+  dim3 grid(m_tiles * n_tiles, 1, 1);
+  if (op == MT_OP_TN) {
+    if (epi != MT_EPI_ATOMIC) return fail(MT_ERR_UNSUPPORTED, "mt_gemm_planes TN: ATOMIC epilogue only (C pre-zeroed)");
+    // K-range-major split-K (gemm_split.hpp): a multiple of 8 ranges, m_tiles * n_tiles blocks per range
+    int splits = d->split_k;
+    if (splits <= 0) {
+      static const int target = getenv("MT_WGRAD_BLOCKS") ? atoi(getenv("MT_WGRAD_BLOCKS")) : 640;
+      splits = (target + (int)grid.x - 1) / (int)grid.x;
+      const int max_splits = d->K / 256 > 0 ? d->K / 256 : 1;
+      if (splits > max_splits) splits = max_splits;
+    }
+    splits = (splits + 4) / 8 * 8;
+    if (splits < 8) splits = 8;
+    int chunk = (d->K + splits - 1) / splits;
+    chunk = (chunk + 15) / 16 * 16;
+    a.k_chunk = chunk; a.xcd_k = 1;
+    grid.y = (unsigned)(((d->K + chunk - 1) / chunk + 7) / 8 * 8);
+    return launch_planes<true, true, EPI_ATOMIC, BAL_NONE, false>(a, grid, s);
+  }
+  if (m_tiles >= 32 && n_tiles >= 2 && !getenv("MT_NO_L2_BLOCKING")) {
+    const int64_t panel = (int64_t)128 * d->K * 6;   // one column group's B panels: three bf16 planes
+    int gn = (int)((2 << 20) / (panel > 0 ? panel : 1));
+    if (gn < 1) gn = 1;
+    if (gn > n_tiles) gn = n_tiles;
+    a.group_n = gn;
+    grid.x = 8 * ((m_tiles + 7) / 8) * n_tiles;
+  }
+#define PL_COMBO(OP, BKM_, EPI_, CPL_) \
+  if (op == OP && epi == EPI_ && cpl == CPL_) return launch_planes<false, BKM_, EPI_, BAL_PAIR, CPL_>(a, grid, s);
+  PL_COMBO(MT_OP_NT, false, EPI_STORE, false)
+  PL_COMBO(MT_OP_NT, false, EPI_BIAS_RES, false)
+  PL_COMBO(MT_OP_NT, false, EPI_GEGLU, false)
+  PL_COMBO(MT_OP_NT, false, EPI_GEGLU, true)
+  PL_COMBO(MT_OP_NN, true, EPI_STORE, false)
+  PL_COMBO(MT_OP_NN, true, EPI_GEGLU_BWD, false)
+  PL_COMBO(MT_OP_NN, true, EPI_GEGLU_BWD, true)
+#undef PL_COMBO
+  return fail(MT_ERR_UNSUPPORTED, "mt_gemm_planes: unsupported op / epilogue %d / %d", op, epi);
+}

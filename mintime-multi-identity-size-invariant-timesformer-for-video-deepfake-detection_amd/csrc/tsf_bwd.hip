@@ -15,6 +15,7 @@
 
 using namespace mt;
 
+#include "planes.hpp"
 namespace {
 
 constexpr int DH = 64;
@@ -145,13 +146,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 template <int NI>
 __device__ __forceinline__ void layernorm_bwd_rows_body(const float* __restrict__ dy, const float* __restrict__ x,
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                        float* __restrict__ dx, const float* __restrict__ dx_in, int rows, int D) {
+                                                        float* __restrict__ dx, const float* __restrict__ dx_in, int rows, int D,
+                                                        const PlaneRef dxp) {
   // register diet (56 VGPRs are what three weight-gradient waves leave on a SIMD lane): pass 1 keeps only the two row sums, pass 2
   // re-reads x / dy / gamma (the row is 2 x 2 KB and still in L1 / L2) one quad at a time
   const int lane = threadIdx.x & 63;
   const int nwaves = gridDim.x * 4;
   const int nq = D >> 2;
   const float inv_d = 1.0f / (float)D;
+  if (dxp.p && blockIdx.x == 0)                      // padding rows of the plane tensor's last row block: zeros
+    for (int row = rows + (threadIdx.x >> 6); row < dxp.rows_pad; row += 4)
+      for (int q = lane; q < nq; q += 64) planes_store4(dxp, row, q * 4, 0.f, 0.f, 0.f, 0.f);
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nwaves) {
     const float mean = stats[2 * (int64_t)row], rstd = stats[2 * (int64_t)row + 1];
     const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
@@ -178,6 +183,7 @@ __device__ __forceinline__ void layernorm_bwd_rows_body(const float* __restrict_
         o.x = rstd * (d.x * g.x - a1 - (xv.x - mean) * rstd * a2) + p.x; o.y = rstd * (d.y * g.y - a1 - (xv.y - mean) * rstd * a2) + p.y;
         o.z = rstd * (d.z * g.z - a1 - (xv.z - mean) * rstd * a2) + p.z; o.w = rstd * (d.w * g.w - a1 - (xv.w - mean) * rstd * a2) + p.w;
         dxr[q] = o;
+        if (dxp.p) planes_store4(dxp, row, q * 4, o.x, o.y, o.z, o.w);
       }
     }
   }
@@ -185,12 +191,12 @@ __device__ __forceinline__ void layernorm_bwd_rows_body(const float* __restrict_
 
 // D <= 512: capped at the 56 VGPRs that are free next to three weight-gradient waves (the allocator rounds their 146 up to 152)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56))) void layernorm_bwd_rows_kernel2(
-    const float* dy, const float* x, const float* stats, const float* gamma, float* dx, const float* dx_in, int rows, int D) {
-  layernorm_bwd_rows_body<2>(dy, x, stats, gamma, dx, dx_in, rows, D);
+    const float* dy, const float* x, const float* stats, const float* gamma, float* dx, const float* dx_in, int rows, int D, PlaneRef dxp) {
+  layernorm_bwd_rows_body<2>(dy, x, stats, gamma, dx, dx_in, rows, D, dxp);
 }
 __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel4(const float* dy, const float* x, const float* stats, const float* gamma,
-                                                                   float* dx, const float* dx_in, int rows, int D) {
-  layernorm_bwd_rows_body<4>(dy, x, stats, gamma, dx, dx_in, rows, D);
+                                                                   float* dx, const float* dx_in, int rows, int D, PlaneRef dxp) {
+  layernorm_bwd_rows_body<4>(dy, x, stats, gamma, dx, dx_in, rows, D, dxp);
 }
 
 template <int NI>
@@ -915,17 +921,20 @@ extern "C" int mt_layernorm_bwd(const float* dy, const float* x, const float* st
 }
 
 extern "C" int mt_layernorm_bwd_rows(const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
-                                     const float* dx_in, int rows, int dim, void* stream) {
+                                     const float* dx_in, int rows, int dim, void* dx_planes, void* stream) {
   if (!dy || !x || !stats || !gamma || !dx || !dx_in) return fail(MT_ERR_ARG, "mt_layernorm_bwd_rows: null pointer");
   if (dim <= 0 || (dim & 3) || dim > 1024) return fail(MT_ERR_ARG, "mt_layernorm_bwd_rows: dim %d unsupported", dim);
+  if (dx_planes && ((dim & 15) || ((uintptr_t)dx_planes & 15))) return fail(MT_ERR_ARG, "mt_layernorm_bwd_rows: plane output needs dim %% 16 == 0 and 16-byte alignment");
   if (rows <= 0) return 0;
+  const int rp = (rows + 31) & ~31;
+  const PlaneRef dxp{reinterpret_cast<__bf16*>(dx_planes), (int64_t)rp * dim, dim >> 4, rp};
   int blocks = (rows + 3) / 4;
   static const int cap = getenv("MT_LN_ROWS_BLOCKS") ? atoi(getenv("MT_LN_ROWS_BLOCKS")) : 1024;    // tuning knob
   if (blocks > cap) blocks = cap;
   if (dim <= 512)
-    hipLaunchKernelGGL(layernorm_bwd_rows_kernel2, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dx_in, rows, dim);
+    hipLaunchKernelGGL(layernorm_bwd_rows_kernel2, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dx_in, rows, dim, dxp);
   else
-    hipLaunchKernelGGL(layernorm_bwd_rows_kernel4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dx_in, rows, dim);
+    hipLaunchKernelGGL(layernorm_bwd_rows_kernel4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dx_in, rows, dim, dxp);
   return check_launch("mt_layernorm_bwd_rows");
 }
 

@@ -21,6 +21,7 @@
 
 using namespace mt;
 
+#include "planes.hpp"
 namespace {
 
 constexpr int DH = 64;   // dim_head (config: dim-head 64)
@@ -40,10 +41,14 @@ __device__ __forceinline__ float wave_max(float v) {
 // one wavefront per row; D % 4 == 0, D <= 1024
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
-                                                            float* __restrict__ stats, int rows, int D, float eps) {
+                                                            float* __restrict__ stats, int rows, int D, float eps, PlaneRef yp) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (row >= rows) return;
+  if (row >= rows) {
+    if (yp.p && row < yp.rows_pad)                   // padding rows of the last row block: zeros
+      for (int q = lane; q < D >> 2; q += 64) planes_store4(yp, row, q * 4, 0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
   const int nq = D >> 2;
   float4 v[4];
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
   }
   const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
-  float4* yr = reinterpret_cast<float4*>(y + (int64_t)row * D);
+  float4* yr = y ? reinterpret_cast<float4*>(y + (int64_t)row * D) : nullptr;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = lane + i * 64;
@@ -77,7 +82,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       o.y = (v[i].y - mean) * rstd * g.y + b.y;
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      yr[q] = o;
+      if (yr) yr[q] = o;
+      if (yp.p) planes_store4(yp, row, q * 4, o.x, o.y, o.z, o.w);
     }
   }
   if (stats && lane == 0) {
@@ -491,12 +497,16 @@ __global__ __launch_bounds__(64) void head_fwd_kernel(const float* __restrict__ 
 }  // namespace
 
 extern "C" int mt_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
-                                int rows, int dim, float eps, void* stream) {
-  if (!x || !gamma || !beta || !y) return fail(MT_ERR_ARG, "mt_layernorm_fwd: null pointer");
+                                int rows, int dim, float eps, void* y_planes, void* stream) {
+  if (!x || !gamma || !beta || (!y && !y_planes)) return fail(MT_ERR_ARG, "mt_layernorm_fwd: null pointer");
   if (dim <= 0 || (dim & 3) || dim > 1024) return fail(MT_ERR_ARG, "mt_layernorm_fwd: dim %d unsupported (need %%4==0, <=1024)", dim);
+  if (y_planes && ((dim & 15) || ((uintptr_t)y_planes & 15))) return fail(MT_ERR_ARG, "mt_layernorm_fwd: plane output needs dim %% 16 == 0 and 16-byte alignment");
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, stats,
-                     rows, dim, eps);
+  const int rp = (rows + 31) & ~31;
+  const PlaneRef yp{reinterpret_cast<__bf16*>(y_planes), (int64_t)rp * dim, dim >> 4, rp};
+  const int cover = y_planes ? rp : rows;            // the plane tensor's padding rows are written too (zeros)
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((cover + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, stats,
+                     rows, dim, eps, yp);
   return check_launch("mt_layernorm_fwd");
 }
 

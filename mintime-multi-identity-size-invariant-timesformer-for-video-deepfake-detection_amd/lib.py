@@ -42,6 +42,13 @@ class GemmDesc(C.Structure):
                 ("e_mi", C.c_void_p), ("e_hw", C.c_int)]
 
 
+class GemmPlanesDesc(C.Structure):
+    _fields_ = [("op", C.c_int), ("epilogue", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("a_planes", C.c_void_p), ("b_planes", C.c_void_p), ("C", C.c_void_p), ("ldc", i64),
+                ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", i64), ("C2", C.c_void_p), ("ldc2", i64),
+                ("n_half", C.c_int), ("col_sum", C.c_void_p), ("c_planes", C.c_void_p), ("split_k", C.c_int)]
+
+
 OP_NT, OP_NN, OP_TN = 0, 1, 2
 PRO_NONE, PRO_BN_SWISH_GATE, PRO_BN_SWISH, PRO_AFFINE, PRO_BN_BWD, PRO_IM2COL = 0, 1, 2, 3, 4, 5
 BPRO_NONE, BPRO_BN_SWISH_GATE, BPRO_IM2COL = 0, 1, 2
@@ -55,7 +62,11 @@ PROTOTYPES = {
     "mt_gemm_set_split": [C.c_int],
     "mt_gemm_get_split": [],
     "mt_split_planes": [f32p, C.c_void_p, C.c_int64, C.c_void_p],
-    "mt_layernorm_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_void_p],
+    "mt_planes_elems": [C.c_int, C.c_int],
+    "mt_split_planes_blk": [f32p, i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "mt_split_planes_blk_multi": [C.c_void_p, C.c_int, i64, C.c_void_p],
+    "mt_gemm_planes": [C.POINTER(GemmPlanesDesc), C.c_void_p],
+    "mt_layernorm_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p],
     "mt_embed_fwd": [f32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                      C.c_void_p],
     "mt_attn_fwd": [f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -73,7 +84,7 @@ PROTOTYPES = {
     "mt_attn_aggregate": [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "mt_build_clip_inputs": [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_void_p],
     "mt_layernorm_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_void_p],
-    "mt_layernorm_bwd_rows": [f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_void_p],
+    "mt_layernorm_bwd_rows": [f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "mt_layernorm_bwd_cols": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_colsum": [f32p, i64, RowMap, C.c_int, C.c_int, f32p, C.c_void_p],
     "mt_head_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -110,7 +121,7 @@ PROTOTYPES = {
     "mt_conv1x1_bwd_fused": [f32p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "mt_stem_conv_wgrad": [f32p] * 4 + [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
 }
-_RESTYPES = {"mt_last_error": C.c_char_p}
+_RESTYPES = {"mt_last_error": C.c_char_p, "mt_planes_elems": C.c_int64}
 
 
 class MintimeHipError(RuntimeError):
@@ -130,6 +141,13 @@ def build(verbose: bool = False):
     return LIB_PATH
 
 
+def header_version() -> int:
+    """MT_VERSION of include/mintime_hip.h -- the one place the ABI version is written down."""
+    import re
+    with open(os.path.join(_HERE, "..", "include", "mintime_hip.h")) as f:
+        return int(re.search(r"#define\s+MT_VERSION\s+(\d+)", f.read()).group(1))
+
+
 def get():
     global _lib
     if _lib is not None:
@@ -147,8 +165,8 @@ def get():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     v = lib.mt_version()
-    if v != 110:
-        raise MintimeHipError(f"libmintime_hip.so version {v} != header version 110; rebuild it")
+    if v != header_version():
+        raise MintimeHipError(f"libmintime_hip.so version {v} != header version {header_version()}; rebuild it")
     _lib = lib
     return lib
 
@@ -167,6 +185,54 @@ def split_planes(w):
     out = torch.empty((3,) + tuple(w.shape), dtype=torch.bfloat16, device=w.device)
     check(get().mt_split_planes(ptr(w), ptr(out), w.numel(), stream_ptr()), "mt_split_planes")
     return out
+
+
+def planes_shape(rows, cols):
+    """[3, Rp/32, Cp/16, 32, 16]: the blocked bf16 plane tensor of an fp32 [rows, cols] matrix (include/mintime_hip.h)."""
+    return (3, (rows + 31) // 32, (cols + 15) // 16, 32, 16)
+
+
+def planes_empty(rows, cols, device):
+    """Uninitialised plane tensor; its producer kernel writes every element including the zero padding."""
+    return torch.empty(planes_shape(rows, cols), dtype=torch.bfloat16, device=device)
+
+
+def split_planes_blk(x, rows=None, cols=None, ld=None, out=None):
+    """Plane tensor of an fp32 matrix (row-major, leading dimension ld): the converter for tensors no producer kernel emits."""
+    if rows is None:
+        rows, cols = x.shape[-2], x.shape[-1]
+    if ld is None:
+        ld = cols
+    if out is None:
+        out = planes_empty(rows, cols, x.device)
+    check(get().mt_split_planes_blk(ptr(x), ld, rows, cols, ptr(out), stream_ptr()), "mt_split_planes_blk")
+    return out
+
+
+def planes_to_float(planes, rows, cols):
+    """fp32 [rows, cols] = p0 + p1 + p2 of a plane tensor (tests / debugging only: plain torch ops)."""
+    p = planes.float().sum(0)                       # exact: the three pieces of an fp32 value add back to it
+    return p.permute(0, 2, 1, 3).reshape(p.shape[0] * 32, p.shape[1] * 16)[:rows, :cols]
+
+
+def gemm_planes(op, a_planes, b_planes, M, N, K, Cout=None, ldc=0, epilogue=EPI_STORE, bias=None, R=None, ldr=0, C2=None, ldc2=0,
+                n_half=0, col_sum=None, c_planes=None, split_k=0):
+    d = GemmPlanesDesc()
+    d.op, d.epilogue, d.M, d.N, d.K = op, epilogue, M, N, K
+    d.a_planes, d.b_planes, d.C, d.ldc = ptr(a_planes), ptr(b_planes), ptr(Cout), ldc
+    d.bias, d.R, d.ldr, d.C2, d.ldc2 = ptr(bias), ptr(R), ldr, ptr(C2), ldc2
+    d.n_half, d.col_sum, d.c_planes, d.split_k = n_half, ptr(col_sum), ptr(c_planes), split_k
+    prof = PROFILE
+    if prof is not None:
+        for pr in prof:
+            if "match_planes" in pr and pr["match_planes"](d):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(get().mt_gemm_planes(C.byref(d), stream_ptr()), "mt_gemm_planes")
+                e1.record()
+                pr["events"].append((e0, e1, 2.0 * M * N * K))
+                return
+    check(get().mt_gemm_planes(C.byref(d), stream_ptr()), "mt_gemm_planes")
 
 
 def gemm_split_enabled() -> bool:

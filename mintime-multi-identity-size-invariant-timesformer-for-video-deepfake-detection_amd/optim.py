@@ -8,6 +8,12 @@ from . import lib as L
 _CHUNK = 4096
 
 
+def _weights_changed():
+    """Parameters were updated through raw pointers (torch's version counters did not move): cached operand planes are stale."""
+    from . import tsf_planes
+    tsf_planes.WEIGHT_EPOCH[0] += 1
+
+
 class FusedSGD(torch.optim.Optimizer):
     """`p -= lr * (grad + weight_decay * p)` (torch.optim.SGD without momentum) for every parameter of a group in one launch.
     param_groups / lr schedulers work as with torch.optim.SGD (lr and weight_decay are read from the group at every step)."""
@@ -58,6 +64,7 @@ class FusedSGD(torch.optim.Optimizer):
             table, blocks = self._table(gi, ps)
             L.check(lib.mt_sgd_multi(table.data_ptr(), len(ps), blocks, float(group["lr"]), float(group["weight_decay"]),
                                      L.stream_ptr()), "mt_sgd_multi")
+        _weights_changed()
         return loss
 
 
@@ -130,6 +137,7 @@ class _FusedAdamBase(torch.optim.Optimizer):
             L.check(lib.mt_adam_multi(table.data_ptr(), len(ps), blocks, float(group["lr"]), float(group["weight_decay"]), float(b1),
                                       float(b2), float(group["eps"]), float(step_size), float(bc2_sqrt), 1 if self._decoupled else 0,
                                       L.stream_ptr()), "mt_adam_multi")
+        _weights_changed()
         return loss
 
 

@@ -113,7 +113,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
         dx_new = torch.empty_like(dx_cur) if ln_oop else dx_cur
         if ln_split:
             x_, st_ = r_["x"], r_["stats"]
-            L.check(lib.mt_layernorm_bwd_rows(L.ptr(dxn_), L.ptr(x_), L.ptr(st_), L.ptr(g_), L.ptr(dx_new), L.ptr(dx_cur), M, D, st),
+            L.check(lib.mt_layernorm_bwd_rows(L.ptr(dxn_), L.ptr(x_), L.ptr(st_), L.ptr(g_), L.ptr(dx_new), L.ptr(dx_cur), M, D, None, st),
                     "mt_layernorm_bwd_rows")
             side.launch(lambda: L.check(lib.mt_layernorm_bwd_cols(L.ptr(dxn_), L.ptr(x_), L.ptr(st_), L.ptr(dx_new), L.ptr(grads[i_g]),
                                                                   L.ptr(grads[i_g + 1]), L.ptr(tgt), skip, M, D, L.stream_ptr()),

@@ -175,7 +175,7 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
                 stats = _new(dev, M, 2)
             else:
                 stats = None
-            L.check(lib.mt_layernorm_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(xn), L.ptr(stats), M, D, eps, st), "mt_layernorm_fwd")
+            L.check(lib.mt_layernorm_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(xn), L.ptr(stats), M, D, eps, None, st), "mt_layernorm_fwd")
             L.gemm(L.OP_NT, xn, w_qkv, qkv, M, 3 * inner, D, D, D, 3 * inner)
             att = None
             if want_att and last:
@@ -206,7 +206,7 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
             # feed-forward block on the cls rows only (x is [B, D] here)
             xn_c, h_c, stats_c = _new(dev, B, D), _new(dev, B, 4 * D), (_new(dev, B, 2) if save else None)
             u_c = _new(dev, B, 8 * D) if save else None
-            L.check(lib.mt_layernorm_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(xn_c), L.ptr(stats_c), B, D, eps, st), "mt_layernorm_fwd")
+            L.check(lib.mt_layernorm_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(xn_c), L.ptr(stats_c), B, D, eps, None, st), "mt_layernorm_fwd")
             L.gemm(L.OP_NT, xn_c, w1, h_c, B, 8 * D, D, D, D, 4 * D, epilogue=L.EPI_GEGLU, bias=b1, C2=u_c, ldc2=8 * D, n_half=4 * D)
             x_out = _new(dev, B, 1, D)
             L.gemm(L.OP_NT, h_c, w2, x_out, B, D, 4 * D, 4 * D, 4 * D, D, epilogue=L.EPI_BIAS_RES, bias=b2, R=x, ldr=D)
@@ -221,7 +221,7 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
             u = _new(dev, M, 8 * D)
         else:
             stats, u = None, None
-        L.check(lib.mt_layernorm_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(xn), L.ptr(stats), M, D, eps, st), "mt_layernorm_fwd")
+        L.check(lib.mt_layernorm_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), L.ptr(xn), L.ptr(stats), M, D, eps, None, st), "mt_layernorm_fwd")
         L.gemm(L.OP_NT, xn, w1, hbuf, M, 8 * D, D, D, D, 4 * D, epilogue=L.EPI_GEGLU, bias=b1, C2=u, ldc2=8 * D, n_half=4 * D)
         # FF2 is skinny (N = 512 -> 396 output tiles on 256 CUs): 5 K-slices accumulated with fp32 atomics onto the residual
         # even out the tail (measured 333 -> 270 us at B = 32).  Training only: atomics make the sum order -- the last bits of
@@ -254,7 +254,11 @@ class _TSFFunction(torch.autograd.Function):
         # the caller's grad mode comes in through `dims`.  Without it an eval forward would keep every activation and take
         # the training-only split-K + atomics branch.
         save = grad_on and any(ctx.needs_input_grad)
-        logits, s_att, t_att, saved = tsf_forward(model, feat, aux, params, B, F, n, save)
+        from . import tsf_planes
+        if tsf_planes.eligible(model, B * (1 + F * n), save):
+            logits, s_att, t_att, saved = tsf_planes.tsf_forward_planes(model, feat, aux, params, B, F, n, save)
+        else:
+            logits, s_att, t_att, saved = tsf_forward(model, feat, aux, params, B, F, n, save)
         ctx.model, ctx.aux, ctx.dims, ctx.saved = model, aux, dims, saved
         ctx.feat, ctx.params = feat, params
         outs = [logits]
@@ -269,6 +273,8 @@ class _TSFFunction(torch.autograd.Function):
         if ctx.saved is None:
             raise RuntimeError("SizeInvariantTimeSformer: backward ran a second time through the same forward; the activation "
                                "buffers are released after the first pass (retain_graph is not supported by the HIP engine)")
+        if ctx.saved.get("planes"):
+            from .tsf_planes import tsf_backward_planes as tsf_backward
         dfeat, dparams = tsf_backward(ctx.model, ctx.feat, ctx.aux, ctx.params, ctx.dims, ctx.saved,
                                       dlogits.contiguous(), ctx.needs_input_grad[3], ctx.needs_input_grad[4:])
         ctx.saved = None

@@ -1,0 +1,184 @@
+"""GPU parity of the plane-operand GEMM path (csrc/gemm_planes.hpp, through the C ABI): the blocked bf16 plane format, its
+producers, and mt_gemm_planes against (a) mt_gemm's split-operand loop on the same fp32 operands -- bit for bit where both use
+the same summation order -- and (b) fp64 CPU matmuls."""
+import pytest
+import torch
+
+import mintime_amd
+from mintime_amd import lib as L
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 32), (77, 40), (393 * 2, 512), (1, 8), (100, 2048)])
+def test_blocked_planes_are_the_exact_split_with_zero_padding(rows, cols):
+    x = _rand(rows, cols, seed=rows + cols)
+    x[0, 0] = 1.0 + 2.0 ** -20                           # needs all three pieces
+    xd = x.cuda()
+    p = L.split_planes_blk(xd)
+    assert p.shape == L.planes_shape(rows, cols) and p.numel() == 3 * L.get().mt_planes_elems(rows, cols)
+    back = L.planes_to_float(p, rows, cols)
+    assert torch.equal(back, xd), "p0 + p1 + p2 must give the fp32 value back exactly"
+    # the pieces are the ones the in-kernel split computes (round-to-nearest bf16 at each level), in the blocked order
+    p0 = x.bfloat16()
+    r1 = x - p0.float()
+    p1 = r1.bfloat16()
+    p2 = (r1 - p1.float()).bfloat16()
+    full = p.permute(0, 1, 3, 2, 4).reshape(3, p.shape[1] * 32, p.shape[2] * 16)
+    for k, piece in enumerate((p0, p1, p2)):
+        assert torch.equal(full[k, :rows, :cols].cpu(), piece), f"plane {k}"
+    assert float(full[:, rows:, :].float().abs().max() if full.shape[1] > rows else 0.0) == 0.0
+    assert float(full[:, :, cols:].float().abs().max() if full.shape[2] > cols else 0.0) == 0.0
+    # strided source (leading dimension > cols)
+    wide = _rand(rows, cols + 24, seed=5).cuda()
+    p_ld = L.split_planes_blk(wide, rows, cols, ld=cols + 24)
+    assert torch.equal(L.planes_to_float(p_ld, rows, cols), wide[:, :cols])
+
+
+@pytest.mark.parametrize("M,N,K", [(786, 1536, 512), (300, 192, 136), (1000, 512, 2048), (129, 128, 16)])
+def test_nt_planes_bit_identical_to_in_kernel_split(M, N, K):
+    A, W, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.05), _rand(N, seed=3)
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    ref = torch.full((M, N), float("nan"), device="cuda")
+    prev = L.set_gemm_split(True)
+    try:
+        L.gemm(L.OP_NT, Ad, Wd, ref, M, N, K, K, K, N, bias=bd)
+    finally:
+        L.set_gemm_split(prev)
+    got = torch.full((M, N), float("nan"), device="cuda")
+    L.gemm_planes(L.OP_NT, L.split_planes_blk(Ad), L.split_planes_blk(Wd), M, N, K, Cout=got, ldc=N, bias=bd)
+    assert_close(got, A.double() @ W.double().T + b.double(), TOL, "NT planes vs fp64")
+    if K >= 512:                                          # (below MT_SPLIT_MIN_K's cached default mt_gemm ran the fp32 pipe)
+        assert torch.equal(got, ref), "same pieces, same products, same order: the results must be bit-identical"
+    # bias + residual
+    R = _rand(M, N, seed=5).cuda()
+    out = torch.empty(M, N, device="cuda")
+    L.gemm_planes(L.OP_NT, L.split_planes_blk(Ad), L.split_planes_blk(Wd), M, N, K, Cout=out, ldc=N, epilogue=L.EPI_BIAS_RES, bias=bd,
+                  R=R, ldr=N)
+    assert_close(out, A.double() @ W.double().T + b.double() + R.cpu().double(), TOL, "NT planes bias + residual")
+
+
+@pytest.mark.parametrize("M", [393 * 2, 1000, 12576])
+def test_geglu_pair_emits_planes(M):
+    D = 512
+    A, W, b = _rand(M, D, seed=1), _rand(8 * D, D, seed=2, scale=0.05), _rand(8 * D, seed=3, scale=0.1)
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    h_ref = torch.empty(M, 4 * D, device="cuda")
+    u_ref = torch.empty(M, 8 * D, device="cuda")
+    prev = L.set_gemm_split(True)
+    try:
+        L.gemm(L.OP_NT, Ad, Wd, h_ref, M, 8 * D, D, D, D, 4 * D, epilogue=L.EPI_GEGLU, bias=bd, C2=u_ref, ldc2=8 * D, n_half=4 * D)
+    finally:
+        L.set_gemm_split(prev)
+    a_p, w_p = L.split_planes_blk(Ad), L.split_planes_blk(Wd)
+    h_p = L.planes_empty(M, 4 * D, "cuda")
+    h_p.fill_(float("nan"))
+    u = torch.full((M, 8 * D), float("nan"), device="cuda")
+    L.gemm_planes(L.OP_NT, a_p, w_p, M, 8 * D, D, epilogue=L.EPI_GEGLU, bias=bd, C2=u, ldc2=8 * D, n_half=4 * D, c_planes=h_p)
+    assert torch.equal(u, u_ref), "pre-activations"
+    assert torch.equal(L.planes_to_float(h_p, M, 4 * D), h_ref), "h planes = the exact split of the fp32 h"
+    assert not torch.isnan(h_p.float()).any() and float(L.planes_to_float(h_p, h_p.shape[1] * 32, 4 * D)[M:].abs().sum()) == 0.0
+    # fp32 h next to the planes
+    h32 = torch.full((M, 4 * D), float("nan"), device="cuda")
+    L.gemm_planes(L.OP_NT, a_p, w_p, M, 8 * D, D, Cout=h32, ldc=4 * D, epilogue=L.EPI_GEGLU, bias=bd, n_half=4 * D)
+    assert torch.equal(h32, h_ref)
+    # ---- GEGLU backward: du = [dh * gelu(g) | dh * a * gelu'(g)] from dh = dx . W2, W2 [D, 4D] read along its rows (NN)
+    dx, W2 = _rand(M, D, seed=7), _rand(D, 4 * D, seed=8, scale=0.05)
+    dxd, W2d = dx.cuda(), W2.cuda()
+    du_ref = torch.empty(M, 8 * D, device="cuda")
+    cs_ref = torch.zeros(8 * D, device="cuda")
+    prev = L.set_gemm_split(True)
+    try:
+        L.gemm(L.OP_NN, dxd, W2d, du_ref, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=u_ref, ldc2=8 * D, n_half=4 * D,
+               col_sum=cs_ref)
+    finally:
+        L.set_gemm_split(prev)
+    du_p = L.planes_empty(M, 8 * D, "cuda")
+    du_p.fill_(float("nan"))
+    cs = torch.zeros(8 * D, device="cuda")
+    L.gemm_planes(L.OP_NN, L.split_planes_blk(dxd), L.split_planes_blk(W2d), M, 4 * D, D, epilogue=L.EPI_GEGLU_BWD, C2=u_ref, ldc2=8 * D,
+                  n_half=4 * D, col_sum=cs, c_planes=du_p)
+    assert torch.equal(L.planes_to_float(du_p, M, 8 * D), du_ref), "du planes = the exact split of the fp32 du"
+    assert_close(cs, du_ref.double().sum(0), 1e-4, "column sums of du (bias gradient)")
+    assert float(L.planes_to_float(du_p, du_p.shape[1] * 32, 8 * D)[M:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(786, 512, 1536), (1000, 512, 4096), (300, 136, 512), (786, 512, 520)])
+def test_nn_planes_reads_the_weight_along_its_rows(M, N, K):
+    """Data gradient dX[M,N] = dY[M,K] . W[K,N] with W as stored: no transposed copy, LDS transpose-reads."""
+    dY, W = _rand(M, K, seed=1), _rand(K, N, seed=2, scale=0.05)
+    dYd, Wd = dY.cuda(), W.cuda()
+    got = torch.full((M, N), float("nan"), device="cuda")
+    L.gemm_planes(L.OP_NN, L.split_planes_blk(dYd), L.split_planes_blk(Wd), M, N, K, Cout=got, ldc=N)
+    assert_close(got, dY.double() @ W.double(), TOL, "NN planes vs fp64")
+    if K % 16 == 0 and N % 4 == 0 and M * N >= 1 << 18:     # (smaller problems: mt_gemm runs them on the fp32 pipe)
+        ref = torch.empty(M, N, device="cuda")
+        prev = L.set_gemm_split(True)
+        try:
+            L.gemm(L.OP_NN, dYd, Wd, ref, M, N, K, K, N, N)
+        finally:
+            L.set_gemm_split(prev)
+        assert torch.equal(got, ref), "bit-identical to the in-kernel split"
+
+
+@pytest.mark.parametrize("Mo,No,K", [(1536, 512, 786), (512, 2048, 1000), (4096, 512, 12576), (136, 200, 3 * 393)])
+def test_tn_planes_weight_gradient(Mo, No, K):
+    """dW[Mo,No] = dY[K,Mo]^T X[K,No]: both operands read along their rows from the planes the forward / data-gradient GEMMs use."""
+    dY, X = _rand(K, Mo, seed=1, scale=0.1), _rand(K, No, seed=2)
+    dW = torch.zeros(Mo, No, device="cuda")
+    L.gemm_planes(L.OP_TN, L.split_planes_blk(dY.cuda()), L.split_planes_blk(X.cuda()), Mo, No, K, Cout=dW, ldc=No, epilogue=L.EPI_ATOMIC)
+    assert_close(dW, dY.double().T @ X.double(), TOL, "TN planes vs fp64")
+    # accumulates onto what is there
+    L.gemm_planes(L.OP_TN, L.split_planes_blk(dY.cuda()), L.split_planes_blk(X.cuda()), Mo, No, K, Cout=dW, ldc=No, epilogue=L.EPI_ATOMIC)
+    assert_close(dW, 2 * (dY.double().T @ X.double()), TOL, "TN planes accumulate")
+
+
+@pytest.mark.parametrize("rows", [393 * 2, 77, 12576])
+def test_layernorm_kernels_emit_planes(rows):
+    D = 512
+    x, g, b = _rand(rows, D, seed=1), _rand(D, seed=2), _rand(D, seed=3)
+    xd, gd, bd = x.cuda(), g.cuda(), b.cuda()
+    y = torch.empty(rows, D, device="cuda")
+    stats = torch.empty(rows, 2, device="cuda")
+    y_p = L.planes_empty(rows, D, "cuda")
+    y_p.fill_(float("nan"))
+    L.check(L.get().mt_layernorm_fwd(L.ptr(xd), L.ptr(gd), L.ptr(bd), L.ptr(y), L.ptr(stats), rows, D, 1e-5, L.ptr(y_p), L.stream_ptr()), "ln fwd")
+    assert_close(y, torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double(), 1e-5), 1e-5, "LayerNorm")
+    assert torch.equal(L.planes_to_float(y_p, rows, D), y)
+    assert float(L.planes_to_float(y_p, y_p.shape[1] * 32, D)[rows:].abs().sum()) == 0.0 and not torch.isnan(y_p.float()).any()
+    # planes only (no fp32 output)
+    y_p2 = L.planes_empty(rows, D, "cuda")
+    L.check(L.get().mt_layernorm_fwd(L.ptr(xd), L.ptr(gd), L.ptr(bd), None, None, rows, D, 1e-5, L.ptr(y_p2), L.stream_ptr()), "ln fwd planes only")
+    assert torch.equal(y_p2, y_p)
+    # backward rows kernel: dx fp32 and its planes
+    dy, dx_in = _rand(rows, D, seed=4).cuda(), _rand(rows, D, seed=5).cuda()
+    dx = torch.empty(rows, D, device="cuda")
+    dx_ref = torch.empty(rows, D, device="cuda")
+    dx_p = L.planes_empty(rows, D, "cuda")
+    dx_p.fill_(float("nan"))
+    L.check(L.get().mt_layernorm_bwd_rows(L.ptr(dy), L.ptr(xd), L.ptr(stats), L.ptr(gd), L.ptr(dx_ref), L.ptr(dx_in), rows, D, None,
+                                          L.stream_ptr()), "ln bwd rows")
+    L.check(L.get().mt_layernorm_bwd_rows(L.ptr(dy), L.ptr(xd), L.ptr(stats), L.ptr(gd), L.ptr(dx), L.ptr(dx_in), rows, D, L.ptr(dx_p),
+                                          L.stream_ptr()), "ln bwd rows + planes")
+    assert torch.equal(dx, dx_ref) and torch.equal(L.planes_to_float(dx_p, rows, D), dx)
+    assert float(L.planes_to_float(dx_p, dx_p.shape[1] * 32, D)[rows:].abs().sum()) == 0.0 and not torch.isnan(dx_p.float()).any()
+
+
+def test_multi_tensor_split_matches_single():
+    ws = [_rand(1536, 512, seed=1).cuda(), _rand(512, 512, seed=2).cuda(), _rand(512, 2048, seed=3).cuda(), _rand(40, 24, seed=4).cuda()]
+    outs = [L.planes_empty(w.shape[0], w.shape[1], "cuda") for w in ws]
+    rows, first = [], 0
+    for w, o in zip(ws, outs):
+        rows.append((w.data_ptr(), o.data_ptr(), w.shape[0], w.shape[1], first))
+        first += o.shape[1] * o.shape[2]
+    table = torch.tensor(rows, dtype=torch.int64).cuda()
+    L.check(L.get().mt_split_planes_blk_multi(table.data_ptr(), len(rows), first, L.stream_ptr()), "multi split")
+    for w, o in zip(ws, outs):
+        assert torch.equal(o, L.split_planes_blk(w))

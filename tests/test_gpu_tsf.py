@@ -306,7 +306,7 @@ def test_layernorm_backward_emits_column_sums_of_updated_dx(rows, skip):
     dx_rows = torch.full((rows, D), float("nan"), device="cuda")
     dg3, db3, cs3 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
     L.check(L.get().mt_layernorm_bwd_rows(L.ptr(dy_d), L.ptr(x_d), L.ptr(stats), L.ptr(gamma_d), L.ptr(dx_rows), L.ptr(dx_in), rows, D,
-                                          L.stream_ptr()), "ln bwd rows")
+                                          None, L.stream_ptr()), "ln bwd rows")
     L.check(L.get().mt_layernorm_bwd_cols(L.ptr(dy_d), L.ptr(x_d), L.ptr(stats), L.ptr(dx_rows), L.ptr(dg3), L.ptr(db3), L.ptr(cs3), skip,
                                           rows, D, L.stream_ptr()), "ln bwd cols")
     assert_close(dx_rows, dx_ref, 1e-5, "dx (rows kernel)")

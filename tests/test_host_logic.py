@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     """Every function include/mintime_hip.h declares is exported by the built .so and bound in lib.PROTOTYPES."""
     hdr = open(os.path.join(ROOT, "include", "mintime_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(mt_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(mt_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 20
     if not os.path.exists(lib.LIB_PATH):
         lib.build()
@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in the header but not exported"
     assert declared == set(lib.PROTOTYPES), declared ^ set(lib.PROTOTYPES)
-    assert lib.get().mt_version() == 110
+    assert lib.get().mt_version() == lib.header_version() == 111
 
 
 def test_errors_are_reported_not_swallowed():
