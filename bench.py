@@ -177,7 +177,7 @@ def attention_modules_leg(dev, B, F=8, reps=3):
             for mode in (0, 1):
                 lib.gemm(lib.OP_NT, xn, wqkv, qkv, M, 3 * D, D, D, D, 3 * D)
                 lib.check(h.mt_attn_fwd(lib.ptr(qkv), lib.ptr(o), None, lib.ptr(mask), lib.ptr(ident), B, H, F, n, mode, 0.125,
-                                        lib.stream_ptr()), "mt_attn_fwd")
+                                        None, lib.stream_ptr()), "mt_attn_fwd")
                 lib.gemm(lib.OP_NT, o, wo, x, M, D, D, D, D, D, epilogue=lib.EPI_BIAS_RES, bias=bo, R=x, ldr=D)
 
     flops = B * 2 * 7638018048            # attention-module MACs per clip (QKV + core + out-proj, x18)

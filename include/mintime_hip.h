@@ -135,9 +135,15 @@ typedef struct {
   float* col_sum;                   /* GEGLU_BWD: optional [2*n_half] column sums of the gradient (bias gradient), caller zero-fills       */
   void* c_planes;                   /* GEGLU: plane tensor of h [M][n_half]; GEGLU_BWD: of du [M][2*n_half]; NULL: fp32 output only        */
   int split_k;                      /* TN: number of K ranges; <= 0 picks one                                                               */
+  void* sk_workspace;               /* NT / NN, optional: mt_gemm_planes_workspace_bytes() of device memory, 256-byte aligned, ZERO-FILLED   */
+  int64_t sk_workspace_bytes;       /* once by the caller and lent to every launch of ONE stream (launches leave it zero-filled again).    */
+                                    /* With it the launch runs stream-K: a persistent grid shares the (tile, k-step) list evenly instead of */
+                                    /* one block per tile -- same result up to the association of a split tile's partial sums, which is     */
+                                    /* fixed (bit-reproducible run to run).  NULL: one block per output tile.                               */
 } mt_gemm_planes_desc;
 
 int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream);
+int64_t mt_gemm_planes_workspace_bytes(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Size-Invariant TimeSformer forward, non-GEMM pieces
@@ -161,9 +167,11 @@ int mt_embed_fwd(float* x, const float* cls, const float* pos_emb, const float* 
  * qkv [B, 1+F*n, 3*H*64] -> out [B, 1+F*n, H*64] (merged heads).  mode 0 = time (identity-masked), 1 = space,
  * 2 = the cls query only (out row 0 of each clip; what the LAST layer's space attention needs when only the cls token is read
  * afterwards -- the optional dead-row pruning of tsf_engine.py; mt_attn_bwd mode 2 is its adjoint: dk / dv of all keys, dq of row 0).
- * mask uint8 [B,F], ident uint8 [B,F,F]; cls_att (optional) [(B*H), 1+F*n] = the cls query's probabilities. */
+ * mask uint8 [B,F], ident uint8 [B,F,F]; cls_att (optional) [(B*H), 1+F*n] = the cls query's probabilities.
+ * out_planes (optional, mode 0 / 1): plane tensor of out [B*(1+F*n)][H*64] (mt_gemm_planes), written by the same kernels -- the
+ * operand of the out-projection and of its weight gradient; out may then be NULL. */
 int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const uint8_t* mask, const uint8_t* ident,
-                int B, int H, int F, int n, int mode, float scale, void* stream);
+                int B, int H, int F, int n, int mode, float scale, void* out_planes, void* stream);
 
 /* to_out: LayerNorm + Linear(dim, classes) on the cls row x[:,0] (:270-276). x [B,N,dim] -> logits [B,classes]. */
 int mt_head_fwd(const float* x, const float* gamma, const float* beta, const float* w, const float* bias,
@@ -269,9 +277,11 @@ int mt_head_bwd(const float* dlogits, const float* x, const float* gamma, const 
 int mt_embed_bwd(const float* dx, float* dcls, float* dpos_emb, float* dsize_emb, const int64_t* positions,
                  const int32_t* sizes, int B, int F, int n, int dim, int pos_rows, int size_rows, void* stream);
 
-/* adjoint of mt_attn_fwd: dout [B,N,H*64] -> dqkv [B,N,3*H*64] (fully written). Probabilities are recomputed from qkv. */
+/* adjoint of mt_attn_fwd: dout [B,N,H*64] -> dqkv [B,N,3*H*64] (fully written). Probabilities are recomputed from qkv.
+ * dqkv_planes (optional, mode 0 / 1): the result as a plane tensor [B*N][3*H*64] (operand of the QKV layer's data and weight
+ * gradients).  dqkv is then working memory: its patch rows are left holding the cls query's contribution only. */
 int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, const uint8_t* mask, const uint8_t* ident,
-                int B, int H, int F, int n, int mode, float scale, void* stream);
+                int B, int H, int F, int n, int mode, float scale, void* dqkv_planes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * EfficientNet-B0 backward, everything except the 1x1-convolution dgrad/wgrad (mt_gemm with the BN_BWD prologue).

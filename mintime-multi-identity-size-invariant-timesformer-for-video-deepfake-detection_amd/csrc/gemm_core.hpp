@@ -153,6 +153,8 @@ struct GemmArgs {
   void* c_planes; int64_t c_pstride; int64_t ldcp;   // plane loop: optional bf16 planes of the stored result (row-major, leading dimension ldcp)
   // EPI_SE_RED / EPI_ACT_BWD (epilogue-side vectors; the prologue's scale/shift/gate are taken by PRO_BN_BWD)
   const float* e_scale; const float* e_shift; const float* e_gate; const float* e_dpool; const float* e_mi; int e_hw;
+  // stream-K (gemm_planes.hpp): persistent grid, per-block partial-tile slabs [grid][BM*BN] fp32 + one flag word per block
+  float* sk_ws; int* sk_flags; int sk_on;
   int xcd_k;                            // split-K weight gradients: every XCD owns whole K-ranges (gemm_split.hpp), grid = (tiles, splits % 8 == 0)
 };
 

@@ -51,10 +51,25 @@ __global__ __launch_bounds__(256) void split_planes_blk_multi_kernel(const Split
   to_blk_block(it.src, Cc, R, Cc, o, (int)(loc / cb16), (int)(loc % cb16), threadIdx.x & 63);
 }
 
-template <bool AKM, bool BKM, int EPI, int BAL, bool CPL>
+constexpr int kSkMaxGrid = 1024;                      // persistent blocks a stream-K launch may use (workspace is sized for this)
+constexpr int64_t kSkFlagBytes = 4096;                // kSkMaxGrid ints, then the slabs
+
+int cu_count() {
+  static int cus[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& c = cus[dev & 63];
+  if (c == 0) {
+    hipDeviceProp_t pr;
+    c = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+  }
+  return c;
+}
+
+template <bool AKM, bool BKM, int EPI, int BAL, bool CPL, bool SK = false>
 int launch_planes(const GemmArgs& a, dim3 grid, hipStream_t s) {
   constexpr int ST = 2;
-  auto k = gemm_planes_kernel<2, 2, 2, 2, AKM, BKM, EPI, ST, BAL == BAL_PAIR ? 2 : 3, BAL, CPL>;
+  auto k = gemm_planes_kernel<2, 2, 2, 2, AKM, BKM, EPI, ST, BAL == BAL_PAIR ? 2 : 3, BAL, CPL, SK>;
   constexpr size_t lds = (size_t)ST * 3 * (128 + 128) * 32;
   static bool raised_dev[64] = {false};
   int dev = 0;
@@ -69,6 +84,8 @@ int launch_planes(const GemmArgs& a, dim3 grid, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int64_t mt_gemm_planes_workspace_bytes(void) { return kSkFlagBytes + (int64_t)kSkMaxGrid * 128 * 128 * 4; }
 
 extern "C" int64_t mt_planes_elems(int rows, int cols) {
   if (rows <= 0 || cols <= 0) return 0;
@@ -150,13 +167,38 @@ extern "C" int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream) {
     a.group_n = gn;
     grid.x = 8 * ((m_tiles + 7) / 8) * n_tiles;
   }
+  // stream-K over a persistent grid (gemm_planes.hpp) when the caller lends a workspace: two resident blocks per CU share the
+  // linearised (tile, k-step) list evenly.  Tiny problems (less than ~4 k-steps per block) keep one block per tile.
+  const int sk_env = 1;   // (the caller decides by lending a workspace; measured slower than one block per tile on the TimeSformer's shapes: the loop is power-bound and a tile tail's idle CUs give their power to the busy ones)
+  bool sk = false;
+  if (sk_env && d->sk_workspace && d->sk_workspace_bytes >= mt_gemm_planes_workspace_bytes() && !((uintptr_t)d->sk_workspace & 255)) {
+    static const int per_cu = getenv("MT_PLANES_SK_BLOCKS") ? atoi(getenv("MT_PLANES_SK_BLOCKS")) : 2;
+    int g = cu_count() * per_cu;
+    g = g / 8 * 8;
+    if (g > kSkMaxGrid) g = kSkMaxGrid;
+    const int64_t units = (int64_t)m_tiles * n_tiles * (((d->K + 15) / 16 + 1) / 2);     // pairs of k-steps
+    if (g >= 8 && units >= (int64_t)g * 2 && units < (1ll << 30)) {
+      sk = true;
+      grid = dim3((unsigned)g, 1, 1);
+      a.sk_on = 1;
+      a.sk_flags = reinterpret_cast<int*>(d->sk_workspace);
+      a.sk_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(d->sk_workspace) + kSkFlagBytes);
+    }
+  }
 #define PL_COMBO(OP, BKM_, EPI_, CPL_) \
-  if (op == OP && epi == EPI_ && cpl == CPL_) return launch_planes<false, BKM_, EPI_, BAL_PAIR, CPL_>(a, grid, s);
+  if (op == OP && epi == EPI_ && cpl == CPL_)                                                       \
+    return sk ? launch_planes<false, BKM_, EPI_, BAL_PAIR, CPL_, true>(a, grid, s)                  \
+              : launch_planes<false, BKM_, EPI_, BAL_PAIR, CPL_, false>(a, grid, s);
   PL_COMBO(MT_OP_NT, false, EPI_STORE, false)
   PL_COMBO(MT_OP_NT, false, EPI_BIAS_RES, false)
   PL_COMBO(MT_OP_NT, false, EPI_GEGLU, false)
   PL_COMBO(MT_OP_NT, false, EPI_GEGLU, true)
   PL_COMBO(MT_OP_NN, true, EPI_STORE, false)
+  {
+    static const int gb = getenv("MT_PLANES_GEGLU_BWD_BAL") ? atoi(getenv("MT_PLANES_GEGLU_BWD_BAL")) : BAL_PAIR;   // tuning experiment
+    if (op == MT_OP_NN && epi == EPI_GEGLU_BWD && cpl && !sk && gb == BAL_PHASE) return launch_planes<false, true, EPI_GEGLU_BWD, BAL_PHASE, true>(a, grid, s);
+    if (op == MT_OP_NN && epi == EPI_GEGLU_BWD && cpl && !sk && gb == BAL_NONE) return launch_planes<false, true, EPI_GEGLU_BWD, BAL_NONE, true>(a, grid, s);
+  }
   PL_COMBO(MT_OP_NN, true, EPI_GEGLU_BWD, false)
   PL_COMBO(MT_OP_NN, true, EPI_GEGLU_BWD, true)
 #undef PL_COMBO

@@ -141,10 +141,49 @@ __device__ __forceinline__ void planes_epilogue(const GemmArgs& p, f32x16 (&acc)
   }
 }
 
+// ---- stream-K (SK): a persistent grid splits the linearised (tile, k-step) space evenly instead of handing out whole tiles.
+// 396 tiles of a 12576 x 512 output fill 77 % of 2 x 256 resident blocks and 1188 tiles of the QKV layer take 3 rounds for 2.3
+// rounds of work; here every block gets total / grid k-steps: a contiguous run of the XCD-ordered tile list -- the tail of one tile
+// (stored as an fp32 slab + flag for the block that owns that tile), whole tiles, and the head of a last tile, which it OWNS: it adds
+// the slabs of the blocks that follow it (they produced them at the START of their runs) in a fixed order and runs the epilogue.
+// Deterministic; a block only ever waits for work its successors do first, so any residency >= 3 blocks makes progress.
+// Hand-off = the agent-scope release / acquire recipe of the CDNA4 guide (plain slab stores, every wave drains, barrier, lane 0
+// release fence + drain, relaxed flag store | relaxed poll, ONE acquire fence, barrier, plain loads); the owner clears the flag.
+template <int BM, int BN>
+__device__ __forceinline__ void sk_tile_coords(const GemmArgs& p, int t, int& mt_, int& nt_) {
+  const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + BM - 1) / BM;
+  if (p.group_n > 0) {
+    // the L2-blocked order of tile_coords(): XCD x sweeps its band of tile rows one column group at a time; bands are listed one
+    // after the other, so a block's contiguous run stays inside one band (except at a band seam)
+    const int q = m_tiles >> 3, r = m_tiles & 7;
+    int xcd = 0, base = 0;
+    for (; xcd < 7; ++xcd) {
+      const int cnt = (q + (xcd < r ? 1 : 0)) * n_tiles;
+      if (t < base + cnt) break;
+      base += cnt;
+    }
+    const int rows = q + (xcd < r ? 1 : 0);
+    const int row0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int idx = t - base;
+    const int per_group = rows * p.group_n;
+    const int g = idx / per_group;
+    const int rem = idx - g * per_group;
+    const int groups = (n_tiles + p.group_n - 1) / p.group_n;
+    const int gw = (g == groups - 1) ? n_tiles - g * p.group_n : p.group_n;
+    // (the last group is narrower: its per-group count is rows * gw, and it is the last one, so idx / per_group is still right)
+    const int ml = rem / gw;
+    mt_ = row0 + ml;
+    nt_ = g * p.group_n + (rem - ml * gw);
+  } else {
+    mt_ = t / n_tiles;
+    nt_ = t - mt_ * n_tiles;
+  }
+}
+
 // GemmArgs for this loop: a_planes / b_planes with a_pstride / b_pstride (elements between planes), lda / ldb = the operand's
-// number of 16-column blocks (C / 16); M, N, K logical; p.a_rows / p.b_rows are not needed: rows past the end are clamped to the
-// last row block (whose padding rows are zeros).
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int EPI, int STAGES, int MINW, int BAL, bool CPL = false>
+// number of 16-column blocks (C / 16); M, N, K logical; rows past the end are clamped to the last row block (whose padding rows are
+// zeros).
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int EPI, int STAGES, int MINW, int BAL, bool CPL = false, bool SK = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW)
 void gemm_planes_kernel(const GemmArgs p) {
   constexpr int NW = WAVES_M * WAVES_N;
@@ -159,6 +198,7 @@ void gemm_planes_kernel(const GemmArgs p) {
   constexpr int IPW = (PA + PB) / NW;
   static_assert(STAGES >= 2 && STAGES <= 4, "2..4 stages");
   static_assert((!AKM || BM == 128) && (!BKM || BN == 128), "k-major images are laid out for 128-column tiles");
+  static_assert(!SK || !AKM, "stream-K: forward / data-gradient forms (weight gradients split K over the grid already)");
   constexpr bool PAIR = BAL == BAL_PAIR, PHASE = BAL == BAL_PHASE;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_pl[];
@@ -170,97 +210,10 @@ void gemm_planes_kernel(const GemmArgs p) {
   const int wm = wave / WAVES_N;
   const int wn = wave % WAVES_N;
 
-  int mt_, nt_;
-  int k_begin = 0, k_end = p.K;
-  if (p.xcd_k) {                                     // split-K weight gradient, K-range-major over the XCDs (see gemm_split.hpp)
-    const int tiles = gridDim.x, lin = blockIdx.y * gridDim.x + blockIdx.x;
-    const int xcd = lin & 7, idx = lin >> 3;
-    const int split = xcd + 8 * (idx / tiles), t = idx % tiles;
-    const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + BM - 1) / BM;
-    if (m_tiles >= n_tiles) { mt_ = t / n_tiles; nt_ = t - mt_ * n_tiles; }
-    else { nt_ = t / m_tiles; mt_ = t - nt_ * m_tiles; }
-    k_begin = split * p.k_chunk;
-    k_end = min(p.K, k_begin + p.k_chunk);
-    if (k_begin >= k_end) return;
-  } else {
-    if (!tile_coords<BM, BN>(p, mt_, nt_)) return;
-    if (p.k_chunk > 0) {
-      k_begin = blockIdx.y * p.k_chunk;
-      k_end = min(p.K, k_begin + p.k_chunk);
-      if (k_begin >= k_end) return;
-    }
-  }
-  const int m0 = mt_ * BM;
-  const int n0 = nt_ * BN;
-  const int nk = (k_end - k_begin + BK - 1) / BK;    // k_begin % 16 == 0; a ragged end reads the planes' zero padding
-
-  // ---- DMA sources.  Piece q of a stage (q = wave * IPW + j): q < PA -> A plane q / PPA, else B plane; inside a plane the piece
-  // index selects a 32-row block (k-contiguous) or 4 k-rows (k-major).  Per piece a constant 32-bit byte offset from a uniform
-  // base that depends on the operand and the k-step only.
   const __bf16* a_base = reinterpret_cast<const __bf16*>(p.a_planes);
   const __bf16* b_base = reinterpret_cast<const __bf16*>(p.b_planes);
-  unsigned voff[IPW];
-  bool is_a[IPW];
-#pragma unroll
-  for (int j = 0; j < IPW; ++j) {
-    const int q = wave * IPW + j;
-    is_a[j] = q < PA;
-    const int qq = is_a[j] ? q : q - PA;
-    const int plane = is_a[j] ? qq / PPA : qq / PPB;
-    const int piece = is_a[j] ? qq % PPA : qq % PPB;
-    const int64_t pstride = is_a[j] ? p.a_pstride : p.b_pstride;
-    const int64_t cb16 = is_a[j] ? p.lda : p.ldb;
-    const bool kmaj = is_a[j] ? AKM : BKM;
-    int64_t off;                                     // elements, without the k-step term
-    if (!kmaj) {
-      // rows = output rows, 16 k = one column block: the piece is row block (g0 / 32 + piece), the lane permutes inside it
-      const int row = lane >> 1, slot = lane & 1;
-      const int kh = slot ^ ((row >> 3) & 1);
-      int g0;                                        // first global row of the piece's 32 tile rows
-      int lim;
-      if (is_a[j]) { g0 = m0 + piece * 32; lim = p.M; }
-      else if constexpr (EPI == EPI_GEGLU) {         // tile row -> weight row: 'a' and 'gate' halves interleaved per 32 columns
-        static_assert(EPI != EPI_GEGLU || TN == 2, "GEGLU wants TN == 2");
-        const int w = piece >> 1, sel = piece & 1;
-        g0 = sel * p.n_half + (n0 >> 1) + w * 32; lim = 2 * p.n_half;
-        if ((n0 >> 1) + w * 32 >= p.n_half) g0 = 0;
-      } else { g0 = n0 + piece * 32; lim = p.N; }
-      if (g0 >= lim) g0 = (lim - 1) & ~31;           // row blocks past the end are never stored: any valid block will do
-      off = plane * pstride + (int64_t)(g0 >> 5) * cb16 * 512 + row * 16 + kh * 8;
-    } else {
-      // rows = k, 128 columns = 8 column blocks: 4 k-rows per piece
-      const int kl = piece * 4 + (lane >> 4), s16 = lane & 15;
-      const int seg = (s16 >> 1) ^ (2 * (kl & 3)), half = s16 & 1;
-      int cb = ((is_a[j] ? m0 : n0) >> 4) + seg;
-      const int cbmax = (int)cb16 - 1;
-      cb = cb < cbmax ? cb : cbmax;                  // column blocks past the end are never stored
-      off = plane * pstride + (int64_t)cb * 512 + kl * 16 + half * 8;
-    }
-    voff[j] = (unsigned)(off * 2);
-  }
 
-  auto issue = [&](int kt, int slot) {               // DMA of k-tile kt into ring slot `slot`
-    if (MT_PLANES_ABLATE & 1) return;
-    const int kb = k_begin + kt * BK;
-    // k-contiguous: column block kb / 16.  k-major: row block kb / 32 (all of its column blocks), row kb % 32 inside it.
-    const __bf16* as = a_base + (AKM ? ((int64_t)(kb >> 5) * p.lda * 512 + (kb & 31) * 16) : (int64_t)(kb >> 4) * 512);
-    const __bf16* bs = b_base + (BKM ? ((int64_t)(kb >> 5) * p.ldb * 512 + (kb & 31) * 16) : (int64_t)(kb >> 4) * 512);
-    const unsigned dst = lds_base + (unsigned)(slot * STAGE);
-#pragma unroll
-    for (int j = 0; j < IPW; ++j)
-      lds_dma16_s(is_a[j] ? as : bs, voff[j], dst + (unsigned)((wave * IPW + j) * 1024));
-  };
-
-  f32x16 acc[TM][TN];
-  f32x16 nacc[PAIR ? TM : 1][PAIR ? TN : 1];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if constexpr (PAIR) nacc[i][j][r] = 0.f; }
-
-  // ---- fragment addressing (byte offsets inside a plane image)
+  // ---- fragment addressing (byte offsets inside a plane image; independent of the tile)
   int a_frag[TM], b_frag[TN];
   {
     const int kh = lane >> 5;
@@ -346,6 +299,9 @@ void gemm_planes_kernel(const GemmArgs p) {
     v = *reinterpret_cast<bf16x8_t*>(&u);
   };
 
+  f32x16 acc[TM][TN];
+  f32x16 nacc[PAIR ? TM : 1][PAIR ? TN : 1];
+
   auto mma = [&](Frags& f, auto odd_c, unsigned phase_mask) {
     constexpr bool ODD = PAIR && decltype(odd_c)::value;
     if (MT_PLANES_ABLATE & 16) {                     // keep the fragments live without the matrix pipe
@@ -389,81 +345,255 @@ void gemm_planes_kernel(const GemmArgs p) {
   };
 #define MT_PL_BARRIER() do { if (!(MT_PLANES_ABLATE & 2)) __builtin_amdgcn_s_barrier(); } while (0)
 
-  if (nk <= 0) return;
+  // ---- one piece of work: k-steps [kt_lo, kt_lo + nk) (absolute step index counted from k_begin) of tile (mt_, nt_) into acc
+  auto run_piece = [&](int mt_, int nt_, int k_begin, int kt_lo, int nk) {
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
+    // DMA sources.  Piece q of a stage (q = wave * IPW + j): q < PA -> A plane q / PPA, else B plane; inside a plane the piece
+    // index selects a 32-row block (k-contiguous) or 4 k-rows (k-major).  Per piece a constant 32-bit byte offset from a uniform
+    // base that depends on the operand and the k-step only.
+    unsigned voff[IPW];
+    bool is_a[IPW];
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const int q = wave * IPW + j;
+      is_a[j] = q < PA;
+      const int qq = is_a[j] ? q : q - PA;
+      const int plane = is_a[j] ? qq / PPA : qq / PPB;
+      const int piece = is_a[j] ? qq % PPA : qq % PPB;
+      const int64_t pstride = is_a[j] ? p.a_pstride : p.b_pstride;
+      const int64_t cb16 = is_a[j] ? p.lda : p.ldb;
+      const bool kmaj = is_a[j] ? AKM : BKM;
+      int64_t off;                                     // elements, without the k-step term
+      if (!kmaj) {
+        // rows = output rows, 16 k = one column block: the piece is row block (g0 / 32 + piece), the lane permutes inside it
+        const int row = lane >> 1, slot = lane & 1;
+        const int kh = slot ^ ((row >> 3) & 1);
+        int g0;                                        // first global row of the piece's 32 tile rows
+        int lim;
+        if (is_a[j]) { g0 = m0 + piece * 32; lim = p.M; }
+        else if constexpr (EPI == EPI_GEGLU) {         // tile row -> weight row: 'a' and 'gate' halves interleaved per 32 columns
+          static_assert(EPI != EPI_GEGLU || TN == 2, "GEGLU wants TN == 2");
+          const int w = piece >> 1, sel = piece & 1;
+          g0 = sel * p.n_half + (n0 >> 1) + w * 32; lim = 2 * p.n_half;
+          if ((n0 >> 1) + w * 32 >= p.n_half) g0 = 0;
+        } else { g0 = n0 + piece * 32; lim = p.N; }
+        if (g0 >= lim) g0 = (lim - 1) & ~31;           // row blocks past the end are never stored: any valid block will do
+        off = plane * pstride + (int64_t)(g0 >> 5) * cb16 * 512 + row * 16 + kh * 8;
+      } else {
+        // rows = k, 128 columns = 8 column blocks: 4 k-rows per piece
+        const int kl = piece * 4 + (lane >> 4), s16 = lane & 15;
+        const int seg = (s16 >> 1) ^ (2 * (kl & 3)), half = s16 & 1;
+        int cb = ((is_a[j] ? m0 : n0) >> 4) + seg;
+        const int cbmax = (int)cb16 - 1;
+        cb = cb < cbmax ? cb : cbmax;                  // column blocks past the end are never stored
+        off = plane * pstride + (int64_t)cb * 512 + kl * 16 + half * 8;
+      }
+      voff[j] = (unsigned)(off * 2);
+    }
+
+    auto issue = [&](int kt, int slot) {               // DMA of k-tile kt (counted from kt_lo) into ring slot `slot`
+      if (MT_PLANES_ABLATE & 1) return;
+      const int kb = k_begin + (kt_lo + kt) * BK;
+      // k-contiguous: column block kb / 16.  k-major: row block kb / 32 (all of its column blocks), row kb % 32 inside it.
+      const __bf16* as = a_base + (AKM ? ((int64_t)(kb >> 5) * p.lda * 512 + (kb & 31) * 16) : (int64_t)(kb >> 4) * 512);
+      const __bf16* bs = b_base + (BKM ? ((int64_t)(kb >> 5) * p.ldb * 512 + (kb & 31) * 16) : (int64_t)(kb >> 4) * 512);
+      const unsigned dst = lds_base + (unsigned)(slot * STAGE);
+#pragma unroll
+      for (int j = 0; j < IPW; ++j)
+        lds_dma16_s(is_a[j] ? as : bs, voff[j], dst + (unsigned)((wave * IPW + j) * 1024));
+    };
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if constexpr (PAIR) nacc[i][j][r] = 0.f; }
+
+    // sign phases + - - + : negated operands (and a negated accumulator) for k-steps [q1, q2)
+    const int q1 = PHASE ? nk >> 2 : nk, q2 = PHASE ? nk - (nk >> 2) : nk;
+
+    // tiles kt+1 .. kt+STAGES-1 in flight while tile kt is multiplied
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (s < nk) issue(s, s);
+    int slot = 0;                                      // ring slot of tile kt
+    auto step = [&](int kt, auto odd_c) {
+      const int later = min(STAGES - 2, nk - 1 - kt);
+      if (later >= 2) wait_vmcnt<2 * IPW>();
+      else if (later == 1) wait_vmcnt<IPW>();
+      else wait_vmcnt<0>();
+      MT_PL_BARRIER();                                 // every wave's share of tile kt is visible; the slot of tile kt-1 is free
+      int nslot = slot + STAGES - 1; nslot = nslot >= STAGES ? nslot - STAGES : nslot;
+      if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, nslot);
+      Frags f;
+      read_frags(slot, f);
+      unsigned mask = 0;
+      if constexpr (PHASE) {
+        if (kt == q1 || kt == q2) flip_acc();
+        mask = (kt >= q1 && kt < q2) ? 0x80008000u : 0u;
+      }
+      mma(f, odd_c, mask);
+      slot = slot + 1 >= STAGES ? 0 : slot + 1;
+    };
+    // the accumulator pair alternates with the ABSOLUTE k-step: pieces start on even steps (stream-K hands out pairs of k-steps)
+    for (int kt = 0; kt < nk; kt += 2) {
+      step(kt, std::false_type{});
+      if (kt + 1 >= nk) break;
+      step(kt + 1, std::true_type{});
+    }
+    if constexpr (PHASE) {
+      if (q2 >= nk && q1 < nk) flip_acc();             // (only when the last phase is empty: nk < 4)
+    }
+    if constexpr (PAIR) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] -= nacc[i][j][r];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
+    }
+  };
+
+  auto epilogue = [&](int mt_, int nt_) {
+    if (MT_PLANES_ABLATE & 8) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+      if (sacc == 123.456f) p.C[0] = sacc;
+      return;
+    }
+    int m0e = mt_ * BM, n0e = nt_ * BN, lane_e = lane;
+    asm volatile("" : "+s"(m0e), "+s"(n0e), "+v"(lane_e));
+    if constexpr (CPL) {
+      static_assert(!CPL || STAGES * STAGE >= NW * 32 * 36 * 4, "the plane epilogue's LDS patches live in the main loop's stages");
+      __syncthreads();                                  // every wave has finished reading the stages
+      planes_epilogue<TM, TN, EPI>(p, acc, m0e, n0e, wm, wn, lane_e, reinterpret_cast<float*>(smem_pl) + wave * (32 * 36));
+    } else {
+      gemm_epilogue<TM, TN, EPI>(p, acc, m0e, n0e, wm, wn, lane_e);
+    }
+  };
+
   if (MT_PLANES_PRIO == 1) {
     const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));     // HW_ID[3:0] = wave slot on the SIMD
     if (__builtin_amdgcn_readfirstlane(hwid) & 1) __builtin_amdgcn_s_setprio(1);
   } else if (MT_PLANES_PRIO == 2) {
     if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
   }
-  // sign phases + - - + : negated operands (and a negated accumulator) for k-steps [q1, q2)
-  const int q1 = PHASE ? nk >> 2 : nk, q2 = PHASE ? nk - (nk >> 2) : nk;
 
-  // tiles kt+1 .. kt+STAGES-1 in flight while tile kt is multiplied
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue(s, s);
-  int slot = 0;                                      // ring slot of tile kt
-  auto step = [&](int kt, auto odd_c) {
-    const int later = min(STAGES - 2, nk - 1 - kt);
-    if (later >= 2) wait_vmcnt<2 * IPW>();
-    else if (later == 1) wait_vmcnt<IPW>();
-    else wait_vmcnt<0>();
-    MT_PL_BARRIER();                                 // every wave's share of tile kt is visible; the slot of tile kt-1 is free
-    int nslot = slot + STAGES - 1; nslot = nslot >= STAGES ? nslot - STAGES : nslot;
-    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, nslot);
-    Frags f;
-    read_frags(slot, f);
-    unsigned mask = 0;
-    if constexpr (PHASE) {
-      if (kt == q1 || kt == q2) flip_acc();
-      mask = (kt >= q1 && kt < q2) ? 0x80008000u : 0u;
+  if constexpr (!SK) {
+    int mt_, nt_;
+    int k_begin = 0, k_end = p.K;
+    if (p.xcd_k) {                                     // split-K weight gradient, K-range-major over the XCDs (see gemm_split.hpp)
+      const int tiles = gridDim.x, lin = blockIdx.y * gridDim.x + blockIdx.x;
+      const int xcd = lin & 7, idx = lin >> 3;
+      const int split = xcd + 8 * (idx / tiles), t = idx % tiles;
+      const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + BM - 1) / BM;
+      if (m_tiles >= n_tiles) { mt_ = t / n_tiles; nt_ = t - mt_ * n_tiles; }
+      else { nt_ = t / m_tiles; mt_ = t - nt_ * m_tiles; }
+      k_begin = split * p.k_chunk;
+      k_end = min(p.K, k_begin + p.k_chunk);
+      if (k_begin >= k_end) return;
+    } else {
+      if (!tile_coords<BM, BN>(p, mt_, nt_)) return;
+      if (p.k_chunk > 0) {
+        k_begin = blockIdx.y * p.k_chunk;
+        k_end = min(p.K, k_begin + p.k_chunk);
+        if (k_begin >= k_end) return;
+      }
     }
-    mma(f, odd_c, mask);
-    slot = slot + 1 >= STAGES ? 0 : slot + 1;
-  };
-  for (int kt = 0; kt < nk; kt += 2) {
-    step(kt, std::false_type{});
-    if (kt + 1 >= nk) break;
-    step(kt + 1, std::true_type{});
+    const int nk = (k_end - k_begin + BK - 1) / BK;    // k_begin % 16 == 0; a ragged end reads the planes' zero padding
+    if (nk <= 0) return;
+    run_piece(mt_, nt_, k_begin, 0, nk);
+    epilogue(mt_, nt_);
+  } else {
+    // logical block index: the blocks of one XCD (blockIdx % 8, observed placement; only speed depends on it) take a contiguous
+    // eighth of the work list, i.e. of the XCD-ordered tile list
+    const int G = gridDim.x;
+    const int L = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int nkt = (p.K + BK - 1) / BK;               // k-steps per tile
+    const int npt = (nkt + 1) >> 1;                    // work units per tile: PAIRS of k-steps (the accumulator pair's parity stays static)
+    const int U = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * npt;     // (host: fits an int)
+    const int uq = U / G, ur = U % G;
+    int u = L * uq + min(L, ur);
+    const int u_end = u + uq + (L < ur ? 1 : 0);
+    constexpr int SLAB = BM * BN;                      // floats per block slab
+    while (u < u_end) {
+      const int t = u / npt;
+      const int kt0 = 2 * (u - t * npt);
+      const int ulen = min(npt - (u - t * npt), u_end - u);
+      const int len = min(nkt - kt0, 2 * ulen);
+      int mt_, nt_;
+      sk_tile_coords<BM, BN>(p, t, mt_, nt_);
+      __builtin_amdgcn_s_barrier();                    // the previous piece's last stage reads are done before new tiles land
+      run_piece(mt_, nt_, 0, kt0, len);
+      u += ulen;
+      if (len != nkt) {
+        // per-lane slab offset, kept out of the loop-invariant hoisting (it would sit in registers through every k-loop)
+        int lane_s = lane, wave_s = wave;
+        asm volatile("" : "+v"(lane_s), "+s"(wave_s));
+        const int my_off = wave_s * (TM * TN * 1024) + lane_s * 4;
+        if (kt0 != 0) {
+          // tail of a tile whose head belongs to an earlier block: publish the partial sums (the first thing this block does)
+          float* slab = p.sk_ws + (int64_t)L * SLAB + my_off;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(slab + ((i * TN + j) * 4 + q) * 256) =
+                    make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(p.sk_flags + L, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          continue;
+        }
+        // head of a tile that later blocks finish: add their slabs in order, then the epilogue
+        int covered = ulen;
+        for (int lb = L + 1; covered < npt; ++lb) {
+          const int span = uq + (lb < ur ? 1 : 0);
+          if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(p.sk_flags + lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+              __builtin_amdgcn_s_sleep(8);
+              if (++spins > (1 << 24)) break;          // bounded: a lost producer must not hang the device (the result is then wrong)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          __syncthreads();
+          const float* slab = p.sk_ws + (int64_t)lb * SLAB + my_off;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(slab + ((i * TN + j) * 4 + q) * 256);
+                acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+              }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();                             // every wave has read the slab: the flag may be cleared for the next launch
+          if (tid == 0) __hip_atomic_store(p.sk_flags + lb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          covered += min(npt - covered, span);
+        }
+      }
+      epilogue(mt_, nt_);
+    }
   }
 #undef MT_PL_BARRIER
-  if constexpr (PHASE) {
-    if (q2 >= nk && q1 < nk) flip_acc();             // (only when the last phase is empty: nk < 4)
-  }
-
-  if constexpr (PAIR) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] -= nacc[i][j][r];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
-  }
-  if (MT_PLANES_ABLATE & 8) {
-    float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-    if (sacc == 123.456f) p.C[0] = sacc;
-    return;
-  }
-  int m0e = m0, n0e = n0, lane_e = lane;
-  asm volatile("" : "+s"(m0e), "+s"(n0e), "+v"(lane_e));
-  if constexpr (CPL) {
-    static_assert(!CPL || STAGES * STAGE >= NW * 32 * 36 * 4, "the plane epilogue's LDS patches live in the main loop's stages");
-    __syncthreads();                                  // every wave has finished reading the stages
-    planes_epilogue<TM, TN, EPI>(p, acc, m0e, n0e, wm, wn, lane_e, reinterpret_cast<float*>(smem_pl) + wave * (32 * 36));
-  } else {
-    gemm_epilogue<TM, TN, EPI>(p, acc, m0e, n0e, wm, wn, lane_e);
-  }
 }
 
 }  // namespace mt

@@ -28,6 +28,9 @@ __host__ __device__ __forceinline__ int64_t planes_blk_off(int64_t r, int64_t c,
 
 // exact three-piece split of two values
 __device__ __forceinline__ void split2(f32x2_t v, bf16x2_t& a, bf16x2_t& b, bf16x2_t& c) {
+  // no contraction across this boundary: with -ffp-contract=fast a caller's final multiply (o * inv) would fuse into the residual
+  // subtraction below, and the planes would hold the pieces of the UNROUNDED product instead of the fp32 value
+#pragma clang fp contract(off)
   a = __builtin_convertvector(v, bf16x2_t);
   const f32x2_t r = v - __builtin_convertvector(a, f32x2_t);
   b = __builtin_convertvector(r, bf16x2_t);
@@ -61,6 +64,12 @@ __device__ __forceinline__ void planes_store8(const PlaneRef& o, int r, int c, c
   *reinterpret_cast<bf16x8_t*>(dst) = x0;
   *reinterpret_cast<bf16x8_t*>(dst + o.pstride) = x1;
   *reinterpret_cast<bf16x8_t*>(dst + 2 * o.pstride) = x2;
+}
+
+// zeros into the padding rows [rows, rows_pad) of every column block (one caller block; D % 4 == 0 columns)
+__device__ __forceinline__ void planes_zero_pad(const PlaneRef& o, int rows, int tid, int nthreads) {
+  const int npad = o.rows_pad - rows, nq = o.cb16 * 4;
+  for (int i = tid; i < npad * nq; i += nthreads) planes_store4(o, rows + i / nq, (i % nq) * 4, 0.f, 0.f, 0.f, 0.f);
 }
 
 }  // namespace mt

@@ -477,7 +477,7 @@ __device__ __forceinline__ void load_row32(const float* __restrict__ p, float (&
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void attn_space_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                       float* __restrict__ dqkv, int B, int H, int F, int n,
-                                                                      float scale) {
+                                                                      float scale, const PlaneRef dp) {
   __shared__ float2 stat_all[WPB][64];                      // (logsumexp, delta) per query of the wavefront's group
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = lane & 31, hf = lane >> 5;
@@ -567,9 +567,11 @@ __global__ __launch_bounds__(WPB * 64) void attn_space_bwd_mfma_kernel(const flo
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(drow + 32 * i + 8 * g + 4 * hf) =
-              make_float4(scale * dq[i][4 * g], scale * dq[i][4 * g + 1], scale * dq[i][4 * g + 2], scale * dq[i][4 * g + 3]);
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = make_float4(scale * dq[i][4 * g], scale * dq[i][4 * g + 1], scale * dq[i][4 * g + 2], scale * dq[i][4 * g + 3]);
+          if (dp.p) planes_store4(dp, b * N + t0 + q, h * DH + 32 * i + 8 * g + 4 * hf, v.x, v.y, v.z, v.w);   // final: nothing else writes a patch row's dq
+          else *reinterpret_cast<float4*>(drow + 32 * i + 8 * g + 4 * hf) = v;
+        }
     }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the statistics are in LDS
@@ -643,8 +645,14 @@ __global__ __launch_bounds__(WPB * 64) void attn_space_bwd_mfma_kernel(const flo
             float4 a = *reinterpret_cast<const float4*>(krow + d0), v = *reinterpret_cast<const float4*>(vrow + d0);
             a.x += dk[i][4 * g]; a.y += dk[i][4 * g + 1]; a.z += dk[i][4 * g + 2]; a.w += dk[i][4 * g + 3];
             v.x += dv[i][4 * g]; v.y += dv[i][4 * g + 1]; v.z += dv[i][4 * g + 2]; v.w += dv[i][4 * g + 3];
-            *reinterpret_cast<float4*>(krow + d0) = a;
-            *reinterpret_cast<float4*>(vrow + d0) = v;
+            if (dp.p) {                           // the group owns its patch keys: these are the final dk / dv values
+              const int row = b * N + tok_k(key);
+              planes_store4(dp, row, inner + h * DH + d0, a.x, a.y, a.z, a.w);
+              planes_store4(dp, row, 2 * inner + h * DH + d0, v.x, v.y, v.z, v.w);
+            } else {
+              *reinterpret_cast<float4*>(krow + d0) = a;
+              *reinterpret_cast<float4*>(vrow + d0) = v;
+            }
           }
         }
     }
@@ -660,7 +668,7 @@ template <int MODE, int NKEYS, int PPW, int STRIDE, int WPB>
 __global__ __launch_bounds__(WPB * 64) void attn_patch_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                  float* __restrict__ dqkv, const uint8_t* __restrict__ mask,
                                                                  const uint8_t* __restrict__ ident, int B, int H, int F, int n,
-                                                                 float scale) {
+                                                                 float scale, const PlaneRef dp) {
   constexpr int ROWS = MODE == 0 ? 1 + PPW * (NKEYS - 1) : NKEYS;
   constexpr int QROWS = 64;                                  // pass-2 tiles hold one row per query lane
   constexpr int TROWS = ROWS > QROWS ? ROWS : QROWS;
@@ -809,9 +817,11 @@ __global__ __launch_bounds__(WPB * 64) void attn_patch_bwd_kernel(const float* _
   if (qtok >= 0) {
     float* dqr = dbase + (int64_t)qtok * ld;
 #pragma unroll
-    for (int i = 0; i < DH / 4; ++i)
-      *reinterpret_cast<float4*>(dqr + i * 4) =
+    for (int i = 0; i < DH / 4; ++i) {
+      if (dp.p) planes_store4(dp, b * N + qtok, h * DH + i * 4, dq[4 * i] * scale, dq[4 * i + 1] * scale, dq[4 * i + 2] * scale, dq[4 * i + 3] * scale);
+      else *reinterpret_cast<float4*>(dqr + i * 4) =
           make_float4(dq[4 * i] * scale, dq[4 * i + 1] * scale, dq[4 * i + 2] * scale, dq[4 * i + 3] * scale);
+    }
   }
   __builtin_amdgcn_wave_barrier();
 
@@ -862,10 +872,15 @@ __global__ __launch_bounds__(WPB * 64) void attn_patch_bwd_kernel(const float* _
       for (int i = 0; i < DH / 4; ++i) {
         float4 a = *reinterpret_cast<float4*>(dkr + i * 4);
         a.x += dk[4 * i]; a.y += dk[4 * i + 1]; a.z += dk[4 * i + 2]; a.w += dk[4 * i + 3];
-        *reinterpret_cast<float4*>(dkr + i * 4) = a;
         float4 v = *reinterpret_cast<float4*>(dvr + i * 4);
         v.x += dv[4 * i]; v.y += dv[4 * i + 1]; v.z += dv[4 * i + 2]; v.w += dv[4 * i + 3];
-        *reinterpret_cast<float4*>(dvr + i * 4) = v;
+        if (dp.p) {
+          planes_store4(dp, b * N + qtok, inner + h * DH + i * 4, a.x, a.y, a.z, a.w);
+          planes_store4(dp, b * N + qtok, 2 * inner + h * DH + i * 4, v.x, v.y, v.z, v.w);
+        } else {
+          *reinterpret_cast<float4*>(dkr + i * 4) = a;
+          *reinterpret_cast<float4*>(dvr + i * 4) = v;
+        }
       }
     }
   }
@@ -881,9 +896,24 @@ __global__ __launch_bounds__(WPB * 64) void attn_patch_bwd_kernel(const float* _
   }
 }
 
+// plane output of mt_attn_bwd: the cls row of every clip (its dk / dv collect fp32 atomics from every group and are only final when
+// the patch kernels have finished) and the zero padding rows
+__global__ __launch_bounds__(256) void attn_bwd_cls_planes_kernel(const float* __restrict__ dqkv, int B, int N, int ld, const PlaneRef dp) {
+  const int b = blockIdx.x;
+  if (b < B) {
+    const float* row = dqkv + (int64_t)b * N * ld;
+    for (int q = threadIdx.x; q < ld >> 2; q += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(row + q * 4);
+      planes_store4(dp, b * N, q * 4, v.x, v.y, v.z, v.w);
+    }
+  } else {
+    planes_zero_pad(dp, B * N, threadIdx.x, 256);
+  }
+}
+
 template <int MODE, int NKEYS, int PPW, int STRIDE, int WPB>
 int launch_patch_bwd(const float* qkv, const float* dout, float* dqkv, const uint8_t* mask, const uint8_t* ident, int B, int H,
-                     int F, int n, float scale, hipStream_t s) {
+                     int F, int n, float scale, const PlaneRef& dp, hipStream_t s) {
   constexpr int ROWS = MODE == 0 ? 1 + PPW * (NKEYS - 1) : NKEYS;
   constexpr int TROWS = ROWS > 64 ? ROWS : 64;
   constexpr int SP = (NKEYS % 2 == 0) ? NKEYS + 1 : NKEYS;
@@ -896,7 +926,7 @@ int launch_patch_bwd(const float* qkv, const float* dout, float* dqkv, const uin
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_attn_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, dout, dqkv, mask, ident, B, H, F,
-                     n, scale);
+                     n, scale, dp);
   return check_launch("mt_attn_bwd(patch)");
 }
 
@@ -985,27 +1015,38 @@ extern "C" int mt_embed_bwd(const float* dx, float* dcls, float* dpos_emb, float
 }
 
 extern "C" int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, const uint8_t* mask, const uint8_t* ident,
-                           int B, int H, int F, int n, int mode, float scale, void* stream) {
+                           int B, int H, int F, int n, int mode, float scale, void* dqkv_planes, void* stream) {
   if (!qkv || !dout || !dqkv) return fail(MT_ERR_ARG, "mt_attn_bwd: null pointer");
   if (mode == 0 && (!mask || !ident)) return fail(MT_ERR_ARG, "mt_attn_bwd: time attention needs mask and identities_mask");
   if (n != 49) return fail(MT_ERR_UNSUPPORTED, "mt_attn_bwd: num-patches %d unsupported (49)", n);
+  if (dqkv_planes && (mode == 2 || ((uintptr_t)dqkv_planes & 15))) return fail(MT_ERR_ARG, "mt_attn_bwd: plane output needs mode 0 / 1 and 16-byte alignment");
   hipStream_t s = (hipStream_t)stream;
   const int N = 1 + F * n;
+  const int rp = (B * N + 31) & ~31, ld = 3 * H * DH;
+  const PlaneRef dp{reinterpret_cast<__bf16*>(dqkv_planes), (int64_t)rp * ld, ld / 16, rp};
   hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(CLS_W * 64), (2 * N + CLS_W + 4 + CLS_W * 64) * sizeof(float), s, qkv, dout, dqkv, mask, B, H, F, n, scale);
   int rc = check_launch("mt_attn_bwd(cls)");
   if (rc || mode == 2) return rc;                 // mode 2: the cls query's adjoint only (dk / dv of every key, dq of the cls row)
   if (mode == 1) {
     static const bool valu = getenv("MT_ATTN_VALU") != nullptr;     // A/B aid: the one-lane-per-query kernel
-    if (valu) return launch_patch_bwd<1, 50, 1, 64, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);
-    const int64_t waves = (int64_t)B * H * F;
-    hipLaunchKernelGGL(attn_space_bwd_mfma_kernel<4>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n,
-                       scale);
-    return check_launch("mt_attn_bwd(space, mfma)");
+    if (valu) rc = launch_patch_bwd<1, 50, 1, 64, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, s);
+    else {
+      const int64_t waves = (int64_t)B * H * F;
+      hipLaunchKernelGGL(attn_space_bwd_mfma_kernel<4>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n,
+                         scale, dp);
+      rc = check_launch("mt_attn_bwd(space, mfma)");
+    }
+  } else {
+    switch (F) {
+      case 8: rc = launch_patch_bwd<0, 9, 7, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, s); break;
+      case 16: rc = launch_patch_bwd<0, 17, 4, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, s); break;
+      case 32: rc = launch_patch_bwd<0, 33, 2, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, s); break;
+      default: return fail(MT_ERR_UNSUPPORTED, "mt_attn_bwd: num-frames %d unsupported (8/16/32)", F);
+    }
   }
-  switch (F) {
-    case 8: return launch_patch_bwd<0, 9, 7, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);
-    case 16: return launch_patch_bwd<0, 17, 4, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);
-    case 32: return launch_patch_bwd<0, 33, 2, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, s);
-  }
-  return fail(MT_ERR_UNSUPPORTED, "mt_attn_bwd: num-frames %d unsupported (8/16/32)", F);
+  if (rc || !dqkv_planes) return rc;
+  // the cls rows (final only now) and the padding rows of the plane tensor; with plane output the patch rows of dqkv (fp32) hold
+  // the cls query's contribution only -- the planes are the result
+  hipLaunchKernelGGL(attn_bwd_cls_planes_kernel, dim3(B + (rp > B * N ? 1 : 0)), dim3(256), 0, s, dqkv, B, N, ld, dp);
+  return check_launch("mt_attn_bwd(cls planes)");
 }

@@ -134,7 +134,7 @@ template <int MODE, int NKEYS, int PPW, int STRIDE, int WPB>
 __global__ __launch_bounds__(WPB * 64) void attn_patch_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  const uint8_t* __restrict__ mask,
                                                                  const uint8_t* __restrict__ ident,
-                                                                 int B, int H, int F, int n, float scale) {
+                                                                 int B, int H, int F, int n, float scale, const PlaneRef op) {
   constexpr int ROWS = MODE == 0 ? 1 + PPW * (NKEYS - 1) : NKEYS;
   constexpr int WAVE_LDS = ROWS * STRIDE + NKEYS * 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -243,11 +243,18 @@ __global__ __launch_bounds__(WPB * 64) void attn_patch_fwd_kernel(const float* _
   }
   if (qtok >= 0) {
     const float inv = 1.0f / sum;
-    float* orow = out + ((int64_t)b * N + qtok) * inner + h * DH;
+    if (out) {
+      float* orow = out + ((int64_t)b * N + qtok) * inner + h * DH;
 #pragma unroll
-    for (int i = 0; i < DH / 4; ++i)
-      *reinterpret_cast<float4*>(orow + i * 4) =
-          make_float4(o[4 * i] * inv, o[4 * i + 1] * inv, o[4 * i + 2] * inv, o[4 * i + 3] * inv);
+      for (int i = 0; i < DH / 4; ++i)
+        *reinterpret_cast<float4*>(orow + i * 4) =
+            make_float4(o[4 * i] * inv, o[4 * i + 1] * inv, o[4 * i + 2] * inv, o[4 * i + 3] * inv);
+    }
+    if (op.p) {                                       // the out-projection's operand planes: a lane owns 64 columns of one row
+#pragma unroll
+      for (int i = 0; i < DH / 4; ++i)
+        planes_store4(op, b * N + qtok, h * DH + i * 4, o[4 * i] * inv, o[4 * i + 1] * inv, o[4 * i + 2] * inv, o[4 * i + 3] * inv);
+    }
   }
 }
 
@@ -268,7 +275,7 @@ __device__ __forceinline__ int mfma_slot_row(int r, int hf) { return (r & 3) + 8
 
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void attn_space_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                      int B, int H, int F, int n, float scale) {
+                                                                      int B, int H, int F, int n, float scale, const PlaneRef op) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = lane & 31, hf = lane >> 5;
   const int N = 1 + F * n, inner = H * DH, ld = 3 * inner;
@@ -362,13 +369,16 @@ __global__ __launch_bounds__(WPB * 64) void attn_space_fwd_mfma_kernel(const flo
   for (int j = 0; j < 2; ++j) {
     const int q = 32 * j + c;
     if (q < n) {
-      float* orow = out + ((int64_t)b * N + t0 + q) * inner + h * DH;
+      float* orow = out ? out + ((int64_t)b * N + t0 + q) * inner + h * DH : nullptr;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)          // slots 4g..4g+3 are d = 32 i + 8 g + 4 half + (0..3)
-          *reinterpret_cast<float4*>(orow + 32 * i + 8 * g + 4 * hf) =
-              make_float4(ot[i][j][4 * g] * inv[j], ot[i][j][4 * g + 1] * inv[j], ot[i][j][4 * g + 2] * inv[j], ot[i][j][4 * g + 3] * inv[j]);
+        for (int g = 0; g < 4; ++g) {        // slots 4g..4g+3 are d = 32 i + 8 g + 4 half + (0..3)
+          const float o0 = ot[i][j][4 * g] * inv[j], o1 = ot[i][j][4 * g + 1] * inv[j], o2 = ot[i][j][4 * g + 2] * inv[j],
+                      o3 = ot[i][j][4 * g + 3] * inv[j];
+          if (orow) *reinterpret_cast<float4*>(orow + 32 * i + 8 * g + 4 * hf) = make_float4(o0, o1, o2, o3);
+          if (op.p) planes_store4(op, b * N + t0 + q, h * DH + 32 * i + 8 * g + 4 * hf, o0, o1, o2, o3);
+        }
     }
   }
 }
@@ -394,7 +404,7 @@ __device__ __forceinline__ float block_reduce(float v, float* red, int wave, int
 // 256-byte access.  All reductions have a fixed order (eval stays bit-reproducible).
 __global__ __launch_bounds__(CLS_W * 64) void attn_cls_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  float* __restrict__ att, const uint8_t* __restrict__ mask,
-                                                                 int B, int H, int F, int n, float scale) {
+                                                                 int B, int H, int F, int n, float scale, const PlaneRef op) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // N probabilities, CLS_W reduction slots, CLS_W x 64 partial outputs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = tid & 15, grp = tid >> 4;
@@ -468,8 +478,10 @@ __global__ __launch_bounds__(CLS_W * 64) void attn_cls_fwd_kernel(const float* _
       const float4 u = *reinterpret_cast<const float4*>(part + w * 64 + sub * 4);
       t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
     }
-    *reinterpret_cast<float4*>(out + (int64_t)b * N * inner + h * DH + sub * 4) = t;
+    if (out) *reinterpret_cast<float4*>(out + (int64_t)b * N * inner + h * DH + sub * 4) = t;
+    if (op.p) planes_store4(op, b * N, h * DH + sub * 4, t.x, t.y, t.z, t.w);
   }
+  if (op.p && blockIdx.x == 0) planes_zero_pad(op, B * N, tid, CLS_W * 64);
 }
 
 // ---------------------------------------------------------------------------------------- classification head
@@ -525,7 +537,7 @@ extern "C" int mt_embed_fwd(float* x, const float* cls, const float* pos_emb, co
 namespace {
 template <int MODE, int NKEYS, int PPW, int STRIDE, int WPB>
 int launch_patch(const float* qkv, float* out, const uint8_t* mask, const uint8_t* ident, int B, int H, int F, int n,
-                 float scale, hipStream_t s) {
+                 float scale, const PlaneRef& op, hipStream_t s) {
   constexpr int ROWS = MODE == 0 ? 1 + PPW * (NKEYS - 1) : NKEYS;
   const int chunks = MODE == 0 ? (n + PPW - 1) / PPW : F;
   const int64_t waves = (int64_t)B * H * chunks;
@@ -535,32 +547,35 @@ int launch_patch(const float* qkv, float* out, const uint8_t* mask, const uint8_
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_attn_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, out, mask, ident, B, H, F, n, scale);
+  hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, out, mask, ident, B, H, F, n, scale, op);
   return check_launch("mt_attn_fwd(patch)");
 }
 }  // namespace
 
 extern "C" int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const uint8_t* mask, const uint8_t* ident,
-                           int B, int H, int F, int n, int mode, float scale, void* stream) {
-  if (!qkv || !out) return fail(MT_ERR_ARG, "mt_attn_fwd: null pointer");
+                           int B, int H, int F, int n, int mode, float scale, void* out_planes, void* stream) {
+  if (!qkv || (!out && !out_planes)) return fail(MT_ERR_ARG, "mt_attn_fwd: null pointer");
+  if (out_planes && (mode == 2 || ((uintptr_t)out_planes & 15))) return fail(MT_ERR_ARG, "mt_attn_fwd: plane output needs mode 0 / 1 and 16-byte alignment");
   if (mode == 0 && (!mask || !ident)) return fail(MT_ERR_ARG, "mt_attn_fwd: time attention needs mask and identities_mask");
   if (n != 49) return fail(MT_ERR_UNSUPPORTED, "mt_attn_fwd: num-patches %d unsupported (49)", n);
   hipStream_t s = (hipStream_t)stream;
   const int N = 1 + F * n;
-  hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(CLS_W * 64), (N + CLS_W + 4 + CLS_W * 64) * sizeof(float), s, qkv, out, cls_att, mask, B, H, F, n, scale);
+  const int rp = (B * N + 31) & ~31;
+  const PlaneRef op{reinterpret_cast<__bf16*>(out_planes), (int64_t)rp * H * DH, H * DH / 16, rp};
+  hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(CLS_W * 64), (N + CLS_W + 4 + CLS_W * 64) * sizeof(float), s, qkv, out, cls_att, mask, B, H, F, n, scale, op);
   int rc = check_launch("mt_attn_fwd(cls)");
   if (rc || mode == 2) return rc;                 // mode 2: the cls query only (out row 0 of every clip; the patch rows are not written)
   if (mode == 1) {
     static const bool valu = getenv("MT_ATTN_VALU") != nullptr;     // A/B aid: the one-lane-per-query kernel
-    if (valu) return launch_patch<1, 50, 1, 64, 2>(qkv, out, mask, ident, B, H, F, n, scale, s);
+    if (valu) return launch_patch<1, 50, 1, 64, 2>(qkv, out, mask, ident, B, H, F, n, scale, op, s);
     const int64_t waves = (int64_t)B * H * F;
-    hipLaunchKernelGGL(attn_space_fwd_mfma_kernel<4>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, out, B, H, F, n, scale);
+    hipLaunchKernelGGL(attn_space_fwd_mfma_kernel<4>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, out, B, H, F, n, scale, op);
     return check_launch("mt_attn_fwd(space, mfma)");
   }
   switch (F) {
-    case 8: return launch_patch<0, 9, 7, 68, 4>(qkv, out, mask, ident, B, H, F, n, scale, s);
-    case 16: return launch_patch<0, 17, 4, 68, 4>(qkv, out, mask, ident, B, H, F, n, scale, s);
-    case 32: return launch_patch<0, 33, 2, 68, 4>(qkv, out, mask, ident, B, H, F, n, scale, s);
+    case 8: return launch_patch<0, 9, 7, 68, 4>(qkv, out, mask, ident, B, H, F, n, scale, op, s);
+    case 16: return launch_patch<0, 17, 4, 68, 4>(qkv, out, mask, ident, B, H, F, n, scale, op, s);
+    case 32: return launch_patch<0, 33, 2, 68, 4>(qkv, out, mask, ident, B, H, F, n, scale, op, s);
   }
   return fail(MT_ERR_UNSUPPORTED, "mt_attn_fwd: num-frames %d unsupported (8/16/32, reference train.py:101)", F);
 }

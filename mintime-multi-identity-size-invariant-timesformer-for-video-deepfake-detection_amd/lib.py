@@ -46,7 +46,8 @@ class GemmPlanesDesc(C.Structure):
     _fields_ = [("op", C.c_int), ("epilogue", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("a_planes", C.c_void_p), ("b_planes", C.c_void_p), ("C", C.c_void_p), ("ldc", i64),
                 ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", i64), ("C2", C.c_void_p), ("ldc2", i64),
-                ("n_half", C.c_int), ("col_sum", C.c_void_p), ("c_planes", C.c_void_p), ("split_k", C.c_int)]
+                ("n_half", C.c_int), ("col_sum", C.c_void_p), ("c_planes", C.c_void_p), ("split_k", C.c_int),
+                ("sk_workspace", C.c_void_p), ("sk_workspace_bytes", i64)]
 
 
 OP_NT, OP_NN, OP_TN = 0, 1, 2
@@ -66,11 +67,12 @@ PROTOTYPES = {
     "mt_split_planes_blk": [f32p, i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "mt_split_planes_blk_multi": [C.c_void_p, C.c_int, i64, C.c_void_p],
     "mt_gemm_planes": [C.POINTER(GemmPlanesDesc), C.c_void_p],
+    "mt_gemm_planes_workspace_bytes": [],
     "mt_layernorm_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p],
     "mt_embed_fwd": [f32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                      C.c_void_p],
     "mt_attn_fwd": [f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
-                    C.c_void_p],
+                    C.c_void_p, C.c_void_p],
     "mt_head_fwd": [f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "mt_stem_conv_fwd": [C.c_void_p, C.c_int, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_dwconv_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -91,7 +93,7 @@ PROTOTYPES = {
                     C.c_void_p],
     "mt_embed_bwd": [f32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_attn_bwd": [f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
-                    C.c_void_p],
+                    C.c_void_p, C.c_void_p],
     "mt_bn_act_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_bn_bwd_finalize": [C.c_void_p, C.c_int, C.c_double, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_void_p],
     "mt_se_bwd": [f32p] * 17 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p],
@@ -121,7 +123,7 @@ PROTOTYPES = {
     "mt_conv1x1_bwd_fused": [f32p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "mt_stem_conv_wgrad": [f32p] * 4 + [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
 }
-_RESTYPES = {"mt_last_error": C.c_char_p, "mt_planes_elems": C.c_int64}
+_RESTYPES = {"mt_last_error": C.c_char_p, "mt_planes_elems": C.c_int64, "mt_gemm_planes_workspace_bytes": C.c_int64}
 
 
 class MintimeHipError(RuntimeError):
@@ -215,9 +217,35 @@ def planes_to_float(planes, rows, cols):
     return p.permute(0, 2, 1, 3).reshape(p.shape[0] * 32, p.shape[1] * 16)[:rows, :cols]
 
 
+_SK_WORKSPACES = {}
+
+
+def streamk_workspace(device=None):
+    """The stream-K scratch of the CURRENT stream (flags + one fp32 slab per persistent block): zero-filled once, lent to every
+    mt_gemm_planes launch of that stream that asks for stream-K (include/mintime_hip.h)."""
+    st = torch.cuda.current_stream(device)
+    key = (st.device.index, st.cuda_stream)
+    ws = _SK_WORKSPACES.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        n = get().mt_gemm_planes_workspace_bytes()
+        ws = torch.zeros(n, dtype=torch.uint8, device=st.device)
+        _SK_WORKSPACES[key] = ws
+    return ws
+
+
 def gemm_planes(op, a_planes, b_planes, M, N, K, Cout=None, ldc=0, epilogue=EPI_STORE, bias=None, R=None, ldr=0, C2=None, ldc2=0,
-                n_half=0, col_sum=None, c_planes=None, split_k=0):
+                n_half=0, col_sum=None, c_planes=None, split_k=0, streamk=None):
+    """streamk: True lends the stream's workspace (persistent grid sharing the (tile, k-step) list), False = one block per tile,
+    None = MT_PLANES_STREAMK (default 0: on the TimeSformer's shapes one block per tile measured faster)."""
     d = GemmPlanesDesc()
+    if streamk is None:
+        streamk = os.environ.get("MT_PLANES_STREAMK", "0") != "0"
+    if streamk and op != OP_TN:
+        ws = streamk_workspace(a_planes.device)
+        if ws is not None:
+            d.sk_workspace, d.sk_workspace_bytes = ptr(ws), ws.numel()
     d.op, d.epilogue, d.M, d.N, d.K = op, epilogue, M, N, K
     d.a_planes, d.b_planes, d.C, d.ldc = ptr(a_planes), ptr(b_planes), ptr(Cout), ldc
     d.bias, d.R, d.ldr, d.C2, d.ldc2 = ptr(bias), ptr(R), ldr, ptr(C2), ldc2

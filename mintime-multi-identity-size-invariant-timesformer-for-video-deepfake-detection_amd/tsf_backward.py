@@ -176,7 +176,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             wgrad(dx2, r["o"], grads[i0 + 3], D, inner, B, D, N * inner, inner)             # o's cls rows: ldb = N * inner
             L.gemm(L.OP_NN, dx2, w_o, do, B, inner, D, D, inner, N * inner)                 # row 0 of each clip's do; the rest is not read
             dqkv.zero_()                                                                    # the patch queries' gradients are zero
-            L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, 2, scale, st),
+            L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, 2, scale, None, st),
                     "mt_attn_bwd")
             wgrad(dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
             e_dg = dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner, wT[(li, 7)] if wT is not None else None)
@@ -199,7 +199,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
                 L.gemm(L.OP_NT, dx2, wT[(li, 3)], do, M, inner, D, D, D, inner)
             else:
                 L.gemm(L.OP_NN, dx2, w_o, do, M, inner, D, D, inner, inner)
-            L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, 0, scale, st),
+            L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, 0, scale, None, st),
                     "mt_attn_bwd")
             wgrad(dqkv, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
             e_dg = dgrad_skinny(dqkv, w_qkv, dxn, 3 * inner, wT[(li, 2)] if wT is not None else None)
@@ -255,7 +255,7 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
             else:
                 L.gemm(L.OP_NN, dx2, w_o, do, M, inner, D, D, inner, inner)
             L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dq), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
-                                    scale, st), "mt_attn_bwd")
+                                    scale, None, st), "mt_attn_bwd")
             wgrad(dq, r["xn"], grads[i0 + 2], 3 * inner, D, M, 3 * inner, D, D)
             e_dg = dgrad_skinny(dq, w_qkv, dxn, 3 * inner, wT[(li, 7 if mode == 1 else 2)] if wT is not None else None)
             if e_dx is not None and not ln_oop:

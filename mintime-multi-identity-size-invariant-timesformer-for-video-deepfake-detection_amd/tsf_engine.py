@@ -187,7 +187,7 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
             if last and mode == 1 and prune_last:
                 # cls query only; out-projection + residual on the B cls rows (row stride N: no gather needed)
                 L.check(lib.mt_attn_fwd(L.ptr(qkv), L.ptr(o), L.ptr(att), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, 2,
-                                        scale, st), "mt_attn_fwd")
+                                        scale, None, st), "mt_attn_fwd")
                 x_cls = _new(dev, B, D)
                 L.gemm(L.OP_NT, o, w_o, x_cls, B, D, inner, N * inner, inner, D, epilogue=L.EPI_BIAS_RES, bias=b_o, R=x, ldr=N * D)
                 if save:
@@ -195,7 +195,7 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
                 x = x_cls
                 continue
             L.check(lib.mt_attn_fwd(L.ptr(qkv), L.ptr(o), L.ptr(att), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
-                                    scale, st), "mt_attn_fwd")
+                                    scale, None, st), "mt_attn_fwd")
             x_new = _new(dev, B, N, D) if save else x
             L.gemm(L.OP_NT, o, w_o, x_new, M, D, inner, inner, inner, D, epilogue=L.EPI_BIAS_RES, bias=b_o, R=x, ldr=D)
             if save:

@@ -105,7 +105,6 @@ def tsf_forward_planes(model, feat, aux, params, B, F, n, save):
     o_p = L.planes_empty(M, inner, dev)
     h_p = L.planes_empty(M, 4 * D, dev)
     qkv = _new(dev, M, 3 * inner)
-    o = _new(dev, M, inner)
     for li in range(model.depth):
         last = li == model.depth - 1
         rec = {}
@@ -125,9 +124,8 @@ def tsf_forward_planes(model, feat, aux, params, B, F, n, save):
                     t_att = att
                 else:
                     s_att = att
-            L.check(lib.mt_attn_fwd(L.ptr(qkv), L.ptr(o), L.ptr(att), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
-                                    scale, st), "mt_attn_fwd")
-            L.split_planes_blk(o, M, inner, out=o_p)
+            L.check(lib.mt_attn_fwd(L.ptr(qkv), None, L.ptr(att), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
+                                    scale, L.ptr(o_p), st), "mt_attn_fwd")      # o leaves the attention kernels as planes only
             x_new = _new(dev, B, N, D) if save else x
             L.gemm_planes(L.OP_NT, o_p, wp[(li, 3 if mode == 0 else 8)], M, D, inner, Cout=x_new, ldc=D, epilogue=L.EPI_BIAS_RES,
                           bias=b_o, R=x, ldr=D)
@@ -220,6 +218,7 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
     dx2 = dx.view(M, D)
     dx_p = L.split_planes_blk(dx2, M, D)
     do = torch.empty(M, inner, dtype=torch.float32, device=dev)
+    dqkv = torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)     # scratch of mt_attn_bwd (main stream only)
 
     for li in reversed(range(model.depth)):
         rec = saved["layers"][li]
@@ -242,13 +241,12 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
             i0 = take(5)
             g, b_, w_qkv, w_o, b_o = P[i0:i0 + 5]
             r = rec[mode]
-            dqkv = torch.empty(M, 3 * inner, dtype=torch.float32, device=dev)
             dxn = torch.empty(M, D, dtype=torch.float32, device=dev)
             wgrad(dx_p, r["o_p"], grads[i0 + 3], D, inner)
             L.gemm_planes(L.OP_NN, dx_p, wp[(li, 8 if mode == 1 else 3)], M, inner, D, Cout=do, ldc=inner)
+            dqkv_p = L.planes_empty(M, 3 * inner, dev)
             L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
-                                    scale, st), "mt_attn_bwd")
-            dqkv_p = L.split_planes_blk(dqkv, M, 3 * inner)
+                                    scale, L.ptr(dqkv_p), st), "mt_attn_bwd")    # dqkv (fp32) is working memory here
             wgrad(dqkv_p, r["xn_p"], grads[i0 + 2], 3 * inner, D)
             L.gemm_planes(L.OP_NN, dqkv_p, wp[(li, 7 if mode == 1 else 2)], M, D, 3 * inner, Cout=dxn, ldc=D)
             # the updated dx feeds the sub-block below: time attention's to_out.0.bias (index i0 - 1), the previous layer's

@@ -53,7 +53,7 @@ def test_nt_planes_bit_identical_to_in_kernel_split(M, N, K):
     finally:
         L.set_gemm_split(prev)
     got = torch.full((M, N), float("nan"), device="cuda")
-    L.gemm_planes(L.OP_NT, L.split_planes_blk(Ad), L.split_planes_blk(Wd), M, N, K, Cout=got, ldc=N, bias=bd)
+    L.gemm_planes(L.OP_NT, L.split_planes_blk(Ad), L.split_planes_blk(Wd), M, N, K, Cout=got, ldc=N, bias=bd, streamk=False)
     assert_close(got, A.double() @ W.double().T + b.double(), TOL, "NT planes vs fp64")
     if K >= 512:                                          # (below MT_SPLIT_MIN_K's cached default mt_gemm ran the fp32 pipe)
         assert torch.equal(got, ref), "same pieces, same products, same order: the results must be bit-identical"
@@ -81,13 +81,13 @@ def test_geglu_pair_emits_planes(M):
     h_p = L.planes_empty(M, 4 * D, "cuda")
     h_p.fill_(float("nan"))
     u = torch.full((M, 8 * D), float("nan"), device="cuda")
-    L.gemm_planes(L.OP_NT, a_p, w_p, M, 8 * D, D, epilogue=L.EPI_GEGLU, bias=bd, C2=u, ldc2=8 * D, n_half=4 * D, c_planes=h_p)
+    L.gemm_planes(L.OP_NT, a_p, w_p, M, 8 * D, D, epilogue=L.EPI_GEGLU, bias=bd, C2=u, ldc2=8 * D, n_half=4 * D, c_planes=h_p, streamk=False)
     assert torch.equal(u, u_ref), "pre-activations"
     assert torch.equal(L.planes_to_float(h_p, M, 4 * D), h_ref), "h planes = the exact split of the fp32 h"
     assert not torch.isnan(h_p.float()).any() and float(L.planes_to_float(h_p, h_p.shape[1] * 32, 4 * D)[M:].abs().sum()) == 0.0
     # fp32 h next to the planes
     h32 = torch.full((M, 4 * D), float("nan"), device="cuda")
-    L.gemm_planes(L.OP_NT, a_p, w_p, M, 8 * D, D, Cout=h32, ldc=4 * D, epilogue=L.EPI_GEGLU, bias=bd, n_half=4 * D)
+    L.gemm_planes(L.OP_NT, a_p, w_p, M, 8 * D, D, Cout=h32, ldc=4 * D, epilogue=L.EPI_GEGLU, bias=bd, n_half=4 * D, streamk=False)
     assert torch.equal(h32, h_ref)
     # ---- GEGLU backward: du = [dh * gelu(g) | dh * a * gelu'(g)] from dh = dx . W2, W2 [D, 4D] read along its rows (NN)
     dx, W2 = _rand(M, D, seed=7), _rand(D, 4 * D, seed=8, scale=0.05)
@@ -104,7 +104,7 @@ def test_geglu_pair_emits_planes(M):
     du_p.fill_(float("nan"))
     cs = torch.zeros(8 * D, device="cuda")
     L.gemm_planes(L.OP_NN, L.split_planes_blk(dxd), L.split_planes_blk(W2d), M, 4 * D, D, epilogue=L.EPI_GEGLU_BWD, C2=u_ref, ldc2=8 * D,
-                  n_half=4 * D, col_sum=cs, c_planes=du_p)
+                  n_half=4 * D, col_sum=cs, c_planes=du_p, streamk=False)
     assert torch.equal(L.planes_to_float(du_p, M, 8 * D), du_ref), "du planes = the exact split of the fp32 du"
     assert_close(cs, du_ref.double().sum(0), 1e-4, "column sums of du (bias gradient)")
     assert float(L.planes_to_float(du_p, du_p.shape[1] * 32, 8 * D)[M:].abs().sum()) == 0.0
@@ -116,7 +116,7 @@ def test_nn_planes_reads_the_weight_along_its_rows(M, N, K):
     dY, W = _rand(M, K, seed=1), _rand(K, N, seed=2, scale=0.05)
     dYd, Wd = dY.cuda(), W.cuda()
     got = torch.full((M, N), float("nan"), device="cuda")
-    L.gemm_planes(L.OP_NN, L.split_planes_blk(dYd), L.split_planes_blk(Wd), M, N, K, Cout=got, ldc=N)
+    L.gemm_planes(L.OP_NN, L.split_planes_blk(dYd), L.split_planes_blk(Wd), M, N, K, Cout=got, ldc=N, streamk=False)
     assert_close(got, dY.double() @ W.double(), TOL, "NN planes vs fp64")
     if K % 16 == 0 and N % 4 == 0 and M * N >= 1 << 18:     # (smaller problems: mt_gemm runs them on the fp32 pipe)
         ref = torch.empty(M, N, device="cuda")
@@ -182,3 +182,90 @@ def test_multi_tensor_split_matches_single():
     L.check(L.get().mt_split_planes_blk_multi(table.data_ptr(), len(rows), first, L.stream_ptr()), "multi split")
     for w, o in zip(ws, outs):
         assert torch.equal(o, L.split_planes_blk(w))
+
+
+@pytest.mark.parametrize("op,M,N,K,epi", [(L.OP_NT, 12576, 1536, 512, L.EPI_STORE), (L.OP_NT, 12576, 512, 2048, L.EPI_BIAS_RES),
+                                           (L.OP_NN, 12576, 512, 4096, L.EPI_STORE), (L.OP_NT, 6288, 512, 512, L.EPI_BIAS_RES),
+                                           (L.OP_NN, 3000, 200, 520, L.EPI_STORE)])
+def test_stream_k_matches_one_block_per_tile_and_is_reproducible(op, M, N, K, epi):
+    """Stream-K (persistent grid sharing the (tile, k-step) list) against one block per tile: same sums up to the association of a
+    split tile's two or three partial sums, identical from run to run, and the lent workspace comes back zero-filled."""
+    A = _rand(M, K, seed=1)
+    Bm = _rand(N, K, seed=2, scale=0.05) if op == L.OP_NT else _rand(K, N, seed=2, scale=0.05)
+    b, R = _rand(N, seed=3).cuda(), _rand(M, N, seed=4).cuda()
+    a_p, b_p = L.split_planes_blk(A.cuda()), L.split_planes_blk(Bm.cuda())
+    kw = dict(Cout=None, ldc=N, epilogue=epi, bias=b)
+    if epi == L.EPI_BIAS_RES:
+        kw.update(R=R, ldr=N)
+    outs = []
+    for sk in (False, True, True):
+        c = torch.full((M, N), float("nan"), device="cuda")
+        kw["Cout"] = c
+        L.gemm_planes(op, a_p, b_p, M, N, K, streamk=sk, **kw)
+        outs.append(c)
+    ref = (A.double() @ (Bm.double().T if op == L.OP_NT else Bm.double())) + b.cpu().double()
+    if epi == L.EPI_BIAS_RES:
+        ref = ref + R.cpu().double()
+    assert_close(outs[1], ref, TOL, "stream-K vs fp64")
+    assert_close(outs[1], outs[0], 2e-6, "stream-K vs one block per tile")
+    assert torch.equal(outs[1], outs[2]), "stream-K must be bit-reproducible"
+    ws = L.streamk_workspace("cuda")
+    assert ws is not None and int(ws[:4096].view(torch.int32).abs().sum()) == 0, "flags must be cleared by their consumers"
+
+
+def test_stream_k_under_a_co_running_kernel():
+    """The persistent blocks are not all resident when another stream holds CUs: a block only waits for slabs its successors write
+    FIRST, so the launch still completes (and gives the same bits)."""
+    M, N, K = 12576, 512, 2048
+    a_p, b_p = L.split_planes_blk(_rand(M, K, seed=1).cuda()), L.split_planes_blk(_rand(N, K, seed=2, scale=0.05).cuda())
+    quiet = torch.empty(M, N, device="cuda")
+    L.gemm_planes(L.OP_NT, a_p, b_p, M, N, K, Cout=quiet, ldc=N, streamk=True)
+    torch.cuda.synchronize()
+    other = torch.cuda.Stream()
+    xa, xb = _rand(4096, 4096, seed=5).cuda(), _rand(4096, 4096, seed=6).cuda()
+    xc = torch.empty(4096, 4096, device="cuda")
+    busy = torch.empty(M, N, device="cuda")
+    with torch.cuda.stream(other):
+        for _ in range(6):
+            L.gemm(L.OP_NT, xa, xb, xc, 4096, 4096, 4096, 4096, 4096, 4096)      # ~0.7 ms each, three blocks per CU
+    for _ in range(4):
+        L.gemm_planes(L.OP_NT, a_p, b_p, M, N, K, Cout=busy, ldc=N, streamk=True)
+    torch.cuda.synchronize()
+    assert torch.equal(busy, quiet)
+
+
+@pytest.mark.parametrize("B,F,mode", [(2, 8, 0), (2, 8, 1), (3, 16, 0), (3, 16, 1)])
+def test_attention_kernels_emit_planes(B, F, mode):
+    H, n, dh = 8, 49, 64
+    inner, N = H * dh, 1 + F * n
+    M = B * N
+    qkv = _rand(M, 3 * inner, seed=1, scale=0.5).cuda()
+    mask = torch.ones(B, F, dtype=torch.uint8)
+    mask[0, F - 1] = 0
+    ident = torch.ones(B, F, F, dtype=torch.uint8)
+    ident[0, : F // 2, F // 2:] = 0
+    ident[0, F // 2:, : F // 2] = 0
+    mask_d, ident_d = mask.cuda(), ident.cuda()
+    lib = L.get()
+    o = torch.full((M, inner), float("nan"), device="cuda")
+    L.check(lib.mt_attn_fwd(L.ptr(qkv), L.ptr(o), None, L.ptr(mask_d), L.ptr(ident_d), B, H, F, n, mode, 0.125, None, L.stream_ptr()), "attn fwd")
+    o_p = L.planes_empty(M, inner, "cuda")
+    o_p.fill_(float("nan"))
+    L.check(lib.mt_attn_fwd(L.ptr(qkv), None, None, L.ptr(mask_d), L.ptr(ident_d), B, H, F, n, mode, 0.125, L.ptr(o_p), L.stream_ptr()), "attn fwd planes")
+    assert torch.equal(L.planes_to_float(o_p, M, inner), o)
+    assert not torch.isnan(o_p.float()).any() and float(L.planes_to_float(o_p, o_p.shape[1] * 32, inner)[M:].abs().sum()) == 0.0
+    # backward
+    do = _rand(M, inner, seed=2).cuda()
+    dqkv = torch.full((M, 3 * inner), float("nan"), device="cuda")
+    L.check(lib.mt_attn_bwd(L.ptr(qkv), L.ptr(do), L.ptr(dqkv), L.ptr(mask_d), L.ptr(ident_d), B, H, F, n, mode, 0.125, None, L.stream_ptr()), "attn bwd")
+    work = torch.full((M, 3 * inner), float("nan"), device="cuda")
+    d_p = L.planes_empty(M, 3 * inner, "cuda")
+    d_p.fill_(float("nan"))
+    L.check(lib.mt_attn_bwd(L.ptr(qkv), L.ptr(do), L.ptr(work), L.ptr(mask_d), L.ptr(ident_d), B, H, F, n, mode, 0.125, L.ptr(d_p), L.stream_ptr()), "attn bwd planes")
+    got = L.planes_to_float(d_p, M, 3 * inner)
+    assert not torch.isnan(d_p.float()).any()
+    patch = torch.ones(M, dtype=torch.bool, device="cuda")
+    patch[::N] = False                                   # cls rows: dk / dv are sums of fp32 atomics (order varies)
+    assert torch.equal(got[patch], dqkv[patch]), "patch rows are written by their single owner: identical values"
+    assert_close(got[~patch], dqkv[~patch], 1e-5, "cls rows")
+    assert float(L.planes_to_float(d_p, d_p.shape[1] * 32, 3 * inner)[M:].abs().sum()) == 0.0
