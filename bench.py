@@ -35,8 +35,9 @@ FLOP_PER_CLIP_FWD = 2 * 22097637120          # BASELINE.md §2 (EF 3.076 G MAC +
 FLOP_PER_CLIP_STEP = 3 * FLOP_PER_CLIP_FWD   # backward = 2x forward MACs
 PEAK_FP32_MFMA = 157.3e12                    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
 PEAK_BF16_MFMA = 2500e12                     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
-SPLIT_PIPE = ("split-operand fp32 (csrc/gemm_split.hpp): each fp32 operand = 3 exact bf16 pieces, 6 piece products per fp32 product on "
-              "v_mfma_f32_32x32x16_bf16, fp32 accumulators; error vs fp64 equal to the fp32 MFMA pipe's (tests/test_gpu_gemm.py)")
+SPLIT_PIPE = ("split-operand fp32 (csrc/gemm_planes.hpp, gemm_split.hpp): each fp32 operand = 3 exact bf16 pieces (TimeSformer Linear layers: "
+              "written once by the producing kernel as plane tensors, both GEMM operands by LDS-DMA), 6 piece products per fp32 product on "
+              "v_mfma_f32_32x32x16_bf16, fp32 accumulators; error vs fp64 equal to the fp32 MFMA pipe's (tests/test_gpu_gemm.py, test_gpu_planes.py)")
 
 
 PEAK_SPLIT_PIPE = PEAK_BF16_MFMA / 6          # fp32-equivalent ceiling of the split-operand loop: 6 bf16 MFMA flops per fp32 flop
@@ -123,7 +124,7 @@ def cpu_baseline(num_frames, seed, budget_s=20.0):
     return res
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_families.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_families.json")
 _PMC_WARNED = []
 
 
@@ -172,9 +173,19 @@ def attention_modules_leg(dev, B, F=8, reps=3):
     mask = torch.ones(B, F, dtype=torch.uint8, device=dev)
     ident = torch.block_diag(torch.ones(F // 2, F // 2), torch.ones(F - F // 2, F - F // 2)).to(torch.uint8).to(dev).repeat(B, 1, 1).contiguous()
 
+    xn_p, wqkv_p, wo_p = lib.split_planes_blk(xn), lib.split_planes_blk(wqkv), lib.split_planes_blk(wo)
+    o_p = lib.planes_empty(M, D, dev)
+    planes = [False]
+
     def modules():
         for layer in range(9):
             for mode in (0, 1):
+                if planes[0]:       # the engine's default on the split pipe (tsf_planes.py): plane operands, o leaves the attention kernels as planes
+                    lib.gemm_planes(lib.OP_NT, xn_p, wqkv_p, M, 3 * D, D, Cout=qkv, ldc=3 * D)
+                    lib.check(h.mt_attn_fwd(lib.ptr(qkv), None, None, lib.ptr(mask), lib.ptr(ident), B, H, F, n, mode, 0.125,
+                                            lib.ptr(o_p), lib.stream_ptr()), "mt_attn_fwd")
+                    lib.gemm_planes(lib.OP_NT, o_p, wo_p, M, D, D, Cout=x, ldc=D, epilogue=lib.EPI_BIAS_RES, bias=bo, R=x, ldr=D)
+                    continue
                 lib.gemm(lib.OP_NT, xn, wqkv, qkv, M, 3 * D, D, D, D, 3 * D)
                 lib.check(h.mt_attn_fwd(lib.ptr(qkv), lib.ptr(o), None, lib.ptr(mask), lib.ptr(ident), B, H, F, n, mode, 0.125,
                                         None, lib.stream_ptr()), "mt_attn_fwd")
@@ -203,6 +214,7 @@ def attention_modules_leg(dev, B, F=8, reps=3):
                               "mfma_frac": round(flops / (ms32 * 1e-3) / PEAK_FP32_MFMA, 4)}}
     if was:
         lib.set_gemm_split(True)
+        planes[0] = os.environ.get("MT_TSF_PLANES", "1") != "0"
         ms = timed_leg()
         out["split_pipe"] = {"fwd_ms": round(ms, 3), "tflops": round(flops / ms / 1e9, 2), "peak": round(PEAK_SPLIT_PIPE / 1e12, 1),
                              "frac": round(flops / (ms * 1e-3) / PEAK_SPLIT_PIPE, 4),
@@ -210,8 +222,9 @@ def attention_modules_leg(dev, B, F=8, reps=3):
     return out
 
 
-WGRAD_KERNEL = {True: "TimeSformer weight-gradient GEMMs: mt::gemm_split_kernel<..., TN, EPI_ATOMIC> (dW = dY^T X over B*393 rows, K-range-major "
-                      "split-K over the XCDs; side stream, next to the main stream's data-gradient GEMMs)",
+WGRAD_KERNEL = {True: "TimeSformer weight-gradient GEMMs: mt::gemm_planes_kernel<128x128, k-major x k-major, EPI_ATOMIC> (dW = dY^T X over B*393 rows, both "
+                      "operands as stored plane tensors by LDS-DMA + ds_read_b64_tr_b16, K-range-major split-K over the XCDs; side stream, "
+                      "next to the main stream's data-gradient GEMMs; 54 launches + the row-mapped patch-embedding gradient on gemm_split_kernel)",
                 False: "TimeSformer weight-gradient GEMMs: mt::gemm_dma_kernel<..., TN> (dW = dY^T X over B*393 rows; side stream)"}
 
 WORKLOADS = {   # BASELINE.json configs that fit one GPU: (clips/GPU, frames, identities, extractor, fwd GFLOP/clip)
@@ -428,8 +441,10 @@ def main():
     # live kernel timing over the timed region, HIP events on the stream each kernel is launched on:
     #   the TimeSformer's weight-gradient GEMMs (TN, plain operands; side stream) = the time-dominant kernel family of the step,
     #   FF1 + GEGLU (the largest single GEMM), the EfficientNet depthwise data gradient (the largest HBM-bound family)
-    p_wgrad = {"match": lambda d: d.op == lib.OP_TN and d.prologue == lib.PRO_NONE and d.b_prologue == lib.BPRO_NONE, "events": []}
-    p_ff1 = {"match": lambda d: d.epilogue == lib.EPI_GEGLU, "events": []}
+    # (mt_gemm launches: the in-kernel split / fp32 pipe; mt_gemm_planes launches: the plane path -- whichever the engine runs)
+    p_wgrad = {"match": lambda d: d.op == lib.OP_TN and d.prologue == lib.PRO_NONE and d.b_prologue == lib.BPRO_NONE,
+               "match_planes": lambda d: d.op == lib.OP_TN, "events": []}
+    p_ff1 = {"match": lambda d: d.epilogue == lib.EPI_GEGLU, "match_planes": lambda d: d.epilogue == lib.EPI_GEGLU, "events": []}
     p_dw = {"name": "dwconv_dgrad", "events": []}
     lib.PROFILE = [p_ff1, p_wgrad, p_dw]
     torch.cuda.synchronize()
@@ -498,8 +513,9 @@ def main():
                          "launches_timed": n_w, "launches_per_step": n_w // max(a.steps, 1),
                          "avg_launch_us": round(t_w / max(n_w, 1) * 1e6, 1), "flops_per_launch": f_w / max(n_w, 1),
                          "ms_per_step": round(t_w / max(a.steps, 1) * 1e3, 3)},
-            "roofline_ff1": {"bound": "mfma", "kernel": "mt::gemm_" + ("split" if split_on else "dma")
-                                                        + "_kernel<128x128, NT, EPI_GEGLU> (FF1 512->4096 + GEGLU, M=B*393)",
+            "roofline_ff1": {"bound": "mfma", "kernel": "mt::gemm_" + ("planes" if split_on else "dma")
+                                                        + "_kernel<128x128, NT, EPI_GEGLU> (FF1 512->4096 + GEGLU, M=B*393"
+                                                        + ("; emits h as operand planes)" if split_on else ")"),
                              **mfma_roofline(f_f / t_f if t_f else None, split_on),
                              "traffic": pmc("tsf_ff1").get("bytes_per_launch"), "traffic_unit": "bytes/launch",
                              "algorithmic_bytes": pmc("tsf_ff1").get("algorithmic_bytes_per_launch"),

@@ -87,7 +87,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   a.conv = {d->conv_H, d->conv_W, d->conv_C, d->conv_Ho, d->conv_Wo, d->conv_k, d->conv_stride, d->conv_pad, d->conv_act, d->conv_src_u8};
   a.col_sum = d->col_sum;
   a.b_planes = d->b_planes; a.b_pstride = d->b_plane_stride;
-  a.a_planes = nullptr; a.a_pstride = 0; a.c_planes = nullptr; a.c_pstride = 0; a.ldcp = 0; a.sk_ws = nullptr; a.sk_flags = nullptr; a.sk_on = 0;
+  a.a_planes = nullptr; a.a_pstride = 0; a.c_planes = nullptr; a.c_pstride = 0; a.ldcp = 0; a.sk_ws = nullptr; a.sk_flags = nullptr; a.sk_on = 0; a.wave_prio = 0;
   a.e_scale = d->e_scale; a.e_shift = d->e_shift; a.e_gate = d->e_gate; a.e_dpool = d->e_dpool; a.e_mi = d->e_mi;
   a.e_hw = d->e_hw > 0 ? d->e_hw : 1;
   a.xcd_k = 0;

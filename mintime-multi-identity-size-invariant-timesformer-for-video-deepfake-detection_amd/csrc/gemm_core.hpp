@@ -155,6 +155,7 @@ struct GemmArgs {
   const float* e_scale; const float* e_shift; const float* e_gate; const float* e_dpool; const float* e_mi; int e_hw;
   // stream-K (gemm_planes.hpp): persistent grid, per-block partial-tile slabs [grid][BM*BN] fp32 + one flag word per block
   float* sk_ws; int* sk_flags; int sk_on;
+  int wave_prio;                        // plane loop: s_setprio level of every wave (0-3): main-queue GEMMs above the weight-gradient stream's
   int xcd_k;                            // split-K weight gradients: every XCD owns whole K-ranges (gemm_split.hpp), grid = (tiles, splits % 8 == 0)
 };
 

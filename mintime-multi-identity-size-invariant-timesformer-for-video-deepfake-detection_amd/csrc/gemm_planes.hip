@@ -159,6 +159,11 @@ extern "C" int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream) {
     grid.y = (unsigned)(((d->K + chunk - 1) / chunk + 7) / 8 * 8);
     return launch_planes<true, true, EPI_ATOMIC, BAL_NONE, false>(a, grid, s);
   }
+  {
+    // forward / data-gradient GEMMs sit on the critical queue, the weight gradients they share the matrix cores with do not
+    static const int prio = getenv("MT_PLANES_MAIN_PRIO") ? atoi(getenv("MT_PLANES_MAIN_PRIO")) : 0;
+    a.wave_prio = prio;
+  }
   if (m_tiles >= 32 && n_tiles >= 2 && !getenv("MT_NO_L2_BLOCKING")) {
     const int64_t panel = (int64_t)128 * d->K * 6;   // one column group's B panels: three bf16 planes
     int gn = (int)((2 << 20) / (panel > 0 ? panel : 1));

@@ -482,6 +482,9 @@ void gemm_planes_kernel(const GemmArgs p) {
     }
   };
 
+  if (p.wave_prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p.wave_prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p.wave_prio == 3) __builtin_amdgcn_s_setprio(3);
   if (MT_PLANES_PRIO == 1) {
     const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));     // HW_ID[3:0] = wave slot on the SIMD
     if (__builtin_amdgcn_readfirstlane(hwid) & 1) __builtin_amdgcn_s_setprio(1);

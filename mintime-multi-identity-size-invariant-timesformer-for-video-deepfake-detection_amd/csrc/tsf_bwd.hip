@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 //     wavefront and trip, no LDS, few registers -- its wavefronts fit next to the weight-gradient blocks;
 //   cols kernel (weight-gradient stream): dgamma += sum_r dy*xhat, dbeta += sum_r dy, dxsum += sum_r dx_out (rows with
 //     r % skip_period == 0 left out) -- re-reads dy, x, dx_out (75 MB at B = 32) off the critical path.
-template <int NI>
+template <int NI, bool KEEP = false>
 __device__ __forceinline__ void layernorm_bwd_rows_body(const float* __restrict__ dy, const float* __restrict__ x,
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         float* __restrict__ dx, const float* __restrict__ dx_in, int rows, int D,
@@ -161,6 +161,39 @@ __device__ __forceinline__ void layernorm_bwd_rows_body(const float* __restrict_
     const float mean = stats[2 * (int64_t)row], rstd = stats[2 * (int64_t)row + 1];
     const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
     const float4* dyr = reinterpret_cast<const float4*>(dy + (int64_t)row * D);
+    const float4* pin = reinterpret_cast<const float4*>(dx_in + (int64_t)row * D);
+    float4* dxr = reinterpret_cast<float4*>(dx + (int64_t)row * D);
+    if constexpr (KEEP) {
+      // the row's operands stay in registers between the two passes (every load of the row is in flight at once): the weight-gradient
+      // GEMMs this kernel runs next to take 116-128 VGPRs per wave now, three blocks per CU -- 128 registers per lane are left over
+      float4 xv[NI], d[NI], g[NI], pv[NI];
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int q = min(lane + i * 64, nq - 1);
+        xv[i] = xr[q]; d[i] = dyr[q]; g[i] = reinterpret_cast<const float4*>(gamma)[q]; pv[i] = pin[q];
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const float w = lane + i * 64 < nq ? 1.f : 0.f;
+        const float gx = d[i].x * g[i].x, gy_ = d[i].y * g[i].y, gz = d[i].z * g[i].z, gw = d[i].w * g[i].w;
+        a1 += w * (gx + gy_ + gz + gw);
+        a2 += w * rstd * (gx * (xv[i].x - mean) + gy_ * (xv[i].y - mean) + gz * (xv[i].z - mean) + gw * (xv[i].w - mean));
+      }
+      a1 = wave_sum(a1) * inv_d; a2 = wave_sum(a2) * inv_d;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int q = lane + i * 64;
+        if (q < nq) {
+          float4 o;
+          o.x = rstd * (d[i].x * g[i].x - a1 - (xv[i].x - mean) * rstd * a2) + pv[i].x; o.y = rstd * (d[i].y * g[i].y - a1 - (xv[i].y - mean) * rstd * a2) + pv[i].y;
+          o.z = rstd * (d[i].z * g[i].z - a1 - (xv[i].z - mean) * rstd * a2) + pv[i].z; o.w = rstd * (d[i].w * g[i].w - a1 - (xv[i].w - mean) * rstd * a2) + pv[i].w;
+          dxr[q] = o;
+          if (dxp.p) planes_store4(dxp, row, q * 4, o.x, o.y, o.z, o.w);
+        }
+      }
+      continue;
+    }
     float a1 = 0.f, a2 = 0.f;
 #pragma unroll 1
     for (int i = 0; i < NI; ++i) {
@@ -172,8 +205,6 @@ __device__ __forceinline__ void layernorm_bwd_rows_body(const float* __restrict_
       a2 += w * rstd * (gx * (xv.x - mean) + gy_ * (xv.y - mean) + gz * (xv.z - mean) + gw * (xv.w - mean));
     }
     a1 = wave_sum(a1) * inv_d; a2 = wave_sum(a2) * inv_d;
-    float4* dxr = reinterpret_cast<float4*>(dx + (int64_t)row * D);
-    const float4* pin = reinterpret_cast<const float4*>(dx_in + (int64_t)row * D);
 #pragma unroll 1
     for (int i = 0; i < NI; ++i) {
       const int q = lane + i * 64;
@@ -193,6 +224,11 @@ __device__ __forceinline__ void layernorm_bwd_rows_body(const float* __restrict_
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56))) void layernorm_bwd_rows_kernel2(
     const float* dy, const float* x, const float* stats, const float* gamma, float* dx, const float* dx_in, int rows, int D, PlaneRef dxp) {
   layernorm_bwd_rows_body<2>(dy, x, stats, gamma, dx, dx_in, rows, D, dxp);
+}
+// D <= 512, operands kept in registers (the default next to the plane-operand weight gradients; MT_LN_ROWS_KEEP=0: the 56-VGPR form)
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel2k(
+    const float* dy, const float* x, const float* stats, const float* gamma, float* dx, const float* dx_in, int rows, int D, PlaneRef dxp) {
+  layernorm_bwd_rows_body<2, true>(dy, x, stats, gamma, dx, dx_in, rows, D, dxp);
 }
 __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel4(const float* dy, const float* x, const float* stats, const float* gamma,
                                                                    float* dx, const float* dx_in, int rows, int D, PlaneRef dxp) {
@@ -961,7 +997,10 @@ extern "C" int mt_layernorm_bwd_rows(const float* dy, const float* x, const floa
   int blocks = (rows + 3) / 4;
   static const int cap = getenv("MT_LN_ROWS_BLOCKS") ? atoi(getenv("MT_LN_ROWS_BLOCKS")) : 1024;    // tuning knob
   if (blocks > cap) blocks = cap;
-  if (dim <= 512)
+  static const int keep = getenv("MT_LN_ROWS_KEEP") ? atoi(getenv("MT_LN_ROWS_KEEP")) : 1;
+  if (dim <= 512 && keep)
+    hipLaunchKernelGGL(layernorm_bwd_rows_kernel2k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dx_in, rows, dim, dxp);
+  else if (dim <= 512)
     hipLaunchKernelGGL(layernorm_bwd_rows_kernel2, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dx_in, rows, dim, dxp);
   else
     hipLaunchKernelGGL(layernorm_bwd_rows_kernel4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dx_in, rows, dim, dxp);

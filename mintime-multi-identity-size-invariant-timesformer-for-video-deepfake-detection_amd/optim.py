@@ -84,7 +84,7 @@ class _FusedAdamBase(torch.optim.Optimizer):
         self._tables = {}
 
     def _table(self, gi, ps):
-        key = (gi,) + tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), p.numel()) for p in ps)
+        key = (gi,) + tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), p.numel()) for p in ps)   # gi: (group, step bucket)
         hit = self._tables.get(key)
         if hit is not None:
             return hit[0], hit[1]
@@ -122,21 +122,25 @@ class _FusedAdamBase(torch.optim.Optimizer):
                     self.state[p].update(step=0, exp_avg=flat[0, o:o + p.numel()].view(p.shape),
                                          exp_avg_sq=flat[1, o:o + p.numel()].view(p.shape))
                     o += p.numel()
-            steps = {int(self.state[p]["step"]) for p in ps}
-            if len(steps) != 1:
-                raise L.MintimeHipError("FusedAdam: parameters of one group must share their step count")
-            t = steps.pop() + 1
             for p in ps:
                 if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
                     raise L.MintimeHipError("FusedAdam needs contiguous fp32 gradients")
-                self.state[p]["step"] = t
+            # torch.optim.Adam keeps a step count PER PARAMETER (a parameter that gets its first gradient late, or a loaded state
+            # dict with mixed steps, has its own bias corrections): one launch per distinct step value -- one launch in the usual case
+            by_step = {}
+            for p in ps:
+                by_step.setdefault(int(self.state[p]["step"]), []).append(p)
             b1, b2 = group["betas"]
-            step_size = group["lr"] / (1.0 - b1 ** t)
-            bc2_sqrt = (1.0 - b2 ** t) ** 0.5
-            table, blocks = self._table(gi, ps)
-            L.check(lib.mt_adam_multi(table.data_ptr(), len(ps), blocks, float(group["lr"]), float(group["weight_decay"]), float(b1),
-                                      float(b2), float(group["eps"]), float(step_size), float(bc2_sqrt), 1 if self._decoupled else 0,
-                                      L.stream_ptr()), "mt_adam_multi")
+            for t0, members in sorted(by_step.items()):
+                t = t0 + 1
+                for p in members:
+                    self.state[p]["step"] = t
+                step_size = group["lr"] / (1.0 - b1 ** t)
+                bc2_sqrt = (1.0 - b2 ** t) ** 0.5
+                table, blocks = self._table((gi, t0 if len(by_step) > 1 else -1), members)
+                L.check(lib.mt_adam_multi(table.data_ptr(), len(members), blocks, float(group["lr"]), float(group["weight_decay"]),
+                                          float(b1), float(b2), float(group["eps"]), float(step_size), float(bc2_sqrt),
+                                          1 if self._decoupled else 0, L.stream_ptr()), "mt_adam_multi")
         _weights_changed()
         return loss
 

@@ -399,6 +399,27 @@ def test_fused_adam_and_adamw_match_torch(kind):
     assert F_(ps_gpu).defaults["weight_decay"] == T(ps_ref).defaults["weight_decay"]
 
 
+def test_fused_adam_keeps_a_step_count_per_parameter():
+    """A parameter that gets its first gradient after others have stepped (unfreezing mid-run: train.py:153-170) has its own bias
+    corrections in torch.optim.Adam; the fused optimizer buckets a group's parameters by step count instead of refusing."""
+    from mintime_amd import optim
+    g = torch.Generator().manual_seed(3)
+    ps_ref = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in [(33,), (8, 9), (257,)]]
+    ps_gpu = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ps_ref]
+    o_ref, o_gpu = torch.optim.Adam(ps_ref, lr=0.01), optim.FusedAdam(ps_gpu, lr=0.01)
+    for step in range(4):
+        for i, (pr, pg) in enumerate(zip(ps_ref, ps_gpu)):
+            if i == 2 and step < 2:                                            # the third parameter is "frozen" for two steps
+                pr.grad = pg.grad = None
+                continue
+            gr = torch.randn(pr.shape, generator=g)
+            pr.grad, pg.grad = gr.clone(), gr.clone().cuda()
+        o_ref.step(); o_gpu.step()
+    assert int(o_gpu.state[ps_gpu[2]]["step"]) == 2 and int(o_gpu.state[ps_gpu[0]]["step"]) == 4
+    for pr, pg in zip(ps_ref, ps_gpu):
+        assert_close(pg.detach(), pr.detach(), 2e-6, "parameters with different step counts")
+
+
 _DP2_SCRIPT = r"""
 import os, sys, json, torch, torch.distributed as dist
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

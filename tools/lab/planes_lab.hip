@@ -255,5 +255,11 @@ int main(int argc, char** argv) {
   RUN(EPI_ATOMIC, MT_OP_TN, {"FF2 wgrad", MT_OP_TN, 512, 2048, M, MT_EPI_ATOMIC});
   RUN(EPI_ATOMIC, MT_OP_TN, {"QKV wgrad", MT_OP_TN, 1536, 512, M, MT_EPI_ATOMIC});
   RUN(EPI_ATOMIC, MT_OP_TN, {"out wgrad", MT_OP_TN, 512, 512, M, MT_EPI_ATOMIC});
+  RUN(EPI_STORE, MT_OP_NT, {"4096x4096x512", MT_OP_NT, 4096, 4096, 512, MT_EPI_STORE});
+  RUN(EPI_STORE, MT_OP_NT, {"8192x8192x512", MT_OP_NT, 8192, 8192, 512, MT_EPI_STORE});
+  RUN(EPI_STORE, MT_OP_NT, {"8192x8192x2048", MT_OP_NT, 8192, 8192, 2048, MT_EPI_STORE});
+  RUN(EPI_STORE, MT_OP_NT, {"16384x512x512", MT_OP_NT, 16384, 512, 512, MT_EPI_STORE});
+  RUN(EPI_STORE, MT_OP_NT, {"16384x1024x512", MT_OP_NT, 16384, 1024, 512, MT_EPI_STORE});
+  RUN(EPI_STORE, MT_OP_NT, {"16384x512x2048", MT_OP_NT, 16384, 512, 2048, MT_EPI_STORE});
   return 0;
 }

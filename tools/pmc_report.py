@@ -105,10 +105,14 @@ if a.json_out:
     else:
         M = 32 * 393
         # TN weight gradients / FF1 + GEGLU on whichever main loop ran (gemm_split_kernel by default, gemm_dma_kernel with MT_GEMM_SPLIT=0)
-        tn = family(lambda n: re.match(r"gemm_(dma|split)_kernel<\d+, \d+, \d+, \d+, 1, 1, 4,", n) is not None)
-        ff1 = family(lambda n: re.match(r"gemm_(dma|split)_kernel<2, 2, 2, 2, 0, 0, 2,", n) is not None)
+        # ... or the plane-operand loop (gemm_planes_kernel<..., AKM, BKM, EPI, ...>): both operands are 6 B / element plane tensors
+        tn_pl = family(lambda n: re.match(r"gemm_planes_kernel<\d+, \d+, \d+, \d+, true, true, 4,", n) is not None)
+        ff1_pl = family(lambda n: re.match(r"gemm_planes_kernel<2, 2, 2, 2, false, false, 2,", n) is not None)
+        tn = tn_pl or family(lambda n: re.match(r"gemm_(dma|split)_kernel<\d+, \d+, \d+, \d+, 1, 1, 4,", n) is not None)
+        ff1 = ff1_pl or family(lambda n: re.match(r"gemm_(dma|split)_kernel<2, 2, 2, 2, 0, 0, 2,", n) is not None)
         shapes = [(512, 2048, 9), (4096, 512, 9), (1536, 512, 18), (512, 512, 18)]
-        alg = sum(4.0 * (M * (n1 + n2) + n1 * n2) * c for n1, n2, c in shapes) / sum(c for _, _, c in shapes)
+        opb = 6.0 if tn_pl else 4.0          # operand bytes per element
+        alg = sum((opb * M * (n1 + n2) + 4.0 * n1 * n2) * c for n1, n2, c in shapes) / sum(c for _, _, c in shapes)
         if tn:
             doc["tsf_wgrad"] = {"bytes_per_launch": sum(c["rd"] + c["wr"] for _, c in tn) / len(tn), "launches": len(tn),
                                 "kernel_ms": round(sum(us for us, _ in tn) / 1e3, 3), "algorithmic_bytes_per_launch": alg,
@@ -116,7 +120,8 @@ if a.json_out:
         if ff1:
             doc["tsf_ff1"] = {"bytes_per_launch": sum(c["rd"] + c["wr"] for _, c in ff1) / len(ff1), "launches": len(ff1),
                               "read_bytes": sum(c["rd"] for _, c in ff1) / len(ff1), "write_bytes": sum(c["wr"] for _, c in ff1) / len(ff1),
-                              "algorithmic_bytes_per_launch": 4.0 * (M * 512 + 4096 * 512 + 4096 + M * 2048 + M * 4096), "source": src}
+                              "algorithmic_bytes_per_launch": (6.0 * (M * 512 + 4096 * 512) + 4.0 * 4096 + 6.0 * M * 2048 + 4.0 * M * 4096) if ff1_pl
+                              else 4.0 * (M * 512 + 4096 * 512 + 4096 + M * 2048 + M * 4096), "source": src}
         doc["tsf_families"] = {k: {"ms": round(f["us"] / 1e3, 3), "n": int(f["n"]), "read_GB": round(f["rd"] / 1e9, 3),
                                    "write_GB": round(f["wr"] / 1e9, 3)} for k, f in fam.items() if f["us"] > 100}
     # which kernel sources these counters belong to: bench.py refuses them for any other tree (same hash as bench.csrc_hash)
