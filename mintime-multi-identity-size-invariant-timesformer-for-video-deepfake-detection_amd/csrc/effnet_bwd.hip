@@ -483,7 +483,7 @@ int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, co
   const unsigned bx = xcd_chunk_grid(chunks, ntiles, 4096);
   auto k = dwconv_wgrad_tiled_kernel<K, S, T, ACT, CC>;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(k, dim3(bx), dim3(256), lds, s, du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo);

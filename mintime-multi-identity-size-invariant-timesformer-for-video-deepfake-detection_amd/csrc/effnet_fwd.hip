@@ -188,7 +188,7 @@ int launch_dw_tiled(const float* zin, const float* scale, const float* shift, co
   const unsigned bx = xcd_chunk_grid(chunks, ntiles, 8192);
   auto k = dwconv_tiled_kernel<K, S, T, ACT, CC>;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(k, dim3(bx), dim3(256), lds, s, zin, scale, shift, w, zout, stats, slots > 0 ? slots : 1, N, H,

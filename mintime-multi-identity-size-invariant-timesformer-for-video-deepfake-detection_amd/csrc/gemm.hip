@@ -13,7 +13,7 @@ enum { CFG_BIG = 0, CFG_MID = 1, CFG_NARROW = 2, CFG_SMALL = 3 };
 struct Cfg { int bm, bn, threads; };
 constexpr Cfg kCfg[4] = {{128, 128, 256}, {128, 64, 256}, {256, 32, 256}, {64, 64, 256}};
 
-// Tile choice.  Replaying every GEMM of a B = 32 training step alone under each configuration (tools/lab/tune_gemm_cfg.py, 70
+// Tile choice.  Replaying every GEMM of a B = 32 training step alone under each configuration (round-1 tuning script; results: profiles/r01_gemm_tile_config_sweep.txt, 70
 // shapes) favours 64x64 tiles almost everywhere, but inside the real step -- where the weight-gradient GEMMs of a second stream
 // share the CUs -- only the cases below kept their gain (and Xception's large pointwise GEMMs lost 7 % with 64x64 everywhere):
 //   * tall problems with so few 128x128 tiles that they cannot fill the resident slots once (12576 x 512: 396 tiles on 256 CUs

@@ -50,14 +50,9 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
   if (PRO == PRO_BN_SWISH_GATE) lds += (size_t)(2 + (BM - 1) / a.hw + 2) * a.K * 4;     // scale, shift, gate rows of the images a row tile touches
   if (PRO == PRO_BN_BWD) lds += (size_t)3 * a.K * 4;                                     // ka, kb, kc
   if (lds > 160 * 1024) return 1;      // not this way: caller falls back to the register-staged kernel
-  if (lds > 48 * 1024) {
-    static size_t raised_dev[16] = {0};   // per device (the attribute is per device); idempotent, a benign race at worst repeats the call
-    size_t& raised = raised_dev[cur_device()];
-    if (lds > raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_gemm(dma): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-      raised = lds;
-    }
+  {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
+    if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_gemm(dma): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, s, a);
   return check_launch("mt_gemm(dma)");

@@ -71,13 +71,9 @@ int launch_planes(const GemmArgs& a, dim3 grid, hipStream_t s) {
   constexpr int ST = 2;
   auto k = gemm_planes_kernel<2, 2, 2, 2, AKM, BKM, EPI, ST, BAL == BAL_PAIR ? 2 : 3, BAL, CPL, SK>;
   constexpr size_t lds = (size_t)ST * 3 * (128 + 128) * 32;
-  static bool raised_dev[64] = {false};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (lds > 48 * 1024 && !raised_dev[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_gemm_planes: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-    raised_dev[dev & 63] = true;
   }
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
   return check_launch("mt_gemm_planes");

@@ -40,14 +40,9 @@ int launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
     lds += (size_t)pad;
   }
   if (lds > 160 * 1024) return 1;      // not this way: the caller falls back to the fp32 kernels
-  if (lds > 48 * 1024) {
-    static size_t raised_dev[16] = {0};   // per device (the attribute is per device); idempotent, a benign race at worst repeats the call
-    size_t& raised = raised_dev[cur_device()];
-    if (lds > raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_gemm(split): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-      raised = lds;
-    }
+  {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
+    if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_gemm(split): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), lds, s, a);
   return check_launch("mt_gemm(split)");
@@ -71,7 +66,7 @@ int launch_variant(int v, const GemmArgs& a, dim3 grid, hipStream_t s) {
     // weight pre-split into bf16 planes (mt_split_planes): B by DMA, 128 x 128 tiles only.  Bit-identical to the in-kernel split.
     // Round 2: 7-12 % slower (hipcc's vmcnt for the staged A tile also drained the DMA of the same step).  Round 3: the A loads are
     // inline asm under one counted wait per step (no compiler-inserted vmcnt left in the loop, checked in the ISA) -- and the variant
-    // now runs EQUAL to the in-kernel split, not faster (tools/lab/planes_probe.py, profiles/r03_split_planes_manual_waits.txt:
+    // now runs EQUAL to the in-kernel split, not faster (profiles/r03_split_planes_manual_waits.txt:
     // QKV 154.7 / 153.6 us, FF2 203.8 / 201.2, FF1 data gradient 353.5 / 352.0, 4096^3 747 / 780), with two or with three A register
     // sets in flight: the loop is limited by its matrix + LDS issue, not by operand delivery.  Stays opt-in (MT_SPLIT_PLANES=1).
     const bool planes_on = getenv("MT_SPLIT_PLANES") && atoi(getenv("MT_SPLIT_PLANES")) != 0;
@@ -226,7 +221,9 @@ int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
     static const int xcd_k_on = getenv("MT_WGRAD_XCD_K") ? atoi(getenv("MT_WGRAD_XCD_K")) : 1;
     if (d->op == MT_OP_TN && xcd_k_on && d->split_k <= 0 && d->K >= 8 * 256 && d->a_map.gin == 0 && d->b_map.gin == 0) {
       // K-range-major over the XCDs (gemm_split.hpp): a multiple of 8 ranges, exactly m_tiles * n_tiles blocks per range
+      const int max_splits8 = (d->K / 256) / 8 * 8;                    // (>= 8: K >= 8 * 256 here)
       splits = (splits + 4) / 8 * 8;
+      if (splits > max_splits8) splits = max_splits8;
       if (splits < 8) splits = 8;
       int chunk = (d->K + splits - 1) / splits;
       chunk = (chunk + 15) / 16 * 16;
@@ -234,7 +231,7 @@ int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
       a.xcd_k = 1;
       a.group_n = 0;
       grid.x = m_tiles * n_tiles;
-      grid.y = splits;
+      grid.y = ((d->K + chunk - 1) / chunk + 7) / 8 * 8;               // no K-range beyond the last non-empty group of 8
     } else {
       int chunk = (d->K + splits - 1) / splits;
       chunk = (chunk + 15) / 16 * 16;

@@ -11,7 +11,7 @@
 // Six bf16 MFMAs replace sixteen fp32 ones: 6/16 of the matrix-pipe time.
 //
 // BAL (balanced accumulators).  v_mfma_f32_32x32x16_bf16 does not round  C + sum_k a_k b_k  like an fmaf chain: measured on
-// gfx950 (tools/lab/split_probe.py, mfma_round_probe.hip) its result carries a sign-INDEPENDENT bias of about -3e-9 x sum|a||b|
+// gfx950 (tools/lab/mfma_round_probe.hip; profiles/r02_mfma_bf16_rounding_probe.txt, r02_split_accuracy_probe.txt) its result carries a sign-INDEPENDENT bias of about -3e-9 x sum|a||b|
 // per instruction (rms error equal to the fp32 pipe's, but a mean that the fp32 pipe does not have).  Invisible in one GEMM's
 // max error, it adds up coherently over a deep network (Xception's 36 convolutions moved a logit by 1.6e-3 relative).  Because
 // the bias does not depend on the sign of the products it cancels between two accumulators fed with opposite signs: even k-tiles

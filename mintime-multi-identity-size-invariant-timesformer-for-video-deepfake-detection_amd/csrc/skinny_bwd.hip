@@ -432,7 +432,7 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int blocks = (int)(nchunks < cus ? nchunks : cus);          // one persistent block per CU
   auto k = conv1x1_bwd_fused_kernel<MT, N16>;
-  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipError_t e = ensure_dynamic_lds((const void*)k, smem);
   if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_conv1x1_bwd_fused: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   hipLaunchKernelGGL(k, dim3(blocks), dim3(NTHR), smem, st, a);
   return check_launch("mt_conv1x1_bwd_fused");

@@ -229,7 +229,7 @@ int launch_se(const SeArgs& a, int mode, hipStream_t st) {
   const int64_t nchunks = (a.rows + R - 1) / R;
   const int blocks = (int)(nchunks < 512 ? nchunks : 512);
   auto go = [&](auto k) {
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)ensure_dynamic_lds((const void*)k, smem);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), smem, st, a);
   };
   constexpr int CQB = NT == 1 ? 8 : (NT == 3 ? 24 : 36);

@@ -279,7 +279,7 @@ int launch(const WgradArgs& a, bool gate, hipStream_t st) {
   const int64_t cap = 256 * BPC;                 // BPC resident blocks per CU (measured optimum: 2; 1 for the 10-tile shapes)
   const int blocks = (int)(nchunks < cap ? nchunks : cap);
   auto go = [&](auto k) {
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)ensure_dynamic_lds((const void*)k, smem);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), smem, st, a);
   };
   if (gate) go(conv1x1_wgrad_kernel<MT, NT, R, A_GATE, WM, WN, KREG>);

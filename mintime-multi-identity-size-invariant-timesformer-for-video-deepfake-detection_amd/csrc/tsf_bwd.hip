@@ -958,7 +958,7 @@ int launch_patch_bwd(const float* qkv, const float* dout, float* dqkv, const uin
   const size_t lds = (size_t)WPB * (2 * TROWS * STRIDE + 2 * 64 * SP) * sizeof(float);
   auto k = attn_patch_bwd_kernel<MODE, NKEYS, PPW, STRIDE, WPB>;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_attn_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, dout, dqkv, mask, ident, B, H, F,

@@ -544,7 +544,7 @@ int launch_patch(const float* qkv, float* out, const uint8_t* mask, const uint8_
   const size_t lds = (size_t)WPB * (ROWS * STRIDE + NKEYS * 64) * sizeof(float);
   auto k = attn_patch_fwd_kernel<MODE, NKEYS, PPW, STRIDE, WPB>;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_attn_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, out, mask, ident, B, H, F, n, scale, op);

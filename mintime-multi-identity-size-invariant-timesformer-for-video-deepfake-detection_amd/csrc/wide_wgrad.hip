@@ -243,7 +243,7 @@ int launch_wide(WideArgs a, hipStream_t st) {
   if ((int64_t)a.nsplit > nchunks) a.nsplit = (int)((nchunks + 7) / 8 * 8);
   a.chunks_per_split = (nchunks + a.nsplit - 1) / a.nsplit;
   auto k = wgrad_wide_kernel<MT>;
-  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipError_t e = ensure_dynamic_lds((const void*)k, smem);
   if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_conv1x1_wgrad_wide: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   hipLaunchKernelGGL(k, dim3(a.nsplit * a.nslab), dim3(512), smem, st, a);
   return check_launch("mt_conv1x1_wgrad_wide");

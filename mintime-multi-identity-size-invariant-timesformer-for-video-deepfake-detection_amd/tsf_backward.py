@@ -59,6 +59,9 @@ def tsf_backward(model, feat, aux, params, dims, saved, dlogits, need_dfeat, nee
              and getattr(model, "_grads_ready_hook", None) is None and not torch.cuda.is_current_stream_capturing())
     deferred = []
     wT = saved.get("wT")                              # transposed weights (tsf_engine.tsf_forward): data gradients in NT form
+    if wT is not None and getattr(model, "_wT_cache", {}).get("serial") != saved.get("wT_serial"):
+        wT = None                                     # a later forward rewrote the persistent buffers (two graphs alive): the weights
+                                                      # as stored are still this graph's (torch's version counters guard THEM): NN form
     if wT is not None:
         side.wait(saved["wT_ready"])
 

@@ -151,7 +151,8 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
             L.check(lib.mt_transpose_multi(cache["table"].data_ptr(), cache["count"], cache["tiles"], L.stream_ptr()),
                     "mt_transpose_multi")
         if side.enabled:       # with MT_SIDE_STREAM=0 the transposes would sit on the critical path: the NN form is used instead
-            saved["wT"], saved["wT_ready"] = cache["holder"], side.launch(transpose_all, reads=wts)
+            cache["serial"] = cache.get("serial", 0) + 1       # a later forward rewrites the buffers: backward checks this
+            saved["wT"], saved["wT_ready"], saved["wT_serial"] = cache["holder"], side.launch(transpose_all, reads=wts), cache["serial"]
     # Optional (MT_TSF_PRUNE_LAST=1, off by default): dead-row pruning of the LAST layer.  The classification head reads the cls
     # token only (size_invariant_timesformer.py:270-276), so everything the last layer computes for the 392 patch rows AFTER its
     # time attention is never read: the space attention's patch queries and out-projection rows and the whole feed-forward block

@@ -66,8 +66,9 @@ def weight_planes(model, params, training):
     if training or cache["stamp"] != stamp:
         L.check(lib.mt_split_planes_blk_multi(cache["table"].data_ptr(), cache["count"], cache["blocks"], L.stream_ptr()),
                 "mt_split_planes_blk_multi")
+        if cache["stamp"] != stamp:                  # the weights changed since the planes were last written: graphs that saved the
+            cache["serial"] = cache.get("serial", 0) + 1      # old serial must not run their backward on the new planes
         cache["stamp"] = stamp
-        cache["serial"] = cache.get("serial", 0) + 1
     return cache["holder"], cache["serial"]
 
 
@@ -173,8 +174,8 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
     scale = float(dh) ** -0.5
     cache = getattr(model, "_wplanes_cache", None)
     if cache is None or cache.get("serial") != saved["w_serial"]:
-        raise RuntimeError("SizeInvariantTimeSformer: the weight planes were rewritten by a later forward before this backward ran "
-                           "(two graphs alive across a forward); run backward before the next training forward, or set MT_TSF_PLANES=0")
+        raise RuntimeError("SizeInvariantTimeSformer: the Linear weights were updated between this graph's forward and its backward "
+                           "(their operand planes were rewritten by a later forward): run backward before the optimizer step")
     wp = cache["holder"]
     grads, flat_grads = L.zero_grads(list(params), with_flat=True)
     P = list(params)

@@ -99,12 +99,14 @@ def test_effnet_backward_all_parameters_vs_oracle(training):
     print("worst relative gradient error", worst)
 
 
-def test_config3_full_size_training_step_vs_oracle():
-    """BASELINE config 3 exactly as bench.py times it: B = 32 clips x 8 slots (256 crops), 2 identities [4,4], train-mode
-    BatchNorm, drop-connect 0.2 (gates fed from the reference's RNG draws), BCE loss, backward.  Logits, loss and sampled
-    gradients of both networks against the CPU oracle run in float64 (train.py:332-378)."""
+@pytest.mark.parametrize("B,ids,tag", [(32, 2, "config 3"), (16, 1, "config 2")])
+def test_config3_full_size_training_step_vs_oracle(B, ids, tag):
+    """BASELINE configs 3 and 2 exactly as bench.py times them: B = 32 clips x 8 slots (256 crops), 2 identities [4,4] / B = 16,
+    1 identity (128 crops; 6288 token rows: not a multiple of 32, the operand planes' zero padding is live), train-mode BatchNorm,
+    drop-connect 0.2 (gates fed from the reference's RNG draws), BCE loss, backward.  Logits, loss and every gradient of both
+    networks against the CPU oracle run in float64 (train.py:332-378)."""
     import time
-    B, Fr, seed, rate = 32, 8, 4, 0.2
+    Fr, seed, rate = 8, 4, 0.2
     cfg = arch.default_tsf_config(1280, Fr)
     ef = EfficientNet.from_name("efficientnet-b0", drop_connect_rate=rate)
     ef_sd = synth.effnet_b0_state(seed)
@@ -116,7 +118,7 @@ def test_config3_full_size_training_step_vs_oracle():
     tsf.cuda()
     u = O.drop_connect_uniforms(seed, B * Fr, rate)
     ef.drop_connect_uniform = lambda rows, N, dev: torch.stack([u[i].reshape(N) for i in sorted(u)]).to(dev)
-    inp = synth.clip_inputs(B, Fr, 2, seed, ragged=False)
+    inp = synth.clip_inputs(B, Fr, ids, seed, ragged=False)
     _, y_pred = _step(ef, tsf, inp, require_attention=False)
     loss = torch.nn.functional.binary_cross_entropy_with_logits(y_pred.cpu(), inp["labels"].reshape(-1, 1))
     loss.backward()
@@ -130,8 +132,8 @@ def test_config3_full_size_training_step_vs_oracle():
     yo = O.clip_forward(eo, to, cfg, inp64, training_extractor=True, drop_connect_rate=rate, dc_uniform=u)
     lo = O.bce_with_logits(yo, inp["labels"])
     lo.backward()
-    print(f"oracle fp64 config-3 step on the host: {time.time() - t0:.1f} s")
-    assert_close(y_pred, yo, REL_TOL, "logits (config 3, B=32)")
+    print(f"oracle fp64 {tag} step on the host: {time.time() - t0:.1f} s")
+    assert_close(y_pred, yo, REL_TOL, f"logits ({tag}, B={B})")
     assert bool(((y_pred.detach().cpu().double() - yo.detach()).abs() <= 1e-3 * yo.detach().abs() + 1e-5).all())
     assert_close(loss, lo, REL_TOL, "loss")
     worst = 0.0
@@ -151,7 +153,7 @@ def test_config3_full_size_training_step_vs_oracle():
                 assert float(p.grad.norm()) < 1e-3 * wn, k
                 continue
         worst = max(worst, assert_close(p.grad, ref, 3 * REL_TOL, "ef grad " + k))
-    print("config 3 full size: worst relative gradient error", worst)
+    print(tag, "full size: worst relative gradient error", worst)
 
 
 def test_hip_graph_replay_matches_eager_eval():

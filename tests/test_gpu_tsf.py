@@ -1,4 +1,6 @@
 """GPU parity of the HIP SizeInvariantTimeSformer against the CPU oracle and the reference-generated fixtures."""
+import os
+
 import pytest
 import torch
 
@@ -269,6 +271,37 @@ def test_second_backward_through_the_same_forward_raises_clearly():
     out.sum().backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="second time"):
         out.sum().backward()
+
+
+def test_two_graphs_share_the_weight_planes_until_the_weights_change():
+    """The Linear weights' operand planes live on the module (tsf_planes.weight_planes).  Two forwards followed by their two
+    backwards (gradient accumulation) see the same planes; a backward that would run on planes of UPDATED weights is refused (torch
+    raises its version-counter error in that situation: the fused optimizers update through raw pointers, so the engine checks)."""
+    from mintime_amd import optim
+    Fr, C = 8, 1280
+    cfg = arch.default_tsf_config(C, Fr)
+    model, _ = _build(cfg, 0, require_attention=False)
+    feats = synth.features(2, Fr, C, 0).cuda()
+    aux = synth.clip_inputs(2, Fr, 1, 0, with_video=False)
+    kw = dict(mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(), size_embedding=aux["size_embedding"],
+              positions=aux["positions"].cuda())
+    model(feats, **kw).sum().backward()
+    ref = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    for p in model.parameters():
+        p.grad = None
+    a, b = model(feats, **kw), model(feats, **kw)            # two live graphs, no update in between
+    a.sum().backward()
+    got = [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    b.sum().backward()
+    for g, r in zip(got, ref):
+        assert_close(g, r, 1e-5, "first of two live graphs")
+    opt = optim.FusedSGD(model.parameters(), lr=0.01)
+    stale = model(feats, **kw)
+    opt.step()                                                # weights change through raw pointers ...
+    model(feats, **kw)                                        # ... and the next training forward re-splits them
+    if os.environ.get("MT_TSF_PLANES", "1") != "0":
+        with pytest.raises(RuntimeError, match="weights were updated"):
+            stale.sum().backward()
 
 
 @pytest.mark.parametrize("rows,skip", [(2 * 393, 0), (5 * 393 + 0, 393), (1000, 0)])
