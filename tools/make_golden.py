@@ -387,7 +387,11 @@ def main():
     if only in ("", "switch"):
         tsf_case(TSF, "tsf_nopos", batch=2, frames=8, channels=1280, identities=2, ragged=True, seed=3, pos_emb=False, size_emb=True)
         tsf_case(TSF, "tsf_nosize", batch=2, frames=8, channels=1280, identities=2, ragged=True, seed=4, pos_emb=True, size_emb=False)
-    if only in ("dc", "agg", "slots", "switch"):
+    if only == "tsf":            # the three plain TimeSformer fixtures alone (e.g. after tsf_case() gained keys)
+        tsf_case(TSF, "tsf_cfg1", batch=2, frames=8, channels=1280, identities=1, ragged=False, seed=0)
+        tsf_case(TSF, "tsf_2id_ragged", batch=2, frames=8, channels=1280, identities=2, ragged=True, seed=1)
+        tsf_case(TSF, "tsf_xs_3id", batch=1, frames=16, channels=2048, identities=3, ragged=True, seed=2)
+    if only in ("dc", "agg", "slots", "switch", "tsf"):
         return
     from models.xception import xception as _xc
     man["xception"] = [[k, list(v.shape), str(v.dtype)] for k, v in _xc(num_classes=1).state_dict().items()]
