@@ -181,6 +181,21 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+// gelu(x) and its derivative together (the GEGLU-backward epilogues need both for every element): ONE exponential -- erf's
+// exp(-(x/sqrt 2)^2) is the Gaussian of the density term -- and one polynomial instead of two of each.
+__device__ __forceinline__ void gelu_erf_both(float x, float& gelu, float& grad) {
+  const float z = x * 0.70710678118654752440f;
+  const float az = fabsf(z);
+  const float t = 1.0f / fmaf(0.3275911f, az, 1.0f);
+  float y = fmaf(1.061405429f, t, -1.453152027f);
+  y = fmaf(y, t, 1.421413741f);
+  y = fmaf(y, t, -0.284496736f);
+  y = fmaf(y, t, 0.254829592f);
+  const float e = __expf(-az * az);                  // = exp(-x^2 / 2)
+  const float erfv = copysignf(1.0f - y * t * e, z);
+  gelu = 0.5f * x * (1.0f + erfv);                   // (the same expression as gelu_erf: bit-identical values)
+  grad = fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + erfv));
+}
 
 // ---- XCD-aware tile order.  Block b runs on XCD b % 8 (observed dispatch; used for speed only, never for correctness).
 // Returns false for a padding block of the L2-blocked order.
@@ -371,7 +386,9 @@ __device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&a
               const float2 ag = FAST ? *reinterpret_cast<const float2*>(up + (int64_t)dr * p.ldc2)
                                      : *reinterpret_cast<const float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * n);
               const float a = ag.x, g = ag.y;
-              const float da = v * gelu_erf(g), dg = v * a * gelu_erf_grad(g);
+              float gl, gr;
+              gelu_erf_both(g, gl, gr);
+              const float da = v * gl, dg = v * a * gr;
               c[0] = da;
               c[p.n_half] = dg;
               s1 += da; s2 += dg;

@@ -195,11 +195,6 @@ extern "C" int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream) {
   PL_COMBO(MT_OP_NT, false, EPI_GEGLU, false)
   PL_COMBO(MT_OP_NT, false, EPI_GEGLU, true)
   PL_COMBO(MT_OP_NN, true, EPI_STORE, false)
-  {
-    static const int gb = getenv("MT_PLANES_GEGLU_BWD_BAL") ? atoi(getenv("MT_PLANES_GEGLU_BWD_BAL")) : BAL_PAIR;   // tuning experiment
-    if (op == MT_OP_NN && epi == EPI_GEGLU_BWD && cpl && !sk && gb == BAL_PHASE) return launch_planes<false, true, EPI_GEGLU_BWD, BAL_PHASE, true>(a, grid, s);
-    if (op == MT_OP_NN && epi == EPI_GEGLU_BWD && cpl && !sk && gb == BAL_NONE) return launch_planes<false, true, EPI_GEGLU_BWD, BAL_NONE, true>(a, grid, s);
-  }
   PL_COMBO(MT_OP_NN, true, EPI_GEGLU_BWD, false)
   PL_COMBO(MT_OP_NN, true, EPI_GEGLU_BWD, true)
 #undef PL_COMBO
