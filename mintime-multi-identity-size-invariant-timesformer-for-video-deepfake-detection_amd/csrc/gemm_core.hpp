@@ -339,19 +339,46 @@ __device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&a
     }
     return;
   } else {
+    // Epilogues that READ global memory per element (residual, accumulate, the GEGLU pre-activations) run in two phases: every load
+    // of the wavefront's tiles first, folded into the accumulators, then every store.  Element by element the compiler has to keep
+    // "load, store, load, store" in program order (R / C2 may alias C) and puts s_waitcnt vmcnt(0) in front of every use -- and on
+    // gfx9 that counter also holds the PREVIOUS element's store until it is acknowledged: 64 exposed round trips per wavefront
+    // (the residual add of a K = 512 out-projection cost more than its main loop).
+    // (GEGLU_BWD stays element-wise here: its second gradient would need 16 x TM x TN more registers, which the 168-register variants
+    //  of the in-kernel-split loop do not have -- 321 -> 575 us when tried; the plane loop's own epilogue (gemm_planes.hpp) is two-phase)
+    constexpr bool GATHER = EPI == EPI_BIAS_RES || EPI == EPI_ACCUM;
+    if constexpr (GATHER) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+        const bool nok = FAST || n < p.N;
+        const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+            const int m = mw + row_h + dr;
+            if (FAST || (m < p.M && nok)) {
+              const int64_t crow = FAST ? (int64_t)m : map_row(p.c_map, m);
+              if constexpr (EPI == EPI_BIAS_RES) acc[i][j][r] += bias + p.R[crow * p.ldr + n];
+              else acc[i][j][r] += bias + p.C[crow * p.ldc + n];
+            }
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * TN * 32 + j * 32 + col_l;
       const bool nok = FAST || n < p.N;
       float bias = 0.f;
-      if constexpr (EPI == EPI_STORE || EPI == EPI_BIAS_RES || EPI == EPI_ACCUM)
+      if constexpr (EPI == EPI_STORE)
         bias = (nok && p.bias) ? p.bias[n] : 0.f;
       if constexpr (EPI == EPI_ATOMIC)      // split-K: the bias rides on the first K-slice only
         bias = (nok && p.bias && blockIdx.y == 0) ? p.bias[n] : 0.f;
       float s1 = 0.f, s2 = 0.f;
-      float* cp = p.C + (int64_t)(mw + row_h) * p.ldc + n;                         // FAST path bases
-      const float* rp = (EPI == EPI_BIAS_RES) ? p.R + (int64_t)(mw + row_h) * p.ldr + n : nullptr;
-      const float* up = (EPI == EPI_GEGLU_BWD) ? p.C2 + (int64_t)(mw + row_h) * p.ldc2 + 2 * n : nullptr;
+      float* cp = p.C + (int64_t)(mw + row_h) * p.ldc + n;                         // FAST path base
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -361,21 +388,12 @@ __device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&a
           if (FAST || (m < p.M && nok)) {
             float v = acc[i][j][r];
             float* c;
-            const float* rr = nullptr;
-            if constexpr (FAST) {
-              c = cp + (int64_t)dr * p.ldc;
-              if constexpr (EPI == EPI_BIAS_RES) rr = rp + (int64_t)dr * p.ldr;
-            } else {
-              const int64_t crow = map_row(p.c_map, m);
-              c = p.C + crow * p.ldc + n;
-              if constexpr (EPI == EPI_BIAS_RES) rr = p.R + crow * p.ldr + n;
-            }
+            if constexpr (FAST) c = cp + (int64_t)dr * p.ldc;
+            else c = p.C + map_row(p.c_map, m) * p.ldc + n;
             if constexpr (EPI == EPI_STORE) {
               *c = v + bias;
-            } else if constexpr (EPI == EPI_BIAS_RES) {
-              *c = v + bias + *rr;
-            } else if constexpr (EPI == EPI_ACCUM) {
-              *c += v + bias;
+            } else if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_ACCUM) {
+              *c = v;                               // (bias and the residual / previous value were folded in by the gather phase)
             } else if constexpr (EPI == EPI_STATS) {
               *c = v;
               s1 += v; s2 += v * v;
@@ -383,12 +401,10 @@ __device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&a
               atomicAdd(c, v + bias);
             } else if constexpr (EPI == EPI_GEGLU_BWD) {
               // n indexes h columns [0, n_half); u = [a | g] pre-activations
-              const float2 ag = FAST ? *reinterpret_cast<const float2*>(up + (int64_t)dr * p.ldc2)
-                                     : *reinterpret_cast<const float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * n);
-              const float a = ag.x, g = ag.y;
+              const float2 ag = *reinterpret_cast<const float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * n);
               float gl, gr;
-              gelu_erf_both(g, gl, gr);
-              const float da = v * gl, dg = v * a * gr;
+              gelu_erf_both(ag.y, gl, gr);
+              const float da = v * gl, dg = v * ag.x * gr;
               c[0] = da;
               c[p.n_half] = dg;
               s1 += da; s2 += dg;

@@ -162,7 +162,8 @@ extern "C" int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream) {
   }
   if (m_tiles >= 32 && n_tiles >= 2 && !getenv("MT_NO_L2_BLOCKING")) {
     const int64_t panel = (int64_t)128 * d->K * 6;   // one column group's B panels: three bf16 planes
-    int gn = (int)((2 << 20) / (panel > 0 ? panel : 1));
+    static const int64_t group_bytes = getenv("MT_PLANES_GROUP_KB") ? (int64_t)atoi(getenv("MT_PLANES_GROUP_KB")) << 10 : (2 << 20);
+    int gn = (int)(group_bytes / (panel > 0 ? panel : 1));
     if (gn < 1) gn = 1;
     if (gn > n_tiles) gn = n_tiles;
     a.group_n = gn;

@@ -39,6 +39,9 @@
 #ifndef MT_PLANES_ABLATE      // tuning lab only: 1 no DMA, 2 no barrier, 4 no fragment reads, 8 no epilogue, 16 no MFMA
 #define MT_PLANES_ABLATE 0
 #endif
+#ifndef MT_PLANES_EPI_ABLATE  // tuning lab only (GEGLU-backward plane epilogue): 1 no pre-activation loads, 2 no gelu math, 4 no LDS transposition + plane stores,
+#define MT_PLANES_EPI_ABLATE 0 // 8 no plane stores (transposition kept), 16 no column-sum atomics
+#endif
 #ifndef MT_PLANES_PRIO        // tuning lab only: 1 = static priority 1 for waves in odd hardware wave slots (breaks the lockstep of the
 #define MT_PLANES_PRIO 0      // two co-resident blocks' waves on a SIMD), 2 = for odd blocks of 256 in launch order
 #endif
@@ -73,7 +76,7 @@ __device__ __forceinline__ void planes_emit_tile(const float (&v)[16], float* wl
     const bool live = rg < M;                               // padding rows of the last row block are written as zeros
     const float x[8] = {live ? lo.x : 0.f, live ? lo.y : 0.f, live ? lo.z : 0.f, live ? lo.w : 0.f,
                         live ? hi.x : 0.f, live ? hi.y : 0.f, live ? hi.z : 0.f, live ? hi.w : 0.f};
-    if (rg < o.rows_pad && cgl < o.cb16 * 16) planes_store8(o, rg, cgl, x);
+    if (rg < o.rows_pad && cgl < o.cb16 * 16) { if (MT_PLANES_EPI_ABLATE & 8) { if (x[0] + x[7] == 123.456f) o.p[0] = (__bf16)1.f; } else planes_store8(o, rg, cgl, x); }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next tile overwrites the patch
 }
@@ -105,40 +108,68 @@ __device__ __forceinline__ void planes_epilogue(const GemmArgs& p, f32x16 (&acc)
       planes_emit_tile(hv, wl, o, mw + i * 32, (n0 >> 1) + wn * 32, p.M, lane);
     }
   } else {
-    // (batching the pre-activation loads of a tile pair and sending both result tiles through two LDS patches at once measured
-    //  slower: 325 vs 309 us per launch, the registers it takes cost more than the waits it saves)
+    // Two phases, because loads and stores share the wave's vmcnt queue (gfx9 counts store acknowledgements there too): a tile-by-tile
+    // "load pre-activations, compute, store planes" sequence waits for the PREVIOUS tile's stores to be acknowledged before it sees
+    // its own loads (measured: 148 of 328 us per launch went to the 206 MB of pre-activation loads, 1.4 TB/s).  Phase 1 loads every
+    // pre-activation of the wave's tiles (one MFMA tile per batch) and turns the accumulators into both gradients in place -- da
+    // over acc, dg into `dgs` (the registers of the dead second accumulator); phase 2 only transposes through LDS and stores.
+    f32x16 dgs[TM][TN];
+    float s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * TN * 32 + j * 32 + col_l;
       const bool nok = n < p.N;
-      float s1 = 0.f, s2 = 0.f;
+      s1[j] = 0.f; s2[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float2 ag[16];                                      // one MFMA tile's pre-activations per batch: 32 registers next to acc + dgs
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + i * 32 + row_h + (r & 3) + 8 * (r >> 2);
+          ag[r] = ((MT_PLANES_EPI_ABLATE & 1) || !(m < p.M && nok)) ? make_float2(0.3f, 0.1f)
+                                                                     : *reinterpret_cast<const float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * n);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + i * 32 + row_h + (r & 3) + 8 * (r >> 2);
+          const float v = acc[i][j][r];
+          float gl, gr;
+          if (MT_PLANES_EPI_ABLATE & 2) { gl = ag[r].y; gr = ag[r].y + 1.f; } else gelu_erf_both(ag[r].y, gl, gr);
+          const bool live = m < p.M && nok;
+          const float da = live ? v * gl : 0.f, dg = live ? v * ag[r].x * gr : 0.f;
+          acc[i][j][r] = da;
+          dgs[i][j][r] = dg;
+          s1[j] += da; s2[j] += dg;
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // the next tile's 16 loads stay behind this tile's arithmetic (registers)
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+      const bool nok = n < p.N;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         float da[16], dg[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          da[r] = acc[i][j][r]; dg[r] = dgs[i][j][r];
           const int m = mw + i * 32 + row_h + (r & 3) + 8 * (r >> 2);
-          da[r] = 0.f; dg[r] = 0.f;
-          if (m < p.M && nok) {
-            const float2 ag = *reinterpret_cast<const float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * n);
-            const float v = acc[i][j][r];
-            float gl, gr;
-            gelu_erf_both(ag.y, gl, gr);
-            da[r] = v * gl;
-            dg[r] = v * ag.x * gr;
-            if (p.C) { p.C[(int64_t)m * p.ldc + n] = da[r]; p.C[(int64_t)m * p.ldc + p.n_half + n] = dg[r]; }
-            s1 += da[r]; s2 += dg[r];
-          }
+          if (p.C && m < p.M && nok) { p.C[(int64_t)m * p.ldc + n] = da[r]; p.C[(int64_t)m * p.ldc + p.n_half + n] = dg[r]; }
         }
-        planes_emit_tile(da, wl, o, mw + i * 32, n0 + wn * TN * 32 + j * 32, p.M, lane);
-        planes_emit_tile(dg, wl, o, mw + i * 32, p.n_half + n0 + wn * TN * 32 + j * 32, p.M, lane);
+        if (MT_PLANES_EPI_ABLATE & 4) { if (da[3] + dg[5] == 123.456f) p.col_sum[0] = 1.f; }
+        else {
+          planes_emit_tile(da, wl, o, mw + i * 32, n0 + wn * TN * 32 + j * 32, p.M, lane);
+          planes_emit_tile(dg, wl, o, mw + i * 32, p.n_half + n0 + wn * TN * 32 + j * 32, p.M, lane);
+        }
       }
-      if (p.col_sum) {                                      // bias gradient of the first feed-forward Linear: column sums of du
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
+      if (p.col_sum && !(MT_PLANES_EPI_ABLATE & 16)) {     // bias gradient of the first feed-forward Linear: column sums of du
+        float t1 = s1[j], t2 = s2[j];
+        t1 += __shfl_xor(t1, 32);
+        t2 += __shfl_xor(t2, 32);
         if (lane < 32 && nok) {
-          atomicAdd(p.col_sum + n, s1);
-          atomicAdd(p.col_sum + p.n_half + n, s2);
+          atomicAdd(p.col_sum + n, t1);
+          atomicAdd(p.col_sum + p.n_half + n, t2);
         }
       }
     }

@@ -169,12 +169,22 @@ static GemmArgs make_args(const Problem& pr, int bm, int bn, int& gx, int& gy, i
   return a;
 }
 
-template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, int EPI, int ST, int MINW, int BAL>
+template <int WM, int WN, int TM, int TN, bool AKM, bool BKM, int EPI, int ST, int MINW, int BAL, bool CPL = false>
 static float run_variant(const Problem& pr, int reps, const char* tag, bool check) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   int gx, gy;
   GemmArgs a = make_args(pr, BM, BN, gx, gy, 640);
-  auto k = gemm_planes_kernel<WM, WN, TM, TN, AKM, BKM, EPI, ST, MINW, BAL>;
+  static void* cpl_buf = nullptr;
+  if (CPL) {
+    const int c_cols = EPI == EPI_GEGLU ? a.n_half : 2 * a.n_half;
+    const int64_t el = (int64_t)((a.M + 31) / 32 * 32) * c_cols;
+    if (!cpl_buf) CK(hipMalloc(&cpl_buf, (size_t)el * 6));
+    a.c_planes = cpl_buf; a.c_pstride = el; a.ldcp = c_cols / 16; a.C = nullptr;
+    static float* cs = nullptr;
+    if (!cs) { CK(hipMalloc(&cs, (size_t)c_cols * 4)); CK(hipMemset(cs, 0, (size_t)c_cols * 4)); }
+    a.col_sum = cs;
+  }
+  auto k = gemm_planes_kernel<WM, WN, TM, TN, AKM, BKM, EPI, ST, MINW, BAL, CPL>;
   const size_t lds = (size_t)ST * 3 * (BM + BN) * 32;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   auto f = [&]() {
@@ -218,6 +228,7 @@ static void run_shape(const Shape& s, int reps) {
          "production mt_gemm (in-kernel split)", us, tf, tf / 416.7 * 100);
   constexpr bool AKM = OP == MT_OP_TN, BKM = OP != MT_OP_NT;
 #ifdef LAB_QUICK
+  if constexpr (EPI == EPI_GEGLU_BWD) run_variant<2, 2, 2, 2, AKM, BKM, EPI, 2, 2, BAL_PAIR, true>(pr, reps, "128x128 2 stages PAIR + planes out", false);
   run_variant<2, 2, 2, 2, AKM, BKM, EPI, 2, 2, BAL_PHASE>(pr, reps, "128x128 2 stages PHASE", true);
   if constexpr (OP != MT_OP_TN) run_variant<2, 2, 2, 2, AKM, BKM, EPI, 2, 2, BAL_PAIR>(pr, reps, "128x128 2 stages PAIR", true);
   run_variant<2, 2, 2, 2, AKM, BKM, EPI, 2, 3, BAL_NONE>(pr, reps, "128x128 2 stages NONE minw3", true);
