@@ -422,3 +422,30 @@ def test_bench_drops_pmc_counters_measured_on_other_sources(tmp_path, monkeypatc
     r = bench.mfma_roofline(170e12, True)
     assert r["peak"] == 416.7 and r["frac"] < 1 and r["frac_vs_fp32_mfma"] > 1
     assert bench.mfma_roofline(100e12, False)["peak"] == 157.3
+
+
+def test_plane_tensor_layout_spec():
+    """The operand format of mt_gemm_planes, restated with plain torch on the CPU: planes[3][Rp/32][Cp/16][32][16] bf16 holding the
+    exact three-piece split x = p0 + p1 + p2 (round-to-nearest bf16 at each level) with zero padding -- what every producer kernel
+    writes and what lib.planes_to_float() undoes.  mt_planes_elems (a host function of the library) gives the plane stride."""
+    h = lib.get()
+    for rows, cols in [(77, 40), (64, 32), (1, 8), (393 * 16, 512)]:
+        rp, cp = (rows + 31) // 32 * 32, (cols + 15) // 16 * 16
+        assert h.mt_planes_elems(rows, cols) == rp * cp
+        assert lib.planes_shape(rows, cols) == (3, rp // 32, cp // 16, 32, 16)
+        g = torch.Generator().manual_seed(rows)
+        x = torch.randn(rows, cols, generator=g) * torch.logspace(-6, 3, cols)[None, :]
+        p0 = x.bfloat16()
+        r1 = x - p0.float()
+        p1 = r1.bfloat16()
+        p2 = (r1 - p1.float()).bfloat16()
+        assert torch.equal(p0.float() + p1.float() + p2.float(), x), "three bf16 pieces carry all 24 mantissa bits"
+        full = torch.zeros(3, rp, cp, dtype=torch.bfloat16)
+        full[0, :rows, :cols], full[1, :rows, :cols], full[2, :rows, :cols] = p0, p1, p2
+        planes = full.reshape(3, rp // 32, 32, cp // 16, 16).permute(0, 1, 3, 2, 4).contiguous()      # 1 KB blocks of 32 rows x 16 columns
+        assert planes.shape == lib.planes_shape(rows, cols)
+        assert torch.equal(lib.planes_to_float(planes, rows, cols), x)
+        # element (r, c) of plane k sits at ((r // 32) * (cp // 16) + c // 16) * 512 + (r % 32) * 16 + c % 16
+        r, c = rows - 1, cols - 1
+        off = ((r // 32) * (cp // 16) + c // 16) * 512 + (r % 32) * 16 + c % 16
+        assert planes[1].reshape(-1)[off] == p1[r, c]
