@@ -932,6 +932,186 @@ __global__ __launch_bounds__(WPB * 64) void attn_patch_bwd_kernel(const float* _
   }
 }
 
+// ---------------------------------------------------------------------------------------- time attention backward, one patch per wavefront
+// One wavefront per (b, h, patch): F queries (the patch in every frame) x (cls + F) keys.  Global traffic is by whole 256-byte head rows
+// with lane = d (4F + 2 coalesced loads up front, kept in registers for the rank-1 updates at the end); the rows are mirrored in
+// 9 KB of LDS (F = 8) for the score phase, where lane = (query f, key j): two 64-long dot products per lane, the softmax and delta
+// across the F lanes of a query by shuffles.  dq / dk / dv are formed with lane = d from the registers and the F x (F+1) P / dS
+// matrices in LDS (broadcast reads), parked in the row tiles and written out eight columns per lane (plane blocks or fp32).
+// Against attn_patch_bwd_kernel<0,...> (7 patches per wavefront, 39 KB of LDS each, 4 wavefronts per CU): 16+ wavefronts per CU.
+template <int F, int WPB>
+__global__ __launch_bounds__(WPB * 64, F == 8 ? 4 : 2) void attn_time_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                float* __restrict__ dqkv, const uint8_t* __restrict__ mask,
+                                                                const uint8_t* __restrict__ ident, int B, int H, int n, float scale,
+                                                                const PlaneRef dp) {
+  constexpr int NK = F + 1, ST = 68, SPP = (NK + 3) & ~3;
+  constexpr int WAVE_LDS = (4 * F + 2) * ST + 2 * F * SPP;
+  constexpr int LPF = 64 / F;                                // lanes per query in the cls-column pass (F dims each)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* qT = lds + wave * WAVE_LDS;                         // [F][ST] scaled q, later dq
+  float* dT = qT + F * ST;                                   // [F][ST] dO
+  float* kT = dT + F * ST;                                   // [NK][ST] k (row 0 = cls), later dk
+  float* vT = kT + NK * ST;                                  // [NK][ST] v, later dv
+  float* Pm = vT + NK * ST;                                  // [F][SPP] P   (column 0 = cls key)
+  float* Sm = Pm + F * SPP;                                  // [F][SPP] dS
+  const int N = 1 + F * n, inner = H * DH, ld = 3 * inner;
+  const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
+  if (wid >= (int64_t)B * H * n) return;                     // wave-uniform; no block-level barrier below
+  const int p = (int)(wid % n);
+  const int bh = (int)(wid / n);
+  const int h = bh % H, b = bh / H;
+  const float* base = qkv + (int64_t)b * N * ld + h * DH;
+  float* dbase = dqkv + (int64_t)b * N * ld + h * DH;
+  const float* dob = dout + (int64_t)b * N * inner + h * DH;
+
+  float q[F], dO[F], k[NK], v[NK];
+  k[0] = base[inner + lane];
+  v[0] = base[2 * inner + lane];
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    const int64_t tok = 1 + f * n + p;
+    q[f] = base[tok * ld + lane];
+    k[f + 1] = base[tok * ld + inner + lane];
+    v[f + 1] = base[tok * ld + 2 * inner + lane];
+    dO[f] = dob[tok * inner + lane];
+  }
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    q[f] *= scale;
+    qT[f * ST + lane] = q[f];
+    dT[f * ST + lane] = dO[f];
+  }
+#pragma unroll
+  for (int j = 0; j < NK; ++j) { kT[j * ST + lane] = k[j]; vT[j * ST + lane] = v[j]; }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- the cls key's column: s_f0 = q_f . k_0, dP_f0 = dO_f . v_0 (LPF lanes per query)
+  {
+    const int f = lane / LPF, c = lane % LPF;
+    const float* qr = qT + f * ST + c * F;
+    const float* dr = dT + f * ST + c * F;
+    const float* kr = kT + c * F;
+    const float* vr = vT + c * F;
+    float a = 0.f, d2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < F; i += 4) {
+      const float4 qq = *reinterpret_cast<const float4*>(qr + i), kk = *reinterpret_cast<const float4*>(kr + i);
+      const float4 dd = *reinterpret_cast<const float4*>(dr + i), vv = *reinterpret_cast<const float4*>(vr + i);
+      a = fmaf(qq.x, kk.x, a); a = fmaf(qq.y, kk.y, a); a = fmaf(qq.z, kk.z, a); a = fmaf(qq.w, kk.w, a);
+      d2 = fmaf(dd.x, vv.x, d2); d2 = fmaf(dd.y, vv.y, d2); d2 = fmaf(dd.z, vv.z, d2); d2 = fmaf(dd.w, vv.w, d2);
+    }
+#pragma unroll
+    for (int o = 1; o < LPF; o <<= 1) { a += __shfl_xor(a, o); d2 += __shfl_xor(d2, o); }
+    if (c == 0) { Pm[f * SPP] = a; Sm[f * SPP] = d2; }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- scores, softmax, delta, dS: lane = (f, jj), key j = jj + 1 (frame jj)
+#pragma unroll 1
+  for (int pass = 0; pass < F * F / 64; ++pass) {
+    const int pi = pass * 64 + lane;
+    const int f = pi / F, jj = pi % F, j = jj + 1;
+    const float* qr = qT + f * ST;
+    const float* dr = dT + f * ST;
+    const float* kr = kT + j * ST;
+    const float* vr = vT + j * ST;
+    float s_a = 0.f, s_b = 0.f, d_a = 0.f, d_b = 0.f;
+#pragma unroll 2
+    for (int i = 0; i < DH / 8; ++i) {
+      const float4 q0 = *reinterpret_cast<const float4*>(qr + 8 * i), q1 = *reinterpret_cast<const float4*>(qr + 8 * i + 4);
+      const float4 k0 = *reinterpret_cast<const float4*>(kr + 8 * i), k1 = *reinterpret_cast<const float4*>(kr + 8 * i + 4);
+      s_a = fmaf(q0.x, k0.x, s_a); s_a = fmaf(q0.y, k0.y, s_a); s_a = fmaf(q0.z, k0.z, s_a); s_a = fmaf(q0.w, k0.w, s_a);
+      s_b = fmaf(q1.x, k1.x, s_b); s_b = fmaf(q1.y, k1.y, s_b); s_b = fmaf(q1.z, k1.z, s_b); s_b = fmaf(q1.w, k1.w, s_b);
+      const float4 o0 = *reinterpret_cast<const float4*>(dr + 8 * i), o1 = *reinterpret_cast<const float4*>(dr + 8 * i + 4);
+      const float4 v0 = *reinterpret_cast<const float4*>(vr + 8 * i), v1 = *reinterpret_cast<const float4*>(vr + 8 * i + 4);
+      d_a = fmaf(o0.x, v0.x, d_a); d_a = fmaf(o0.y, v0.y, d_a); d_a = fmaf(o0.z, v0.z, d_a); d_a = fmaf(o0.w, v0.w, d_a);
+      d_b = fmaf(o1.x, v1.x, d_b); d_b = fmaf(o1.y, v1.y, d_b); d_b = fmaf(o1.z, v1.z, d_b); d_b = fmaf(o1.w, v1.w, d_b);
+    }
+    float s = s_a + s_b;
+    const float dpv = d_a + d_b;
+    if (!(mask[b * F + jj] && ident[(b * F + f) * F + jj])) s = -FLT_MAX;        // masked_fill_(~mask, -finfo.max)
+    const float s0 = Pm[f * SPP], dp0 = Sm[f * SPP];
+    float mx = fmaxf(s, s0);
+#pragma unroll
+    for (int o = 1; o < F; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float e = expf(s - mx), e0 = expf(s0 - mx);
+    float sum = e;
+#pragma unroll
+    for (int o = 1; o < F; o <<= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / (sum + e0);
+    const float pj = e * inv, p0 = e0 * inv;
+    float delta = pj * dpv;
+#pragma unroll
+    for (int o = 1; o < F; o <<= 1) delta += __shfl_xor(delta, o);
+    delta = fmaf(p0, dp0, delta);
+    Pm[f * SPP + j] = pj;
+    Sm[f * SPP + j] = pj * (dpv - delta);
+    if (jj == 0) { Pm[f * SPP] = p0; Sm[f * SPP] = p0 * (dp0 - delta); }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- lane = d: dq_f = scale sum_j dS_fj k_j;  dk_j = sum_f dS_fj (scale q_f);  dv_j = sum_f P_fj dO_f
+  // (outer loops rolled: unrolled, the compiler hoists all 2 F (F+1) broadcast reads into registers)
+#pragma unroll 2
+  for (int f = 0; f < F; ++f) {
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) a = fmaf(Sm[f * SPP + j], k[j], a);
+    qT[f * ST + lane] = a * scale;
+  }
+#pragma unroll 1
+  for (int j = 0; j < NK; ++j) {
+    float ak = 0.f, av = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) { ak = fmaf(Sm[f * SPP + j], q[f], ak); av = fmaf(Pm[f * SPP + j], dO[f], av); }
+    if (j == 0) {                                            // the cls key is shared by every patch of this (b, h)
+      atomicAdd(dbase + inner + lane, ak);
+      atomicAdd(dbase + 2 * inner + lane, av);
+    } else {
+      kT[j * ST + lane] = ak;
+      vT[j * ST + lane] = av;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- write-out, eight columns per lane.  The wavefront owns its patch tokens' k / v rows of this head: their fp32 values hold the
+  // cls query's contribution (attn_cls_bwd_kernel) and are completed here.
+  for (int it = lane; it < 3 * F * 8; it += 64) {
+    const int r = it >> 3, seg = it & 7;
+    const int kind = r / F, f = r % F;                       // 0 dq, 1 dk, 2 dv
+    const int tok = 1 + f * n + p;
+    const float* src = (kind == 0 ? qT + f * ST : kind == 1 ? kT + (f + 1) * ST : vT + (f + 1) * ST) + seg * 8;
+    const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+    float o[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    float* g = dbase + (int64_t)tok * ld + kind * inner + seg * 8;
+    if (kind) {
+      const float4 e0 = *reinterpret_cast<const float4*>(g), e1 = *reinterpret_cast<const float4*>(g + 4);
+      o[0] += e0.x; o[1] += e0.y; o[2] += e0.z; o[3] += e0.w; o[4] += e1.x; o[5] += e1.y; o[6] += e1.z; o[7] += e1.w;
+    }
+    if (dp.p) planes_store8(dp, b * N + tok, kind * inner + h * DH + seg * 8, o);
+    else {
+      *reinterpret_cast<float4*>(g) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(g + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  }
+}
+
+template <int F, int WPB>
+int launch_time_bwd(const float* qkv, const float* dout, float* dqkv, const uint8_t* mask, const uint8_t* ident, int B, int H, int n,
+                    float scale, const PlaneRef& dp, hipStream_t s) {
+  constexpr int NK = F + 1, SPP = (NK + 3) & ~3;
+  const size_t lds = (size_t)WPB * ((4 * F + 2) * 68 + 2 * F * SPP) * sizeof(float);
+  const int64_t waves = (int64_t)B * H * n;
+  auto k = attn_time_bwd_kernel<F, WPB>;
+  if (lds > 48 * 1024) {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
+    if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_attn_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, dout, dqkv, mask, ident, B, H, n, scale, dp);
+  return check_launch("mt_attn_bwd(time)");
+}
+
 // plane output of mt_attn_bwd: the cls row of every clip (its dk / dv collect fp32 atomics from every group and are only final when
 // the patch kernels have finished) and the zero padding rows
 __global__ __launch_bounds__(256) void attn_bwd_cls_planes_kernel(const float* __restrict__ dqkv, int B, int N, int ld, const PlaneRef dp) {
@@ -1074,6 +1254,13 @@ extern "C" int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, con
       hipLaunchKernelGGL(attn_space_bwd_mfma_kernel<4>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n,
                          scale, dp);
       rc = check_launch("mt_attn_bwd(space, mfma)");
+    }
+  } else if (!getenv("MT_ATTN_TIME_OLD")) {
+    switch (F) {
+      case 8: rc = launch_time_bwd<8, 4>(qkv, dout, dqkv, mask, ident, B, H, n, scale, dp, s); break;
+      case 16: rc = launch_time_bwd<16, 2>(qkv, dout, dqkv, mask, ident, B, H, n, scale, dp, s); break;
+      case 32: rc = launch_patch_bwd<0, 33, 2, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, s); break;   // (130 row registers: spills)
+      default: return fail(MT_ERR_UNSUPPORTED, "mt_attn_bwd: num-frames %d unsupported (8/16/32)", F);
     }
   } else {
     switch (F) {
