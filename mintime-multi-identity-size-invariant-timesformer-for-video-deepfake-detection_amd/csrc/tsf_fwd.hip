@@ -258,6 +258,121 @@ __global__ __launch_bounds__(WPB * 64) void attn_patch_fwd_kernel(const float* _
   }
 }
 
+// ---------------------------------------------------------------------------------------- time attention, one patch per wavefront
+// One wavefront per (b, h, patch): F queries x (cls + F) keys (the backward twin is attn_time_bwd_kernel, tsf_bwd.hip).  3F + 2
+// coalesced 256-byte row loads with lane = d; q and k are mirrored in LDS for the scores (lane = (query f, key j): one 64-long dot
+// product, softmax across the F lanes of a query by shuffles); o_f = sum_j P_fj v_j with lane = d from the v registers and broadcast
+// reads of P; the rows go out eight columns per lane.  7 KB of LDS per wavefront against the 20+ KB of the 7-patch kernel.
+template <int F, int WPB>
+__global__ __launch_bounds__(WPB * 64, F == 8 ? 4 : 2) void attn_time_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                                const uint8_t* __restrict__ mask,
+                                                                                const uint8_t* __restrict__ ident, int B, int H, int n,
+                                                                                float scale, const PlaneRef op) {
+  constexpr int NK = F + 1, ST = 68, SPP = (NK + 3) & ~3;
+  constexpr int WAVE_LDS = (2 * F + 1) * ST + F * SPP;
+  constexpr int LPF = 64 / F;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* qT = lds + wave * WAVE_LDS;                         // [F][ST] scaled q, later o
+  float* kT = qT + F * ST;                                   // [NK][ST] k (row 0 = cls)
+  float* Pm = kT + NK * ST;                                  // [F][SPP] scores, then P (column 0 = cls key)
+  const int N = 1 + F * n, inner = H * DH, ld = 3 * inner;
+  const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
+  if (wid >= (int64_t)B * H * n) return;                     // wave-uniform; no block-level barrier below
+  const int p = (int)(wid % n);
+  const int bh = (int)(wid / n);
+  const int h = bh % H, b = bh / H;
+  const float* base = qkv + (int64_t)b * N * ld + h * DH;
+
+  float v[NK];
+  {
+    float q[F], k[NK];
+    k[0] = base[inner + lane];
+    v[0] = base[2 * inner + lane];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const int64_t tok = 1 + f * n + p;
+      q[f] = base[tok * ld + lane];
+      k[f + 1] = base[tok * ld + inner + lane];
+      v[f + 1] = base[tok * ld + 2 * inner + lane];
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) qT[f * ST + lane] = q[f] * scale;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) kT[j * ST + lane] = k[j];
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  {   // the cls key's column, LPF lanes per query
+    const int f = lane / LPF, c = lane % LPF;
+    const float* qr = qT + f * ST + c * F;
+    const float* kr = kT + c * F;
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < F; i += 4) {
+      const float4 qq = *reinterpret_cast<const float4*>(qr + i), kk = *reinterpret_cast<const float4*>(kr + i);
+      a = fmaf(qq.x, kk.x, a); a = fmaf(qq.y, kk.y, a); a = fmaf(qq.z, kk.z, a); a = fmaf(qq.w, kk.w, a);
+    }
+#pragma unroll
+    for (int o = 1; o < LPF; o <<= 1) a += __shfl_xor(a, o);
+    if (c == 0) Pm[f * SPP] = a;
+  }
+  __builtin_amdgcn_wave_barrier();
+
+#pragma unroll 1
+  for (int pass = 0; pass < F * F / 64; ++pass) {
+    const int pi = pass * 64 + lane;
+    const int f = pi / F, jj = pi % F, j = jj + 1;
+    const float* qr = qT + f * ST;
+    const float* kr = kT + j * ST;
+    float s_a = 0.f, s_b = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < DH / 8; ++i) {
+      const float4 q0 = *reinterpret_cast<const float4*>(qr + 8 * i), q1 = *reinterpret_cast<const float4*>(qr + 8 * i + 4);
+      const float4 k0 = *reinterpret_cast<const float4*>(kr + 8 * i), k1 = *reinterpret_cast<const float4*>(kr + 8 * i + 4);
+      s_a = fmaf(q0.x, k0.x, s_a); s_a = fmaf(q0.y, k0.y, s_a); s_a = fmaf(q0.z, k0.z, s_a); s_a = fmaf(q0.w, k0.w, s_a);
+      s_b = fmaf(q1.x, k1.x, s_b); s_b = fmaf(q1.y, k1.y, s_b); s_b = fmaf(q1.z, k1.z, s_b); s_b = fmaf(q1.w, k1.w, s_b);
+    }
+    float s = s_a + s_b;
+    if (!(mask[b * F + jj] && ident[(b * F + f) * F + jj])) s = -FLT_MAX;        // masked_fill_(~mask, -finfo.max)  (:82-85)
+    const float s0 = Pm[f * SPP];
+    float mx = fmaxf(s, s0);
+#pragma unroll
+    for (int o = 1; o < F; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float e = expf(s - mx), e0 = expf(s0 - mx);
+    float sum = e;
+#pragma unroll
+    for (int o = 1; o < F; o <<= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / (sum + e0);
+    Pm[f * SPP + j] = e * inv;
+    if (jj == 0) Pm[f * SPP] = e0 * inv;
+  }
+  __builtin_amdgcn_wave_barrier();
+
+#pragma unroll 2
+  for (int f = 0; f < F; ++f) {
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) a = fmaf(Pm[f * SPP + j], v[j], a);
+    qT[f * ST + lane] = a;
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  for (int it = lane; it < F * 8; it += 64) {
+    const int f = it >> 3, seg = it & 7;
+    const int tok = 1 + f * n + p;
+    const float* src = qT + f * ST + seg * 8;
+    const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+    const float o[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    if (out) {
+      float* g = out + ((int64_t)b * N + tok) * inner + h * DH + seg * 8;
+      *reinterpret_cast<float4*>(g) = a0;
+      *reinterpret_cast<float4*>(g + 4) = a1;
+    }
+    if (op.p) planes_store8(op, b * N + tok, h * DH + seg * 8, o);
+  }
+}
+
 // ---------------------------------------------------------------------------------------- space attention on the matrix cores
 // One wavefront per (b, h, frame): n = 49 patch queries x (cls + 49) keys x dim_head 64, padded to 64 x 64 and computed TRANSPOSED
 // so that nothing ever has to change layout between the two products (no LDS at all):
@@ -550,6 +665,21 @@ int launch_patch(const float* qkv, float* out, const uint8_t* mask, const uint8_
   hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, out, mask, ident, B, H, F, n, scale, op);
   return check_launch("mt_attn_fwd(patch)");
 }
+
+template <int F, int WPB>
+int launch_time_fwd(const float* qkv, float* out, const uint8_t* mask, const uint8_t* ident, int B, int H, int n, float scale,
+                    const PlaneRef& op, hipStream_t s) {
+  constexpr int NK = F + 1, SPP = (NK + 3) & ~3;
+  const size_t lds = (size_t)WPB * ((2 * F + 1) * 68 + F * SPP) * sizeof(float);
+  const int64_t waves = (int64_t)B * H * n;
+  auto k = attn_time_fwd_kernel<F, WPB>;
+  if (lds > 48 * 1024) {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
+    if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_attn_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, out, mask, ident, B, H, n, scale, op);
+  return check_launch("mt_attn_fwd(time)");
+}
 }  // namespace
 
 extern "C" int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const uint8_t* mask, const uint8_t* ident,
@@ -571,6 +701,12 @@ extern "C" int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const u
     const int64_t waves = (int64_t)B * H * F;
     hipLaunchKernelGGL(attn_space_fwd_mfma_kernel<4>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, out, B, H, F, n, scale, op);
     return check_launch("mt_attn_fwd(space, mfma)");
+  }
+  if (!getenv("MT_ATTN_TIME_OLD")) {
+    switch (F) {
+      case 8: return launch_time_fwd<8, 4>(qkv, out, mask, ident, B, H, n, scale, op, s);
+      case 16: return launch_time_fwd<16, 2>(qkv, out, mask, ident, B, H, n, scale, op, s);
+    }
   }
   switch (F) {
     case 8: return launch_patch<0, 9, 7, 68, 4>(qkv, out, mask, ident, B, H, F, n, scale, op, s);
