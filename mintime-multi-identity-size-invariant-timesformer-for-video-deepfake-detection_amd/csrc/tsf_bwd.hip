@@ -396,11 +396,28 @@ __device__ __forceinline__ float block_reduce(float v, float* red, int wave, int
   return r;
 }
 
+// The "factored" hand-over of the cls query's contribution to the patch keys (plane output only): per key and head the two scalars
+// dS_j and p_j of dk_j += dS_j (s q_cls), dv_j += p_j dO_cls -- the kernel that owns the key forms the rank-1 terms itself.  They live
+// in a part of the fp32 dqkv working buffer nothing else uses with plane output: the q-section (columns [0, inner)) of the clip's patch
+// rows 1 .., vector (which, h) in R = ceil(N / inner) consecutive rows.  Offsets are relative to the clip's first row.
+__device__ __forceinline__ int64_t cls_fact_off(int which, int h, int H, int j, int N, int inner, int ld) {
+  const int R = (N + inner - 1) / inner;
+  return (int64_t)(1 + (which * H + h) * R + j / inner) * ld + (j % inner);
+}
+
+__device__ __forceinline__ float mul_unfused(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;             // (a rounded product: the caller's addition must not contract it into an fma)
+}
+
 // Lane mapping: 16 lanes per key (lane & 15 = which float4 of the 64-wide head), 16 keys per pass of the block, so every K / V /
 // dK / dV row is one coalesced 256-byte access (one key per lane made each lane walk its own 6 KB-strided row: 105 us per launch).
 __global__ __launch_bounds__(CLS_W * 64) void attn_cls_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                  float* __restrict__ dqkv, const uint8_t* __restrict__ mask,
-                                                                 int B, int H, int F, int n, float scale) {
+                                                                 int B, int H, int F, int n, float scale, int factored) {
+  // factored: the patch keys receive only the two scalars of the rank-1 contribution (cls_fact_off); the patch kernel that owns the key
+  // multiplies them with the cls query / cls dO rows itself.  Saves writing and re-reading two 64-float rows per key and head (52 + 52
+  // MB per call at B = 32).  The cls key's own row (j = 0) stays full: the patch kernels add to it atomically.
   extern __shared__ __attribute__((aligned(16))) float lds[];   // p[N], dS[N], CLS_W reduction slots, CLS_W x 64 partial dq
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = tid & 15, grp = tid >> 4;                     // float4 index inside the head, key slot inside a pass
@@ -465,8 +482,16 @@ __global__ __launch_bounds__(CLS_W * 64) void attn_cls_bwd_kernel(const float* _
       if (j < N) {
         const float p = pl_[j];
         const float dS = p * (ds_[j] - delta);
-        *reinterpret_cast<float4*>(dbase + (int64_t)j * ld + inner) = make_float4(dS * q.x, dS * q.y, dS * q.z, dS * q.w);
-        *reinterpret_cast<float4*>(dbase + (int64_t)j * ld + 2 * inner) = make_float4(p * dO.x, p * dO.y, p * dO.z, p * dO.w);
+        if (factored && j > 0) {
+          if (sub == 0) {
+            float* dclip = dqkv + (int64_t)b * N * ld;
+            dclip[cls_fact_off(0, h, H, j, N, inner, ld)] = dS;
+            dclip[cls_fact_off(1, h, H, j, N, inner, ld)] = p;
+          }
+        } else {
+          *reinterpret_cast<float4*>(dbase + (int64_t)j * ld + inner) = make_float4(dS * q.x, dS * q.y, dS * q.z, dS * q.w);
+          *reinterpret_cast<float4*>(dbase + (int64_t)j * ld + 2 * inner) = make_float4(p * dO.x, p * dO.y, p * dO.z, p * dO.w);
+        }
         dq.x = fmaf(dS, kk[u].x, dq.x); dq.y = fmaf(dS, kk[u].y, dq.y); dq.z = fmaf(dS, kk[u].z, dq.z); dq.w = fmaf(dS, kk[u].w, dq.w);
       }
     }
@@ -510,7 +535,7 @@ __device__ __forceinline__ void load_row32(const float* __restrict__ p, float (&
   }
 }
 
-template <int WPB>
+template <int WPB, bool FACT = false>
 __global__ __launch_bounds__(WPB * 64) void attn_space_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                       float* __restrict__ dqkv, int B, int H, int F, int n,
                                                                       float scale, const PlaneRef dp) {
@@ -678,7 +703,19 @@ __global__ __launch_bounds__(WPB * 64) void attn_space_bwd_mfma_kernel(const flo
 #pragma unroll
             for (int e = 0; e < 4; ++e) { atomicAdd(krow + d0 + e, dk[i][4 * g + e]); atomicAdd(vrow + d0 + e, dv[i][4 * g + e]); }
           } else {
-            float4 a = *reinterpret_cast<const float4*>(krow + d0), v = *reinterpret_cast<const float4*>(vrow + d0);
+            float4 a, v;
+            if constexpr (FACT) {               // the cls query's rank-1 contribution from its two scalars (attn_cls_bwd_kernel, factored)
+              // (the same two roundings as the full rows the non-factored kernel stores: dS * (q * scale), p * dO; no contraction)
+              const float* dclip = dqkv + (int64_t)b * N * ld;
+              const float dsc = dclip[cls_fact_off(0, h, H, tok_k(key), N, inner, ld)];
+              const float pc = dclip[cls_fact_off(1, h, H, tok_k(key), N, inner, ld)];
+              const float4 qc = *reinterpret_cast<const float4*>(base + d0), dc = *reinterpret_cast<const float4*>(dobase + d0);
+              a = make_float4(mul_unfused(dsc, mul_unfused(qc.x, scale)), mul_unfused(dsc, mul_unfused(qc.y, scale)),
+                              mul_unfused(dsc, mul_unfused(qc.z, scale)), mul_unfused(dsc, mul_unfused(qc.w, scale)));
+              v = make_float4(mul_unfused(pc, dc.x), mul_unfused(pc, dc.y), mul_unfused(pc, dc.z), mul_unfused(pc, dc.w));
+            } else {
+              a = *reinterpret_cast<const float4*>(krow + d0); v = *reinterpret_cast<const float4*>(vrow + d0);
+            }
             a.x += dk[i][4 * g]; a.y += dk[i][4 * g + 1]; a.z += dk[i][4 * g + 2]; a.w += dk[i][4 * g + 3];
             v.x += dv[i][4 * g]; v.y += dv[i][4 * g + 1]; v.z += dv[i][4 * g + 2]; v.w += dv[i][4 * g + 3];
             if (dp.p) {                           // the group owns its patch keys: these are the final dk / dv values
@@ -939,7 +976,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_patch_bwd_kernel(const float* _
 // across the F lanes of a query by shuffles.  dq / dk / dv are formed with lane = d from the registers and the F x (F+1) P / dS
 // matrices in LDS (broadcast reads), parked in the row tiles and written out eight columns per lane (plane blocks or fp32).
 // Against attn_patch_bwd_kernel<0,...> (7 patches per wavefront, 39 KB of LDS each, 4 wavefronts per CU): 16+ wavefronts per CU.
-template <int F, int WPB>
+template <int F, int WPB, bool FACT>
 __global__ __launch_bounds__(WPB * 64, F == 8 ? 4 : 2) void attn_time_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 float* __restrict__ dqkv, const uint8_t* __restrict__ mask,
                                                                 const uint8_t* __restrict__ ident, int B, int H, int n, float scale,
@@ -1086,8 +1123,19 @@ __global__ __launch_bounds__(WPB * 64, F == 8 ? 4 : 2) void attn_time_bwd_kernel
     float o[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
     float* g = dbase + (int64_t)tok * ld + kind * inner + seg * 8;
     if (kind) {
-      const float4 e0 = *reinterpret_cast<const float4*>(g), e1 = *reinterpret_cast<const float4*>(g + 4);
-      o[0] += e0.x; o[1] += e0.y; o[2] += e0.z; o[3] += e0.w; o[4] += e1.x; o[5] += e1.y; o[6] += e1.z; o[7] += e1.w;
+      if constexpr (FACT) {                 // the cls query's rank-1 contribution from its two scalars (attn_cls_bwd_kernel, factored)
+        // (the same two roundings as the full rows the non-factored kernel stores: dS * (q * scale), p * dO; no contraction)
+        const float sc = dqkv[(int64_t)b * N * ld + cls_fact_off(kind - 1, h, H, tok, N, inner, ld)];
+        const float mul = kind == 1 ? scale : 1.0f;
+        const float* rc = (kind == 1 ? base : dob) + seg * 8;          // row 0: the cls query / its dO
+        const float4 e0 = *reinterpret_cast<const float4*>(rc), e1 = *reinterpret_cast<const float4*>(rc + 4);
+        const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] += mul_unfused(sc, mul_unfused(e[i], mul));
+      } else {
+        const float4 e0 = *reinterpret_cast<const float4*>(g), e1 = *reinterpret_cast<const float4*>(g + 4);
+        o[0] += e0.x; o[1] += e0.y; o[2] += e0.z; o[3] += e0.w; o[4] += e1.x; o[5] += e1.y; o[6] += e1.z; o[7] += e1.w;
+      }
     }
     if (dp.p) planes_store8(dp, b * N + tok, kind * inner + h * DH + seg * 8, o);
     else {
@@ -1099,11 +1147,11 @@ __global__ __launch_bounds__(WPB * 64, F == 8 ? 4 : 2) void attn_time_bwd_kernel
 
 template <int F, int WPB>
 int launch_time_bwd(const float* qkv, const float* dout, float* dqkv, const uint8_t* mask, const uint8_t* ident, int B, int H, int n,
-                    float scale, const PlaneRef& dp, hipStream_t s) {
+                    float scale, const PlaneRef& dp, bool fact, hipStream_t s) {
   constexpr int NK = F + 1, SPP = (NK + 3) & ~3;
   const size_t lds = (size_t)WPB * ((4 * F + 2) * 68 + 2 * F * SPP) * sizeof(float);
   const int64_t waves = (int64_t)B * H * n;
-  auto k = attn_time_bwd_kernel<F, WPB>;
+  auto k = fact ? attn_time_bwd_kernel<F, WPB, true> : attn_time_bwd_kernel<F, WPB, false>;
   if (lds > 48 * 1024) {
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_attn_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
@@ -1243,22 +1291,27 @@ extern "C" int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, con
   const int N = 1 + F * n;
   const int rp = (B * N + 31) & ~31, ld = 3 * H * DH;
   const PlaneRef dp{reinterpret_cast<__bf16*>(dqkv_planes), (int64_t)rp * ld, ld / 16, rp};
-  hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(CLS_W * 64), (2 * N + CLS_W + 4 + CLS_W * 64) * sizeof(float), s, qkv, dout, dqkv, mask, B, H, F, n, scale);
+  static const bool time_old = getenv("MT_ATTN_TIME_OLD") != nullptr;    // A/B aid: the 7-patches-per-wavefront kernel
+  static const bool valu = getenv("MT_ATTN_VALU") != nullptr;            // A/B aid: the one-lane-per-query space kernel
+  static const bool fact_on = !getenv("MT_ATTN_CLS_FACT") || atoi(getenv("MT_ATTN_CLS_FACT")) != 0;
+  // with plane output the fp32 dqkv is working memory: the cls query's contribution to the patch keys crosses to the patch kernel as two
+  // scalars per key and head (kernels that understand it: the MFMA space kernel, the one-patch-per-wavefront time kernel)
+  const bool fact = fact_on && dqkv_planes && ((mode == 1 && !valu) || (mode == 0 && !time_old && (F == 8 || F == 16)));
+  hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(CLS_W * 64), (2 * N + CLS_W + 4 + CLS_W * 64) * sizeof(float), s, qkv, dout, dqkv, mask, B, H, F, n, scale, fact ? 1 : 0);
   int rc = check_launch("mt_attn_bwd(cls)");
   if (rc || mode == 2) return rc;                 // mode 2: the cls query's adjoint only (dk / dv of every key, dq of the cls row)
   if (mode == 1) {
-    static const bool valu = getenv("MT_ATTN_VALU") != nullptr;     // A/B aid: the one-lane-per-query kernel
     if (valu) rc = launch_patch_bwd<1, 50, 1, 64, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, s);
     else {
       const int64_t waves = (int64_t)B * H * F;
-      hipLaunchKernelGGL(attn_space_bwd_mfma_kernel<4>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n,
-                         scale, dp);
+      if (fact) hipLaunchKernelGGL((attn_space_bwd_mfma_kernel<4, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n, scale, dp);
+      else hipLaunchKernelGGL((attn_space_bwd_mfma_kernel<4, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n, scale, dp);
       rc = check_launch("mt_attn_bwd(space, mfma)");
     }
-  } else if (!getenv("MT_ATTN_TIME_OLD")) {
+  } else if (!time_old) {
     switch (F) {
-      case 8: rc = launch_time_bwd<8, 4>(qkv, dout, dqkv, mask, ident, B, H, n, scale, dp, s); break;
-      case 16: rc = launch_time_bwd<16, 2>(qkv, dout, dqkv, mask, ident, B, H, n, scale, dp, s); break;
+      case 8: rc = launch_time_bwd<8, 4>(qkv, dout, dqkv, mask, ident, B, H, n, scale, dp, fact, s); break;
+      case 16: rc = launch_time_bwd<16, 2>(qkv, dout, dqkv, mask, ident, B, H, n, scale, dp, fact, s); break;
       case 32: rc = launch_patch_bwd<0, 33, 2, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, s); break;   // (130 row registers: spills)
       default: return fail(MT_ERR_UNSUPPORTED, "mt_attn_bwd: num-frames %d unsupported (8/16/32)", F);
     }

@@ -702,7 +702,8 @@ extern "C" int mt_attn_fwd(const float* qkv, float* out, float* cls_att, const u
     hipLaunchKernelGGL(attn_space_fwd_mfma_kernel<4>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, out, B, H, F, n, scale, op);
     return check_launch("mt_attn_fwd(space, mfma)");
   }
-  if (!getenv("MT_ATTN_TIME_OLD")) {
+  static const bool time_old = getenv("MT_ATTN_TIME_OLD") != nullptr;    // A/B aid: the 7-patches-per-wavefront kernel
+  if (!time_old) {
     switch (F) {
       case 8: return launch_time_fwd<8, 4>(qkv, out, mask, ident, B, H, n, scale, op, s);
       case 16: return launch_time_fwd<16, 2>(qkv, out, mask, ident, B, H, n, scale, op, s);
