@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 // one block of CLS_W wavefronts per (b,h).  Writes dq (row 0) and INITIALISES dk, dv for every key row of this head with the cls
 // query's contribution; the patch kernels then accumulate on top.  Keys are spread over all lanes of the block for the per-key
 // work and over its wavefronts for the dq reduction.
-constexpr int CLS_W = 4;
+constexpr int CLS_W = 16;          // (16 wavefronts: the N keys in two trips of 256 -- with 4 the kernel was a chain of 2 x 7 exposed round trips)
 
 __device__ __forceinline__ float block_reduce(float v, float* red, int wave, int lane, bool is_max) {
   v = is_max ? wave_max(v) : wave_sum(v);
