@@ -22,10 +22,24 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 111
+#define MT_VERSION 112
 
 int mt_version(void);
 const char* mt_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Deterministic mode (reference train.py:110 `cudnn.deterministic = True`).  Off by default (MT_DETERMINISTIC=1 in the environment
+ * turns it on at load time).  With the switch on no floating-point atomic is issued anywhere in the training step: partial sums go
+ * through logs / split-K slabs in a per-stream workspace OWNED BY THE LIBRARY (the one exception to "never allocates": grown with
+ * hipMalloc on first use, which may synchronise) and are added in a fixed order, so the same inputs and state give bit-identical
+ * gradients run after run.  Slower (the bench line's `deterministic` leg has the cost).  Returns 0 / the current setting.
+ * mt_det_bn_sums: BatchNorm sums in fixed order from a stored tensor x [rows][C] into stats[0 .. 2C) (fp64, +=): mode 0 = sum x,
+ * sum x^2 (forward batch statistics); mode 1 = sum x, sum x * (z - mean) * invstd (backward; mean_invstd = [2][C]).  The engines call
+ * it instead of the producers' fused statistics when the switch is on.
+ */
+int mt_set_deterministic(int on);
+int mt_get_deterministic(void);
+int mt_det_bn_sums(const float* x, const float* z, const float* mean_invstd, int64_t rows, int C, int mode, double* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense contraction family (fp32 MFMA).  Replaces every nn.Linear / 1x1 Conv2d / their autograd:

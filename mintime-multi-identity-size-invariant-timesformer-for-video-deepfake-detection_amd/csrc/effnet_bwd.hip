@@ -10,6 +10,7 @@
 //   * swish'(u) = sig(u)*(1+u*(1-sig(u))) is recomputed from z (utils.py:70-75 saves only the input as well).
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
+#include "det.hpp"
 #include <stdlib.h>
 
 using namespace mt;
@@ -351,7 +352,7 @@ template <int K, int S, int T, int ACT, int CC>
 __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
     const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ zin,
     const float* __restrict__ scale_in, const float* __restrict__ shift_in, float* __restrict__ dw, int N, int H, int W, int C,
-    int Ho, int Wo) {
+    int Ho, int Wo, const DetLog det) {
   constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
   constexpr int CQN = CC / 4;
   constexpr int IH = (T - 1) * S + K;
@@ -463,8 +464,15 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
     float4 t = f4(0, 0, 0, 0);
     for (int g = 0; g < PS; ++g) t = add4(t, ld4(red + (((g * K + khh) * CQN + q) * K + kw) * 4));
     const int c = c0 + q * 4, tp = khh * K + kw;
-    atomicAdd(dw + (c + 0) * K * K + tp, t.x); atomicAdd(dw + (c + 1) * K * K + tp, t.y);
-    atomicAdd(dw + (c + 2) * K * K + tp, t.z); atomicAdd(dw + (c + 3) * K * K + tp, t.w);
+    if (det.vals) {                               // deterministic mode: group = channel chunk, rank = the block's first tile (det.hpp)
+      const int rk = (int)tile0, jb = q * 4 * K * K + tp;
+      det_put(det, chunk_id, rk, jb, t.x); det_put(det, chunk_id, rk, jb + K * K, t.y);
+      det_put(det, chunk_id, rk, jb + 2 * K * K, t.z); det_put(det, chunk_id, rk, jb + 3 * K * K, t.w);
+      if (rk == 0 && tid == 0) det_base(det, chunk_id, (int64_t)c0 * K * K);
+    } else {
+      atomicAdd(dw + (c + 0) * K * K + tp, t.x); atomicAdd(dw + (c + 1) * K * K + tp, t.y);
+      atomicAdd(dw + (c + 2) * K * K + tp, t.z); atomicAdd(dw + (c + 3) * K * K + tp, t.w);
+    }
   }
 }
 
@@ -486,8 +494,10 @@ int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, co
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(k, dim3(bx), dim3(256), lds, s, du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo);
-  return check_launch("mt_dwconv_bwd(weight, tiled)");
+  DetScope det(s, chunks, (int)((bx >> 3) / chunks) * 8, CC * K * K);     // ranks = first tiles of a chunk's blocks (xcd_chunk_tile)
+  hipLaunchKernelGGL(k, dim3(bx), dim3(256), lds, s, du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, det.log);
+  const int rc = check_launch("mt_dwconv_bwd(weight, tiled)");
+  return rc ? rc : det.reduce_f32(dw);
 }
 
 // ------------------------------------------------------------------------------------------------ K7: depthwise dgrad, LDS-tiled
@@ -713,7 +723,8 @@ int launch_dw_bwd_tiled_any(const float* du, const float* z, const float* kabc, 
 // dW[co,ci,kh,kw] += sum_pix dz0[pix,co] * x[n, 2oh+kh-P, 2ow+kw-P, ci],  dz0 = ka*du+kb*z+kc
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ du, const float* __restrict__ z,
                                                          const float* __restrict__ kabc, const void* __restrict__ xv, int x_u8,
-                                                         float* __restrict__ dw, int N, int H, int W, int Ho, int Wo, int pad0) {
+                                                         float* __restrict__ dw, int N, int H, int W, int Ho, int Wo, int pad0,
+                                                         const DetLog det) {
   const float* x = reinterpret_cast<const float*>(xv);
   const uint8_t* xb = reinterpret_cast<const uint8_t*>(xv);
   constexpr int CO = 32, TP = 64, TAPS = 27;
@@ -769,7 +780,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     const int tp = g + 8 * i;
     if (tp < TAPS) {
       const int ci = tp % 3, kk = tp / 3, kw = kk % 3, kh = kk / 3;
-      atomicAdd(dw + ((co * 3 + ci) * 3 + kh) * 3 + kw, acc[i]);
+      if (det.vals) det_put(det, 0, blockIdx.x, ((co * 3 + ci) * 3 + kh) * 3 + kw, acc[i]);     // deterministic mode: block order
+      else atomicAdd(dw + ((co * 3 + ci) * 3 + kh) * 3 + kw, acc[i]);
     }
   }
 }
@@ -849,6 +861,7 @@ extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, co
   if (parts_mask & 1) {
   int parts = 1;
   while ((int64_t)N * (CQ / CQB) * parts < 2048 && HW / (parts * 2) >= PB * 16) parts *= 2;
+  if (det_enabled()) parts = 1;                  // deterministic mode: one block per (image, channel chunk), plain stores
   if (parts > 1 && hipMemsetAsync(dgate, 0, (size_t)N * C * sizeof(float), s) != hipSuccess)
     return fail(MT_ERR_LAUNCH, "mt_se_bwd: memset failed");
   hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(N, CQ / CQB, parts), dim3(CQB * PB), (size_t)PB * CQB * 4 * sizeof(float), s, da, z,
@@ -866,6 +879,7 @@ extern "C" int mt_se_bwd(const float* da, const float* z, const float* scale, co
   // images per block: enough blocks to cover the chip a few times over, few enough that the atomic partial sums stay cheap
   int ipb = 64;
   while (ipb > 16 && (int64_t)((C + 63) / 64) * ((N + ipb - 1) / ipb) < 128) ipb >>= 1;
+  if (det_enabled()) ipb = N;                    // deterministic mode: every output element has one contributing block
   hipLaunchKernelGGL(se_wgrad_kernel, dim3((C + 63) / 64, (N + ipb - 1) / ipb), dim3(256), 0, s, dpre2, dhid, hidden, pooled, dw1,
                      db1, dw2, db2, N, C, CS, ipb);
   return check_launch("mt_se_bwd(wgrad)");
@@ -893,7 +907,10 @@ extern "C" int mt_stem_conv_wgrad(const float* du, const float* z, const float* 
   if (!du || !z || !kabc || !x || !dw) return fail(MT_ERR_ARG, "mt_stem_conv_wgrad: null pointer");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int padt = max((Ho - 1) * 2 + 3 - H, 0);
-  if (Wo <= 128) return stem_wgrad_mfma(du, z, kabc, x, x_is_u8, dw, N, H, W, Ho, Wo, padt / 2, (hipStream_t)stream);
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, du, z, kabc, x, x_is_u8, dw, N, H, W, Ho, Wo, padt / 2);
-  return check_launch("mt_stem_conv_wgrad");
+  // (deterministic mode takes the outer-product kernel: the MFMA form meets its row groups with LDS atomics)
+  if (Wo <= 128 && !det_enabled()) return stem_wgrad_mfma(du, z, kabc, x, x_is_u8, dw, N, H, W, Ho, Wo, padt / 2, (hipStream_t)stream);
+  DetScope det((hipStream_t)stream, 1, 1024, 32 * 27, true, true);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, du, z, kabc, x, x_is_u8, dw, N, H, W, Ho, Wo, padt / 2, det.log);
+  const int rc = check_launch("mt_stem_conv_wgrad");
+  return rc ? rc : det.reduce_f32(dw);
 }

@@ -2,6 +2,7 @@
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
 #include "gemm_core.hpp"
+#include "det.hpp"
 #include <stdlib.h>
 
 using namespace mt;
@@ -64,7 +65,7 @@ static long long* g_trace = nullptr;
 // tuning aid, not part of the ABI header: per-block phase timestamps of the following mt_gemm launches (NULL = off)
 extern "C" void mt_debug_gemm_trace(long long* buf) { g_trace = buf; }
 
-extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
+static int gemm_impl(const mt_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return fail(MT_ERR_ARG, "mt_gemm: null pointer");
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return fail(MT_ERR_ARG, "mt_gemm: bad shape %d %d %d", d->M, d->N, d->K);
   if ((d->lda & 3) || (d->ldb & 3)) return fail(MT_ERR_ARG, "mt_gemm: lda/ldb must be multiples of 4 floats");
@@ -90,7 +91,10 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   a.a_planes = nullptr; a.a_pstride = 0; a.c_planes = nullptr; a.c_pstride = 0; a.ldcp = 0; a.sk_ws = nullptr; a.sk_flags = nullptr; a.sk_on = 0; a.wave_prio = 0;
   a.e_scale = d->e_scale; a.e_shift = d->e_shift; a.e_gate = d->e_gate; a.e_dpool = d->e_dpool; a.e_mi = d->e_mi;
   a.e_hw = d->e_hw > 0 ? d->e_hw : 1;
-  a.xcd_k = 0;
+  a.xcd_k = 0; a.det_slab = 0;
+  a.det.vals = nullptr; a.det.base = nullptr; a.det.R = 0; a.det.P = 0;
+  if (d->epilogue == MT_EPI_GEGLU_BWD)
+    if (int rc = det_gemm_colsum_setup(a.det, d->M, d->n_half, d->col_sum, s)) return rc;
   a.A2 = d->A2; a.b_scale = d->b_scale; a.b_shift = d->b_shift; a.b_gate = d->b_gate; a.b_hw = d->b_hw > 0 ? d->b_hw : 1;
 
   // K-contiguous operands need K % 4 == 0 (float4 along K); k-major operands need M resp. N % 4 == 0
@@ -171,6 +175,8 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
     splits = (d->K + chunk - 1) / chunk;
     a.k_chunk = chunk;
     grid.y = splits;
+    if (d->epilogue == MT_EPI_ATOMIC)
+      if (int rc = det_gemm_setup(a.C, a.ldc, a.det_slab, d->M, d->N, splits, a.c_map.gin != 0, s)) return rc;
     if (d->b_prologue == MT_BPRO_BN_SWISH_GATE) {
       if (d->prologue == MT_PRO_BN_BWD && d->epilogue == MT_EPI_ATOMIC)
         return launch<LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_ATOMIC, BPRO_BN_SWISH_GATE>(cfg, a, grid, s);
@@ -193,6 +199,7 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
     splits = (d->K + chunk - 1) / chunk;
     a.k_chunk = chunk;
     grid.y = splits;
+    if (int rc = det_gemm_setup(a.C, a.ldc, a.det_slab, d->M, d->N, splits, a.c_map.gin != 0, s)) return rc;
     COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_NONE, EPI_ATOMIC)
     COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_ATOMIC)
     return fail(MT_ERR_UNSUPPORTED, "mt_gemm: split-K atomic epilogue only without prologue");
@@ -215,6 +222,12 @@ extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_ACT_BWD)
 #undef COMBO
   return fail(MT_ERR_UNSUPPORTED, "mt_gemm: unsupported op/prologue/epilogue %d/%d/%d", d->op, d->prologue, d->epilogue);
+}
+
+extern "C" int mt_gemm(const mt_gemm_desc* d, void* stream) {
+  const int rc = gemm_impl(d, stream);
+  if (rc) { (void)mt::det_gemm_finish(nullptr, false); return rc; }
+  return mt::det_gemm_finish((hipStream_t)stream, true);       // deterministic mode: split-K slabs -> C in split order (det.hpp)
 }
 
 extern "C" int mt_version(void) { return MT_VERSION; }

@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "det.hpp"
 
 #ifndef MT_BK
 #define MT_BK 16
@@ -156,6 +157,8 @@ struct GemmArgs {
   // stream-K (gemm_planes.hpp): persistent grid, per-block partial-tile slabs [grid][BM*BN] fp32 + one flag word per block
   float* sk_ws; int* sk_flags; int sk_on;
   int wave_prio;                        // plane loop: s_setprio level of every wave (0-3): main-queue GEMMs above the weight-gradient stream's
+  DetLog det;                           // deterministic mode: log of the epilogue's column sums (col_sum)
+  int64_t det_slab;                     // deterministic mode: C is a [splits][M][N] workspace, this is M * N (0 = atomics)
   int xcd_k;                            // split-K weight gradients: every XCD owns whole K-ranges (gemm_split.hpp), grid = (tiles, splits % 8 == 0)
 };
 
@@ -241,7 +244,7 @@ __device__ __forceinline__ bool tile_coords(const GemmArgs& p, int& mt_, int& nt
 // one base pointer per lane and element offsets that are wave-uniform multiples of the leading dimension (the checked form costs
 // ~60 ISA instructions per stored element -- a tenth of a K = 512 problem's run time).
 template <int TM, int TN, int EPI, bool FAST>
-__device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane) {
+__device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int split) {
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
   const int mw = m0 + wm * TM * 32;               // first row of this wavefront's tile
@@ -376,7 +379,7 @@ __device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&a
       if constexpr (EPI == EPI_STORE)
         bias = (nok && p.bias) ? p.bias[n] : 0.f;
       if constexpr (EPI == EPI_ATOMIC)      // split-K: the bias rides on the first K-slice only
-        bias = (nok && p.bias && blockIdx.y == 0) ? p.bias[n] : 0.f;
+        bias = (nok && p.bias && split == 0) ? p.bias[n] : 0.f;
       float s1 = 0.f, s2 = 0.f;
       float* cp = p.C + (int64_t)(mw + row_h) * p.ldc + n;                         // FAST path base
 #pragma unroll
@@ -398,7 +401,8 @@ __device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&a
               *c = v;
               s1 += v; s2 += v * v;
             } else if constexpr (EPI == EPI_ATOMIC) {
-              atomicAdd(c, v + bias);
+              if (p.det_slab) c[(int64_t)split * p.det_slab] = v + bias;     // deterministic mode: partial tile into its split's slab (det.hpp)
+              else atomicAdd(c, v + bias);
             } else if constexpr (EPI == EPI_GEGLU_BWD) {
               // n indexes h columns [0, n_half); u = [a | g] pre-activations
               const float2 ag = *reinterpret_cast<const float2*>(p.C2 + (int64_t)m * p.ldc2 + 2 * n);
@@ -417,8 +421,15 @@ __device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&a
           s1 += __shfl_xor(s1, 32);
           s2 += __shfl_xor(s2, 32);
           if (lane < 32 && nok) {
-            atomicAdd(p.col_sum + n, s1);
-            atomicAdd(p.col_sum + p.n_half + n, s2);
+            if (p.det.vals) {                 // deterministic mode: group = 32-column block, rank = 32-row block of the wave's first row (det.hpp)
+              const int rk = mw >> 5;
+              det_put(p.det, n >> 5, rk, n & 31, s1);
+              det_put(p.det, (p.n_half + n) >> 5, rk, n & 31, s2);
+              if (rk == 0 && (n & 31) == 0) { det_base(p.det, n >> 5, n); det_base(p.det, (p.n_half + n) >> 5, p.n_half + n); }
+            } else {
+              atomicAdd(p.col_sum + n, s1);
+              atomicAdd(p.col_sum + p.n_half + n, s2);
+            }
           }
         }
       }
@@ -436,14 +447,15 @@ __device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&a
 }
 
 template <int TM, int TN, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int split = -1) {
+  if (split < 0) split = blockIdx.y;                 // split-K index (the XCD-major weight-gradient order passes its own)
   // wave-uniform: is this wavefront's TM*32 x TN*32 tile entirely inside the output, with identity row order?
   const int mw = m0 + wm * TM * 32;
   bool interior = p.c_map.gin == 0 && mw + TM * 32 <= p.M;
   if constexpr (EPI == EPI_GEGLU) interior = interior && (n0 >> 1) + wn * 32 + 32 <= p.n_half;
   else interior = interior && n0 + wn * TN * 32 + TN * 32 <= p.N;
-  if (interior) gemm_epilogue_body<TM, TN, EPI, true>(p, acc, m0, n0, wm, wn, lane);
-  else gemm_epilogue_body<TM, TN, EPI, false>(p, acc, m0, n0, wm, wn, lane);
+  if (interior) gemm_epilogue_body<TM, TN, EPI, true>(p, acc, m0, n0, wm, wn, lane, split);
+  else gemm_epilogue_body<TM, TN, EPI, false>(p, acc, m0, n0, wm, wn, lane, split);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI, int BPRO = BPRO_NONE>

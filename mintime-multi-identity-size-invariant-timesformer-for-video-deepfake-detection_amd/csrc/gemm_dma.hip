@@ -3,6 +3,7 @@
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
 #include "gemm_dma.hpp"
+#include "det.hpp"
 #include <stdlib.h>
 #include <string.h>
 
@@ -188,6 +189,8 @@ int try_launch_dma(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
     chunk = (chunk + var.bk - 1) / var.bk * var.bk;
     a.k_chunk = chunk;
     grid.y = (d->K + chunk - 1) / chunk;
+    if (d->epilogue == MT_EPI_ATOMIC)
+      if (int rc = det_gemm_setup(a.C, a.ldc, a.det_slab, d->M, d->N, (int)grid.y, a.c_map.gin != 0, s)) return rc;
   }
 
 #define DMA_COMBO(OP, AL, BL, EPI)                                 \

@@ -4,6 +4,7 @@
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
 #include "gemm_planes.hpp"
+#include "det.hpp"
 #include <stdlib.h>
 #include <string.h>
 
@@ -105,7 +106,7 @@ extern "C" int mt_split_planes_blk_multi(const void* items, int count, int64_t t
   return check_launch("mt_split_planes_blk_multi");
 }
 
-extern "C" int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream) {
+static int gemm_planes_impl(const mt_gemm_planes_desc* d, void* stream) {
   if (!d || !d->a_planes || !d->b_planes) return fail(MT_ERR_ARG, "mt_gemm_planes: null operand planes");
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return fail(MT_ERR_ARG, "mt_gemm_planes: bad shape %d %d %d", d->M, d->N, d->K);
   if (((uintptr_t)d->a_planes & 15) || ((uintptr_t)d->b_planes & 15) || ((uintptr_t)d->c_planes & 15))
@@ -130,6 +131,8 @@ extern "C" int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream) {
   a.b_planes = d->b_planes; a.b_pstride = mt_planes_elems(b_rows, b_cols); a.ldb = (b_cols + 15) >> 4;
   a.bias = d->bias; a.R = d->R; a.ldr = d->ldr; a.C2 = d->C2; a.ldc2 = d->ldc2; a.n_half = d->n_half; a.col_sum = d->col_sum;
   a.hw = 1; a.stats_slots = 1; a.b_hw = 1; a.e_hw = 1;
+  if (epi == MT_EPI_GEGLU_BWD)
+    if (int rc = det_gemm_colsum_setup(a.det, d->M, d->n_half, d->col_sum, s)) return rc;
   if (cpl) {
     const int c_cols = epi == MT_EPI_GEGLU ? d->n_half : 2 * d->n_half;
     a.c_planes = d->c_planes; a.c_pstride = mt_planes_elems(d->M, c_cols); a.ldcp = (c_cols + 15) >> 4;
@@ -153,6 +156,7 @@ extern "C" int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream) {
     chunk = (chunk + 15) / 16 * 16;
     a.k_chunk = chunk; a.xcd_k = 1;
     grid.y = (unsigned)(((d->K + chunk - 1) / chunk + 7) / 8 * 8);
+    if (int rc = det_gemm_setup(a.C, a.ldc, a.det_slab, d->M, d->N, (d->K + chunk - 1) / chunk, false, s)) return rc;
     return launch_planes<true, true, EPI_ATOMIC, BAL_NONE, false>(a, grid, s);
   }
   {
@@ -200,4 +204,10 @@ extern "C" int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream) {
   PL_COMBO(MT_OP_NN, true, EPI_GEGLU_BWD, true)
 #undef PL_COMBO
   return fail(MT_ERR_UNSUPPORTED, "mt_gemm_planes: unsupported op / epilogue %d / %d", op, epi);
+}
+
+extern "C" int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream) {
+  const int rc = gemm_planes_impl(d, stream);
+  if (rc) { (void)mt::det_gemm_finish(nullptr, false); return rc; }
+  return mt::det_gemm_finish((hipStream_t)stream, true);       // deterministic mode: split-K slabs / column-sum log -> their targets (det.hpp)
 }

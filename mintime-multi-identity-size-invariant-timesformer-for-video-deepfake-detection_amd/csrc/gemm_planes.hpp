@@ -168,8 +168,15 @@ __device__ __forceinline__ void planes_epilogue(const GemmArgs& p, f32x16 (&acc)
         t1 += __shfl_xor(t1, 32);
         t2 += __shfl_xor(t2, 32);
         if (lane < 32 && nok) {
-          atomicAdd(p.col_sum + n, t1);
-          atomicAdd(p.col_sum + p.n_half + n, t2);
+          if (p.det.vals) {                 // deterministic mode: group = 32-column block, rank = 32-row block of the wave's first row (det.hpp)
+            const int rk = mw >> 5;
+            det_put(p.det, n >> 5, rk, n & 31, t1);
+            det_put(p.det, (p.n_half + n) >> 5, rk, n & 31, t2);
+            if (rk == 0 && (n & 31) == 0) { det_base(p.det, n >> 5, n); det_base(p.det, (p.n_half + n) >> 5, p.n_half + n); }
+          } else {
+            atomicAdd(p.col_sum + n, t1);
+            atomicAdd(p.col_sum + p.n_half + n, t2);
+          }
         }
       }
     }
@@ -494,7 +501,7 @@ void gemm_planes_kernel(const GemmArgs p) {
     }
   };
 
-  auto epilogue = [&](int mt_, int nt_) {
+  auto epilogue = [&](int mt_, int nt_, int split_idx = -1) {
     if (MT_PLANES_ABLATE & 8) {
       float sacc = 0.f;
 #pragma unroll
@@ -513,7 +520,7 @@ void gemm_planes_kernel(const GemmArgs p) {
       __syncthreads();                                  // every wave has finished reading the stages
       planes_epilogue<TM, TN, EPI>(p, acc, m0e, n0e, wm, wn, lane_e, reinterpret_cast<float*>(smem_pl) + wave * (32 * 36));
     } else {
-      gemm_epilogue<TM, TN, EPI>(p, acc, m0e, n0e, wm, wn, lane_e);
+      gemm_epilogue<TM, TN, EPI>(p, acc, m0e, n0e, wm, wn, lane_e, split_idx);
     }
   };
 
@@ -530,6 +537,7 @@ void gemm_planes_kernel(const GemmArgs p) {
   if constexpr (!SK) {
     int mt_, nt_;
     int k_begin = 0, k_end = p.K;
+    int split_idx = blockIdx.y;
     if (p.xcd_k) {                                     // split-K weight gradient, K-range-major over the XCDs (see gemm_split.hpp)
       const int tiles = gridDim.x, lin = blockIdx.y * gridDim.x + blockIdx.x;
       const int xcd = lin & 7, idx = lin >> 3;
@@ -540,6 +548,7 @@ void gemm_planes_kernel(const GemmArgs p) {
       k_begin = split * p.k_chunk;
       k_end = min(p.K, k_begin + p.k_chunk);
       if (k_begin >= k_end) return;
+      split_idx = split;
     } else {
       if (!tile_coords<BM, BN>(p, mt_, nt_)) return;
       if (p.k_chunk > 0) {
@@ -551,7 +560,7 @@ void gemm_planes_kernel(const GemmArgs p) {
     const int nk = (k_end - k_begin + BK - 1) / BK;    // k_begin % 16 == 0; a ragged end reads the planes' zero padding
     if (nk <= 0) return;
     run_piece(mt_, nt_, k_begin, 0, nk);
-    epilogue(mt_, nt_);
+    epilogue(mt_, nt_, split_idx);
   } else {
     // logical block index: the blocks of one XCD (blockIdx % 8, observed placement; only speed depends on it) take a contiguous
     // eighth of the work list, i.e. of the XCD-ordered tile list

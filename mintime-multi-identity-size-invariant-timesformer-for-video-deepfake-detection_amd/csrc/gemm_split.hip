@@ -4,6 +4,7 @@
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
 #include "gemm_split.hpp"
+#include "det.hpp"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -238,6 +239,8 @@ int try_launch_split(const mt_gemm_desc* d, GemmArgs a, hipStream_t s) {
       a.k_chunk = chunk;
       grid.y = (d->K + chunk - 1) / chunk;
     }
+    if (d->epilogue == MT_EPI_ATOMIC)
+      if (int rc = det_gemm_setup(a.C, a.ldc, a.det_slab, d->M, d->N, (d->K + a.k_chunk - 1) / a.k_chunk, a.c_map.gin != 0, s)) return rc;
   }
 
   if (bn_bwd) {

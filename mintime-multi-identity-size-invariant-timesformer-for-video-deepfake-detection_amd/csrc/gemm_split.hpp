@@ -91,6 +91,7 @@ void gemm_split_kernel(const GemmArgs p) {
 
   int mt_, nt_;
   int k_begin = 0, k_end = p.K;
+  int split_idx = blockIdx.y;
   if (p.xcd_k) {
     // Split-K weight gradient, K-range-major over the XCDs.  Workgroups are dealt round-robin to the 8 XCDs in flattened
     // (y, x) order; with the split index on blockIdx.y every XCD ran a slice of the TILES for ALL K-ranges, so each XCD's L2
@@ -106,6 +107,7 @@ void gemm_split_kernel(const GemmArgs p) {
     k_begin = split * p.k_chunk;
     k_end = min(p.K, k_begin + p.k_chunk);
     if (k_begin >= k_end) return;
+    split_idx = split;
   } else {
     if (!tile_coords<BM, BN>(p, mt_, nt_)) return;
     if (p.k_chunk > 0) {
@@ -604,7 +606,7 @@ void gemm_split_kernel(const GemmArgs p) {
   // the main loop and carries it through (60-100 VGPRs: spills in the balanced variants)
   int m0e = m0, n0e = n0, lane_e = lane;
   asm volatile("" : "+s"(m0e), "+s"(n0e), "+v"(lane_e));
-  gemm_epilogue<TM, TN, EPI>(p, acc, m0e, n0e, wm, wn, lane_e);
+  gemm_epilogue<TM, TN, EPI>(p, acc, m0e, n0e, wm, wn, lane_e, split_idx);
 }
 
 }  // namespace mt

@@ -16,6 +16,7 @@
 using namespace mt;
 
 #include "planes.hpp"
+#include "det.hpp"
 namespace {
 
 constexpr int DH = 64;
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             float* __restrict__ dx, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int rows, int D, int accumulate,
-                                                            float* __restrict__ dxsum, int skip_period, const float* dx_in) {
+                                                            float* __restrict__ dxsum, int skip_period, const float* dx_in, const DetLog det) {
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
@@ -130,7 +131,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
     __syncthreads();
     float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
-    for (int c = threadIdx.x; c < D; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    for (int c = threadIdx.x; c < D; c += 256) {
+      const float v = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+      if (det.vals) det_put(det, which, blockIdx.x, c, v);        // deterministic mode: one log row per block, summed in block order
+      else atomicAdd(dst + c, v);
+    }
     __syncthreads();
   }
 }
@@ -239,7 +244,7 @@ template <int NI>
 __global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                  const float* __restrict__ stats, const float* __restrict__ dxn,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                 float* __restrict__ dxsum, int skip_period, int rows, int D) {
+                                                                 float* __restrict__ dxsum, int skip_period, int rows, int D, const DetLog det) {
   const int lane = threadIdx.x & 63;
   const int nwaves = gridDim.x * 4;
   const int nq = D >> 2;
@@ -277,7 +282,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const float* __
     }
     __syncthreads();
     float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
-    for (int cidx = threadIdx.x; cidx < D; cidx += 256) atomicAdd(dst + cidx, red[0][cidx] + red[1][cidx] + red[2][cidx] + red[3][cidx]);
+    for (int cidx = threadIdx.x; cidx < D; cidx += 256) {
+      const float v = red[0][cidx] + red[1][cidx] + red[2][cidx] + red[3][cidx];
+      if (det.vals) det_put(det, which, blockIdx.x, cidx, v);     // deterministic mode: one log row per block, summed in block order
+      else atomicAdd(dst + cidx, v);
+    }
     __syncthreads();
   }
 }
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const float* __
 // ---------------------------------------------------------------------------------------- column sums (bias grads)
 // out[n] += sum_m A[map(m)*lda + n];  block = 64 columns x 4 row-lanes, grid (ceil(N/64), row chunks)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t lda, int gin, int gout, int off,
-                                                     int M, int N, float* __restrict__ out, int rows_per_block) {
+                                                     int M, int N, float* __restrict__ out, int rows_per_block, const DetLog det) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + cl;
@@ -301,7 +310,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
   }
   red[rl][cl] = s;
   __syncthreads();
-  if (rl == 0 && n < N) atomicAdd(out + n, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+  if (rl == 0 && n < N) {
+    const float v = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (det.vals) {                                               // deterministic mode: group = 64-column block, rank = row chunk
+      det_put(det, blockIdx.x, blockIdx.y, cl, v);
+      if (blockIdx.y == 0 && cl == 0) det_base(det, blockIdx.x, (int64_t)blockIdx.x * 64);
+    } else atomicAdd(out + n, v);
+  }
 }
 
 // ---------------------------------------------------------------------------------------- head backward
@@ -376,6 +391,39 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     if (t == 0 && dcls) atomicAdd(dcls + i, v);
     if (dpos) atomicAdd(dpos + pi * D + i, v);
     if (dsize) atomicAdd(dsize + (int64_t)si * D + i, v);
+  }
+}
+
+// Deterministic mode: one block per table row (cls | positions | sizes), scanning the token rows in order.
+__global__ __launch_bounds__(256) void embed_bwd_det_kernel(const float* __restrict__ dx, float* __restrict__ dcls,
+                                                            float* __restrict__ dpos, float* __restrict__ dsize,
+                                                            const int64_t* __restrict__ positions, const int* __restrict__ sizes,
+                                                            int B, int N, int n, int F, int D, int pos_rows, int size_rows) {
+  const int r = blockIdx.x;                              // 0: cls;  1 .. pos_rows: position r - 1;  then size rows
+  const int kind = r == 0 ? 0 : (r <= pos_rows ? 1 : 2);
+  const int want = kind == 1 ? r - 1 : r - 1 - pos_rows;
+  float* dst = kind == 0 ? dcls : (kind == 1 ? dpos + (int64_t)want * D : dsize + (int64_t)want * D);
+  if ((kind == 0 && !dcls) || (kind == 1 && !dpos) || (kind == 2 && !dsize)) return;
+  for (int i0 = 0; i0 < D; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    float acc = 0.f;
+    for (int row = 0; row < B * N; ++row) {
+      const int b = row / N, t = row - b * N;
+      bool hit;
+      if (kind == 0) hit = t == 0;
+      else if (kind == 1) {
+        int64_t pi = positions ? positions[row] : (int64_t)t;
+        pi = pi < 0 ? 0 : (pi >= pos_rows ? pos_rows - 1 : pi);
+        hit = pi == want;
+      } else {
+        int si = 0;
+        if (t > 0 && sizes) si = sizes[b * F + (t - 1) / n];
+        si = si < 0 ? 0 : (si >= size_rows ? size_rows - 1 : si);
+        hit = si == want;
+      }
+      if (hit && i < D) acc += dx[(int64_t)row * D + i];
+    }
+    if (i < D) dst[i] += acc;
   }
 }
 
@@ -538,7 +586,7 @@ __device__ __forceinline__ void load_row32(const float* __restrict__ p, float (&
 template <int WPB, bool FACT = false>
 __global__ __launch_bounds__(WPB * 64) void attn_space_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                       float* __restrict__ dqkv, int B, int H, int F, int n,
-                                                                      float scale, const PlaneRef dp) {
+                                                                      float scale, const PlaneRef dp, const DetLog det) {
   __shared__ float2 stat_all[WPB][64];                      // (logsumexp, delta) per query of the wavefront's group
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = lane & 31, hf = lane >> 5;
@@ -700,8 +748,17 @@ __global__ __launch_bounds__(WPB * 64) void attn_space_bwd_mfma_kernel(const flo
         for (int g = 0; g < 4; ++g) {
           const int d0 = 32 * i + 8 * g + 4 * hf;
           if (key == 0) {                       // the cls key is shared by every frame of the clip
+            if (det.vals) {                     // deterministic mode: one log row per frame, summed in frame order (det.hpp)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { atomicAdd(krow + d0 + e, dk[i][4 * g + e]); atomicAdd(vrow + d0 + e, dv[i][4 * g + e]); }
+              for (int e = 0; e < 4; ++e) { det_put(det, 2 * bh, f, d0 + e, dk[i][4 * g + e]); det_put(det, 2 * bh + 1, f, d0 + e, dv[i][4 * g + e]); }
+              if (f == 0 && d0 == 0) {
+                det_base(det, 2 * bh, (int64_t)b * N * ld + h * DH + inner);
+                det_base(det, 2 * bh + 1, (int64_t)b * N * ld + h * DH + 2 * inner);
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { atomicAdd(krow + d0 + e, dk[i][4 * g + e]); atomicAdd(vrow + d0 + e, dv[i][4 * g + e]); }
+            }
           } else {
             float4 a, v;
             if constexpr (FACT) {               // the cls query's rank-1 contribution from its two scalars (attn_cls_bwd_kernel, factored)
@@ -741,7 +798,7 @@ template <int MODE, int NKEYS, int PPW, int STRIDE, int WPB>
 __global__ __launch_bounds__(WPB * 64) void attn_patch_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                  float* __restrict__ dqkv, const uint8_t* __restrict__ mask,
                                                                  const uint8_t* __restrict__ ident, int B, int H, int F, int n,
-                                                                 float scale, const PlaneRef dp) {
+                                                                 float scale, const PlaneRef dp, const DetLog det) {
   constexpr int ROWS = MODE == 0 ? 1 + PPW * (NKEYS - 1) : NKEYS;
   constexpr int QROWS = 64;                                  // pass-2 tiles hold one row per query lane
   constexpr int TROWS = ROWS > QROWS ? ROWS : QROWS;
@@ -964,8 +1021,17 @@ __global__ __launch_bounds__(WPB * 64) void attn_patch_bwd_kernel(const float* _
       ak = fmaf(Sm[iq * SP], tA[iq * STRIDE + lane], ak);
       av = fmaf(Pm[iq * SP], tB[iq * STRIDE + lane], av);
     }
-    atomicAdd(dbase + inner + lane, ak);
-    atomicAdd(dbase + 2 * inner + lane, av);
+    if (det.vals) {                             // deterministic mode: one log row per chunk of this (b, h), summed in chunk order
+      det_put(det, 2 * bh, c, lane, ak);
+      det_put(det, 2 * bh + 1, c, lane, av);
+      if (c == 0 && lane == 0) {
+        det_base(det, 2 * bh, (int64_t)b * N * ld + h * DH + inner);
+        det_base(det, 2 * bh + 1, (int64_t)b * N * ld + h * DH + 2 * inner);
+      }
+    } else {
+      atomicAdd(dbase + inner + lane, ak);
+      atomicAdd(dbase + 2 * inner + lane, av);
+    }
   }
 }
 
@@ -980,7 +1046,7 @@ template <int F, int WPB, bool FACT>
 __global__ __launch_bounds__(WPB * 64, F == 8 ? 4 : 2) void attn_time_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                 float* __restrict__ dqkv, const uint8_t* __restrict__ mask,
                                                                 const uint8_t* __restrict__ ident, int B, int H, int n, float scale,
-                                                                const PlaneRef dp) {
+                                                                const PlaneRef dp, const DetLog det) {
   constexpr int NK = F + 1, ST = 68, SPP = (NK + 3) & ~3;
   constexpr int WAVE_LDS = (4 * F + 2) * ST + 2 * F * SPP;
   constexpr int LPF = 64 / F;                                // lanes per query in the cls-column pass (F dims each)
@@ -1103,8 +1169,17 @@ __global__ __launch_bounds__(WPB * 64, F == 8 ? 4 : 2) void attn_time_bwd_kernel
 #pragma unroll
     for (int f = 0; f < F; ++f) { ak = fmaf(Sm[f * SPP + j], q[f], ak); av = fmaf(Pm[f * SPP + j], dO[f], av); }
     if (j == 0) {                                            // the cls key is shared by every patch of this (b, h)
-      atomicAdd(dbase + inner + lane, ak);
-      atomicAdd(dbase + 2 * inner + lane, av);
+      if (det.vals) {                                        // deterministic mode: one log row per patch, summed in patch order
+        det_put(det, 2 * bh, p, lane, ak);
+        det_put(det, 2 * bh + 1, p, lane, av);
+        if (p == 0 && lane == 0) {
+          det_base(det, 2 * bh, (int64_t)b * N * ld + h * DH + inner);
+          det_base(det, 2 * bh + 1, (int64_t)b * N * ld + h * DH + 2 * inner);
+        }
+      } else {
+        atomicAdd(dbase + inner + lane, ak);
+        atomicAdd(dbase + 2 * inner + lane, av);
+      }
     } else {
       kT[j * ST + lane] = ak;
       vT[j * ST + lane] = av;
@@ -1147,7 +1222,7 @@ __global__ __launch_bounds__(WPB * 64, F == 8 ? 4 : 2) void attn_time_bwd_kernel
 
 template <int F, int WPB>
 int launch_time_bwd(const float* qkv, const float* dout, float* dqkv, const uint8_t* mask, const uint8_t* ident, int B, int H, int n,
-                    float scale, const PlaneRef& dp, bool fact, hipStream_t s) {
+                    float scale, const PlaneRef& dp, bool fact, const DetLog& det, hipStream_t s) {
   constexpr int NK = F + 1, SPP = (NK + 3) & ~3;
   const size_t lds = (size_t)WPB * ((4 * F + 2) * 68 + 2 * F * SPP) * sizeof(float);
   const int64_t waves = (int64_t)B * H * n;
@@ -1156,7 +1231,7 @@ int launch_time_bwd(const float* qkv, const float* dout, float* dqkv, const uint
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_attn_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, dout, dqkv, mask, ident, B, H, n, scale, dp);
+  hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, dout, dqkv, mask, ident, B, H, n, scale, dp, det);
   return check_launch("mt_attn_bwd(time)");
 }
 
@@ -1177,7 +1252,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_planes_kernel(const float* _
 
 template <int MODE, int NKEYS, int PPW, int STRIDE, int WPB>
 int launch_patch_bwd(const float* qkv, const float* dout, float* dqkv, const uint8_t* mask, const uint8_t* ident, int B, int H,
-                     int F, int n, float scale, const PlaneRef& dp, hipStream_t s) {
+                     int F, int n, float scale, const PlaneRef& dp, const DetLog& det, hipStream_t s) {
   constexpr int ROWS = MODE == 0 ? 1 + PPW * (NKEYS - 1) : NKEYS;
   constexpr int TROWS = ROWS > 64 ? ROWS : 64;
   constexpr int SP = (NKEYS % 2 == 0) ? NKEYS + 1 : NKEYS;
@@ -1190,7 +1265,7 @@ int launch_patch_bwd(const float* qkv, const float* dout, float* dqkv, const uin
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_attn_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(k, dim3((unsigned)((waves + WPB - 1) / WPB)), dim3(WPB * 64), lds, s, qkv, dout, dqkv, mask, ident, B, H, F,
-                     n, scale, dp);
+                     n, scale, dp, det);
   return check_launch("mt_attn_bwd(patch)");
 }
 
@@ -1205,13 +1280,18 @@ extern "C" int mt_layernorm_bwd(const float* dy, const float* x, const float* st
   int blocks = (rows + 3) / 4;
   static const int cap = getenv("MT_LN_BWD_BLOCKS") ? atoi(getenv("MT_LN_BWD_BLOCKS")) : 256;     // tuning knob
   if (blocks > cap) blocks = cap;
+  DetScope det((hipStream_t)stream, 3, blocks, dim, true, true);     // deterministic mode: the three column sums by block order
   if (dim <= 512)
     hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dgamma, dbeta,
-                       rows, dim, accumulate, dx_colsum, skip_period, dx_in ? dx_in : dx);
+                       rows, dim, accumulate, dx_colsum, skip_period, dx_in ? dx_in : dx, det.log);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dgamma, dbeta,
-                       rows, dim, accumulate, dx_colsum, skip_period, dx_in ? dx_in : dx);
-  return check_launch("mt_layernorm_bwd");
+                       rows, dim, accumulate, dx_colsum, skip_period, dx_in ? dx_in : dx, det.log);
+  int rc = check_launch("mt_layernorm_bwd");
+  if (!rc) rc = det.reduce_f32(dgamma, 0, 1);
+  if (!rc) rc = det.reduce_f32(dbeta, 1, 1);
+  if (!rc && dx_colsum) rc = det.reduce_f32(dx_colsum, 2, 1);
+  return rc;
 }
 
 extern "C" int mt_layernorm_bwd_rows(const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
@@ -1242,21 +1322,28 @@ extern "C" int mt_layernorm_bwd_cols(const float* dy, const float* x, const floa
   if (rows <= 0) return 0;
   int blocks = (rows + 3) / 4;
   if (blocks > 256) blocks = 256;
+  DetScope det((hipStream_t)stream, 3, blocks, dim, true, true);     // deterministic mode: the three column sums by block order
   if (dim <= 512)
     hipLaunchKernelGGL(layernorm_bwd_cols_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, dx_new, dgamma, dbeta,
-                       dx_colsum, skip_period, rows, dim);
+                       dx_colsum, skip_period, rows, dim, det.log);
   else
     hipLaunchKernelGGL(layernorm_bwd_cols_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, dx_new, dgamma, dbeta,
-                       dx_colsum, skip_period, rows, dim);
-  return check_launch("mt_layernorm_bwd_cols");
+                       dx_colsum, skip_period, rows, dim, det.log);
+  int rc = check_launch("mt_layernorm_bwd_cols");
+  if (!rc) rc = det.reduce_f32(dgamma, 0, 1);
+  if (!rc) rc = det.reduce_f32(dbeta, 1, 1);
+  if (!rc && dx_colsum) rc = det.reduce_f32(dx_colsum, 2, 1);
+  return rc;
 }
 
 extern "C" int mt_colsum(const float* A, int64_t lda, mt_rowmap map, int M, int N, float* out, void* stream) {
   if (!A || !out) return fail(MT_ERR_ARG, "mt_colsum: null pointer");
   const int rpb = 256;
+  DetScope det((hipStream_t)stream, (N + 63) / 64, (M + rpb - 1) / rpb, 64);
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, A, lda, map.gin,
-                     map.gout, map.off, M, N, out, rpb);
-  return check_launch("mt_colsum");
+                     map.gout, map.off, M, N, out, rpb, det.log);
+  const int rc = check_launch("mt_colsum");
+  return rc ? rc : det.reduce_f32(out);
 }
 
 extern "C" int mt_head_bwd(const float* dlogits, const float* x, const float* gamma, const float* beta, const float* w,
@@ -1276,6 +1363,12 @@ extern "C" int mt_embed_bwd(const float* dx, float* dcls, float* dpos_emb, float
   if (!dx) return fail(MT_ERR_ARG, "mt_embed_bwd: null pointer");
   if (pos_rows <= 0 || (dsize_emb && size_rows <= 0)) return fail(MT_ERR_ARG, "mt_embed_bwd: empty embedding table");
   const int N = 1 + F * n;
+  if (det_enabled()) {
+    const int srows = dsize_emb ? size_rows : 1;
+    hipLaunchKernelGGL(embed_bwd_det_kernel, dim3(1 + pos_rows + (dsize_emb ? srows : 0)), dim3(256), 0, (hipStream_t)stream, dx, dcls,
+                       dpos_emb, dsize_emb, positions, sizes, B, N, n, F, dim, pos_rows, srows);
+    return check_launch("mt_embed_bwd(deterministic)");
+  }
   hipLaunchKernelGGL(embed_bwd_kernel, dim3((B * N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dx, dcls, dpos_emb, dsize_emb,
                      positions, sizes, B, N, n, F, dim, pos_rows, dsize_emb ? size_rows : 1);
   return check_launch("mt_embed_bwd");
@@ -1300,30 +1393,36 @@ extern "C" int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, con
   hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(CLS_W * 64), (2 * N + CLS_W + 4 + CLS_W * 64) * sizeof(float), s, qkv, dout, dqkv, mask, B, H, F, n, scale, fact ? 1 : 0);
   int rc = check_launch("mt_attn_bwd(cls)");
   if (rc || mode == 2) return rc;                 // mode 2: the cls query's adjoint only (dk / dv of every key, dq of the cls row)
+  // deterministic mode: the cls key's dk / dv (one row per (b, head), shared by every frame / patch group) go through a log with one
+  // rank per group of the launched kernel, and are added to the cls kernel's values in rank order (det.hpp)
+  const int det_ranks = mode == 1 ? F : (!time_old && (F == 8 || F == 16) ? n : (F == 8 ? (n + 6) / 7 : (F == 16 ? (n + 3) / 4 : (n + 1) / 2)));
+  DetScope det(s, 2 * B * H, det_ranks, DH);
   if (mode == 1) {
-    if (valu) rc = launch_patch_bwd<1, 50, 1, 64, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, s);
+    if (valu) rc = launch_patch_bwd<1, 50, 1, 64, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, det.log, s);
     else {
       const int64_t waves = (int64_t)B * H * F;
-      if (fact) hipLaunchKernelGGL((attn_space_bwd_mfma_kernel<4, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n, scale, dp);
-      else hipLaunchKernelGGL((attn_space_bwd_mfma_kernel<4, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n, scale, dp);
+      if (fact) hipLaunchKernelGGL((attn_space_bwd_mfma_kernel<4, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n, scale, dp, det.log);
+      else hipLaunchKernelGGL((attn_space_bwd_mfma_kernel<4, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n, scale, dp, det.log);
       rc = check_launch("mt_attn_bwd(space, mfma)");
     }
   } else if (!time_old) {
     switch (F) {
-      case 8: rc = launch_time_bwd<8, 4>(qkv, dout, dqkv, mask, ident, B, H, n, scale, dp, fact, s); break;
-      case 16: rc = launch_time_bwd<16, 2>(qkv, dout, dqkv, mask, ident, B, H, n, scale, dp, fact, s); break;
-      case 32: rc = launch_patch_bwd<0, 33, 2, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, s); break;   // (130 row registers: spills)
+      case 8: rc = launch_time_bwd<8, 4>(qkv, dout, dqkv, mask, ident, B, H, n, scale, dp, fact, det.log, s); break;
+      case 16: rc = launch_time_bwd<16, 2>(qkv, dout, dqkv, mask, ident, B, H, n, scale, dp, fact, det.log, s); break;
+      case 32: rc = launch_patch_bwd<0, 33, 2, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, det.log, s); break;   // (130 row registers: spills)
       default: return fail(MT_ERR_UNSUPPORTED, "mt_attn_bwd: num-frames %d unsupported (8/16/32)", F);
     }
   } else {
     switch (F) {
-      case 8: rc = launch_patch_bwd<0, 9, 7, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, s); break;
-      case 16: rc = launch_patch_bwd<0, 17, 4, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, s); break;
-      case 32: rc = launch_patch_bwd<0, 33, 2, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, s); break;
+      case 8: rc = launch_patch_bwd<0, 9, 7, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, det.log, s); break;
+      case 16: rc = launch_patch_bwd<0, 17, 4, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, det.log, s); break;
+      case 32: rc = launch_patch_bwd<0, 33, 2, 68, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, det.log, s); break;
       default: return fail(MT_ERR_UNSUPPORTED, "mt_attn_bwd: num-frames %d unsupported (8/16/32)", F);
     }
   }
-  if (rc || !dqkv_planes) return rc;
+  if (rc) return rc;
+  if ((rc = det.reduce_f32(dqkv))) return rc;
+  if (!dqkv_planes) return rc;
   // the cls rows (final only now) and the padding rows of the plane tensor; with plane output the patch rows of dqkv (fp32) hold
   // the cls query's contribution only -- the planes are the result
   hipLaunchKernelGGL(attn_bwd_cls_planes_kernel, dim3(B + (rp > B * N ? 1 : 0)), dim3(256), 0, s, dqkv, B, N, ld, dp);

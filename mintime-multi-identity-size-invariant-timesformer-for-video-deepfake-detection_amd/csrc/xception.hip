@@ -8,6 +8,7 @@
 //                                        is itself an im2col GEMM)
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
+#include "det.hpp"
 #include <float.h>
 
 using namespace mt;
@@ -111,6 +112,46 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
+// Deterministic mode: the same routing as a gather.  One thread per INPUT element visits the (at most four) windows that contain it in
+// (oh, ow) order, recomputes each window's arg-max and adds dy where the arg-max is this element -- every du element has one writer.
+__global__ __launch_bounds__(256) void maxpool_bwd_gather_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 float* __restrict__ du, int N, int H, int W, int C, int Ho, int Wo) {
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int iw0 = (int)(t % W); t /= W;
+    const int ih0 = (int)(t % H);
+    const int n = (int)(t / H);
+    const float sc = scale[c], sh = shift[c];
+    float acc = 0.f;
+    // windows oh with ih0 in {2 oh - 1, 2 oh, 2 oh + 1}: even ih0 -> oh = ih0 / 2; odd -> (ih0 - 1) / 2 and (ih0 + 1) / 2
+    const int oh_lo = ih0 >> 1, oh_hi = (ih0 + 1) >> 1, ow_lo = iw0 >> 1, ow_hi = (iw0 + 1) >> 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      if (oh >= Ho) continue;
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        if (ow >= Wo) continue;
+        float best = -FLT_MAX;
+        int64_t arg = -1;
+        for (int kh = 0; kh < 3; ++kh) {
+          const int ih = oh * 2 + kh - 1;
+          if (ih < 0 || ih >= H) continue;
+          for (int kw = 0; kw < 3; ++kw) {
+            const int iw = ow * 2 + kw - 1;
+            if (iw < 0 || iw >= W) continue;
+            const int64_t off = (((int64_t)n * H + ih) * W + iw) * C + c;
+            const float v = fmaf(z[off], sc, sh);
+            if (v > best) { best = v; arg = off; }
+          }
+        }
+        if (arg == i) acc += dy[(((int64_t)n * Ho + oh) * Wo + ow) * C + c];
+      }
+    }
+    du[i] += acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ du, const float* __restrict__ z,
                                                            const float* __restrict__ kabc, float* __restrict__ dz, int64_t total4,
                                                            int C) {
@@ -164,6 +205,11 @@ extern "C" int mt_maxpool_bwd(const float* dy, const float* z, const float* scal
                               int W, int C, void* stream) {
   if (!dy || !z || !scale || !shift || !du) return fail(MT_ERR_ARG, "mt_maxpool_bwd: null pointer");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if (det_enabled()) {
+    hipLaunchKernelGGL(maxpool_bwd_gather_kernel, dim3(grid_for((int64_t)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, z, scale,
+                       shift, du, N, H, W, C, Ho, Wo);
+    return check_launch("mt_maxpool_bwd(deterministic)");
+  }
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)N * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, dy, z, scale, shift,
                      du, N, H, W, C, Ho, Wo);
   return check_launch("mt_maxpool_bwd");

@@ -74,7 +74,21 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
     tr = 1 if training else 0
     side = L.SideStream(dev)
 
-    def bn_finalize(bnctx, sums, gidx_gamma):
+    # deterministic mode (MT_DETERMINISTIC / lib.set_deterministic): only kernels whose reductions have a fixed-order form -- the
+    # streaming fusions that meet their partial sums with LDS / global atomics step aside for the GEMM (split-K slabs), the
+    # row-streaming data gradient and the unfused squeeze-excite stage
+    det = L.deterministic()
+    expand_fused, wide_wgrad, se_stream, se_fused = (EXPAND_FUSED and not det, WIDE_WGRAD and not det, SE_STREAM and not det,
+                                                     SE_FUSED and not det)
+    fused_dw = "0" if det else FUSED_DW
+
+    def bn_finalize(bnctx, sums, gidx_gamma, d=None, z=None, rows=0):
+        if det:
+            # deterministic mode: the producers' fused (atomic) sums are discarded and retaken in a fixed order from the stored
+            # gradient d and the forward's pre-normalisation tensor z (csrc/det.hip)
+            sums.zero_()
+            L.check(lib.mt_det_bn_sums(L.ptr(d), L.ptr(z), L.ptr(bnctx.mean_invstd), int(rows), bnctx.C, 1, L.ptr(sums), st),
+                    "mt_det_bn_sums")
         kabc = _new(dev, 3, bnctx.C)
         L.check(lib.mt_bn_bwd_finalize(L.ptr(sums), SLOTS, bnctx.count, L.ptr(P[gidx_gamma]), L.ptr(bnctx.mean_invstd), L.ptr(kabc),
                                        L.ptr(grads[gidx_gamma]), L.ptr(grads[gidx_gamma + 1]), bnctx.C, tr, st), "mt_bn_bwd_finalize")
@@ -94,7 +108,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         if b_pro is not None:
             kw = dict(b_prologue=L.BPRO_BN_SWISH_GATE, b_scale=b_pro[0], b_shift=b_pro[1], b_gate=b_pro[2], b_hw=b_pro[3])
         reads = (du, z, x_in, kabc) + (tuple(b_pro[:3]) if b_pro is not None else ())
-        if (EXPAND_FUSED and b_pro is None and epi is None and need[gw_idx] and need_dx_in and rows >= 100000
+        if (expand_fused and b_pro is None and epi is None and need[gw_idx] and need_dx_in and rows >= 100000
                 and lib.mt_conv1x1_bwd_fused_supported(cout, cin)):
             # expand convs of stages 1-3: data AND weight gradient in one streaming pass over du (z is folded: 1 instead of 4 passes
             # over the widest tensors of the step; skinny_bwd.hip).  Runs on the main stream: it is the data gradient's critical path.
@@ -105,14 +119,14 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
             return dx_in
         if not need[gw_idx]:
             pass                                      # frozen weight: no launch
-        elif rows >= 100000 and lib.mt_conv1x1_wgrad_supported(cout, cin):
+        elif rows >= 100000 and not det and lib.mt_conv1x1_wgrad_supported(cout, cin):
             run["wgrad_launches"] += 1
             # few channels, very many rows: the result stays in MFMA accumulators while the rows stream (skinny_wgrad.hip)
             bp = b_pro if b_pro is not None else (None, None, None, 1)
             side.launch(lambda: L.check(lib.mt_conv1x1_wgrad(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(x_in), L.ptr(bp[0]), L.ptr(bp[1]),
                                                              L.ptr(bp[2]), bp[3], L.ptr(grads[gw_idx]), rows, cout, cin,
                                                              L.stream_ptr()), "mt_conv1x1_wgrad"), reads=reads)
-        elif WIDE_WGRAD and b_pro is not None and lib.mt_conv1x1_wgrad_wide_supported(cout, cin):
+        elif wide_wgrad and b_pro is not None and lib.mt_conv1x1_wgrad_wide_supported(cout, cin):
             run["wgrad_launches"] += 1
             # project convs of the late stages: 128-column slabs of the result, both operand transforms applied once (wide_wgrad.hip)
             side.launch(lambda: L.check(lib.mt_conv1x1_wgrad_wide(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(x_in), L.ptr(b_pro[0]),
@@ -150,7 +164,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
     M = N * s_last.hout * s_last.hout
     du_h = _new(dev, M, arch.HEAD_COUT)
     sums = act_bwd(dfeat, hd["z"], hd["bn"], du_h, M, 1, 1)
-    kabc = bn_finalize(hd["bn"], sums, ih + 1)
+    kabc = bn_finalize(hd["bn"], sums, ih + 1, du_h, hd["z"], M)
     dy = conv1x1_bwd(du_h, hd["z"], kabc, P[ih], hd["y_in"], M, arch.HEAD_COUT, arch.HEAD_CIN, ih, lowest < len(blocks))
     del du_h
 
@@ -167,8 +181,8 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         dc = rec["dc"]
         dyb = _new(dev, M_out, s.cout) if dc is not None else None
         sums = act_bwd(dy, rec["z_p"], rec["bn_p"], dyb, M_out, hw, 0, rowscale=dc)
-        kabc_p = bn_finalize(rec["bn_p"], sums, ix["p"] + 1)
         dsrc = dyb if dc is not None else dy
+        kabc_p = bn_finalize(rec["bn_p"], sums, ix["p"] + 1, dsrc, rec["z_p"], M_out)
         # (b,c) project conv: z_p = (swish(bn1(z_d))*gate) . Wp^T
         bn_d = rec["bn_d"]
         b_pro = (bn_d.scale, bn_d.shift, rec["gate"], hw)
@@ -181,7 +195,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                                   L.ptr(_rec["hidden"]), L.ptr(_rec["pooled"]), L.ptr(P[_se]), L.ptr(P[_se + 2]), L.ptr(_dg), L.ptr(_dp),
                                   L.ptr(_dh), L.ptr(_dpo), L.ptr(grads[_se]), L.ptr(grads[_se + 1]), L.ptr(grads[_se + 2]),
                                   L.ptr(grads[_se + 3]), N, _hw, _s.cexp, _s.cse, parts, L.ptr(_scr), L.stream_ptr()), "mt_se_bwd")
-        if (SE_STREAM and not SE_FUSED and M_out >= 100000
+        if (se_stream and not se_fused and M_out >= 100000
                 and lib.mt_se_stage_fused_supported(s.cout, s.cexp, hw)):
             conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], False, b_pro=b_pro)   # weight gradient only
             def stage(mode, dg, g_, dpo, mi, out, st_):
@@ -197,7 +211,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
             da = _new(dev, M_out, s.cexp)                                         # (c+e) du_d and the bn1 sums
             sums = pool.take(s.cexp)
             stage(1, None, rec["gate"], dpooled, bn_d.mean_invstd, da, sums)
-        elif SE_FUSED:
+        elif se_fused:
             # (c+d) d gate straight from the accumulators of  dz_p . Wp  (da is never written)
             dgate.zero_()
             conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], True, b_pro=b_pro,
@@ -223,7 +237,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                 side.launch(lambda: se_part(2), reads=(dpre2, dhid, rec["hidden"], rec["pooled"]))     # SE weight gradients: off the path
             # (e) through swish + bn1: du_d (in place over da)
             sums = act_bwd(da, rec["z_d"], bn_d, da, M_out, hw, 1, gate=rec["gate"], dpool=dpooled)
-        kabc_d = bn_finalize(bn_d, sums, ix["d"] + 1)
+        kabc_d = bn_finalize(bn_d, sums, ix["d"] + 1, da, rec["z_d"], M_out)
         # (f,g) depthwise conv adjoint -> du wrt the dw input's pre-activation (+ its BN sums)
         in_bn = rec["dw_bn"]
         du_in = _new(dev, M_in, s.cexp)
@@ -243,7 +257,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                 side.launch(lambda: dw_part(1), reads=(da, rec["z_d"], kabc_d, rec["dw_in"], in_bn.scale, in_bn.shift))
             if need_du_in:
                 L.timed("dwconv_dgrad", lambda: dw_part(2), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
-        elif FUSED_DW == "1" or (FUSED_DW == "3" and s.k == 3):
+        elif fused_dw == "1" or (fused_dw == "3" and s.k == 3):
             run["wgrad_launches"] += 1
             # data AND weight gradient in one pass over da / z_d / the dw input (the separate weight-gradient kernel re-read all three)
             L.timed("dwconv_dgrad", lambda: dw_part(3), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
@@ -256,12 +270,12 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
             dy = None
         elif s.has_expand:
             # (h,i,j) bn0 + expand conv: z_e = y_in . We^T
-            kabc_e = bn_finalize(in_bn, sums_in, ix["e"] + 1)
+            kabc_e = bn_finalize(in_bn, sums_in, ix["e"] + 1, du_in, rec["dw_in"], M_in)
             dy = conv1x1_bwd(du_in, rec["z_e"], kabc_e, P[ix["e"]], rec["y_in"], M_in, s.cexp, s.cin, ix["e"], need_below[bi],
                              res=dy if s.skip else None)
         else:
             # block 0: the dw input is the stem's activated output
-            kabc0 = bn_finalize(in_bn, sums_in, 1)
+            kabc0 = bn_finalize(in_bn, sums_in, 1, du_in, rec["dw_in"], M_in)
             stem = saved["stem"]
             # the dedicated kernel (LDS-staged outer products) beats the im2col-gather wgrad GEMM here (1.15 vs 2.5 ms at 256 crops):
             # with 3 input channels the gather is scalar

@@ -51,8 +51,10 @@ class _StatsPool:
         return v
 
 
-def _finalize(lib, st, bn_mod, ctx, count, training, gamma, beta):
+def _finalize(lib, st, bn_mod, ctx, count, training, gamma, beta, z=None):
     ctx.count = float(count)
+    if z is not None:      # deterministic mode: the producer took no statistics; fixed-order sums of the stored tensor (csrc/det.hip)
+        L.check(lib.mt_det_bn_sums(L.ptr(z), None, None, int(count), ctx.C, 0, L.ptr(ctx.stats), st), "mt_det_bn_sums")
     L.check(lib.mt_bn_finalize(L.ptr(ctx.stats), SLOTS, float(count), L.ptr(gamma), L.ptr(beta), L.ptr(bn_mod.running_mean),
                                L.ptr(bn_mod.running_var), L.ptr(ctx.scale), L.ptr(ctx.shift), L.ptr(ctx.mean_invstd), ctx.C,
                                bn_mod.eps, bn_mod.momentum, 1 if training else 0, st), "mt_bn_finalize")
@@ -89,7 +91,10 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
                                                     for b in blocks)
     pool = _StatsPool(dev, total_c) if training else None
     it = iter(params)
-    epi = L.EPI_STATS if training else L.EPI_STORE
+    det = training and L.deterministic()          # MT_DETERMINISTIC: no fused (atomic) statistics, see _finalize
+    epi = L.EPI_STATS if training and not det else L.EPI_STORE
+    sptr = (lambda b_: None) if det or not training else (lambda b_: L.ptr(b_.stats))
+    zdet = (lambda z_: z_) if det else (lambda z_: None)
     saved = {"blocks": []} if save else None
 
     # ---- stem
@@ -101,13 +106,13 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
     # im2col-prologue GEMM it replaced (K = 27 taps padded to 28) stays the path for crops wider than the kernel's LDS row tile.
     if W <= 512 and H == W and STEM_DIRECT:
         L.check(lib.mt_stem_conv_fwd(L.ptr(x_nhwc), 1 if x_nhwc.dtype == torch.uint8 else 0, L.ptr(w_stem), L.ptr(z),
-                                     L.ptr(bn.stats) if training else None, SLOTS, N, H, W, st), "mt_stem_conv_fwd")
+                                     sptr(bn), SLOTS, N, H, W, st), "mt_stem_conv_fwd")
     else:
         wp = _new(dev, arch.STEM_COUT, 28)
         L.check(lib.mt_conv_weight_pack(L.ptr(w_stem), L.ptr(wp), arch.STEM_COUT, 3, 3, 28, 0, st), "mt_conv_weight_pack")
         L.gemm(L.OP_NT, x_nhwc, wp, z, N * Hc * Wc, arch.STEM_COUT, 28, 28, 28, arch.STEM_COUT, prologue=L.PRO_IM2COL, epilogue=epi,
                stats=bn.stats, stats_slots=SLOTS, conv=(H, W, 3, Hc, Wc, 3, 2, 0, 0, 1 if x_nhwc.dtype == torch.uint8 else 0))
-    _finalize(lib, st, model._bn0, bn, N * Hc * Wc, training, g0, b0)
+    _finalize(lib, st, model._bn0, bn, N * Hc * Wc, training, g0, b0, zdet(z))
     if save:
         saved["stem"] = dict(x=x_nhwc, z=z, bn=bn)
     cur_z, cur_bn = z, bn        # "virtual" activated tensor: swish(bn(z))
@@ -142,10 +147,10 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
             z_e = _new(dev, M_in, s.cexp)
             if M_in >= STREAM_ROWS and lib.mt_conv1x1_rows_supported(s.cin, s.cexp, 0):   # few channels, very many rows: streaming kernel
                 L.check(lib.mt_conv1x1_rows(L.ptr(y), None, L.ptr(w_e), s.cin, 0, None, None, None, 1, 0, None, L.ptr(z_e),
-                                            L.ptr(bn_e.stats), SLOTS, M_in, s.cin, s.cexp, st), "mt_conv1x1_rows")
+                                            sptr(bn_e), SLOTS, M_in, s.cin, s.cexp, st), "mt_conv1x1_rows")
             else:
                 L.gemm(L.OP_NT, y, w_e, z_e, M_in, s.cexp, s.cin, s.cin, s.cin, s.cexp, epilogue=epi, stats=bn_e.stats, stats_slots=SLOTS)
-            _finalize(lib, st, blk._bn0, bn_e, M_in, training, g, b)
+            _finalize(lib, st, blk._bn0, bn_e, M_in, training, g, b, zdet(z_e))
             rec.update(z_e=z_e, bn_e=bn_e)
             dw_in, dw_bn = z_e, bn_e
         else:
@@ -153,9 +158,9 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
         w_d, g, b = next(it), next(it), next(it)
         bn_d = _BNCtx(dev, s.cexp, training, pool)
         z_d = _new(dev, M_out, s.cexp)
-        L.check(lib.mt_dwconv_fwd(L.ptr(dw_in), L.ptr(dw_bn.scale), L.ptr(dw_bn.shift), L.ptr(w_d), L.ptr(z_d), L.ptr(bn_d.stats),
+        L.check(lib.mt_dwconv_fwd(L.ptr(dw_in), L.ptr(dw_bn.scale), L.ptr(dw_bn.shift), L.ptr(w_d), L.ptr(z_d), sptr(bn_d),
                                   SLOTS, N, s.hin, s.hin, s.cexp, s.k, s.s, 1, st), "mt_dwconv_fwd")
-        _finalize(lib, st, blk._bn1, bn_d, M_out, training, g, b)
+        _finalize(lib, st, blk._bn1, bn_d, M_out, training, g, b, zdet(z_d))
         w_r, b_r, w_x, b_x = next(it), next(it), next(it), next(it)
         pooled, gate = _new(dev, N, s.cexp), _new(dev, N, s.cexp)
         hidden = _new(dev, N, s.cse)          # squeeze pre-activations: the gate kernel reads them (and backward keeps them)
@@ -171,11 +176,11 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
         z_p = _new(dev, M_out, s.cout)
         if M_out >= STREAM_ROWS and lib.mt_conv1x1_rows_supported(s.cexp, s.cout, 1):
             L.check(lib.mt_conv1x1_rows(L.ptr(z_d), None, L.ptr(w_p), s.cexp, 0, L.ptr(bn_d.scale), L.ptr(bn_d.shift), L.ptr(gate), hw, 1,
-                                        None, L.ptr(z_p), L.ptr(bn_p.stats), SLOTS, M_out, s.cexp, s.cout, st), "mt_conv1x1_rows")
+                                        None, L.ptr(z_p), sptr(bn_p), SLOTS, M_out, s.cexp, s.cout, st), "mt_conv1x1_rows")
         else:
             L.gemm(L.OP_NT, z_d, w_p, z_p, M_out, s.cout, s.cexp, s.cexp, s.cexp, s.cout, prologue=L.PRO_BN_SWISH_GATE, epilogue=epi,
                    scale=bn_d.scale, shift=bn_d.shift, gate=gate, hw=hw, stats=bn_p.stats, stats_slots=SLOTS)
-        _finalize(lib, st, blk._bn2, bn_p, M_out, training, g, b)
+        _finalize(lib, st, blk._bn2, bn_p, M_out, training, g, b, zdet(z_p))
         # block output: bn2(z_p) [* drop-connect gate] [+ block input]
         dc = dc_gates.get(bi)
         y_new = _new(dev, M_out, s.cout)
@@ -197,7 +202,7 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
     z_h = _new(dev, M, arch.HEAD_COUT)
     L.gemm(L.OP_NT, y, w_h, z_h, M, arch.HEAD_COUT, arch.HEAD_CIN, arch.HEAD_CIN, arch.HEAD_CIN, arch.HEAD_COUT, epilogue=epi,
            stats=bn_h.stats, stats_slots=SLOTS)
-    _finalize(lib, st, model._bn1, bn_h, M, training, g, b)
+    _finalize(lib, st, model._bn1, bn_h, M, training, g, b, zdet(z_h))
     feat = _new(dev, M, arch.HEAD_COUT)
     L.check(lib.mt_bn_act_fwd(L.ptr(z_h), L.ptr(bn_h.scale), L.ptr(bn_h.shift), None, L.ptr(feat), M, arch.HEAD_COUT, 1, None, 1,
                               st), "mt_bn_act_fwd")

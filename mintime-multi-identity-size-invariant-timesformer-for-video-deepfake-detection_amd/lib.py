@@ -59,6 +59,9 @@ EPI_STORE, EPI_BIAS_RES, EPI_GEGLU, EPI_STATS, EPI_ATOMIC, EPI_GEGLU_BWD, EPI_AC
 PROTOTYPES = {
     "mt_version": [],
     "mt_last_error": [],
+    "mt_set_deterministic": [C.c_int],
+    "mt_get_deterministic": [],
+    "mt_det_bn_sums": [f32p, f32p, f32p, i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "mt_gemm": [C.POINTER(GemmDesc), C.c_void_p],
     "mt_gemm_set_split": [C.c_int],
     "mt_gemm_get_split": [],
@@ -171,6 +174,18 @@ def get():
         raise MintimeHipError(f"libmintime_hip.so version {v} != header version {header_version()}; rebuild it")
     _lib = lib
     return lib
+
+
+def set_deterministic(on: bool) -> bool:
+    """Deterministic mode (include/mintime_hip.h; reference train.py:110): no floating-point atomics anywhere in the training step,
+    every reduction in a fixed order.  Also switched on by MT_DETERMINISTIC=1.  Returns the previous setting."""
+    prev = bool(get().mt_get_deterministic())
+    get().mt_set_deterministic(1 if on else 0)
+    return prev
+
+
+def deterministic() -> bool:
+    return bool(get().mt_get_deterministic())
 
 
 def set_gemm_split(on: bool) -> bool:

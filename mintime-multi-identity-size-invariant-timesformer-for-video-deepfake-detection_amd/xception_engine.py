@@ -64,8 +64,10 @@ def _total_channels(model):
     return c
 
 
-def _finalize(lib, bn_mod, ctx, count, training, gamma, beta):
+def _finalize(lib, bn_mod, ctx, count, training, gamma, beta, z=None):
     ctx.count = float(count)
+    if z is not None:      # deterministic mode: fixed-order sums of the stored tensor instead of the producer's fused atomics
+        L.check(lib.mt_det_bn_sums(L.ptr(z), None, None, int(count), ctx.C, 0, L.ptr(ctx.stats), L.stream_ptr()), "mt_det_bn_sums")
     L.check(lib.mt_bn_finalize(L.ptr(ctx.stats), SLOTS, float(count), L.ptr(gamma), L.ptr(beta), L.ptr(bn_mod.running_mean),
                                L.ptr(bn_mod.running_var), L.ptr(ctx.scale), L.ptr(ctx.shift), L.ptr(ctx.mean_invstd), ctx.C,
                                bn_mod.eps, bn_mod.momentum, 1 if training else 0, L.stream_ptr()), "mt_bn_finalize")
@@ -79,7 +81,8 @@ def xception_forward(model, x, params, training, save):
     N, H, W, _ = x.shape
     pool = _StatsPool(dev, _total_channels(model)) if training else None
     consts = _Consts(dev)
-    epi = L.EPI_STATS if training else L.EPI_STORE
+    det = training and L.deterministic()
+    epi = L.EPI_STATS if training and not det else L.EPI_STORE
     it = iter(params)
     saved = {"x": x, "blocks": [], "consts": consts} if save else None
 
@@ -96,7 +99,7 @@ def xception_forward(model, x, params, training, save):
         z = _new(dev, M, Cout)
         L.gemm(L.OP_NT, src.t, wp, z, M, Cout, K, K, K, Cout, prologue=L.PRO_IM2COL, epilogue=epi, scale=src.scale, shift=src.shift,
                stats=ctx.stats, stats_slots=SLOTS, conv=(Hh, Ww, Cc, Ho, Wo, k, s_, p_, src.act, 1 if u8 else 0))
-        _finalize(lib, bn_mod, ctx, M, training, gamma, beta)
+        _finalize(lib, bn_mod, ctx, M, training, gamma, beta, z if det else None)
         return z, ctx
 
     def sep_unit(src, act, w_dw, w_pw, co, bn_mod, gamma, beta):
@@ -111,7 +114,7 @@ def xception_forward(model, x, params, training, save):
         ctx = _BNCtx(dev, co, training, pool)
         z = _new(dev, M, co)
         L.gemm(L.OP_NT, d, w_pw, z, M, co, ci, ci, ci, co, epilogue=epi, stats=ctx.stats, stats_slots=SLOTS)
-        _finalize(lib, bn_mod, ctx, M, training, gamma, beta)
+        _finalize(lib, bn_mod, ctx, M, training, gamma, beta, z if det else None)
         rec = dict(src=src, eff=eff, sc=sc, sh=sh, d=d, z=z, bn=ctx, ci=ci, co=co, H=Hh) if save else None
         return _Src(z, co, Hh, ctx.scale, ctx.shift, NONE, ctx), rec
 
@@ -205,7 +208,14 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
                                   L.ptr(dout), L.ptr(sums), SLOTS, rows, ctx.C, 1, act, L.stream_ptr()), "mt_bn_act_bwd")
         return sums
 
-    def bn_kabc(ctx, sums, gi):
+    det = L.deterministic()
+
+    def bn_kabc(ctx, sums, gi, d, z, rows):
+        """(d, z, rows): the gradient w.r.t. the BatchNorm's output and its input tensor -- deterministic mode retakes the sums from them."""
+        if det:
+            sums.zero_()
+            L.check(lib.mt_det_bn_sums(L.ptr(d), L.ptr(z), L.ptr(ctx.mean_invstd), int(rows), ctx.C, 1, L.ptr(sums), L.stream_ptr()),
+                    "mt_det_bn_sums")
         kabc = _new(dev, 3, ctx.C)
         L.check(lib.mt_bn_bwd_finalize(L.ptr(sums), SLOTS, ctx.count, L.ptr(P[gi]), L.ptr(ctx.mean_invstd), L.ptr(kabc), L.ptr(grads[gi]),
                                        L.ptr(grads[gi + 1]), ctx.C, tr, L.stream_ptr()), "mt_bn_bwd_finalize")
@@ -218,7 +228,7 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
         M = N * Hh * Hh
         if sums is None:
             sums = bn_sums(g, rec["z"], rec["bn"], M)
-        kabc = bn_kabc(rec["bn"], sums, pi + 2)
+        kabc = bn_kabc(rec["bn"], sums, pi + 2, g, rec["z"], M)
         w_dw, w_pw = P[pi], P[pi + 1]
         # pointwise: z = d . Wpw^T
         side.launch(lambda: L.gemm(L.OP_TN, g, rec["d"], grads[pi + 1], co, ci, M, co, ci, ci, prologue=L.PRO_BN_BWD,
@@ -261,7 +271,7 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
             Ho = brec["Ho"]
             Mo = N * Ho * Ho
             # skip path: y += skipbn(z_s), z_s = conv1x1_s2(value of inp)
-            ks = bn_kabc(brec["bn_s"], bn_sums(dy, brec["z_s"], brec["bn_s"], Mo), bm["skip"] + 1)
+            ks = bn_kabc(brec["bn_s"], bn_sums(dy, brec["z_s"], brec["bn_s"], Mo), bm["skip"] + 1, dy, brec["z_s"], Mo)
             geom = (Hin, Hin, cin, Ho, Ho, 1, 2, 0, inp.act)
             side.launch(lambda dy=dy, ks=ks, brec=brec, geom=geom, inp=inp, gi=bm["skip"]:
                         L.gemm(L.OP_TN, dy, inp.t, grads[gi].view(cout, cin), cout, cin, Mo, cout, cin, cin, prologue=L.PRO_BN_BWD,
@@ -299,7 +309,7 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
     z1, z2, bn1, bn2, s1 = saved["z1"], saved["z2"], saved["bn1"], saved["bn2"], saved["s1"]
     H1, H2 = saved["H1"], saved["H2"]
     M1, M2 = N * H1 * H1, N * H2 * H2
-    k2 = bn_kabc(bn2, bn2_sums, 4)
+    k2 = bn_kabc(bn2, bn2_sums, 4, dy, z2, M2)
     dwp2 = torch.zeros(64, 288, dtype=torch.float32, device=dev)
     geom2 = (H1, H1, 32, H2, H2, 3, 1, 0, RELU)
     L.gemm(L.OP_TN, dy, z1, dwp2, 64, 288, M2, 64, 288, 288, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC, split_k=0, A2=z2, scale=k2[0],
@@ -313,7 +323,7 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
     da1 = _new(dev, M1, 32)
     L.gemm(L.OP_NT, dz2, wp2t, da1, M1, 32, 576, 576, 576, 32, prologue=L.PRO_IM2COL, conv=(H2, H2, 64, H1, H1, 3, 1, 2, NONE))
     du1 = _new(dev, M1, 32)
-    k1 = bn_kabc(bn1, bn_sums(da1, z1, bn1, M1, act=RELU, dout=du1), 1)
+    k1 = bn_kabc(bn1, bn_sums(da1, z1, bn1, M1, act=RELU, dout=du1), 1, du1, z1, M1)
     dwp1 = torch.zeros(32, 28, dtype=torch.float32, device=dev)
     L.gemm(L.OP_TN, du1, saved["x"], dwp1, 32, 28, M1, 32, 28, 28, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC, split_k=0, A2=z1,
            scale=k1[0], shift=k1[1], gate=k1[2], b_prologue=L.BPRO_IM2COL,
