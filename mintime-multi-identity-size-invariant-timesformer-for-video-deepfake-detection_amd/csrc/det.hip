@@ -114,7 +114,7 @@ int det_gemm_colsum_setup(DetLog& log, int M, int n_half, float* col_sum, hipStr
   log.vals = nullptr; log.base = nullptr; log.R = 0; log.P = 0;
   if (!det_enabled() || !col_sum) return 0;
   if (n_half & 31) return fail(MT_ERR_UNSUPPORTED, "deterministic mode: col_sum needs n_half %% 32 == 0");
-  DetScope sc(s, 2 * n_half / 32, (M + 31) / 32, 32);
+  DetScope sc(s, 2 * n_half / 32, (M + 255) / 256 * 8, 32);     // ranks up to the end of the last (<= 256-row) block tile: rows past M log zeros
   if (!sc.on) return fail(MT_ERR_LAUNCH, "deterministic mode: no workspace for the column-sum log");
   log = sc.log;
   tl_log.log = sc.log; tl_log.G = sc.G; tl_log.out = col_sum; tl_log.on = true;

@@ -449,3 +449,14 @@ def test_plane_tensor_layout_spec():
         r, c = rows - 1, cols - 1
         off = ((r // 32) * (cp // 16) + c // 16) * 512 + (r % 32) * 16 + c % 16
         assert planes[1].reshape(-1)[off] == p1[r, c]
+
+
+def test_deterministic_switch_round_trips_without_a_gpu():
+    """mt_set_deterministic / mt_get_deterministic (train.py:110's switch) are plain host state: callable on a CPU-only box."""
+    prev = lib.set_deterministic(True)
+    try:
+        assert lib.deterministic() is True and lib.get().mt_get_deterministic() == 1
+        assert lib.set_deterministic(False) is True
+        assert lib.deterministic() is False
+    finally:
+        lib.set_deterministic(prev)
