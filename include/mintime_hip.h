@@ -135,9 +135,14 @@ int mt_split_planes_blk(const float* src, int64_t ld, int rows, int cols, void* 
  * total_blocks = that sum over all items. */
 int mt_split_planes_blk_multi(const void* items, int count, int64_t total_blocks, void* stream);
 
+/* planes of dz = ka * du + kb * z + kc  (du, z [rows][C] fp32, kabc = [3][C]: the BatchNorm-backward affine of mt_bn_bwd_finalize):
+ * the operand a 1x1 convolution's data- AND weight-gradient GEMMs share, written once (Xception's pointwise convolutions,
+ * reference models/xception.py:17-27 under autograd). */
+int mt_bn_bwd_apply_planes(const float* du, const float* z, const float* kabc, void* planes, int rows, int C, void* stream);
+
 typedef struct {
   int op;                           /* MT_OP_NT: C = A[M,K] B[N,K]^T ; MT_OP_NN: C = A[M,K] B[K,N] ; MT_OP_TN: C += A[K,M]^T B[K,N]        */
-  int epilogue;                     /* NT: STORE, BIAS_RES, GEGLU ; NN: STORE, GEGLU_BWD ; TN: ATOMIC (C pre-zeroed, split-K)              */
+  int epilogue;                     /* NT: STORE, BIAS_RES, GEGLU, STATS ; NN: STORE, GEGLU_BWD ; TN: ATOMIC (C pre-zeroed, split-K)       */
   int M, N, K;                      /* GEGLU: N = 2 * n_half ; GEGLU_BWD: N = n_half                                                       */
   const void* a_planes;             /* plane tensor of A as stored ([M][K], TN: [K][M])                                                    */
   const void* b_planes;             /* plane tensor of B as stored (NT: [N][K], NN / TN: [K][N])                                           */
@@ -154,6 +159,8 @@ typedef struct {
                                     /* With it the launch runs stream-K: a persistent grid shares the (tile, k-step) list evenly instead of */
                                     /* one block per tile -- same result up to the association of a split tile's partial sums, which is     */
                                     /* fixed (bit-reproducible run to run).  NULL: one block per output tile.                               */
+  double* stats; int stats_slots;   /* NT + MT_EPI_STATS (a 1x1 convolution with train-mode BatchNorm): column sums and sums of squares     */
+                                    /* of the stored result into [slots][2][N] fp64 accumulators, like mt_gemm                              */
 } mt_gemm_planes_desc;
 
 int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream);

@@ -37,6 +37,30 @@ __global__ __launch_bounds__(256) void split_planes_blk_kernel(const float* __re
   to_blk_block(src, ld, R, C, o, rb, cb, lane);
 }
 
+// BatchNorm-backward affine dz = ka * du + kb * z + kc (per column; kabc = [3][C]) written straight as planes: the operand of a
+// convolution's data- and weight-gradient GEMMs, evaluated once instead of in both GEMMs' prologues
+__global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float* __restrict__ du, const float* __restrict__ z,
+                                                                  const float* __restrict__ kabc, int R, int C, PlaneRef o) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rb = blockIdx.y, cb = blockIdx.x * 4 + wave;
+  if (cb >= o.cb16) return;
+  const int r = rb * 32 + (lane >> 1), c = cb * 16 + (lane & 1) * 8;
+  float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (r < R) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 4) {
+      if (c + e + 4 <= C) {
+        const float4 a = *reinterpret_cast<const float4*>(du + (int64_t)r * C + c + e), b = *reinterpret_cast<const float4*>(z + (int64_t)r * C + c + e);
+        const float4 ka = *reinterpret_cast<const float4*>(kabc + c + e), kb = *reinterpret_cast<const float4*>(kabc + C + c + e),
+                     kc = *reinterpret_cast<const float4*>(kabc + 2 * C + c + e);
+        x[e] = fmaf(ka.x, a.x, fmaf(kb.x, b.x, kc.x)); x[e + 1] = fmaf(ka.y, a.y, fmaf(kb.y, b.y, kc.y));
+        x[e + 2] = fmaf(ka.z, a.z, fmaf(kb.z, b.z, kc.z)); x[e + 3] = fmaf(ka.w, a.w, fmaf(kb.w, b.w, kc.w));
+      }
+    }
+  }
+  planes_store8(o, r, c, x);
+}
+
 struct SplitItem { const float* src; __bf16* planes; int64_t rows, cols, first; };   // first = index of the item's first wave-block
 
 __global__ __launch_bounds__(256) void split_planes_blk_multi_kernel(const SplitItem* __restrict__ items, int count, int64_t total) {
@@ -99,6 +123,16 @@ extern "C" int mt_split_planes_blk(const float* src, int64_t ld, int rows, int c
   return check_launch("mt_split_planes_blk");
 }
 
+extern "C" int mt_bn_bwd_apply_planes(const float* du, const float* z, const float* kabc, void* planes, int rows, int C, void* stream) {
+  if (!du || !z || !kabc || !planes || rows <= 0 || C <= 0) return fail(MT_ERR_ARG, "mt_bn_bwd_apply_planes: bad arguments");
+  if ((C & 3) || (((uintptr_t)du | (uintptr_t)z | (uintptr_t)kabc | (uintptr_t)planes) & 15))
+    return fail(MT_ERR_ARG, "mt_bn_bwd_apply_planes: C %% 4 == 0 and 16-byte alignment");
+  const int cb16 = (C + 15) >> 4, rp = (rows + 31) & ~31;
+  const PlaneRef o{reinterpret_cast<__bf16*>(planes), (int64_t)rp * cb16 * 16, cb16, rp};
+  hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3((cb16 + 3) / 4, rp / 32), dim3(256), 0, (hipStream_t)stream, du, z, kabc, rows, C, o);
+  return check_launch("mt_bn_bwd_apply_planes");
+}
+
 extern "C" int mt_split_planes_blk_multi(const void* items, int count, int64_t total_blocks, void* stream) {
   if (!items || count <= 0 || total_blocks <= 0) return fail(MT_ERR_ARG, "mt_split_planes_blk_multi: bad arguments");
   hipLaunchKernelGGL(split_planes_blk_multi_kernel, dim3((unsigned)((total_blocks + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
@@ -130,7 +164,8 @@ static int gemm_planes_impl(const mt_gemm_planes_desc* d, void* stream) {
   a.a_planes = d->a_planes; a.a_pstride = mt_planes_elems(a_rows, a_cols); a.lda = (a_cols + 15) >> 4;
   a.b_planes = d->b_planes; a.b_pstride = mt_planes_elems(b_rows, b_cols); a.ldb = (b_cols + 15) >> 4;
   a.bias = d->bias; a.R = d->R; a.ldr = d->ldr; a.C2 = d->C2; a.ldc2 = d->ldc2; a.n_half = d->n_half; a.col_sum = d->col_sum;
-  a.hw = 1; a.stats_slots = 1; a.b_hw = 1; a.e_hw = 1;
+  a.hw = 1; a.stats_slots = d->stats_slots > 0 ? d->stats_slots : 1; a.stats = d->stats; a.b_hw = 1; a.e_hw = 1;
+  if (epi == MT_EPI_STATS && !d->stats) return fail(MT_ERR_ARG, "mt_gemm_planes: STATS needs stats");
   if (epi == MT_EPI_GEGLU_BWD)
     if (int rc = det_gemm_colsum_setup(a.det, d->M, d->n_half, d->col_sum, s)) return rc;
   if (cpl) {
@@ -197,6 +232,7 @@ static int gemm_planes_impl(const mt_gemm_planes_desc* d, void* stream) {
               : launch_planes<false, BKM_, EPI_, BAL_PAIR, CPL_, false>(a, grid, s);
   PL_COMBO(MT_OP_NT, false, EPI_STORE, false)
   PL_COMBO(MT_OP_NT, false, EPI_BIAS_RES, false)
+  PL_COMBO(MT_OP_NT, false, EPI_STATS, false)
   PL_COMBO(MT_OP_NT, false, EPI_GEGLU, false)
   PL_COMBO(MT_OP_NT, false, EPI_GEGLU, true)
   PL_COMBO(MT_OP_NN, true, EPI_STORE, false)

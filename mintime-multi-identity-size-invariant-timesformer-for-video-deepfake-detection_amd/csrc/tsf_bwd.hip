@@ -394,37 +394,48 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
   }
 }
 
-// Deterministic mode: one block per table row (cls | positions | sizes), scanning the token rows in order.
-__global__ __launch_bounds__(256) void embed_bwd_det_kernel(const float* __restrict__ dx, float* __restrict__ dcls,
-                                                            float* __restrict__ dpos, float* __restrict__ dsize,
-                                                            const int64_t* __restrict__ positions, const int* __restrict__ sizes,
-                                                            int B, int N, int n, int F, int D, int pos_rows, int size_rows) {
-  const int r = blockIdx.x;                              // 0: cls;  1 .. pos_rows: position r - 1;  then size rows
-  const int kind = r == 0 ? 0 : (r <= pos_rows ? 1 : 2);
-  const int want = kind == 1 ? r - 1 : r - 1 - pos_rows;
-  float* dst = kind == 0 ? dcls : (kind == 1 ? dpos + (int64_t)want * D : dsize + (int64_t)want * D);
-  if ((kind == 0 && !dcls) || (kind == 1 && !dpos) || (kind == 2 && !dsize)) return;
-  for (int i0 = 0; i0 < D; i0 += 256) {
-    const int i = i0 + threadIdx.x;
+// Deterministic mode: one wavefront per (table, 64 columns), one lane per column, walks the token rows in order and adds each RUN of
+// rows that share a table row to it (tokens of one frame share their position / size row, so runs are long): every element of the
+// tables has one writer and a fixed summation order.  ~B N sequential, pipelined 4-byte loads per lane.
+__global__ __launch_bounds__(64) void embed_bwd_det_kernel(const float* __restrict__ dx, float* __restrict__ dcls,
+                                                           float* __restrict__ dpos, float* __restrict__ dsize,
+                                                           const int64_t* __restrict__ positions, const int* __restrict__ sizes,
+                                                           int B, int N, int n, int F, int D, int pos_rows, int size_rows) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int kind = blockIdx.y;                           // 0: cls, 1: positions, 2: sizes
+  if (col >= D) return;
+  if (kind == 0) {
+    if (!dcls) return;
     float acc = 0.f;
-    for (int row = 0; row < B * N; ++row) {
-      const int b = row / N, t = row - b * N;
-      bool hit;
-      if (kind == 0) hit = t == 0;
-      else if (kind == 1) {
-        int64_t pi = positions ? positions[row] : (int64_t)t;
-        pi = pi < 0 ? 0 : (pi >= pos_rows ? pos_rows - 1 : pi);
-        hit = pi == want;
-      } else {
-        int si = 0;
-        if (t > 0 && sizes) si = sizes[b * F + (t - 1) / n];
-        si = si < 0 ? 0 : (si >= size_rows ? size_rows - 1 : si);
-        hit = si == want;
-      }
-      if (hit && i < D) acc += dx[(int64_t)row * D + i];
-    }
-    if (i < D) dst[i] += acc;
+    for (int b = 0; b < B; ++b) acc += dx[(int64_t)b * N * D + col];
+    dcls[col] += acc;
+    return;
   }
+  float* dst = kind == 1 ? dpos : dsize;
+  if (!dst) return;
+  int cur = -1;
+  float run = 0.f;
+  int b = 0, t = 0;
+  for (int row = 0; row < B * N; ++row) {
+    int idx;
+    if (kind == 1) {
+      int64_t pi = positions ? positions[row] : (int64_t)t;
+      idx = (int)(pi < 0 ? 0 : (pi >= pos_rows ? pos_rows - 1 : pi));
+    } else {
+      int si = 0;
+      if (t > 0 && sizes) si = sizes[b * F + (t - 1) / n];
+      idx = si < 0 ? 0 : (si >= size_rows ? size_rows - 1 : si);
+    }
+    const float v = dx[(int64_t)row * D + col];
+    if (idx != cur) {
+      if (cur >= 0) dst[(int64_t)cur * D + col] += run;
+      cur = idx;
+      run = 0.f;
+    }
+    run += v;
+    if (++t == N) { t = 0; ++b; }
+  }
+  if (cur >= 0) dst[(int64_t)cur * D + col] += run;
 }
 
 // ---------------------------------------------------------------------------------------- attention backward: cls query
@@ -1365,7 +1376,7 @@ extern "C" int mt_embed_bwd(const float* dx, float* dcls, float* dpos_emb, float
   const int N = 1 + F * n;
   if (det_enabled()) {
     const int srows = dsize_emb ? size_rows : 1;
-    hipLaunchKernelGGL(embed_bwd_det_kernel, dim3(1 + pos_rows + (dsize_emb ? srows : 0)), dim3(256), 0, (hipStream_t)stream, dx, dcls,
+    hipLaunchKernelGGL(embed_bwd_det_kernel, dim3((dim + 63) / 64, 3), dim3(64), 0, (hipStream_t)stream, dx, dcls,
                        dpos_emb, dsize_emb, positions, sizes, B, N, n, F, dim, pos_rows, srows);
     return check_launch("mt_embed_bwd(deterministic)");
   }

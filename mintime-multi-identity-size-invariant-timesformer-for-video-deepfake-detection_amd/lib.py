@@ -47,7 +47,7 @@ class GemmPlanesDesc(C.Structure):
                 ("a_planes", C.c_void_p), ("b_planes", C.c_void_p), ("C", C.c_void_p), ("ldc", i64),
                 ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", i64), ("C2", C.c_void_p), ("ldc2", i64),
                 ("n_half", C.c_int), ("col_sum", C.c_void_p), ("c_planes", C.c_void_p), ("split_k", C.c_int),
-                ("sk_workspace", C.c_void_p), ("sk_workspace_bytes", i64)]
+                ("sk_workspace", C.c_void_p), ("sk_workspace_bytes", i64), ("stats", C.c_void_p), ("stats_slots", C.c_int)]
 
 
 OP_NT, OP_NN, OP_TN = 0, 1, 2
@@ -69,6 +69,7 @@ PROTOTYPES = {
     "mt_planes_elems": [C.c_int, C.c_int],
     "mt_split_planes_blk": [f32p, i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "mt_split_planes_blk_multi": [C.c_void_p, C.c_int, i64, C.c_void_p],
+    "mt_bn_bwd_apply_planes": [f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "mt_gemm_planes": [C.POINTER(GemmPlanesDesc), C.c_void_p],
     "mt_gemm_planes_workspace_bytes": [],
     "mt_layernorm_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p],
@@ -251,7 +252,7 @@ def streamk_workspace(device=None):
 
 
 def gemm_planes(op, a_planes, b_planes, M, N, K, Cout=None, ldc=0, epilogue=EPI_STORE, bias=None, R=None, ldr=0, C2=None, ldc2=0,
-                n_half=0, col_sum=None, c_planes=None, split_k=0, streamk=None):
+                n_half=0, col_sum=None, c_planes=None, split_k=0, streamk=None, stats=None, stats_slots=0):
     """streamk: True lends the stream's workspace (persistent grid sharing the (tile, k-step) list), False = one block per tile,
     None = MT_PLANES_STREAMK (default 0: on the TimeSformer's shapes one block per tile measured faster)."""
     d = GemmPlanesDesc()
@@ -265,6 +266,7 @@ def gemm_planes(op, a_planes, b_planes, M, N, K, Cout=None, ldc=0, epilogue=EPI_
     d.a_planes, d.b_planes, d.C, d.ldc = ptr(a_planes), ptr(b_planes), ptr(Cout), ldc
     d.bias, d.R, d.ldr, d.C2, d.ldc2 = ptr(bias), ptr(R), ldr, ptr(C2), ldc2
     d.n_half, d.col_sum, d.c_planes, d.split_k = n_half, ptr(col_sum), ptr(c_planes), split_k
+    d.stats, d.stats_slots = ptr(stats), stats_slots
     prof = PROFILE
     if prof is not None:
         for pr in prof:

@@ -13,6 +13,11 @@ from .effnet_engine import SLOTS, _StatsPool, _BNCtx, _track, _bump_tracked
 RELU, NONE = 2, 0
 
 
+# pointwise convolutions with at least this many input channels run on plane operands (MT_XC_PLANES=0: the in-kernel-split loop)
+XC_PLANES = __import__("os").environ.get("MT_XC_PLANES", "1") != "0"
+PLANES_MIN_C = int(__import__("os").environ.get("MT_XC_PLANES_MIN_C", "256"))
+
+
 def _new(dev, *shape):
     return torch.empty(*shape, dtype=torch.float32, device=dev)
 
@@ -83,6 +88,7 @@ def xception_forward(model, x, params, training, save):
     consts = _Consts(dev)
     det = training and L.deterministic()
     epi = L.EPI_STATS if training and not det else L.EPI_STORE
+    planes_on = XC_PLANES and L.gemm_split_enabled()
     it = iter(params)
     saved = {"x": x, "blocks": [], "consts": consts} if save else None
 
@@ -113,9 +119,19 @@ def xception_forward(model, x, params, training, save):
                                   L.stream_ptr()), "mt_dwconv_fwd")
         ctx = _BNCtx(dev, co, training, pool)
         z = _new(dev, M, co)
-        L.gemm(L.OP_NT, d, w_pw, z, M, co, ci, ci, ci, co, epilogue=epi, stats=ctx.stats, stats_slots=SLOTS)
+        d_p = w_p = None
+        if planes_on and ci >= PLANES_MIN_C and M >= 512:
+            # wide pointwise convolutions on plane operands (csrc/gemm_planes.hpp): d and the weight are split once; forward, data
+            # gradient and weight gradient read the same plane tensors by LDS-DMA (728 -> 728 over 100 352 rows: 0.81 -> 0.58 ms)
+            d_p = L.split_planes_blk(d, M, ci)
+            w_p = L.split_planes_blk(w_pw.view(co, ci), co, ci)
+            L.gemm_planes(L.OP_NT, d_p, w_p, M, co, ci, Cout=z, ldc=co, epilogue=epi, stats=ctx.stats, stats_slots=SLOTS)
+            if save:
+                d = None                                   # backward reads d through its planes only
+        else:
+            L.gemm(L.OP_NT, d, w_pw, z, M, co, ci, ci, ci, co, epilogue=epi, stats=ctx.stats, stats_slots=SLOTS)
         _finalize(lib, bn_mod, ctx, M, training, gamma, beta, z if det else None)
-        rec = dict(src=src, eff=eff, sc=sc, sh=sh, d=d, z=z, bn=ctx, ci=ci, co=co, H=Hh) if save else None
+        rec = dict(src=src, eff=eff, sc=sc, sh=sh, d=d, d_p=d_p, w_p=w_p, z=z, bn=ctx, ci=ci, co=co, H=Hh) if save else None
         return _Src(z, co, Hh, ctx.scale, ctx.shift, NONE, ctx), rec
 
     # ---- conv1 (3x3 s2 p0, 3 -> 32) and conv2 (3x3 s1 p0, 32 -> 64) as im2col GEMMs
@@ -231,11 +247,21 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
         kabc = bn_kabc(rec["bn"], sums, pi + 2, g, rec["z"], M)
         w_dw, w_pw = P[pi], P[pi + 1]
         # pointwise: z = d . Wpw^T
-        side.launch(lambda: L.gemm(L.OP_TN, g, rec["d"], grads[pi + 1], co, ci, M, co, ci, ci, prologue=L.PRO_BN_BWD,
-                                   epilogue=L.EPI_ATOMIC, split_k=0, A2=rec["z"], scale=kabc[0], shift=kabc[1], gate=kabc[2]),
-                    reads=(g, rec["d"], rec["z"], kabc))
         dd = _new(dev, M, ci)
-        L.gemm(L.OP_NN, g, w_pw, dd, M, ci, co, co, ci, ci, prologue=L.PRO_BN_BWD, A2=rec["z"], scale=kabc[0], shift=kabc[1], gate=kabc[2])
+        if rec["d_p"] is not None:
+            # plane operands: dz = ka g + kb z + kc is evaluated ONCE, as planes, and feeds both gradient GEMMs
+            dz_p = L.planes_empty(M, co, dev)
+            L.check(lib.mt_bn_bwd_apply_planes(L.ptr(g), L.ptr(rec["z"]), L.ptr(kabc), L.ptr(dz_p), M, co, L.stream_ptr()),
+                    "mt_bn_bwd_apply_planes")
+            side.launch(lambda: L.gemm_planes(L.OP_TN, dz_p, rec["d_p"], co, ci, M, Cout=grads[pi + 1].view(co, ci), ldc=ci,
+                                              epilogue=L.EPI_ATOMIC), reads=(dz_p, rec["d_p"]))
+            L.gemm_planes(L.OP_NN, dz_p, rec["w_p"], M, ci, co, Cout=dd, ldc=ci)
+        else:
+            side.launch(lambda: L.gemm(L.OP_TN, g, rec["d"], grads[pi + 1], co, ci, M, co, ci, ci, prologue=L.PRO_BN_BWD,
+                                       epilogue=L.EPI_ATOMIC, split_k=0, A2=rec["z"], scale=kabc[0], shift=kabc[1], gate=kabc[2]),
+                        reads=(g, rec["d"], rec["z"], kabc))
+            L.gemm(L.OP_NN, g, w_pw, dd, M, ci, co, co, ci, ci, prologue=L.PRO_BN_BWD, A2=rec["z"], scale=kabc[0], shift=kabc[1],
+                   gate=kabc[2])
         # depthwise: d = dw(act(affine(src)))
         src = rec["src"]
         kid = consts.kabc_ident(ci)

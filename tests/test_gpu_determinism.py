@@ -165,7 +165,7 @@ def test_xception_training_step_is_bit_identical(det_mode):
     L.set_deterministic(False)
     c = _grads(xc, tsf, inp)
     L.set_deterministic(True)
-    assert_close(a["logits"], c["logits"], 1e-4, "logits, deterministic vs default")
+    assert_close(a["logits"], c["logits"], REL_TOL, "logits, deterministic vs default")
     # (ReLU / max-pool masks flip at rounding level between any two summation orders: relative L2, like tests/test_gpu_xception.py)
     for k in a:
         if float(c[k].norm()) == 0.0:
