@@ -269,3 +269,40 @@ def test_attention_kernels_emit_planes(B, F, mode):
     assert torch.equal(got[patch], dqkv[patch]), "patch rows are written by their single owner: identical values"
     assert_close(got[~patch], dqkv[~patch], 1e-5, "cls rows")
     assert float(L.planes_to_float(d_p, d_p.shape[1] * 32, 3 * inner)[M:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("rows,C", [(200, 728), (96, 64), (1000, 1536)])
+def test_bn_bwd_apply_planes_is_the_split_of_the_fp32_kernel(rows, C):
+    """mt_bn_bwd_apply_planes = the planes of exactly what mt_bn_bwd_apply stores (dz = ka du + kb z + kc), zero padded
+    (728 columns: the last 16-column block is half padding)."""
+    lib = L.get()
+    du, z = _rand(rows, C, seed=1).cuda(), _rand(rows, C, seed=2).cuda()
+    kabc = _rand(3, C, seed=3).cuda()
+    dz = torch.empty(rows, C, device="cuda")
+    L.check(lib.mt_bn_bwd_apply(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(dz), rows, C, L.stream_ptr()), "mt_bn_bwd_apply")
+    p = L.planes_empty(rows, C, "cuda")
+    p.fill_(7.0)                                          # the kernel must overwrite everything, padding included
+    L.check(lib.mt_bn_bwd_apply_planes(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(p), rows, C, L.stream_ptr()), "mt_bn_bwd_apply_planes")
+    assert torch.equal(L.planes_to_float(p, rows, C), dz)
+    assert torch.equal(p, L.split_planes_blk(dz, rows, C)), "same pieces and zero padding as the converter"
+    ref = kabc[0].double() * du.double() + kabc[1].double() * z.double() + kabc[2].double()
+    assert_close(dz, ref, 1e-6, "dz vs fp64")
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 728, 728), (512, 256, 1024)])
+def test_plane_gemm_stats_epilogue(M, N, K):
+    """MT_EPI_STATS on the plane loop (a 1x1 convolution under train-mode BatchNorm): the stored result is the STORE epilogue's,
+    the [slots][2][N] fp64 accumulators sum to the column sums / sums of squares of what was stored."""
+    a, w = _rand(M, K, seed=4).cuda(), _rand(N, K, seed=5, scale=0.05).cuda()
+    ap, wp = L.split_planes_blk(a, M, K), L.split_planes_blk(w, N, K)
+    ref = torch.empty(M, N, device="cuda")
+    L.gemm_planes(L.OP_NT, ap, wp, M, N, K, Cout=ref, ldc=N)
+    slots = 32
+    out = torch.empty(M, N, device="cuda")
+    stats = torch.zeros(slots, 2, N, dtype=torch.float64, device="cuda")
+    L.gemm_planes(L.OP_NT, ap, wp, M, N, K, Cout=out, ldc=N, epilogue=L.EPI_STATS, stats=stats, stats_slots=slots)
+    assert torch.equal(out, ref)
+    s = stats.sum(0)
+    assert_close(s[0], out.double().sum(0), 1e-6, "column sums")
+    assert_close(s[1], (out.double() ** 2).sum(0), 1e-6, "column sums of squares")
+    assert_close(out, a.double() @ w.double().t(), TOL, "result vs fp64")
