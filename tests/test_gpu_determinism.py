@@ -66,9 +66,9 @@ def _restore(snaps, *models):
         m.load_state_dict(s)
 
 
-@pytest.mark.parametrize("B,ids,ragged", [(2, 2, True), (32, 2, False)])
+@pytest.mark.parametrize("B,ids,ragged", [(1, 1, False), (2, 2, True), (32, 2, False)])
 def test_two_training_steps_from_the_same_state_are_bit_identical(det_mode, B, ids, ragged):
-    """Small ragged batch (short grids, masked frames) and BASELINE config 3 at full size (B = 32: 256 crops, 12 576 token rows --
+    """One clip (393 token rows: the in-kernel-split TimeSformer path), a small ragged batch (short grids, masked frames) and BASELINE config 3 at full size (B = 32: 256 crops, 12 576 token rows --
     every split-K slab count, log rank count and streaming-kernel replacement of the benchmarked step)."""
     Fr, seed = 8, 5
     cfg, ef, tsf = _models(seed, Fr)
