@@ -271,8 +271,11 @@ def _attention(x, sd, prefix, heads, dim_head, mode, n, f, frame_mask, cls_mask)
 
 def tsf_forward(sd: Dict[str, torch.Tensor], cfg: dict, x: torch.Tensor, mask: torch.Tensor,
                 identities_mask: torch.Tensor, size_embedding: torch.Tensor, positions: torch.Tensor,
-                require_attention: bool = False, taps: Optional[dict] = None):
-    """x [B,F,C,7,7] -> logits [B,1] (and [space_cls_att, time_cls_att] of the last layer).  :224-276."""
+                require_attention: bool = False, taps: Optional[dict] = None, dropout_masks: Optional[dict] = None):
+    """x [B,F,C,7,7] -> logits [B,1] (and [space_cls_att, time_cls_att] of the last layer).  :224-276.
+    dropout_masks (train mode with attn-dropout / ff-dropout > 0): {(layer, 0 | 1 | 2): multiplier tensor} -- the keep / (1 - p)
+    factors nn.Dropout applied after the time / space attention's output projection (:98-101, [B, N, dim]) and between GEGLU and
+    the second feed-forward Linear (:66-70, [B, N, 4 dim]); the draws themselves are the caller's (tests feed the reference's)."""
     m = cfg["model"]
     heads, dim_head, depth, dim = m["heads"], m["dim-head"], m["depth"], m["dim"]
     b, f, c, h, w = x.shape
@@ -304,13 +307,20 @@ def tsf_forward(sd: Dict[str, torch.Tensor], cfg: dict, x: torch.Tensor, mask: t
     cls_rows = []
     for i in range(depth):                                                  # :263-268
         p = f"layers.{i}."
+        dm = dropout_masks or {}
         y, t_att = _attention(ln(x, p + "0.norm"), sd, p + "0.fn.", heads, dim_head, "time", n, f, frame_mask, cls_mask)
+        if (i, 0) in dm:
+            y = y * dm[(i, 0)].to(y.dtype)                                  # to_out = Sequential(Linear, Dropout)  :98-101
         x = x + y
         y, s_att = _attention(ln(x, p + "1.norm"), sd, p + "1.fn.", heads, dim_head, "space", n, f, None, cls_mask)
+        if (i, 1) in dm:
+            y = y * dm[(i, 1)].to(y.dtype)
         x = x + y
         hdn = F.linear(ln(x, p + "2.norm"), sd[p + "2.fn.net.0.weight"], sd[p + "2.fn.net.0.bias"])
         a, g = hdn.chunk(2, dim=-1)                                         # :61-63 GEGLU, exact-erf gelu
         hdn = a * F.gelu(g)
+        if (i, 2) in dm:
+            hdn = hdn * dm[(i, 2)].to(hdn.dtype)                            # net = Linear, GEGLU, Dropout, Linear  :66-70
         x = F.linear(hdn, sd[p + "2.fn.net.3.weight"], sd[p + "2.fn.net.3.bias"]) + x
         cls_rows.append(x[:, 0])
     if taps is not None:

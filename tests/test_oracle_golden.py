@@ -248,3 +248,38 @@ def test_xception_fp32_rounding_flips_relu_and_maxpool_decisions():
     print(f"fp32-vs-fp64 decision flips: ReLU {flips['relu']} of {total['relu']}, max-pool {flips['maxpool']} of {total['maxpool']}")
     assert flips["relu"] > 0 and flips["maxpool"] > 0            # the phenomenon exists ...
     assert flips["relu"] < 1e-3 * total["relu"] and flips["maxpool"] < 1e-3 * total["maxpool"]      # ... and is rare
+
+
+def test_tsf_dropout_matches_reference():
+    """attn-dropout 0.1 / ff-dropout 0.2 in train mode (size_invariant_timesformer.py:66-70, 98-101): with the reference's own draws
+    (its nn.Dropout multipliers, read off by tools/make_golden.py) the oracle reproduces its logits, loss and gradients."""
+    from tests.util import dropout_multipliers
+    g = golden("tsf_dropout")
+    B, Fr, C, depth = int(g["batch"]), int(g["frames"]), int(g["channels"]), int(g["depth"])
+    cfg = arch.default_tsf_config(C, Fr)
+    cfg["model"]["depth"], cfg["model"]["attn-dropout"], cfg["model"]["ff-dropout"] = depth, float(g["attn_p"]), float(g["ff_p"])
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in synth.tsf_state(cfg, int(g["seed"])).items()}
+    feats = synth.features(B, Fr, C, int(g["seed"])).requires_grad_(True)
+    aux = synth.clip_inputs(B, Fr, int(g["identities"]), int(g["seed"]), ragged=True, with_video=False)
+    dm = dropout_multipliers(g, B, 1 + Fr * 49, cfg["model"]["dim"])
+    rates = [float((dm[(li, k)] != 0).float().mean()) for li in range(depth) for k in range(3)]
+    assert np.allclose(rates, g["keep_rates"], atol=1e-6)
+    assert abs(rates[0] - 0.9) < 0.01 and abs(rates[2] - 0.8) < 0.01
+    out = O.tsf_forward(sd, cfg, feats, aux["mask"], aux["identities_mask"], aux["size_embedding"], aux["positions"], dropout_masks=dm)
+    loss = O.bce_with_logits(out, aux["labels"])
+    loss.backward()
+    assert_close(out, g["logits"], ORACLE_TOL, "logits")
+    assert_close(loss, g["loss"], ORACLE_TOL, "loss")
+    n = 0
+    for k in g.files:
+        if k.startswith("gnorm."):
+            key = k[len("gnorm."):]
+            assert_close(sd[key].grad.norm(), g[k], 1e-4, k)
+            assert_close(sd[key].grad.reshape(-1)[:128], g["gslice." + key], 1e-4, "gslice." + key)
+            n += 1
+    assert n >= 16 * depth
+    assert_close(feats.grad.norm(), g["dfeats_norm"], 1e-4, "dfeats norm")
+    # without the masks the result is a different one (the fixture does exercise dropout)
+    with torch.no_grad():
+        plain = O.tsf_forward(sd, cfg, feats, aux["mask"], aux["identities_mask"], aux["size_embedding"], aux["positions"])
+    assert float((plain - torch.as_tensor(g["logits"])).abs().max()) > 1e-3

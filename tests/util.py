@@ -33,3 +33,16 @@ def assert_close(got, ref, tol=REL_TOL, what=""):
 
 def checksum(t):
     return float(t.double().sum())
+
+
+def dropout_multipliers(g, batch, tokens, dim):
+    """{(layer, kind): keep / (1 - p) multiplier tensor} from the bit-packed keep masks of tests/golden/tsf_dropout.npz
+    (kind 0 / 1: after the time / space attention's output projection, [B, N, dim]; kind 2: between GEGLU and net.3, [B, N, 4 dim])."""
+    out = {}
+    for li in range(int(g["depth"])):
+        for kind in range(3):
+            width = 4 * dim if kind == 2 else dim
+            p = float(g["ff_p"] if kind == 2 else g["attn_p"])
+            bits = np.unpackbits(g[f"keep.{li}.{kind}"])[:batch * tokens * width]
+            out[(li, kind)] = torch.from_numpy(bits.astype(np.float32)).reshape(batch, tokens, width) / (1.0 - p)
+    return out

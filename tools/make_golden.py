@@ -151,6 +151,51 @@ def tsf_case(TSF, name, batch, frames, channels, identities, ragged, seed, pos_e
          pos_emb=int(pos_emb), size_emb=int(size_emb), **grads)
 
 
+def tsf_dropout_case(TSF, name, batch, frames, channels, identities, seed, depth=3, attn_p=0.1, ff_p=0.2):
+    """Train-mode TimeSformer with attn-dropout / ff-dropout > 0 (size_invariant_timesformer.py:66-70, 98-101).  The multipliers
+    nn.Dropout applied (keep / (1 - p)) are read off its input / output with forward hooks and stored bit-packed; the fixture pins the
+    reference's logits, loss and gradients for exactly those draws."""
+    import numpy as np
+    cfg = arch.default_tsf_config(channels=channels, num_frames=frames)
+    cfg["model"]["depth"], cfg["model"]["attn-dropout"], cfg["model"]["ff-dropout"] = depth, attn_p, ff_p
+    model, sd = build_tsf(TSF, cfg, seed, False)
+    model.train()
+    feats = synth.features(batch, frames, channels, seed)
+    aux = synth.clip_inputs(batch, frames, identities, seed, ragged=True, with_video=False)
+    keeps = {}
+    hooks = []
+    for li in range(depth):
+        mods = [(0, model.layers[li][0].fn.to_out[1]), (1, model.layers[li][1].fn.to_out[1]), (2, model.layers[li][2].fn.net[2])]
+        for kind, mod in mods:
+            assert isinstance(mod, torch.nn.Dropout) and mod.p == (ff_p if kind == 2 else attn_p)
+            def hook(m, a, out, key=(li, kind)):
+                x = a[0]
+                keeps[key] = ((out != 0) | (x == 0)).detach().clone()       # (an input that is exactly 0 tells nothing: count it kept)
+            hooks.append(mod.register_forward_hook(hook))
+    torch.manual_seed(seed)
+    feats_g = feats.clone().requires_grad_(True)
+    out = model(feats_g, mask=aux["mask"], identities_mask=aux["identities_mask"], size_embedding=aux["size_embedding"],
+                positions=aux["positions"])
+    out = out[0] if isinstance(out, tuple) else out
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out, aux["labels"].reshape(-1, 1))
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    assert len(keeps) == 3 * depth
+    named = dict(model.named_parameters())
+    grads = {}
+    for key, p in named.items():
+        if p.grad is not None and (key.startswith("layers.") or key in ("cls_token", "to_patch_embedding.weight", "to_out.1.weight")):
+            grads["gnorm." + key] = p.grad.norm()
+            grads["gslice." + key] = p.grad.reshape(-1)[:128].clone()
+    packed = {f"keep.{li}.{kind}": torch.from_numpy(np.packbits(k.numpy().reshape(-1))) for (li, kind), k in keeps.items()}
+    rates = torch.tensor([float(keeps[(li, kind)].float().mean()) for li in range(depth) for kind in range(3)])
+    save(name, logits=out.detach(), loss=loss.detach(), dfeats_norm=feats_g.grad.norm(),
+         dfeats_slice=feats_g.grad.permute(0, 1, 3, 4, 2).reshape(-1)[:512].clone(), keep_rates=rates,
+         batch=batch, frames=frames, channels=channels, identities=identities, seed=seed, depth=depth,
+         attn_p=torch.tensor(attn_p), ff_p=torch.tensor(ff_p), **packed, **grads)
+
+
 GRAD_KEYS_TSF = ["cls_token", "to_patch_embedding.weight", "to_patch_embedding.bias",
                  "layers.0.0.fn.to_qkv.weight", "layers.0.0.fn.to_out.0.weight", "layers.0.0.fn.to_out.0.bias",
                  "layers.0.0.norm.weight", "layers.0.0.norm.bias", "layers.4.1.fn.to_qkv.weight",
@@ -387,11 +432,13 @@ def main():
     if only in ("", "switch"):
         tsf_case(TSF, "tsf_nopos", batch=2, frames=8, channels=1280, identities=2, ragged=True, seed=3, pos_emb=False, size_emb=True)
         tsf_case(TSF, "tsf_nosize", batch=2, frames=8, channels=1280, identities=2, ragged=True, seed=4, pos_emb=True, size_emb=False)
+    if only in ("", "dropout"):
+        tsf_dropout_case(TSF, "tsf_dropout", batch=2, frames=8, channels=1280, identities=2, seed=7)
     if only == "tsf":            # the three plain TimeSformer fixtures alone (e.g. after tsf_case() gained keys)
         tsf_case(TSF, "tsf_cfg1", batch=2, frames=8, channels=1280, identities=1, ragged=False, seed=0)
         tsf_case(TSF, "tsf_2id_ragged", batch=2, frames=8, channels=1280, identities=2, ragged=True, seed=1)
         tsf_case(TSF, "tsf_xs_3id", batch=1, frames=16, channels=2048, identities=3, ragged=True, seed=2)
-    if only in ("dc", "agg", "slots", "switch", "tsf"):
+    if only in ("dc", "agg", "slots", "switch", "tsf", "dropout"):
         return
     from models.xception import xception as _xc
     man["xception"] = [[k, list(v.shape), str(v.dtype)] for k, v in _xc(num_classes=1).state_dict().items()]
