@@ -164,6 +164,15 @@ typedef struct {
 } mt_gemm_planes_desc;
 
 int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream);
+
+/* nn.Dropout inside the TimeSformer (size_invariant_timesformer.py:66-70 between GEGLU and net.3, :98-101 behind to_out.0), train mode
+ * with attn-dropout / ff-dropout > 0 (the shipped YAML uses 0: these passes run only then).  m = keep / (1 - p), an fp32 tensor the
+ * caller draws.  mt_mul_planes: planes of x * m ([rows][cols]; optionally the fp32 product too); mt_mul_add: out = r + y * m;
+ * mt_geglu_bwd: du = [dh m gelu(g) | dh m a gelu'(g)] from the forward's interleaved pre-activations u = (a_0, g_0, a_1, g_1, ...),
+ * as planes [rows][2 n_half] and optionally fp32 (m may be NULL). */
+int mt_mul_planes(const float* x, const float* m, void* planes, float* out, int rows, int cols, void* stream);
+int mt_mul_add(const float* y, const float* m, const float* r, float* out, int64_t n, void* stream);
+int mt_geglu_bwd(const float* dh, const float* m, const float* u, void* du_planes, float* du, int rows, int n_half, void* stream);
 int64_t mt_gemm_planes_workspace_bytes(void);
 
 /* ------------------------------------------------------------------------------------------------

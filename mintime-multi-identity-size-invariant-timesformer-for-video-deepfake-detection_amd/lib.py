@@ -72,6 +72,9 @@ PROTOTYPES = {
     "mt_bn_bwd_apply_planes": [f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "mt_gemm_planes": [C.POINTER(GemmPlanesDesc), C.c_void_p],
     "mt_gemm_planes_workspace_bytes": [],
+    "mt_mul_planes": [f32p, f32p, C.c_void_p, f32p, C.c_int, C.c_int, C.c_void_p],
+    "mt_mul_add": [f32p, f32p, f32p, f32p, i64, C.c_void_p],
+    "mt_geglu_bwd": [f32p, f32p, f32p, C.c_void_p, f32p, C.c_int, C.c_int, C.c_void_p],
     "mt_layernorm_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p],
     "mt_embed_fwd": [f32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                      C.c_void_p],

@@ -106,8 +106,12 @@ class SizeInvariantTimeSformer(nn.Module):
         if self.shift_tokens:
             # the reference itself raises NameError on this path (size_invariant_timesformer.py:189)
             raise NotImplementedError("shift-tokens: True is a dead path in the reference (NameError at :189)")
-        if self.attn_dropout or self.ff_dropout:
-            raise NotImplementedError("dropout > 0 is not part of the MINTIME configs (yaml: attn/ff-dropout 0.)")
+        if not (0.0 <= float(self.attn_dropout) < 1.0 and 0.0 <= float(self.ff_dropout) < 1.0):
+            raise ValueError("attn-dropout / ff-dropout must be in [0, 1)")
+        # dropout > 0 (not in the MINTIME configs, accepted like the reference's constructor :89-106): train-mode forwards draw the
+        # multipliers with torch.rand -- or `self.dropout_uniform(shape, device)` when set (parity tests feed the reference's draws) --
+        # and run on the plane path (tsf_planes.py)
+        self.dropout_uniform = None
         if self.dim_head != 64:
             raise NotImplementedError("dim-head must be 64 (the attention kernels are specialised for it)")
 

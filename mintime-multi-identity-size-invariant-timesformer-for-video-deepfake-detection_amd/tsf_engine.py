@@ -258,6 +258,9 @@ class _TSFFunction(torch.autograd.Function):
         from . import tsf_planes
         if tsf_planes.eligible(model, B * (1 + F * n), save):
             logits, s_att, t_att, saved = tsf_planes.tsf_forward_planes(model, feat, aux, params, B, F, n, save)
+        elif tsf_planes.dropout_active(model):
+            raise NotImplementedError("attn-dropout / ff-dropout > 0 in train mode runs on the plane path only (MT_TSF_PLANES=1, "
+                                      "MT_GEMM_SPLIT=1, no MT_TSF_PRUNE_LAST / MT_WGRAD_DEFER, not under stream capture)")
         else:
             logits, s_att, t_att, saved = tsf_forward(model, feat, aux, params, B, F, n, save)
         ctx.model, ctx.aux, ctx.dims, ctx.saved = model, aux, dims, saved

@@ -36,7 +36,19 @@ def eligible(model, M, save):
     if torch.cuda.is_current_stream_capturing() and save:
         return False
     D, inner = model.dim, model.heads * model.dim_head
-    return M >= 512 and D % 16 == 0 and inner % 16 == 0 and model.dim_head == 64
+    return (M >= 512 or dropout_active(model)) and D % 16 == 0 and inner % 16 == 0 and model.dim_head == 64
+
+
+def dropout_active(model):
+    """nn.Dropout is the identity in eval mode (size_invariant_timesformer.py:66-70, 98-101)."""
+    return model.training and (float(model.attn_dropout) > 0.0 or float(model.ff_dropout) > 0.0)
+
+
+def _dropout_mult(model, shape, p, dev):
+    """keep / (1 - p) multipliers of one nn.Dropout call; the uniforms come from torch.rand or from model.dropout_uniform."""
+    sampler = getattr(model, "dropout_uniform", None)
+    u = sampler(shape, dev) if sampler is not None else torch.rand(shape, device=dev, dtype=torch.float32)
+    return ((u.to(device=dev, dtype=torch.float32) >= p).float() / (1.0 - p)).contiguous()
 
 
 def weight_planes(model, params, training):
@@ -100,6 +112,8 @@ def tsf_forward_planes(model, feat, aux, params, B, F, n, save):
     _publish_index_flag(aux.err)
 
     saved = {"layers": [], "planes": True, "w_serial": serial} if save else None
+    drop = dropout_active(model)
+    p_att, p_ff = (float(model.attn_dropout), float(model.ff_dropout)) if drop else (0.0, 0.0)
     want_att = model.require_attention
     s_att = t_att = None
     xn_p = L.planes_empty(M, D, dev)
@@ -128,10 +142,18 @@ def tsf_forward_planes(model, feat, aux, params, B, F, n, save):
             L.check(lib.mt_attn_fwd(L.ptr(qkv), None, L.ptr(att), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
                                     scale, L.ptr(o_p), st), "mt_attn_fwd")      # o leaves the attention kernels as planes only
             x_new = _new(dev, B, N, D) if save else x
-            L.gemm_planes(L.OP_NT, o_p, wp[(li, 3 if mode == 0 else 8)], M, D, inner, Cout=x_new, ldc=D, epilogue=L.EPI_BIAS_RES,
-                          bias=b_o, R=x, ldr=D)
+            dm = None
+            if p_att > 0.0:
+                # to_out = Sequential(Linear, Dropout): x + (o Wo^T + b) * m   (the residual add moves behind the multiplier)
+                dm = _dropout_mult(model, (M, D), p_att, dev)
+                y0 = _new(dev, M, D)
+                L.gemm_planes(L.OP_NT, o_p, wp[(li, 3 if mode == 0 else 8)], M, D, inner, Cout=y0, ldc=D, bias=b_o)
+                L.check(lib.mt_mul_add(L.ptr(y0), L.ptr(dm), L.ptr(x), L.ptr(x_new), M * D, st), "mt_mul_add")
+            else:
+                L.gemm_planes(L.OP_NT, o_p, wp[(li, 3 if mode == 0 else 8)], M, D, inner, Cout=x_new, ldc=D, epilogue=L.EPI_BIAS_RES,
+                              bias=b_o, R=x, ldr=D)
             if save:
-                rec[mode] = dict(x=x, stats=stats, xn_p=xn_p, qkv=qkv, o_p=o_p)
+                rec[mode] = dict(x=x, stats=stats, xn_p=xn_p, qkv=qkv, o_p=o_p, dm=dm)
             x = x_new
         g, b_, w1, b1, w2, b2 = next(it), next(it), next(it), next(it), next(it), next(it)
         if save:
@@ -140,12 +162,22 @@ def tsf_forward_planes(model, feat, aux, params, B, F, n, save):
         else:
             stats, u = None, None
         L.check(lib.mt_layernorm_fwd(L.ptr(x), L.ptr(g), L.ptr(b_), None, L.ptr(stats), M, D, eps, L.ptr(xn_p), st), "mt_layernorm_fwd")
-        L.gemm_planes(L.OP_NT, xn_p, wp[(li, 12)], M, 8 * D, D, epilogue=L.EPI_GEGLU, bias=b1, C2=u, ldc2=8 * D, n_half=4 * D,
-                      c_planes=h_p)
+        dm = None
+        if p_ff > 0.0:
+            # net = Linear, GEGLU, Dropout, Linear: h leaves the GEGLU epilogue as fp32, its planes are those of h * m
+            dm = _dropout_mult(model, (M, 4 * D), p_ff, dev)
+            h = _new(dev, M, 4 * D)
+            L.gemm_planes(L.OP_NT, xn_p, wp[(li, 12)], M, 8 * D, D, epilogue=L.EPI_GEGLU, bias=b1, C2=u, ldc2=8 * D, n_half=4 * D,
+                          Cout=h, ldc=4 * D)
+            L.check(lib.mt_mul_planes(L.ptr(h), L.ptr(dm), L.ptr(h_p), None, M, 4 * D, st), "mt_mul_planes")
+            del h
+        else:
+            L.gemm_planes(L.OP_NT, xn_p, wp[(li, 12)], M, 8 * D, D, epilogue=L.EPI_GEGLU, bias=b1, C2=u, ldc2=8 * D, n_half=4 * D,
+                          c_planes=h_p)
         x_new = _new(dev, B, N, D) if save else x
         L.gemm_planes(L.OP_NT, h_p, wp[(li, 14)], M, D, 4 * D, Cout=x_new, ldc=D, epilogue=L.EPI_BIAS_RES, bias=b2, R=x, ldr=D)
         if save:
-            rec[2] = dict(x=x, stats=stats, xn_p=xn_p, u=u, h_p=h_p)
+            rec[2] = dict(x=x, stats=stats, xn_p=xn_p, u=u, h_p=h_p, dm=dm)
             saved["layers"].append(rec)
         x = x_new
     g, b_, w_h, b_h = next(it), next(it), next(it), next(it)
@@ -231,11 +263,22 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
         dxn = torch.empty(M, D, dtype=torch.float32, device=dev)
         last = li == model.depth - 1
         wgrad(dx_p, r["h_p"], grads[i0 + 4], D, 4 * D, bias_src=dx2 if last else None, bias_out=grads[i0 + 5] if last else None)
-        L.gemm_planes(L.OP_NN, dx_p, wp[(li, 14)], M, 4 * D, D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D, n_half=4 * D,
-                      col_sum=grads[i0 + 3], c_planes=du_p)          # net.0.bias gradient = column sums of du, taken in the epilogue
+        if r.get("dm") is not None:
+            # ff-dropout: dh = (dx W2) * m, then GEGLU' as a pass (the fused epilogue has no multiplier); bias gradient = column sums of du
+            dh, du_f = torch.empty(M, 4 * D, dtype=torch.float32, device=dev), torch.empty(M, 8 * D, dtype=torch.float32, device=dev)
+            L.gemm_planes(L.OP_NN, dx_p, wp[(li, 14)], M, 4 * D, D, Cout=dh, ldc=4 * D)
+            L.check(lib.mt_geglu_bwd(L.ptr(dh), L.ptr(r["dm"]), L.ptr(r["u"]), L.ptr(du_p), L.ptr(du_f), M, 4 * D, st), "mt_geglu_bwd")
+            side.launch(lambda du_f=du_f, out=grads[i0 + 3]: L.check(lib.mt_colsum(L.ptr(du_f), 8 * D, L.RowMap(0, 0, 0), M, 8 * D,
+                                                                                 L.ptr(out), L.stream_ptr()), "mt_colsum"), reads=(du_f,))
+            del dh
+        else:
+            L.gemm_planes(L.OP_NN, dx_p, wp[(li, 14)], M, 4 * D, D, epilogue=L.EPI_GEGLU_BWD, C2=r["u"], ldc2=8 * D, n_half=4 * D,
+                          col_sum=grads[i0 + 3], c_planes=du_p)      # net.0.bias gradient = column sums of du, taken in the epilogue
         wgrad(du_p, r["xn_p"], grads[i0 + 2], 8 * D, D)
         L.gemm_planes(L.OP_NN, du_p, wp[(li, 12)], M, D, 8 * D, Cout=dxn, ldc=D)
-        dx2, dx_p = ln_bwd(dxn, r, g, dx2, i0, grads[i0 - 1], 0)      # column sums -> space to_out.0.bias
+        # column sums of the new dx -> space to_out.0.bias -- unless that projection sits under a dropout (its own sub-block sums the
+        # masked gradient then)
+        dx2, dx_p = ln_bwd(dxn, r, g, dx2, i0, None if rec[1].get("dm") is not None else grads[i0 - 1], 0)
         r.clear()
         # ---- attention blocks: x_out = o Wo^T + bo + x ; o = attn(qkv) ; qkv = LN(x) Wqkv^T
         for mode in (1, 0):
@@ -243,8 +286,16 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
             g, b_, w_qkv, w_o, b_o = P[i0:i0 + 5]
             r = rec[mode]
             dxn = torch.empty(M, D, dtype=torch.float32, device=dev)
-            wgrad(dx_p, r["o_p"], grads[i0 + 3], D, inner)
-            L.gemm_planes(L.OP_NN, dx_p, wp[(li, 8 if mode == 1 else 3)], M, inner, D, Cout=do, ldc=inner)
+            dy_p = dx_p                                  # gradient w.r.t. the projection's output
+            if r.get("dm") is not None:
+                # attn-dropout: d(o Wo^T + b) = dx * m -- as planes for both GEMMs, as fp32 for the bias gradient's column sums
+                dy_p = L.planes_empty(M, D, dev)
+                dy_f = torch.empty(M, D, dtype=torch.float32, device=dev)
+                L.check(lib.mt_mul_planes(L.ptr(dx2), L.ptr(r["dm"]), L.ptr(dy_p), L.ptr(dy_f), M, D, st), "mt_mul_planes")
+                side.launch(lambda dy_f=dy_f, out=grads[i0 + 4]: L.check(lib.mt_colsum(L.ptr(dy_f), D, L.RowMap(0, 0, 0), M, D, L.ptr(out),
+                                                                                     L.stream_ptr()), "mt_colsum"), reads=(dy_f,))
+            wgrad(dy_p, r["o_p"], grads[i0 + 3], D, inner)
+            L.gemm_planes(L.OP_NN, dy_p, wp[(li, 8 if mode == 1 else 3)], M, inner, D, Cout=do, ldc=inner)
             dqkv_p = L.planes_empty(M, 3 * inner, dev)
             L.check(lib.mt_attn_bwd(L.ptr(r["qkv"]), L.ptr(do), L.ptr(dqkv), L.ptr(aux.mask), L.ptr(aux.ident), B, H, F, n, mode,
                                     scale, L.ptr(dqkv_p), st), "mt_attn_bwd")    # dqkv (fp32) is working memory here
@@ -254,6 +305,8 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
             # net.3.bias (i0 - 1 as well), or -- below layer 0 -- the patch embedding's bias (index 1), which skips the cls rows
             if mode == 0 and li == 0:
                 tgt, skip = grads[1], N
+            elif mode == 1 and rec[0].get("dm") is not None:
+                tgt, skip = None, 0                      # time to_out.0.bias sits under a dropout: summed in its own sub-block
             else:
                 tgt, skip = grads[i0 - 1], 0
             dx2, dx_p = ln_bwd(dxn, r, g, dx2, i0, tgt, skip)

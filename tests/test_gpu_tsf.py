@@ -402,3 +402,82 @@ def test_transpose_multi_is_exact():
     L.check(L.get().mt_transpose_multi(table.data_ptr(), len(rows), tiles, L.stream_ptr()), "mt_transpose_multi")
     for s, d in zip(src, dst):
         assert torch.equal(d, s.t().contiguous())
+
+
+def _dropout_model(g):
+    from tests.util import dropout_multipliers
+    B, Fr, C, depth = int(g["batch"]), int(g["frames"]), int(g["channels"]), int(g["depth"])
+    cfg = arch.default_tsf_config(C, Fr)
+    cfg["model"]["depth"], cfg["model"]["attn-dropout"], cfg["model"]["ff-dropout"] = depth, float(g["attn_p"]), float(g["ff_p"])
+    model, _ = _build(cfg, int(g["seed"]), require_attention=False)
+    dm = dropout_multipliers(g, B, 1 + Fr * 49, cfg["model"]["dim"])
+    order = [(li, kind) for li in range(depth) for kind in range(3)]          # forward order: time, space, feed-forward per layer
+    calls = []
+
+    def sampler(shape, dev):          # uniforms that reproduce the reference's keeps: 1 >= p keeps, 0 < p drops
+        key = order[len(calls) % len(order)]
+        calls.append(key)
+        keep = (dm[key] != 0).reshape(shape)
+        return keep.float().to(dev)
+
+    model.dropout_uniform = sampler
+    feats = synth.features(B, Fr, C, int(g["seed"]))
+    aux = synth.clip_inputs(B, Fr, int(g["identities"]), int(g["seed"]), ragged=True, with_video=False)
+    return model, cfg, feats, aux, calls
+
+
+def test_dropout_train_step_matches_reference_fixture():
+    """attn-dropout 0.1 / ff-dropout 0.2, train mode (size_invariant_timesformer.py:66-70, 98-101), fed the reference's own draws:
+    logits, loss and the gradients of every layer parameter against the reference's fp32 run (tests/golden/tsf_dropout.npz)."""
+    g = golden("tsf_dropout")
+    model, cfg, feats, aux, calls = _dropout_model(g)
+    model.train()
+    x = feats.cuda().requires_grad_(True)
+    kw = dict(mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(), size_embedding=aux["size_embedding"],
+              positions=aux["positions"].cuda())
+    out = model(x, **kw)
+    assert len(calls) == 3 * int(g["depth"])
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out.cpu(), aux["labels"].reshape(-1, 1))
+    loss.backward()
+    assert_close(out, g["logits"], REL_TOL, "logits")
+    assert_close(loss, g["loss"], REL_TOL, "loss")
+    named = dict(model.named_parameters())
+    n = 0
+    for k in g.files:
+        if k.startswith("gnorm."):
+            key = k[len("gnorm."):]
+            assert_close(named[key].grad.norm(), g[k], REL_TOL, k)
+            assert_close(named[key].grad.reshape(-1)[:128], g["gslice." + key], 2 * REL_TOL, "gslice." + key)
+            n += 1
+    assert n >= 16 * int(g["depth"])
+    assert_close(x.grad.norm(), g["dfeats_norm"], REL_TOL, "dfeats norm")
+    assert_close(x.grad.permute(0, 1, 3, 4, 2).reshape(-1)[:512], g["dfeats_slice"], 2 * REL_TOL, "dfeats slice")
+    # eval mode: nn.Dropout is the identity -- same logits as a model built without dropout, no draws taken
+    model.eval()
+    with torch.no_grad():
+        ev = model(feats.cuda(), **kw)
+    cfg0 = {**cfg, "model": {**cfg["model"], "attn-dropout": 0.0, "ff-dropout": 0.0}}
+    plain, _ = _build(cfg0, int(g["seed"]), require_attention=False)
+    plain.eval()
+    with torch.no_grad():
+        ref = plain(feats.cuda(), **kw)
+    assert torch.equal(ev, ref) and len(calls) == 3 * int(g["depth"])
+    assert float((ev.cpu() - torch.as_tensor(g["logits"])).abs().max()) > 1e-3       # ... and train mode did drop something
+
+
+def test_dropout_default_draws_keep_the_expected_fraction():
+    """Without a sampler the multipliers come from torch.rand: keep rate 1 - p, scale 1 / (1 - p); two forwards differ."""
+    from mintime_amd import tsf_planes
+    cfg = arch.default_tsf_config(1280, 8)
+    cfg["model"]["depth"], cfg["model"]["attn-dropout"], cfg["model"]["ff-dropout"] = 2, 0.25, 0.5
+    model, _ = _build(cfg, 3, require_attention=False)
+    model.train()
+    m = tsf_planes._dropout_mult(model, (4096, 512), 0.25, "cuda")
+    assert abs(float((m != 0).float().mean()) - 0.75) < 0.01 and abs(float(m.max()) - 1.0 / 0.75) < 1e-6
+    feats = synth.features(2, 8, 1280, 3).cuda()
+    aux = synth.clip_inputs(2, 8, 2, 3, ragged=False, with_video=False)
+    kw = dict(mask=aux["mask"].cuda(), identities_mask=aux["identities_mask"].cuda(), size_embedding=aux["size_embedding"],
+              positions=aux["positions"].cuda())
+    with torch.no_grad():
+        a, b = model(feats, **kw), model(feats, **kw)
+    assert not torch.equal(a, b)

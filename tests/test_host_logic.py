@@ -86,6 +86,14 @@ model: {image-size: 224, patch-size: 1, num-classes: 1, num-patches: 49, num-fra
     bad["model"]["shift-tokens"] = True
     with pytest.raises(NotImplementedError):
         SizeInvariantTimeSformer(config=bad)
+    # dropout > 0 is accepted like the reference's constructor (size_invariant_timesformer.py:89-106); out of range raises
+    drop = yaml.safe_load(text)
+    drop["model"]["attn-dropout"], drop["model"]["ff-dropout"] = 0.1, 0.2
+    md = SizeInvariantTimeSformer(config=drop)
+    assert (md.attn_dropout, md.ff_dropout) == (0.1, 0.2) and md.dropout_uniform is None
+    drop["model"]["ff-dropout"] = 1.0
+    with pytest.raises(ValueError):
+        SizeInvariantTimeSformer(config=drop)
 
 
 def test_load_matching_state_dict_semantics():
