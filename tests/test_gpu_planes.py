@@ -306,3 +306,32 @@ def test_plane_gemm_stats_epilogue(M, N, K):
     assert_close(s[0], out.double().sum(0), 1e-6, "column sums")
     assert_close(s[1], (out.double() ** 2).sum(0), 1e-6, "column sums of squares")
     assert_close(out, a.double() @ w.double().t(), TOL, "result vs fp64")
+
+
+def test_dropout_passes_match_torch():
+    """csrc/dropout.hip through the C ABI: planes of x * m, out = r + y * m, and the GEGLU backward pass (with and without a
+    multiplier) against torch autograd of a * gelu(g)."""
+    lib = L.get()
+    rows, nh = 100, 72
+    x, m = _rand(rows, nh, seed=1).cuda(), (torch.rand(rows, nh, generator=torch.Generator().manual_seed(2)) > 0.3).float().cuda() / 0.7
+    p, out = L.planes_empty(rows, nh, "cuda"), torch.empty(rows, nh, device="cuda")
+    L.check(lib.mt_mul_planes(L.ptr(x), L.ptr(m), L.ptr(p), L.ptr(out), rows, nh, L.stream_ptr()), "mt_mul_planes")
+    assert torch.equal(out, x * m) and torch.equal(p, L.split_planes_blk(x * m, rows, nh))
+    r = _rand(rows, nh, seed=3).cuda()
+    y = torch.empty_like(r)
+    L.check(lib.mt_mul_add(L.ptr(x), L.ptr(m), L.ptr(r), L.ptr(y), rows * nh, L.stream_ptr()), "mt_mul_add")
+    assert_close(y, r.double() + x.double() * m.double(), 1e-6, "r + y m")
+    # GEGLU backward
+    a = _rand(rows, nh, seed=4).double().requires_grad_(True)
+    g = _rand(rows, nh, seed=5).double().requires_grad_(True)
+    dh = _rand(rows, nh, seed=6)
+    for mult in (None, m):
+        a.grad = g.grad = None
+        h = a * torch.nn.functional.gelu(g)
+        h.backward(dh.double() * (mult.cpu().double() if mult is not None else 1.0))
+        u = torch.stack([a.detach().float(), g.detach().float()], dim=-1).reshape(rows, 2 * nh).contiguous().cuda()    # (a_0, g_0, a_1, g_1, ...)
+        du_p, du = L.planes_empty(rows, 2 * nh, "cuda"), torch.empty(rows, 2 * nh, device="cuda")
+        L.check(lib.mt_geglu_bwd(L.ptr(dh.cuda()), L.ptr(mult), L.ptr(u), L.ptr(du_p), L.ptr(du), rows, nh, L.stream_ptr()), "mt_geglu_bwd")
+        assert_close(du[:, :nh], a.grad, 1e-5, "da")
+        assert_close(du[:, nh:], g.grad, 1e-5, "dg")
+        assert torch.equal(L.planes_to_float(du_p, rows, 2 * nh), du)
