@@ -68,21 +68,22 @@ static int launch_reduce(const DetLog& L, int G, OUT* out, int g0, int count, hi
   return check_launch("det_reduce");
 }
 
-DetScope::DetScope(hipStream_t stream, int groups, int ranks, int p, bool enable, bool base_zero) : s(stream), G(groups), on(false) {
+DetScope::DetScope(hipStream_t stream, int groups, int ranks, int p, bool enable, bool base_zero) : s(stream), G(groups), on(false), failed(false) {
   log.vals = nullptr; log.base = nullptr; log.R = ranks; log.P = p;
   if (!enable || !det_enabled() || groups <= 0 || ranks <= 0 || p <= 0) return;
   const size_t vbytes = ((size_t)groups * ranks * p * sizeof(float) + 255) & ~(size_t)255;
   const size_t bbytes = ((size_t)groups * sizeof(int) + 255) & ~(size_t)255;
   char* a = reinterpret_cast<char*>(det_arena(stream, vbytes + bbytes));
-  if (!a) return;                                        // (the kernel falls back to atomics; the caller sees on == false)
+  if (!a) { failed = true; return; }                     // (the kernel falls back to atomics; reduce_* turns that into an error)
   log.vals = reinterpret_cast<float*>(a);
   log.base = reinterpret_cast<int*>(a + vbytes);
   (void)hipMemsetAsync(log.vals, 0, vbytes, stream);
   (void)hipMemsetAsync(log.base, base_zero ? 0 : 0xFF, bbytes, stream);
   on = true;
 }
-int DetScope::reduce_f32(float* out, int g0, int count) { return on ? launch_reduce<float>(log, G, out, g0, count, s) : 0; }
-int DetScope::reduce_f64(double* out, int g0, int count) { return on ? launch_reduce<double>(log, G, out, g0, count, s) : 0; }
+static int no_arena() { return fail(MT_ERR_LAUNCH, "deterministic mode: no workspace for the partial-sum log (hipMalloc failed)"); }
+int DetScope::reduce_f32(float* out, int g0, int count) { return failed ? no_arena() : (on ? launch_reduce<float>(log, G, out, g0, count, s) : 0); }
+int DetScope::reduce_f64(double* out, int g0, int count) { return failed ? no_arena() : (on ? launch_reduce<double>(log, G, out, g0, count, s) : 0); }
 
 // ---- split-K slabs
 __global__ __launch_bounds__(256) void det_slab_reduce_kernel(float* __restrict__ C, int64_t ldc, const float* __restrict__ ws, int splits,

@@ -35,6 +35,7 @@ struct DetScope {
   hipStream_t s;
   int G;
   bool on;
+  bool failed;        // the switch is on but the arena could not be had: the kernel fell back to atomics, reduce_* reports it
   // base_zero: every group's output offset is 0 (the kernel need not write it; reduce group ranges into different targets)
   DetScope(hipStream_t stream, int groups, int ranks, int p, bool enable = true, bool base_zero = false);
   // out[base[g] + j] += sum_r vals[g][r][j]   (r ascending, fp64 accumulator); groups [g0, g0 + count), count < 0 = all
