@@ -13,7 +13,8 @@
  *   - every function enqueues on `stream` (a hipStream_t passed as void*), never synchronises,
  *     never allocates; scratch comes from the caller
  *   - return 0 on success, negative on error; mt_last_error() gives a thread-local message
- *   - re-entrant: no global mutable state, launches go to the caller's stream on the current device
+ *   - re-entrant: launches go to the caller's stream on the current device; the only process-wide state are two switches
+ *     (mt_gemm_set_split, mt_set_deterministic) and, with the latter on, the per-stream workspace described there
  */
 #ifndef MINTIME_HIP_H
 #define MINTIME_HIP_H
