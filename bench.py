@@ -234,11 +234,17 @@ WORKLOADS = {   # BASELINE.json configs that fit one GPU: (clips/GPU, frames, id
 }
 
 
-def _probe_summary(pr):
+def _probe_summary(pr, tag=None):
+    """(launches, seconds, work) of a probed kernel family over the timed region: launches issued eagerly carry torch events
+    (lib.PROFILE), launches re-issued from a recorded plan are bracketed with HIP events inside mt_plan_run (their tag)."""
     durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in pr["events"]]
     work = [w for _, _, w in pr["events"]]
-    tot_t, tot_w = sum(durs), sum(work)
-    return len(durs), tot_t, tot_w
+    n, tot_t, tot_w = len(durs), sum(durs), sum(work)
+    if tag is not None:
+        from mintime_amd import plans
+        pn, pt, pw = plans.probe_totals(tag)
+        n, tot_t, tot_w = n + pn, tot_t + pt, tot_w + pw
+    return n, tot_t, tot_w
 
 
 def phases_leg(ef, tsf, opt, batch, reps=3):
@@ -447,6 +453,8 @@ def main():
     p_ff1 = {"match": lambda d: d.epilogue == lib.EPI_GEGLU, "match_planes": lambda d: d.epilogue == lib.EPI_GEGLU, "events": []}
     p_dw = {"name": "dwconv_dgrad", "events": []}
     lib.PROFILE = [p_ff1, p_wgrad, p_dw]
+    from mintime_amd import plans
+    plans.PROBE_MASK[0] = (1 << lib.TAG_WGRAD) | (1 << lib.TAG_FF1) | (1 << lib.TAG_DWCONV_DGRAD)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -460,6 +468,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     lib.PROFILE = None
+    plans.PROBE_MASK[0] = 0
     # launch-side cost: wall time the host needs to ENQUEUE one step (~790 launches through ctypes) onto an idle device, i.e. without
     # back-pressure from a full queue.  The step is device-bound as long as this stays below ms_per_step.
     t_enq = 0.0
@@ -480,9 +489,9 @@ def main():
         clips_s = world * B * a.steps / dt
         flop_step = 3 * wl["flop_fwd"]
         headline = a.config == 3 and B == 32 and frames == 8 and not a.ragged
-        n_w, t_w, f_w = _probe_summary(p_wgrad)
-        n_f, t_f, f_f = _probe_summary(p_ff1)
-        n_d, t_d, b_d = _probe_summary(p_dw)
+        n_w, t_w, f_w = _probe_summary(p_wgrad, lib.TAG_WGRAD)
+        n_f, t_f, f_f = _probe_summary(p_ff1, lib.TAG_FF1)
+        n_d, t_d, b_d = _probe_summary(p_dw, lib.TAG_DWCONV_DGRAD)
         pmc = lambda key: (committed_counters(key) or {}) if headline else {}
         split_on = lib.gemm_split_enabled()
         out = {
@@ -503,7 +512,10 @@ def main():
                        "matrix_pipe": SPLIT_PIPE + "; convolution GEMMs with operand prologues and K < 512: v_mfma_f32_32x32x2_f32"
                        if split_on else "v_mfma_f32_32x32x2_f32 (MT_GEMM_SPLIT=0)",
                        "loss": round(float(loss.item()), 5),
-                       "host_enqueue_ms_per_step": round(1e3 * t_enq, 3)},
+                       "host_enqueue_ms_per_step": round(1e3 * t_enq, 3),
+                       "launch_plans": {"enabled": plans.ENABLED, **{k: plans.STATS[k] for k in ("recorded", "replayed")},
+                                        "calls_per_phase": sorted(pl.ops for np_ in plans.ALL for pl in (np_.fwd, np_.bwd)
+                                                                  if pl is not None)}},
             # the time-dominant kernel family: in-step duration (next to the main stream's data-gradient GEMMs), all launches summed
             "roofline": {"bound": "mfma", "kernel": WGRAD_KERNEL[split_on],
                          **mfma_roofline(f_w / t_w if t_w else None, split_on),

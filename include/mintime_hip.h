@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 112
+#define MT_VERSION 113
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -441,6 +441,36 @@ int mt_maxpool_bwd(const float* dy, const float* z, const float* scale, const fl
                    int W, int C, void* stream);
 /* dz = ka*du + kb*z + kc materialised (dense conv2's data gradient is itself an im2col GEMM over dz). */
 int mt_bn_bwd_apply(const float* du, const float* z, const float* kabc, float* dz, int64_t rows, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Launch plans (the caller side of the step: reference train.py:332-378, the Python loop that issues every op).
+ * A plan holds the SEQUENCE of entry-point calls of one phase (EfficientNet forward, TimeSformer forward, TimeSformer backward,
+ * EfficientNet backward) so that the host issues a phase with one call instead of hundreds through its FFI.
+ *   mt_plan_record_begin .. mt_plan_record_end   every call the CALLING THREAD makes in between to an entry point of this header
+ *       that takes a `stream` (and to mt_plan_fork) is executed as usual AND appended to the plan with its argument values:
+ *       pointers, shapes, scalars, descriptors (copied), the stream.
+ *   mt_plan_run     re-issues the recorded calls in order, on the streams they were recorded on.  The caller guarantees what it
+ *       guarantees for the calls themselves -- every buffer alive at the recorded address -- and that the recording thread's
+ *       stream order is a valid order (cross-stream dependencies are part of the plan through mt_plan_fork).
+ *       probe_mask: bit t set = bracket every call tagged t with timing events on its own stream (mt_plan_probe_read).
+ *   mt_plan_fork    `to_stream` waits for everything enqueued so far on `from_stream` (event record + wait); recorded when recording.
+ *   mt_plan_tag     tags the NEXT recorded call of this thread with tag 1..31 and a work figure (bytes or flops).
+ *   mt_plan_probe_read   waits for the probe events of `tag`, returns launches / summed milliseconds / summed work, and clears them.
+ *   mt_memset_async / mt_copy_async   hipMemsetAsync / device-to-device hipMemcpyAsync as entry points, so a plan can hold them.
+ * A plan is bound to the device that was current at mt_plan_create.  Not thread-safe per plan; different plans are independent.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mt_plan mt_plan;
+int mt_plan_create(mt_plan** out);
+int mt_plan_destroy(mt_plan* plan);
+int mt_plan_record_begin(mt_plan* plan);
+int mt_plan_record_end(mt_plan* plan);
+int mt_plan_size(const mt_plan* plan);
+int mt_plan_tag(int tag, double work);
+int mt_plan_fork(void* from_stream, void* to_stream);
+int mt_plan_run(mt_plan* plan, unsigned probe_mask);
+int mt_plan_probe_read(mt_plan* plan, int tag, int* launches, double* ms, double* work);
+int mt_memset_async(void* p, int value, int64_t bytes, void* stream);
+int mt_copy_async(void* dst, const void* src, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from . import arch, synth, lib  # noqa: F401,E402
 from . import timesformer, tsf_engine, tsf_backward  # noqa: F401
 from . import efficientnet, effnet_engine, effnet_backward  # noqa: F401
-from . import ddp, optim, harness, sequence  # noqa: F401
+from . import ddp, optim, harness, sequence, plans  # noqa: F401
 from .timesformer import SizeInvariantTimeSformer  # noqa: F401
 from .efficientnet import EfficientNet  # noqa: F401
 from . import xception as xception_module, xception_engine  # noqa: F401

@@ -152,7 +152,8 @@ static int gemm_planes_impl(const mt_gemm_planes_desc* d, void* stream) {
   if (!cpl && !d->C) return fail(MT_ERR_ARG, "mt_gemm_planes: C is null");
   if (epi == MT_EPI_BIAS_RES && !d->R) return fail(MT_ERR_ARG, "mt_gemm_planes: BIAS_RES needs R");
   if (epi == MT_EPI_GEGLU && (d->n_half * 2 != d->N || (d->n_half & 63))) return fail(MT_ERR_ARG, "mt_gemm_planes GEGLU: N must be 2*n_half, n_half %% 64 == 0");
-  if (epi == MT_EPI_GEGLU_BWD && (!d->C2 || d->n_half != d->N)) return fail(MT_ERR_ARG, "mt_gemm_planes GEGLU_BWD: needs C2 and n_half == N");
+  if (epi == MT_EPI_GEGLU_BWD && (!d->C2 || d->n_half != d->N || (d->n_half & 31)))
+    return fail(MT_ERR_ARG, "mt_gemm_planes GEGLU_BWD: needs C2, n_half == N and n_half %% 32 == 0");
   hipStream_t s = (hipStream_t)stream;
 
   // operand geometry as stored: A is [M][K] (NT, NN) or [K][M] (TN); B is [N][K] (NT) or [K][N] (NN, TN)

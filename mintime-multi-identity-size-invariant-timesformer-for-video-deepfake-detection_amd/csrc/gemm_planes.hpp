@@ -158,7 +158,9 @@ __device__ __forceinline__ void planes_epilogue(const GemmArgs& p, f32x16 (&acc)
           if (p.C && m < p.M && nok) { p.C[(int64_t)m * p.ldc + n] = da[r]; p.C[(int64_t)m * p.ldc + p.n_half + n] = dg[r]; }
         }
         if (MT_PLANES_EPI_ABLATE & 4) { if (da[3] + dg[5] == 123.456f) p.col_sum[0] = 1.f; }
-        else {
+        else if (n0 + wn * TN * 32 + j * 32 < p.N) {
+          // (a 32-column tile past N = n_half belongs to nobody: with n_half % 128 != 0 the last block tile's upper waves would
+          // otherwise write zeros over dg columns [n_half, ...) that another block owns; n_half % 32 == 0, so tiles are whole)
           planes_emit_tile(da, wl, o, mw + i * 32, n0 + wn * TN * 32 + j * 32, p.M, lane);
           planes_emit_tile(dg, wl, o, mw + i * 32, p.n_half + n0 + wn * TN * 32 + j * 32, p.M, lane);
         }

@@ -35,7 +35,9 @@ def _splits(rows):
 LAST_RUN = {"blocks_run": 0, "wgrad_launches": 0, "stem_run": False}
 
 
-def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_dparams):
+def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_dparams, keep_saved=False, plan=None):
+    """keep_saved: the activation records belong to a launch plan (plans.py) and stay for its next replay; plan: the NetPlan whose
+    backward phase is being recorded (it keeps the flat gradient buffer)."""
     lib = L.get()
     st = L.stream_ptr()
     dev = dfeat.device
@@ -86,7 +88,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         if det:
             # deterministic mode: the producers' fused (atomic) sums are discarded and retaken in a fixed order from the stored
             # gradient d and the forward's pre-normalisation tensor z (csrc/det.hip)
-            sums.zero_()
+            L.zero_(sums)
             L.check(lib.mt_det_bn_sums(L.ptr(d), L.ptr(z), L.ptr(bnctx.mean_invstd), int(rows), bnctx.C, 1, L.ptr(sums), st),
                     "mt_det_bn_sums")
         kabc = _new(dev, 3, bnctx.C)
@@ -202,7 +204,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                 L.check(lib.mt_se_stage_fused(L.ptr(dsrc), L.ptr(rec["z_p"]), L.ptr(kabc_p), L.ptr(P[ix["p"]]), L.ptr(rec["z_d"]),
                                               L.ptr(bn_d.scale), L.ptr(bn_d.shift), mode, L.ptr(dg), L.ptr(g_), L.ptr(dpo), L.ptr(mi),
                                               L.ptr(out), L.ptr(st_), SLOTS, M_out, s.cout, s.cexp, hw, st), "mt_se_stage_fused")
-            dgate.zero_()
+            L.zero_(dgate)
             stage(0, dgate, None, None, None, None, None)                       # (c+d) d gate
             se_part(4)                                                            # dgate -> dpooled
             if any(need[se:se + 4]):
@@ -213,7 +215,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
             stage(1, None, rec["gate"], dpooled, bn_d.mean_invstd, da, sums)
         elif se_fused:
             # (c+d) d gate straight from the accumulators of  dz_p . Wp  (da is never written)
-            dgate.zero_()
+            L.zero_(dgate)
             conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], True, b_pro=b_pro,
                         epi=[(L.EPI_SE_RED, dgate, dict(C2=rec["z_d"], ldc2=s.cexp, epi=(bn_d.scale, bn_d.shift, None, None, None, hw)))])
             se_part(4)                                # dgate -> dpooled
@@ -286,13 +288,16 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                         "mt_stem_conv_wgrad")
             dy = None
         del du_in
-        rec.clear()
+        if not keep_saved:
+            rec.clear()
 
     side.wait()
     if need_dx:
         raise NotImplementedError("gradient w.r.t. the input crops is not part of the MINTIME training path "
                                   "(train.py never sets requires_grad on videos)")
     LAST_RUN.update(run)
+    if plan is not None:
+        plan.extra["flat_grads"] = flat_grads
     L.grads_ready(model, params, flat_grads)
     out = [g if nd else None for nd, g in zip(need_dparams, grads)]
     return None, out

@@ -42,7 +42,7 @@ class _StatsPool:
     """One zero-filled fp64 buffer per forward, carved into [SLOTS][2][C] accumulators."""
 
     def __init__(self, dev, total_channels):
-        self.buf = torch.zeros(total_channels * 2 * SLOTS, dtype=torch.float64, device=dev)
+        self.buf = L.zeros(total_channels * 2 * SLOTS, torch.float64, dev)
         self.off = 0
 
     def take(self, C):
@@ -73,15 +73,40 @@ def _track(counter):
     _TLS.tracked.append(counter)
 
 
-def _bump_tracked():
+def _bump_tracked(plan=None):
     tracked = getattr(_TLS, "tracked", None)
     if tracked:
+        if plan is not None:
+            plan.extra["tracked"] = list(tracked)       # a replayed forward bumps the same counters (plans.py)
         torch._foreach_add_(tracked, 1)
         tracked.clear()
 
 
-def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
-    """x_nhwc [N,H,W,3] contiguous fp32.  Returns (feat [N*Ho*Wo, 1280], saved or None, block outputs or None)."""
+def _dc_gates(model, N, dev):
+    """Per-sample drop-connect gates (utils.py:129-154), train mode only: floor(keep + U[0,1)) / keep, keep = 1 - rate*idx/16
+    (model.py:280-282).  ONE draw for all gated blocks (rows in block order); `model.drop_connect_uniform`, when set, supplies
+    the uniforms instead of torch.rand (callable (n_rows, N, device) -> [n_rows, N]; parity tests feed the oracle's draws).
+    Returns (gated block indices, gates [n_gated, N]) or ([], None)."""
+    blocks = model._blocks
+    if not (model.training and model.drop_connect_rate > 0):
+        return [], None
+    gated = [bi for bi, blk in enumerate(blocks) if blk.spec.skip and model.drop_connect_rate * float(bi) / len(blocks) > 0]
+    if not gated:
+        return [], None
+    sampler = getattr(model, "drop_connect_uniform", None)
+    u = sampler(len(gated), N, dev) if sampler is not None else torch.rand(len(gated), N, device=dev, dtype=torch.float32)
+    cache = model.__dict__.setdefault("_dc_keep_cache", {})
+    key = (str(dev), model.drop_connect_rate)
+    if key not in cache:    # uploaded once, not per step
+        cache[key] = torch.tensor([1.0 - model.drop_connect_rate * float(bi) / len(blocks) for bi in gated],
+                                  dtype=torch.float32, device=dev).unsqueeze(1)
+    keep = cache[key]
+    return gated, torch.floor(keep + u.to(device=dev, dtype=torch.float32)) / keep
+
+
+def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False, plan=None):
+    """x_nhwc [N,H,W,3] contiguous fp32.  Returns (feat [N*Ho*Wo, 1280], saved or None, block outputs or None).
+    plan: the plans.NetPlan being recorded (it keeps the gate buffer and the tracked counters for its replays)."""
     lib = L.get()
     st = L.stream_ptr()
     dev = x_nhwc.device
@@ -119,23 +144,10 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
     y = None                     # materialised block output (narrow tensor)
     ys = [] if want_blocks else None
 
-    # per-sample drop-connect gates (utils.py:129-154), train mode only: floor(keep + U[0,1)) / keep, keep = 1 - rate*idx/16
-    # (model.py:280-282).  ONE draw for all gated blocks (rows in block order); `model.drop_connect_uniform`, when set, supplies
-    # the uniforms instead of torch.rand (callable (n_rows, N, device) -> [n_rows, N]; parity tests feed the oracle's draws).
-    dc_gates = {}
-    if training and model.drop_connect_rate > 0:
-        gated = [bi for bi, blk in enumerate(blocks) if blk.spec.skip and model.drop_connect_rate * float(bi) / len(blocks) > 0]
-        if gated:
-            sampler = getattr(model, "drop_connect_uniform", None)
-            u = sampler(len(gated), N, dev) if sampler is not None else torch.rand(len(gated), N, device=dev, dtype=torch.float32)
-            cache = model.__dict__.setdefault("_dc_keep_cache", {})
-            key = (str(dev), model.drop_connect_rate)
-            if key not in cache:    # uploaded once, not per step
-                cache[key] = torch.tensor([1.0 - model.drop_connect_rate * float(bi) / len(blocks) for bi in gated],
-                                          dtype=torch.float32, device=dev).unsqueeze(1)
-            keep = cache[key]
-            gates = torch.floor(keep + u.to(device=dev, dtype=torch.float32)) / keep
-            dc_gates = {bi: gates[j] for j, bi in enumerate(gated)}
+    gated, gates = _dc_gates(model, N, dev) if training else ([], None)
+    dc_gates = {bi: gates[j] for j, bi in enumerate(gated)}
+    if plan is not None:
+        plan.extra["gates"] = gates
     for bi, blk in enumerate(blocks):
         s = blk.spec
         M_in = N * s.hin * s.hin
@@ -208,35 +220,110 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False):
                               st), "mt_bn_act_fwd")
     if save:
         saved["head"] = dict(y_in=y, z=z_h, bn=bn_h)
-    _bump_tracked()
+    _bump_tracked(plan)
     return feat, saved, ys
+
+
+def _state_tensors(model, params):
+    """Everything a recorded phase holds an address of besides its own buffers: parameters and BatchNorm buffers."""
+    return list(params) + [b for b in model.buffers()]
 
 
 class _EffNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, want_blocks, x_nhwc, *params):
+        from . import plans
         want_blocks, grad_on = want_blocks
         save = grad_on and any(ctx.needs_input_grad)      # see tsf_engine._TSFFunction.forward
-        feat, saved, ys = effnet_forward(model, x_nhwc, params, model.training, save, want_blocks)
-        ctx.model, ctx.saved, ctx.params, ctx.training = model, saved, params, model.training
         N, H, W, _ = x_nhwc.shape
         ctx.shape = (N, H, W)
-        outs = [feat]
-        if want_blocks:
-            for t in ys:
-                ctx.mark_non_differentiable(t)
-            outs += ys
-        return tuple(outs)
+        ctx.model, ctx.params, ctx.training = model, params, model.training
+        ctx.plan = ctx.token = None
+        np_, mode = None, "eager"
+        if save and not want_blocks:
+            stream = torch.cuda.current_stream(x_nhwc.device).cuda_stream
+            key = ("ef", tuple(x_nhwc.shape), x_nhwc.dtype, model.training, L.deterministic(), L.gemm_split_enabled(),
+                   float(model.drop_connect_rate), tuple(ctx.needs_input_grad[3:]), stream)
+            np_, mode = plans.lookup(model, key)
+            if mode == "replay" and np_.state_ptrs != plans.state_ptrs(_state_tensors(model, params)):
+                plans.drop(model, np_)                   # parameters / buffers moved (load_state_dict, .to()): record afresh later
+                np_, mode = None, "eager"
+        if mode == "eager":
+            feat, saved, ys = effnet_forward(model, x_nhwc, params, model.training, save, want_blocks)
+            ctx.saved = saved
+            outs = [feat]
+            if want_blocks:
+                for t in ys:
+                    ctx.mark_non_differentiable(t)
+                outs += ys
+            return tuple(outs)
+        if mode == "record":
+            np_.stream = stream
+            x_s = plans.static_input(np_, "x", x_nhwc)
+            pl = L.Plan()
+            try:
+                with pl:
+                    feat, saved, _ = effnet_forward(model, x_s, params, model.training, True, False, plan=np_)
+            except Exception:
+                np_.broken = True
+                raise
+            np_.fwd = pl
+            np_.extra.update(saved=saved, feat=feat)
+            np_.state_ptrs = plans.state_ptrs(_state_tensors(model, params))
+            plans.own(np_, feat)
+            plans.STATS["recorded"] += 1
+        else:
+            plans.refresh_input(np_, "x", x_nhwc)
+            if np_.extra.get("gates") is not None:
+                np_.extra["gates"].copy_(_dc_gates(model, N, x_nhwc.device)[1])
+            plans.run(np_.fwd)
+            if np_.extra.get("tracked"):
+                torch._foreach_add_(np_.extra["tracked"], 1)
+        ctx.plan, ctx.token = np_, np_.begin()
+        ctx.saved = np_.extra["saved"]
+        return (np_.extra["feat"].detach(),)
 
     @staticmethod
     def backward(ctx, dfeat, *unused):
         if ctx.saved is None:
             raise RuntimeError("EfficientNet: backward ran a second time through the same forward; the activation buffers are "
                                "released after the first pass (retain_graph is not supported by the HIP engine)")
-        from .effnet_backward import effnet_backward
-        dx, dparams = effnet_backward(ctx.model, ctx.params, ctx.saved, ctx.shape, ctx.training, dfeat.contiguous(),
-                                      ctx.needs_input_grad[2], ctx.needs_input_grad[3:])
+        from . import plans
+        from .effnet_backward import effnet_backward, LAST_RUN
+        np_ = ctx.plan
+        dfeat = dfeat.contiguous()
+        need_dx, need_dp = ctx.needs_input_grad[2], ctx.needs_input_grad[3:]
+        if np_ is None:
+            dx, dparams = effnet_backward(ctx.model, ctx.params, ctx.saved, ctx.shape, ctx.training, dfeat, need_dx, need_dp)
+        elif (plans.grads_exist(ctx.params) or torch.cuda.current_stream(dfeat.device).cuda_stream != np_.stream
+              or torch.cuda.is_current_stream_capturing()):
+            # gradients that already exist are ADDED to by autograd: they alias the plan's gradient buffer, so this pass needs
+            # fresh ones -- the eager launch sequence over the plan's saved activations (which stay for the next replay)
+            plans.STATS["eager_accumulate"] += 1
+            dx, dparams = effnet_backward(ctx.model, ctx.params, ctx.saved, ctx.shape, ctx.training, dfeat, need_dx, need_dp,
+                                          keep_saved=True)
+        elif np_.bwd is None:
+            d_s = plans.static_input(np_, "dfeat", dfeat)
+            pl = L.Plan()
+            try:
+                with pl:
+                    dx, dparams = effnet_backward(ctx.model, ctx.params, ctx.saved, ctx.shape, ctx.training, d_s, need_dx, need_dp,
+                                                  keep_saved=True, plan=np_)
+            except Exception:
+                np_.broken = True
+                raise
+            np_.bwd = pl
+            np_.extra.update(grads=list(dparams), last_run=dict(LAST_RUN))
+            dparams = plans.fresh_aliases(dparams)
+        else:
+            plans.refresh_input(np_, "dfeat", dfeat)
+            plans.run(np_.bwd)
+            LAST_RUN.update(np_.extra["last_run"])
+            L.grads_ready(ctx.model, ctx.params, np_.extra["flat_grads"])
+            dx, dparams = None, plans.fresh_aliases(np_.extra["grads"])
         ctx.saved = None
+        if np_ is not None:
+            np_.release()
         return (None, None, dx) + tuple(dparams)
 
 

@@ -6,6 +6,7 @@ header declares is not exported, and every wrapper raises on a non-zero return c
 import ctypes as C
 import os
 import subprocess
+import threading
 
 import torch
 
@@ -129,6 +130,17 @@ PROTOTYPES = {
     "mt_se_stage_fused": [f32p] * 7 + [C.c_int] + [f32p] * 5 + [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_conv1x1_bwd_fused": [f32p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "mt_stem_conv_wgrad": [f32p] * 4 + [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_plan_create": [C.POINTER(C.c_void_p)],
+    "mt_plan_destroy": [C.c_void_p],
+    "mt_plan_record_begin": [C.c_void_p],
+    "mt_plan_record_end": [C.c_void_p],
+    "mt_plan_size": [C.c_void_p],
+    "mt_plan_tag": [C.c_int, C.c_double],
+    "mt_plan_fork": [C.c_void_p, C.c_void_p],
+    "mt_plan_run": [C.c_void_p, C.c_uint],
+    "mt_plan_probe_read": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "mt_memset_async": [C.c_void_p, C.c_int, i64, C.c_void_p],
+    "mt_copy_async": [C.c_void_p, C.c_void_p, i64, C.c_void_p],
 }
 _RESTYPES = {"mt_last_error": C.c_char_p, "mt_planes_elems": C.c_int64, "mt_gemm_planes_workspace_bytes": C.c_int64}
 
@@ -150,8 +162,13 @@ def build(verbose: bool = False):
     return LIB_PATH
 
 
+# MT_VERSION of include/mintime_hip.h this binding was written against (tests/test_host_logic.py keeps the two equal; the package
+# itself does not need the header at run time -- it may be copied or installed without the repository's include/ directory)
+ABI_VERSION = 113
+
+
 def header_version() -> int:
-    """MT_VERSION of include/mintime_hip.h -- the one place the ABI version is written down."""
+    """MT_VERSION as written in include/mintime_hip.h (repository checkouts only)."""
     import re
     with open(os.path.join(_HERE, "..", "include", "mintime_hip.h")) as f:
         return int(re.search(r"#define\s+MT_VERSION\s+(\d+)", f.read()).group(1))
@@ -174,8 +191,9 @@ def get():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     v = lib.mt_version()
-    if v != header_version():
-        raise MintimeHipError(f"libmintime_hip.so version {v} != header version {header_version()}; rebuild it")
+    if v != ABI_VERSION:
+        raise MintimeHipError(f"libmintime_hip.so version {v} != binding version {ABI_VERSION}; rebuild it "
+                              "(`python -c 'import __graft_entry__ as g; g.build()'`)")
     _lib = lib
     return lib
 
@@ -270,6 +288,11 @@ def gemm_planes(op, a_planes, b_planes, M, N, K, Cout=None, ldc=0, epilogue=EPI_
     d.bias, d.R, d.ldr, d.C2, d.ldc2 = ptr(bias), ptr(R), ldr, ptr(C2), ldc2
     d.n_half, d.col_sum, d.c_planes, d.split_k = n_half, ptr(col_sum), ptr(c_planes), split_k
     d.stats, d.stats_slots = ptr(stats), stats_slots
+    if recording() is not None:
+        if op == OP_TN:
+            tag_next(TAG_WGRAD, 2.0 * M * N * K)
+        elif epilogue == EPI_GEGLU:
+            tag_next(TAG_FF1, 2.0 * M * N * K)
     prof = PROFILE
     if prof is not None:
         for pr in prof:
@@ -298,12 +321,96 @@ def stream_ptr():
 
 
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL). Refuses CPU tensors: the library only takes device memory."""
+    """Device pointer of a tensor (None -> NULL). Refuses CPU tensors: the library only takes device memory.
+    While this thread records a launch plan the tensor is pinned by the plan: every address a recorded call holds stays allocated
+    (and is therefore never handed out again) for as long as the plan lives."""
     if t is None:
         return None
     if not t.is_cuda:
         raise MintimeHipError("libmintime_hip takes device pointers only; got a CPU tensor (no CPU fallback exists)")
+    rec = getattr(_REC, "plan", None)
+    if rec is not None:
+        rec.keep[id(t)] = t
     return C.c_void_p(t.data_ptr())
+
+
+# ---- launch plans (include/mintime_hip.h "Launch plans"; csrc/plan.hip) ---------------------------------------------------------
+_REC = threading.local()
+
+TAG_WGRAD, TAG_FF1, TAG_DWCONV_DGRAD = 1, 2, 3      # probe tags of the bench legs (mt_plan_tag)
+
+
+def recording():
+    """The plan this thread is recording, or None."""
+    return getattr(_REC, "plan", None)
+
+
+class Plan:
+    """One recorded phase: the C-side call list plus every tensor whose address it holds."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(get().mt_plan_create(C.byref(h)), "mt_plan_create")
+        self.handle = h
+        self.keep = {}
+        self.ops = 0
+
+    def __enter__(self):
+        if recording() is not None:
+            raise MintimeHipError("a launch plan is already being recorded on this thread")
+        check(get().mt_plan_record_begin(self.handle), "mt_plan_record_begin")
+        _REC.plan = self
+        return self
+
+    def __exit__(self, *exc):
+        _REC.plan = None
+        check(get().mt_plan_record_end(self.handle), "mt_plan_record_end")
+        self.ops = get().mt_plan_size(self.handle)
+        return False
+
+    def pin(self, *tensors):
+        for t in tensors:
+            if t is not None:
+                self.keep[id(t)] = t
+
+    def run(self, probe_mask=0):
+        check(get().mt_plan_run(self.handle, probe_mask), "mt_plan_run")
+
+    def probe_read(self, tag):
+        n, ms, work = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
+        check(get().mt_plan_probe_read(self.handle, tag, C.byref(n), C.byref(ms), C.byref(work)), "mt_plan_probe_read")
+        return n.value, ms.value, work.value
+
+    def __del__(self):
+        try:
+            if self.handle and _lib is not None:
+                _lib.mt_plan_destroy(self.handle)
+        except Exception:        # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def tag_next(tag, work=0.0):
+    """Tag the next recorded call (bench.py's probe legs time tagged calls with events inside mt_plan_run)."""
+    if recording() is not None:
+        get().mt_plan_tag(tag, float(work))
+
+
+def zeros(shape, dtype, device):
+    """torch.zeros as torch.empty + mt_memset_async: the fill is an entry point of the library, so a recorded phase re-issues it."""
+    if torch.device(device).type != "cuda":
+        return torch.zeros(shape, dtype=dtype, device=device)      # host-side buffer carving (the gloo tests of ddp.py): no launch
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if t.numel():
+        check(get().mt_memset_async(ptr(t), 0, t.numel() * t.element_size(), stream_ptr()), "mt_memset_async")
+    return t
+
+
+def zero_(t):
+    if not t.is_contiguous():
+        raise MintimeHipError("zero_: contiguous tensor expected")
+    if t.numel():
+        check(get().mt_memset_async(ptr(t), 0, t.numel() * t.element_size(), stream_ptr()), "mt_memset_async")
+    return t
 
 
 # Optional live kernel timing (bench.py's roofline legs): a list of probes {"match": fn(desc) -> bool, "events": [...]} for
@@ -315,6 +422,8 @@ PROFILE = None
 
 def timed(name, fn, work=0.0):
     """Run fn() (one kernel launch); if a probe called `name` is active, bracket it with events and note `work` (bytes or flops)."""
+    if name == "dwconv_dgrad":
+        tag_next(TAG_DWCONV_DGRAD, work)
     prof = PROFILE
     if prof is not None:
         for pr in prof:
@@ -352,6 +461,11 @@ def gemm(op, A, B, Cout, M, N, K, lda, ldb, ldc, prologue=PRO_NONE, epilogue=EPI
     if conv is not None:   # (H, W, C, Ho, Wo, k, stride, pad, act[, src_u8])
         (d.conv_H, d.conv_W, d.conv_C, d.conv_Ho, d.conv_Wo, d.conv_k, d.conv_stride, d.conv_pad, d.conv_act) = conv[:9]
         d.conv_src_u8 = conv[9] if len(conv) > 9 else 0
+    if recording() is not None:
+        if op == OP_TN and prologue == PRO_NONE and b_prologue == BPRO_NONE:
+            tag_next(TAG_WGRAD, 2.0 * M * N * K)
+        elif epilogue == EPI_GEGLU:
+            tag_next(TAG_FF1, 2.0 * M * N * K)
     prof = PROFILE
     if prof is not None:
         for pr in prof:
@@ -375,7 +489,7 @@ def zero_grads(params, with_flat=False):
         if p is not None:
             total += (p.numel() + 3) // 4 * 4
     dev = next(p for p in params if p is not None).device
-    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    flat = zeros(total, torch.float32, dev)
     views = [None if p is None else flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)]
     return (views, flat) if with_flat else views
 
@@ -448,6 +562,16 @@ class SideStream:
             fn()
             return None
         main = torch.cuda.current_stream(self.device)
+        rec = recording()
+        if rec is not None:
+            # recording a launch plan: the dependency is an entry point of the library (recorded with the launches), and the
+            # tensors the side launch reads are pinned by the plan instead of by the caching allocator's stream bookkeeping
+            check(get().mt_plan_fork(C.c_void_p(main.cuda_stream), C.c_void_p(self.stream.cuda_stream)), "mt_plan_fork")
+            rec.pin(*reads)
+            with torch.cuda.stream(self.stream):
+                fn()
+            self.pending = [None]
+            return None
         ready = torch.cuda.Event()
         ready.record(main)
         self.stream.wait_event(ready)
@@ -470,5 +594,8 @@ class SideStream:
             main.wait_event(event)
             return
         if self.pending:
-            main.wait_event(self.pending[-1])        # the side stream is in order: its last launch implies all earlier ones
+            if self.pending[-1] is None:             # launches made while recording a plan
+                check(get().mt_plan_fork(C.c_void_p(self.stream.cuda_stream), C.c_void_p(main.cuda_stream)), "mt_plan_fork")
+            else:
+                main.wait_event(self.pending[-1])    # the side stream is in order: its last launch implies all earlier ones
         self.pending = []

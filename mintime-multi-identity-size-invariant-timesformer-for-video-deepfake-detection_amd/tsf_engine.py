@@ -246,6 +246,24 @@ def tsf_forward(model, feat, aux, params, B, F, n, save):
     return logits, s_att, t_att, saved
 
 
+class _StaticAux:
+    """The per-clip side inputs of a recorded forward in static buffers (plans.py): same attributes as _Aux."""
+
+    NAMES = ("mask", "ident", "sizes", "positions")
+
+    def __init__(self, np_, aux):
+        from . import plans
+        for nm in self.NAMES:
+            setattr(self, nm, plans.static_input(np_, "aux_" + nm, getattr(aux, nm)))
+        self.err = aux.err
+
+    def refresh(self, np_, aux):
+        from . import plans
+        for nm in self.NAMES:
+            plans.refresh_input(np_, "aux_" + nm, getattr(aux, nm))
+        self.err = aux.err
+
+
 class _TSFFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, aux, dims, feat, *params):
@@ -255,16 +273,56 @@ class _TSFFunction(torch.autograd.Function):
         # the caller's grad mode comes in through `dims`.  Without it an eval forward would keep every activation and take
         # the training-only split-K + atomics branch.
         save = grad_on and any(ctx.needs_input_grad)
-        from . import tsf_planes
-        if tsf_planes.eligible(model, B * (1 + F * n), save):
-            logits, s_att, t_att, saved = tsf_planes.tsf_forward_planes(model, feat, aux, params, B, F, n, save)
-        elif tsf_planes.dropout_active(model):
-            raise NotImplementedError("attn-dropout / ff-dropout > 0 in train mode runs on the plane path only (MT_TSF_PLANES=1, "
-                                      "MT_GEMM_SPLIT=1, no MT_TSF_PRUNE_LAST / MT_WGRAD_DEFER, not under stream capture)")
+        from . import tsf_planes, plans
+        ctx.model, ctx.dims, ctx.params = model, dims, params
+        ctx.plan = ctx.token = None
+        planes = tsf_planes.eligible(model, B * (1 + F * n), save)
+        np_, mode = None, "eager"
+        if planes and save and not tsf_planes.dropout_active(model):
+            stream = torch.cuda.current_stream(feat.device).cuda_stream
+            key = ("tsf", B, F, n, feat.dtype, model.training, model.require_attention, L.deterministic(),
+                   tuple(ctx.needs_input_grad[3:]), stream, os.environ.get("MT_PLANES_STREAMK", "0"),
+                   tuple(getattr(aux, nm) is None for nm in _StaticAux.NAMES))
+            np_, mode = plans.lookup(model, key)
+            if mode == "replay" and np_.state_ptrs != plans.state_ptrs(params):
+                plans.drop(model, np_)
+                np_, mode = None, "eager"
+        if mode == "eager":
+            if planes:
+                logits, s_att, t_att, saved = tsf_planes.tsf_forward_planes(model, feat, aux, params, B, F, n, save)
+            elif tsf_planes.dropout_active(model):
+                raise NotImplementedError("attn-dropout / ff-dropout > 0 in train mode runs on the plane path only (MT_TSF_PLANES=1, "
+                                          "MT_GEMM_SPLIT=1, no MT_TSF_PRUNE_LAST / MT_WGRAD_DEFER, not under stream capture)")
+            else:
+                logits, s_att, t_att, saved = tsf_forward(model, feat, aux, params, B, F, n, save)
+            ctx.aux, ctx.saved, ctx.feat = aux, saved, feat
+        elif mode == "record":
+            np_.stream = stream
+            feat_s = plans.static_input(np_, "feat", feat)
+            aux_s = _StaticAux(np_, aux)
+            pl = L.Plan()
+            try:
+                with pl:
+                    logits, s_att, t_att, saved = tsf_planes.tsf_forward_planes(model, feat_s, aux_s, params, B, F, n, True)
+            except Exception:
+                np_.broken = True
+                raise
+            np_.fwd = pl
+            np_.extra.update(saved=saved, outs=(logits, s_att, t_att), aux=aux_s, feat=feat_s)
+            np_.state_ptrs = plans.state_ptrs(params)
+            plans.own(np_, logits)
+            plans.STATS["recorded"] += 1
         else:
-            logits, s_att, t_att, saved = tsf_forward(model, feat, aux, params, B, F, n, save)
-        ctx.model, ctx.aux, ctx.dims, ctx.saved = model, aux, dims, saved
-        ctx.feat, ctx.params = feat, params
+            plans.refresh_input(np_, "feat", feat)
+            np_.extra["aux"].refresh(np_, aux)
+            np_.extra["saved"]["w_serial"] = tsf_planes.weight_planes_touch(model, params)   # the split launch is in the plan
+            plans.run(np_.fwd)
+            _publish_index_flag(aux.err)
+            logits, s_att, t_att = np_.extra["outs"]
+        if np_ is not None:
+            ctx.plan, ctx.token = np_, np_.begin()
+            ctx.aux, ctx.saved, ctx.feat = np_.extra["aux"], np_.extra["saved"], np_.extra["feat"]
+            logits, s_att, t_att = (None if t is None else t.detach() for t in (logits, s_att, t_att))
         outs = [logits]
         if model.require_attention:
             ctx.mark_non_differentiable(s_att, t_att)
@@ -274,14 +332,48 @@ class _TSFFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits, *unused):
         from .tsf_backward import tsf_backward
+        from . import plans
         if ctx.saved is None:
             raise RuntimeError("SizeInvariantTimeSformer: backward ran a second time through the same forward; the activation "
                                "buffers are released after the first pass (retain_graph is not supported by the HIP engine)")
         if ctx.saved.get("planes"):
             from .tsf_planes import tsf_backward_planes as tsf_backward
-        dfeat, dparams = tsf_backward(ctx.model, ctx.feat, ctx.aux, ctx.params, ctx.dims, ctx.saved,
-                                      dlogits.contiguous(), ctx.needs_input_grad[3], ctx.needs_input_grad[4:])
+        np_ = ctx.plan
+        dlogits = dlogits.contiguous()
+        need_df, need_dp = ctx.needs_input_grad[3], ctx.needs_input_grad[4:]
+        if np_ is None:
+            dfeat, dparams = tsf_backward(ctx.model, ctx.feat, ctx.aux, ctx.params, ctx.dims, ctx.saved, dlogits, need_df, need_dp)
+        elif (plans.grads_exist(ctx.params) or torch.cuda.current_stream(dlogits.device).cuda_stream != np_.stream
+              or torch.cuda.is_current_stream_capturing()):
+            plans.STATS["eager_accumulate"] += 1        # see effnet_engine._EffNetFunction.backward
+            dfeat, dparams = tsf_backward(ctx.model, ctx.feat, ctx.aux, ctx.params, ctx.dims, ctx.saved, dlogits, need_df, need_dp,
+                                          keep_saved=True)
+        elif np_.bwd is None:
+            d_s = plans.static_input(np_, "dlogits", dlogits)
+            pl = L.Plan()
+            try:
+                with pl:
+                    dfeat, dparams = tsf_backward(ctx.model, ctx.feat, ctx.aux, ctx.params, ctx.dims, ctx.saved, d_s, need_df,
+                                                  need_dp, keep_saved=True, plan=np_)
+            except Exception:
+                np_.broken = True
+                raise
+            np_.bwd = pl
+            np_.extra.update(grads=list(dparams), dfeat=dfeat)
+            plans.own(np_, dfeat)
+            dparams = plans.fresh_aliases(dparams)
+            dfeat = None if dfeat is None else dfeat.detach()
+        else:
+            from .tsf_planes import check_weight_serial
+            check_weight_serial(ctx.model, ctx.saved)
+            plans.refresh_input(np_, "dlogits", dlogits)
+            plans.run(np_.bwd)
+            L.grads_ready(ctx.model, ctx.params, np_.extra["flat_grads"])
+            dfeat = None if np_.extra["dfeat"] is None else np_.extra["dfeat"].detach()
+            dparams = plans.fresh_aliases(np_.extra["grads"])
         ctx.saved = None
+        if np_ is not None:
+            np_.release()
         return (None, None, None, dfeat) + tuple(dparams)
 
 

@@ -52,8 +52,8 @@ def _dropout_mult(model, shape, p, dev):
 
 
 def weight_planes(model, params, training):
-    """Plane tensors of the 6 Linear weights of every layer, kept on the module and re-split when the weights may have changed:
-    always before a training forward, otherwise when a parameter's storage / version / the optimizer epoch moved."""
+    """Plane tensors of the 6 Linear weights of every layer, kept on the module (their storage is allocated once) and re-split from
+    the fp32 weights at the start of every forward."""
     lib = L.get()
     wts = list(params[5:5 + 16 * model.depth])
     sel = [(li, off) for li in range(model.depth) for off in _SEL]
@@ -74,14 +74,36 @@ def weight_planes(model, params, training):
         cache = dict(ident=ident, holder=holder, host=host, table=host.to(dev, non_blocking=True), blocks=first, count=len(rows),
                      stamp=None)
         model._wplanes_cache = cache
+    # The planes are re-written on EVERY forward (one launch, ~60 us for the 54 matrices): updates that move no version counter
+    # (p.data.copy_, dist.broadcast(p.data), a fused optimizer step through raw pointers) cannot leave them stale, and a forward
+    # captured into a HIP graph (harness.GraphedEval) holds the split as a node, so its replays read the weights of the replay's time.
     stamp = (tuple(w._version for w in ws), WEIGHT_EPOCH[0])
-    if training or cache["stamp"] != stamp:
-        L.check(lib.mt_split_planes_blk_multi(cache["table"].data_ptr(), cache["count"], cache["blocks"], L.stream_ptr()),
-                "mt_split_planes_blk_multi")
-        if cache["stamp"] != stamp:                  # the weights changed since the planes were last written: graphs that saved the
-            cache["serial"] = cache.get("serial", 0) + 1      # old serial must not run their backward on the new planes
-        cache["stamp"] = stamp
+    L.check(lib.mt_split_planes_blk_multi(cache["table"].data_ptr(), cache["count"], cache["blocks"], L.stream_ptr()),
+            "mt_split_planes_blk_multi")
+    if cache["stamp"] != stamp:                      # the weights changed since the planes were last written: graphs that saved the
+        cache["serial"] = cache.get("serial", 0) + 1          # old serial must not run their backward on the new planes
+    cache["stamp"] = stamp
     return cache["holder"], cache["serial"]
+
+
+def weight_planes_touch(model, params):
+    """Bookkeeping of weight_planes() for a replayed forward (the split launch itself is part of the recorded phase): a new serial
+    when the weights changed since the planes were last written.  Returns the serial the replayed forward's planes carry."""
+    cache = model._wplanes_cache
+    wts = list(params[5:5 + 16 * model.depth])
+    ws = [wts[16 * li + off] for li in range(model.depth) for off in _SEL]
+    stamp = (tuple(w._version for w in ws), WEIGHT_EPOCH[0])
+    if cache["stamp"] != stamp:
+        cache["serial"] = cache.get("serial", 0) + 1
+        cache["stamp"] = stamp
+    return cache["serial"]
+
+
+def check_weight_serial(model, saved):
+    cache = getattr(model, "_wplanes_cache", None)
+    if cache is None or cache.get("serial") != saved["w_serial"]:
+        raise RuntimeError("SizeInvariantTimeSformer: the Linear weights were updated between this graph's forward and its backward "
+                           "(their operand planes were rewritten by a later forward): run backward before the optimizer step")
 
 
 def _new(dev, *shape):
@@ -189,7 +211,7 @@ def tsf_forward_planes(model, feat, aux, params, B, F, n, save):
     return logits, s_att, t_att, saved
 
 
-def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfeat, need_dparams):
+def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfeat, need_dparams, keep_saved=False, plan=None):
     """Reverse launch sequence on plane operands: data gradients (NN, the weight planes read along their rows) on the main stream,
     weight gradients (TN, both operands read along their rows, K-range-major split-K + fp32 atomics) and the parameter-gradient sums
     of the LayerNorm backward on the weight-gradient stream.  Every sub-block writes its gradients into fresh buffers that the side
@@ -204,11 +226,8 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
     M = B * N
     eps = arch.LN_EPS
     scale = float(dh) ** -0.5
-    cache = getattr(model, "_wplanes_cache", None)
-    if cache is None or cache.get("serial") != saved["w_serial"]:
-        raise RuntimeError("SizeInvariantTimeSformer: the Linear weights were updated between this graph's forward and its backward "
-                           "(their operand planes were rewritten by a later forward): run backward before the optimizer step")
-    wp = cache["holder"]
+    check_weight_serial(model, saved)
+    wp = model._wplanes_cache["holder"]
     grads, flat_grads = L.zero_grads(list(params), with_flat=True)
     P = list(params)
     idx = len(P)
@@ -244,7 +263,7 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
     # ---- head
     i0 = take(4)
     g, b_, w_h, b_h = P[i0:i0 + 4]
-    dx = torch.zeros(B, N, D, dtype=torch.float32, device=dev)
+    dx = L.zeros((B, N, D), torch.float32, dev)
     L.check(lib.mt_head_bwd(L.ptr(dlogits), L.ptr(saved["x_final"]), L.ptr(g), L.ptr(b_), L.ptr(w_h), L.ptr(dx), L.ptr(grads[i0]),
                             L.ptr(grads[i0 + 1]), L.ptr(grads[i0 + 2]), L.ptr(grads[i0 + 3]), B, N, D, model.num_classes, eps,
                             st), "mt_head_bwd")
@@ -279,7 +298,8 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
         # column sums of the new dx -> space to_out.0.bias -- unless that projection sits under a dropout (its own sub-block sums the
         # masked gradient then)
         dx2, dx_p = ln_bwd(dxn, r, g, dx2, i0, None if rec[1].get("dm") is not None else grads[i0 - 1], 0)
-        r.clear()
+        if not keep_saved:
+            r.clear()
         # ---- attention blocks: x_out = o Wo^T + bo + x ; o = attn(qkv) ; qkv = LN(x) Wqkv^T
         for mode in (1, 0):
             i0 = take(5)
@@ -310,7 +330,8 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
             else:
                 tgt, skip = grads[i0 - 1], 0
             dx2, dx_p = ln_bwd(dxn, r, g, dx2, i0, tgt, skip)
-            r.clear()
+            if not keep_saved:
+                r.clear()
 
     # ---- embeddings + patch embedding (row-mapped operands: the fp32 GEMM family)
     i0 = take(5)
@@ -329,5 +350,7 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
         L.gemm(L.OP_NN, dx2, w_pe, dfeat, Mt, C_in, D, D, C_in, C_in, a_map=tok_map)
     side.wait()
     assert idx == 0
+    if plan is not None:
+        plan.extra["flat_grads"] = flat_grads
     L.grads_ready(model, params, flat_grads)
     return dfeat, [gr if gneed else None for gneed, gr in zip(need_dparams, grads)]

@@ -110,6 +110,33 @@ def test_geglu_pair_emits_planes(M):
     assert float(L.planes_to_float(du_p, du_p.shape[1] * 32, 8 * D)[M:].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("D", [48, 80, 144])
+def test_geglu_backward_planes_when_the_half_width_is_not_a_multiple_of_the_block_tile(D):
+    """n_half = 4 D with D % 32 == 16 is not a multiple of the 128-column block tile: the last tile's upper waves own no columns and
+    must not touch the dg half of the planes (they once wrote zeros over columns another block owns)."""
+    M = 786
+    A, W, b = _rand(M, D, seed=1), _rand(8 * D, D, seed=2, scale=0.2), _rand(8 * D, seed=3, scale=0.1)
+    u = torch.empty(M, 8 * D, device="cuda")
+    h = torch.empty(M, 4 * D, device="cuda")
+    L.gemm(L.OP_NT, A.cuda(), W.cuda(), h, M, 8 * D, D, D, D, 4 * D, epilogue=L.EPI_GEGLU, bias=b.cuda(), C2=u, ldc2=8 * D, n_half=4 * D)
+    dx, W2 = _rand(M, D, seed=7), _rand(D, 4 * D, seed=8, scale=0.2)
+    du_ref = torch.empty(M, 8 * D, device="cuda")
+    cs_ref = torch.zeros(8 * D, device="cuda")
+    L.gemm(L.OP_NN, dx.cuda(), W2.cuda(), du_ref, M, 4 * D, D, D, 4 * D, 8 * D, epilogue=L.EPI_GEGLU_BWD, C2=u, ldc2=8 * D, n_half=4 * D,
+           col_sum=cs_ref)
+    for rep in range(3):                                  # (the overwrite was a race between blocks: give it a few chances)
+        du_p = L.planes_empty(M, 8 * D, "cuda")
+        du_p.fill_(float("nan"))
+        cs = torch.zeros(8 * D, device="cuda")
+        L.gemm_planes(L.OP_NN, L.split_planes_blk(dx.cuda()), L.split_planes_blk(W2.cuda()), M, 4 * D, D, epilogue=L.EPI_GEGLU_BWD,
+                      C2=u, ldc2=8 * D, n_half=4 * D, col_sum=cs, c_planes=du_p, streamk=False)
+        got = L.planes_to_float(du_p, M, 8 * D)
+        assert not torch.isnan(got).any()
+        assert_close(got, du_ref, TOL, f"du planes, D = {D}")
+        assert_close(got[:, 4 * D:], du_ref[:, 4 * D:], TOL, f"dg half of du, D = {D}")
+        assert_close(cs, du_ref.double().sum(0), 1e-4, "column sums of du")
+
+
 @pytest.mark.parametrize("M,N,K", [(786, 512, 1536), (1000, 512, 4096), (300, 136, 512), (786, 512, 520)])
 def test_nn_planes_reads_the_weight_along_its_rows(M, N, K):
     """Data gradient dX[M,N] = dY[M,K] . W[K,N] with W as stored: no transposed copy, LDS transpose-reads."""

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in the header but not exported"
     assert declared == set(lib.PROTOTYPES), declared ^ set(lib.PROTOTYPES)
-    assert lib.get().mt_version() == lib.header_version() == 112
+    assert lib.get().mt_version() == lib.header_version() == lib.ABI_VERSION
 
 
 def test_errors_are_reported_not_swallowed():
