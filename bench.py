@@ -303,6 +303,63 @@ def forward_only_leg(ef, tsf, batch, iters=5):
     return out
 
 
+def pin_launch_thread(local_rank, world):
+    """One launch thread per rank: give each rank its own slice of the host's cores (rank r of N takes the r-th N-th of the cores
+    this process may use -- on a two-socket node that is also the socket next to GPUs r of each half), so that 8 Python launch loops
+    and their RCCL proxy threads do not migrate over each other.  MT_BENCH_NO_PIN=1 leaves the affinity alone."""
+    if world <= 1 or os.environ.get("MT_BENCH_NO_PIN"):
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cores) // world)
+        mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+        os.sched_setaffinity(0, mine)
+        return [mine[0], mine[-1]]
+    except (AttributeError, OSError):
+        return None
+
+
+def other_config_leg(config, dev, steps=5, warm=6):
+    """Another single-GPU BASELINE configuration timed in the same process (the driver's line carries config 3 as `value`; configs 2
+    and 5 ride along so that they are driver-timed too): fresh models, `warm` untimed steps (they also grow the caching allocator's
+    pools: the first steps of a large configuration on a warm box pay fresh hipMallocs), then `steps` timed steps."""
+    import gc
+    from mintime_amd import harness
+    wl = WORKLOADS[config]
+    B, frames = wl["B"], wl["frames"]
+    try:
+        if wl["extractor"] == "xception":
+            cfg, ef, tsf = harness.build_models_xs(frames, seed=0, device=dev)
+        else:
+            cfg, ef, tsf = harness.build_models(frames, seed=0, device=dev)
+        opt = harness.make_optimizer(cfg, ef, tsf)
+        batch = harness.device_batch(B, frames, wl["ids"], seed=0, device=dev)
+        for _ in range(warm):
+            harness.train_step(ef, tsf, opt, batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = harness.train_step(ef, tsf, opt, batch)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        t_enq = 0.0
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            harness.train_step(ef, tsf, opt, batch)
+            t_enq += time.perf_counter() - t1
+        torch.cuda.synchronize()
+        out = {"workload": f"{wl['name']}: B={B}, {frames} frames, {wl['ids']} identit{'y' if wl['ids'] == 1 else 'ies'}, {wl['extractor']}",
+               "ms_per_step": round(ms, 3), "clips_s": round(B / (ms * 1e-3), 2), "steps": steps, "warmup": warm,
+               "host_enqueue_ms_per_step": round(1e3 * t_enq / 2, 3), "loss": round(float(loss.item()), 5)}
+    except Exception as e:       # noqa: BLE001  (an extra leg must never cost the line)
+        out = {"error": f"{type(e).__name__}: {e}"}
+    ef = tsf = opt = batch = None
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def free_port():
     import socket
     with socket.socket() as so:
@@ -405,6 +462,7 @@ def main():
         return stub_main(a, rank, world)
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    pinned = pin_launch_thread(local_rank, world)
     if world > 1 or a.force_reducer:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -452,6 +510,8 @@ def main():
                "match_planes": lambda d: d.op == lib.OP_TN, "events": []}
     p_ff1 = {"match": lambda d: d.epilogue == lib.EPI_GEGLU, "match_planes": lambda d: d.epilogue == lib.EPI_GEGLU, "events": []}
     p_dw = {"name": "dwconv_dgrad", "events": []}
+    if reducer is not None and hasattr(reducer, "time_exposed"):
+        reducer.time_exposed = True
     lib.PROFILE = [p_ff1, p_wgrad, p_dw]
     from mintime_amd import plans
     plans.PROBE_MASK[0] = (1 << lib.TAG_WGRAD) | (1 << lib.TAG_FF1) | (1 << lib.TAG_DWCONV_DGRAD)
@@ -479,10 +539,20 @@ def main():
         t_enq += time.perf_counter() - t1
     torch.cuda.synchronize()
     t_enq /= 3
+    exposed = reducer.exposed_ms() if reducer is not None and hasattr(reducer, "exposed_ms") else None
+    if reducer is not None and hasattr(reducer, "time_exposed"):
+        reducer.time_exposed = False
+    # per-rank readings (first contact with an 8-GPU node should be diagnostic, not one number): step time, host enqueue time and
+    # the exposed part of the gradient all-reduce of every rank
+    mine = torch.tensor([1e3 * dt / a.steps, 1e3 * t_enq, -1.0 if exposed is None else exposed], device=dev, dtype=torch.float64)
+    per_rank = [mine]
     if world > 1:
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    per_rank = [[round(float(v), 3) for v in r.tolist()] for r in per_rank]
     out = None
     if rank == 0:
         ms = 1e3 * dt / a.steps
@@ -507,6 +577,9 @@ def main():
                                    + ", step = fwd + BCE loss + bwd"
                                    + (" + RCCL grad all-reduce" if world > 1 else "") + " + SGD(lr .01, wd 1e-4)",
                        "global_batch": world * B, "frames": frames, "parallelism": f"dp{world}", "reducer_path": reducer_path,
+                       "per_rank": {"ms_per_step": [r[0] for r in per_rank], "host_enqueue_ms_per_step": [r[1] for r in per_rank],
+                                    "allreduce_exposed_ms": [None if r[2] < 0 else r[2] for r in per_rank],
+                                    "launch_thread_cores": pinned},
                        "model_tflops": round(clips_s * flop_step / 1e12, 2),
                        "model_frac_vs_fp32_mfma": round(clips_s * flop_step / (world * PEAK_FP32_MFMA), 4),
                        "matrix_pipe": SPLIT_PIPE + "; convolution GEMMs with operand prologues and K < 512: v_mfma_f32_32x32x2_f32"
@@ -629,6 +702,8 @@ def main():
                     out["deterministic"] = {"error": f"{type(e).__name__}: {e}"}
                 finally:
                     lib.set_deterministic(False)
+        if world == 1 and not a.no_extras and headline:
+            out["other_configs"] = {"config2": other_config_leg(2, dev), "config5": other_config_leg(5, dev)}
         if world == 1 and not a.no_cpu_baseline and a.config != 5:
             out["cpu_baseline"] = cpu_baseline_subprocess(frames)
     line = json.dumps(out) if rank == 0 else None

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 113
+#define MT_VERSION 115
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -296,6 +296,17 @@ int mt_layernorm_bwd_rows(const float* dy, const float* x, const float* stats, c
 int mt_layernorm_bwd_cols(const float* dy, const float* x, const float* stats, const float* dx_new, float* dgamma, float* dbeta,
                           float* dx_colsum, int skip_period, int rows, int dim, void* stream);
 
+/* The rows kernel with the parameter-gradient sums folded in: besides dx (and its planes) every block stores one row of
+ * partials[blocks][3][dim] = its rows' column sums of dy * xhat, dy and dx_new (rows with r % skip_period == 0 left out of the
+ * third when skip_period > 0); blocks = mt_layernorm_bwd_rows_blocks(rows).  mt_layernorm_bwd_cols_reduce adds the block rows,
+ * in block order (a fixed summation order: deterministic as it is), into dgamma, dbeta and dx_colsum (NULL = skipped) -- 6 MB read at
+ * B = 32 instead of the 75 MB mt_layernorm_bwd_cols re-reads.  dim <= 512. */
+int mt_layernorm_bwd_rows_blocks(int rows);
+int mt_layernorm_bwd_rows_sums(const float* dy, const float* x, const float* stats, const float* gamma, float* dx, const float* dx_in,
+                               int rows, int dim, void* dx_planes, float* partials, int skip_period, void* stream);
+int mt_layernorm_bwd_cols_reduce(const float* partials, int blocks, int dim, float* dgamma, float* dbeta, float* dx_colsum,
+                                 void* stream);
+
 /* out[n] += sum_m A[map(m)*lda + n]   (bias gradients). */
 int mt_colsum(const float* A, int64_t lda, mt_rowmap map, int M, int N, float* out, void* stream);
 
@@ -441,6 +452,19 @@ int mt_maxpool_bwd(const float* dy, const float* z, const float* scale, const fl
                    int W, int C, void* stream);
 /* dz = ka*du + kb*z + kc materialised (dense conv2's data gradient is itself an im2col GEMM over dz). */
 int mt_bn_bwd_apply(const float* du, const float* z, const float* kabc, float* dz, int64_t rows, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operand-plane producers for EfficientNet-B0's late stages (model.py:89-128; csrc/effnet_planes.hip): the MBConv 1x1 convolutions of
+ * the 14 x 14 / 7 x 7 stages and the head on mt_gemm_planes.
+ * mt_bn_act_fwd_planes: mt_bn_act_fwd (block output y = act(z * scale + shift) [* rowscale[row / rows_per_group]] [+ res]) that also
+ *   writes y as a plane tensor -- the next expand convolution's operand (forward and weight gradient).
+ * mt_bn_swish_gate_planes: the project convolution's operand swish(z * scale[c] + shift[c]) * gate[(row / hw) * C + c] (model.py:104-116:
+ *   _bn1, swish, squeeze-excite gate) as a plane tensor.
+ * ------------------------------------------------------------------------------------------------ */
+int mt_bn_act_fwd_planes(const float* z, const float* scale, const float* shift, const float* res, float* y, int rows, int C, int act,
+                         const float* rowscale, int rows_per_group, void* y_planes, void* stream);
+int mt_bn_swish_gate_planes(const float* z, const float* scale, const float* shift, const float* gate, int hw, void* planes, int rows,
+                            int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Launch plans (the caller side of the step: reference train.py:332-378, the Python loop that issues every op).

@@ -237,6 +237,7 @@ static int gemm_planes_impl(const mt_gemm_planes_desc* d, void* stream) {
   PL_COMBO(MT_OP_NT, false, EPI_GEGLU, false)
   PL_COMBO(MT_OP_NT, false, EPI_GEGLU, true)
   PL_COMBO(MT_OP_NN, true, EPI_STORE, false)
+  PL_COMBO(MT_OP_NN, true, EPI_BIAS_RES, false)
   PL_COMBO(MT_OP_NN, true, EPI_GEGLU_BWD, false)
   PL_COMBO(MT_OP_NN, true, EPI_GEGLU_BWD, true)
 #undef PL_COMBO

@@ -240,6 +240,101 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel4(const float* d
   layernorm_bwd_rows_body<4>(dy, x, stats, gamma, dx, dx_in, rows, D, dxp);
 }
 
+// Rows kernel + per-block column partial sums (round 5).  The split above made the column sums a second pass on the weight-gradient
+// queue: 75 MB re-read per LayerNorm, 2.3 ms of that queue per step.  Here the wavefront that holds a row's dy / x / dx_out in registers
+// also adds them into three [D] partial sums (24 more VGPRs: 108, still next to three 120-VGPR weight-gradient waves), the block's
+// four wavefronts meet in 8 KB of LDS once at the end, and the block stores ONE row of partials[blocks][3][D] -- no atomics, no
+// re-read.  layernorm_cols_reduce_kernel (weight-gradient queue) adds the block rows in block order into dgamma / dbeta / dx_colsum:
+// 6 MB read instead of 75, and a fixed summation order (nothing for the deterministic mode to replace).
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_sums_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+    float* __restrict__ dx, const float* __restrict__ dx_in, int rows, int D, PlaneRef dxp, float* __restrict__ partials, int skip_period) {
+  constexpr int NI = 2;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nwaves = gridDim.x * 4;
+  const int nq = D >> 2;
+  const float inv_d = 1.0f / (float)D;
+  if (dxp.p && blockIdx.x == 0)                      // padding rows of the plane tensor's last row block: zeros
+    for (int row = rows + wv; row < dxp.rows_pad; row += 4)
+      for (int q = lane; q < nq; q += 64) planes_store4(dxp, row, q * 4, 0.f, 0.f, 0.f, 0.f);
+  float4 dg[NI], db[NI], ds[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) { dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i]; ds[i] = dg[i]; }
+  for (int row = blockIdx.x * 4 + wv; row < rows; row += nwaves) {
+    const float mean = stats[2 * (int64_t)row], rstd = stats[2 * (int64_t)row + 1];
+    const float keep = (skip_period > 0 && row % skip_period == 0) ? 0.f : 1.f;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+    const float4* dyr = reinterpret_cast<const float4*>(dy + (int64_t)row * D);
+    const float4* pin = reinterpret_cast<const float4*>(dx_in + (int64_t)row * D);
+    float4* dxr = reinterpret_cast<float4*>(dx + (int64_t)row * D);
+    float4 xv[NI], d[NI], g[NI], pv[NI];
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int q = min(lane + i * 64, nq - 1);
+      xv[i] = xr[q]; d[i] = dyr[q]; g[i] = reinterpret_cast<const float4*>(gamma)[q]; pv[i] = pin[q];
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float w = lane + i * 64 < nq ? 1.f : 0.f;
+      xv[i].x = (xv[i].x - mean) * rstd; xv[i].y = (xv[i].y - mean) * rstd; xv[i].z = (xv[i].z - mean) * rstd; xv[i].w = (xv[i].w - mean) * rstd;
+      const float gx = d[i].x * g[i].x, gy_ = d[i].y * g[i].y, gz = d[i].z * g[i].z, gw = d[i].w * g[i].w;
+      a1 += w * (gx + gy_ + gz + gw);
+      a2 += w * (gx * xv[i].x + gy_ * xv[i].y + gz * xv[i].z + gw * xv[i].w);
+    }
+    a1 = wave_sum(a1) * inv_d; a2 = wave_sum(a2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int q = lane + i * 64;
+      if (q < nq) {
+        float4 o;
+        o.x = rstd * (d[i].x * g[i].x - a1 - xv[i].x * a2) + pv[i].x; o.y = rstd * (d[i].y * g[i].y - a1 - xv[i].y * a2) + pv[i].y;
+        o.z = rstd * (d[i].z * g[i].z - a1 - xv[i].z * a2) + pv[i].z; o.w = rstd * (d[i].w * g[i].w - a1 - xv[i].w * a2) + pv[i].w;
+        dxr[q] = o;
+        if (dxp.p) planes_store4(dxp, row, q * 4, o.x, o.y, o.z, o.w);
+        dg[i].x += d[i].x * xv[i].x; dg[i].y += d[i].y * xv[i].y; dg[i].z += d[i].z * xv[i].z; dg[i].w += d[i].w * xv[i].w;
+        db[i].x += d[i].x; db[i].y += d[i].y; db[i].z += d[i].z; db[i].w += d[i].w;
+        ds[i].x += keep * o.x; ds[i].y += keep * o.y; ds[i].z += keep * o.z; ds[i].w += keep * o.w;
+      }
+    }
+  }
+  __shared__ float red[4][512];
+  auto meet = [&](const float4 (&v)[NI], int which) {        // (three explicit calls: a dynamic pick among dg / db / ds goes to scratch)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int q = lane + i * 64;
+      if (q < nq) *reinterpret_cast<float4*>(&red[wv][4 * q]) = v[i];
+    }
+    __syncthreads();
+    float* dst = partials + ((int64_t)blockIdx.x * 3 + which) * D;
+    for (int c = threadIdx.x; c < D; c += 256) dst[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    __syncthreads();
+  };
+  meet(dg, 0);
+  meet(db, 1);
+  meet(ds, 2);
+}
+
+// out_which[c] += sum over blocks (in block order) of partials[b][which][c]; one thread per (which, column), 4 partial chains per
+// thread for memory-level parallelism (added in a fixed order)
+__global__ __launch_bounds__(256) void layernorm_cols_reduce_kernel(const float* __restrict__ partials, int blocks, int D,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                    float* __restrict__ dxsum) {
+  const int which = blockIdx.y;
+  float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+  if (!dst) return;
+  // 64 columns per block, 4 block-row phases per column; phase p sums blocks p, p + 4, ...
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (c < D)
+    for (int b = ph; b < blocks; b += 4) s += partials[((int64_t)b * 3 + which) * D + c];
+  red[ph][cl] = s;
+  __syncthreads();
+  if (ph == 0 && c < D) dst[c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
 template <int NI>
 __global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                  const float* __restrict__ stats, const float* __restrict__ dxn,
@@ -1305,6 +1400,8 @@ extern "C" int mt_layernorm_bwd(const float* dy, const float* x, const float* st
   return rc;
 }
 
+static int ln_rows_blocks(int rows);
+
 extern "C" int mt_layernorm_bwd_rows(const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
                                      const float* dx_in, int rows, int dim, void* dx_planes, void* stream) {
   if (!dy || !x || !stats || !gamma || !dx || !dx_in) return fail(MT_ERR_ARG, "mt_layernorm_bwd_rows: null pointer");
@@ -1313,9 +1410,7 @@ extern "C" int mt_layernorm_bwd_rows(const float* dy, const float* x, const floa
   if (rows <= 0) return 0;
   const int rp = (rows + 31) & ~31;
   const PlaneRef dxp{reinterpret_cast<__bf16*>(dx_planes), (int64_t)rp * dim, dim >> 4, rp};
-  int blocks = (rows + 3) / 4;
-  static const int cap = getenv("MT_LN_ROWS_BLOCKS") ? atoi(getenv("MT_LN_ROWS_BLOCKS")) : 1024;    // tuning knob
-  if (blocks > cap) blocks = cap;
+  const int blocks = ln_rows_blocks(rows);
   static const int keep = getenv("MT_LN_ROWS_KEEP") ? atoi(getenv("MT_LN_ROWS_KEEP")) : 1;
   if (dim <= 512 && keep)
     hipLaunchKernelGGL(layernorm_bwd_rows_kernel2k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dx_in, rows, dim, dxp);
@@ -1324,6 +1419,38 @@ extern "C" int mt_layernorm_bwd_rows(const float* dy, const float* x, const floa
   else
     hipLaunchKernelGGL(layernorm_bwd_rows_kernel4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma, dx, dx_in, rows, dim, dxp);
   return check_launch("mt_layernorm_bwd_rows");
+}
+
+static int ln_rows_blocks(int rows) {
+  int blocks = (rows + 3) / 4;
+  static const int cap = getenv("MT_LN_ROWS_BLOCKS") ? atoi(getenv("MT_LN_ROWS_BLOCKS")) : 1024;    // tuning knob
+  if (blocks > cap) blocks = cap;
+  return blocks < 1 ? 1 : blocks;
+}
+
+extern "C" int mt_layernorm_bwd_rows_blocks(int rows) { return ln_rows_blocks(rows); }
+
+extern "C" int mt_layernorm_bwd_rows_sums(const float* dy, const float* x, const float* stats, const float* gamma, float* dx,
+                                          const float* dx_in, int rows, int dim, void* dx_planes, float* partials, int skip_period,
+                                          void* stream) {
+  if (!dy || !x || !stats || !gamma || !dx || !dx_in || !partials) return fail(MT_ERR_ARG, "mt_layernorm_bwd_rows_sums: null pointer");
+  if (dim <= 0 || (dim & 3) || dim > 512) return fail(MT_ERR_UNSUPPORTED, "mt_layernorm_bwd_rows_sums: dim %d unsupported (<= 512, %% 4 == 0)", dim);
+  if (dx_planes && ((dim & 15) || ((uintptr_t)dx_planes & 15))) return fail(MT_ERR_ARG, "mt_layernorm_bwd_rows_sums: plane output needs dim %% 16 == 0 and 16-byte alignment");
+  if (rows <= 0) return fail(MT_ERR_ARG, "mt_layernorm_bwd_rows_sums: no rows");
+  const int rp = (rows + 31) & ~31;
+  const PlaneRef dxp{reinterpret_cast<__bf16*>(dx_planes), (int64_t)rp * dim, dim >> 4, rp};
+  hipLaunchKernelGGL(layernorm_bwd_rows_sums_kernel, dim3(ln_rows_blocks(rows)), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma,
+                     dx, dx_in, rows, dim, dxp, partials, skip_period);
+  return check_launch("mt_layernorm_bwd_rows_sums");
+}
+
+extern "C" int mt_layernorm_bwd_cols_reduce(const float* partials, int blocks, int dim, float* dgamma, float* dbeta, float* dx_colsum,
+                                            void* stream) {
+  if (!partials || !dgamma || !dbeta) return fail(MT_ERR_ARG, "mt_layernorm_bwd_cols_reduce: null pointer");
+  if (blocks <= 0 || dim <= 0) return fail(MT_ERR_ARG, "mt_layernorm_bwd_cols_reduce: bad shape");
+  hipLaunchKernelGGL(layernorm_cols_reduce_kernel, dim3((dim + 63) / 64, 3), dim3(256), 0, (hipStream_t)stream, partials, blocks, dim,
+                     dgamma, dbeta, dx_colsum);
+  return check_launch("mt_layernorm_bwd_cols_reduce");
 }
 
 extern "C" int mt_layernorm_bwd_cols(const float* dy, const float* x, const float* stats, const float* dx_new, float* dgamma,

@@ -107,6 +107,9 @@ class OverlappedGradReducer:
         self.pending = []
         self.staging = [None] * len(self.buckets)
         self.stats = {"overlapped_launches": 0, "in_place": 0, "staged": 0, "synchronous": 0}
+        # bench.py: event pairs around the wait in allreduce() = the part of the collectives the backward pass did not hide
+        self.time_exposed = False
+        self._exposed = []
         if self.active:
             for bi, b in enumerate(self.buckets):
                 if self.modules[bi] is not None:
@@ -225,6 +228,10 @@ class OverlappedGradReducer:
                 raise RuntimeError(f"bucket {bi}: {self.seen[bi]} of {len(self.live[bi])} gradients arrived; the set of "
                                    "parameters receiving gradients must not change between steps")
         n = 0
+        ev = None
+        if self.time_exposed and self.pending and self.pending[0][1].is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for work, flat, back in self.pending:
             if work is not None:
                 work.wait()
@@ -240,7 +247,19 @@ class OverlappedGradReducer:
                     torch._foreach_copy_([p.grad for p, _ in stale], [v for _, v in stale])
                     self.stats["staged"] += 1
             n += flat.numel()
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
         self.pending = []
         self.seen = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         return n
+
+    def exposed_ms(self):
+        """Mean stream time per step between entering allreduce() and the averaged gradients being ready (collective wait + scaling):
+        what the overlap with the backward pass left exposed.  Clears the readings; call after a synchronize."""
+        if not self._exposed:
+            return None
+        t = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return sum(t) / len(t)

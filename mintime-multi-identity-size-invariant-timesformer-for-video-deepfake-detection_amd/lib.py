@@ -96,6 +96,9 @@ PROTOTYPES = {
     "mt_layernorm_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_void_p],
     "mt_layernorm_bwd_rows": [f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "mt_layernorm_bwd_cols": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_layernorm_bwd_rows_blocks": [C.c_int],
+    "mt_layernorm_bwd_rows_sums": [f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_void_p, f32p, C.c_int, C.c_void_p],
+    "mt_layernorm_bwd_cols_reduce": [f32p, C.c_int, C.c_int, f32p, f32p, f32p, C.c_void_p],
     "mt_colsum": [f32p, i64, RowMap, C.c_int, C.c_int, f32p, C.c_void_p],
     "mt_head_bwd": [f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                     C.c_void_p],
@@ -130,6 +133,8 @@ PROTOTYPES = {
     "mt_se_stage_fused": [f32p] * 7 + [C.c_int] + [f32p] * 5 + [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_conv1x1_bwd_fused": [f32p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "mt_stem_conv_wgrad": [f32p] * 4 + [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_bn_act_fwd_planes": [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_void_p, C.c_void_p],
+    "mt_bn_swish_gate_planes": [f32p, f32p, f32p, f32p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "mt_plan_create": [C.POINTER(C.c_void_p)],
     "mt_plan_destroy": [C.c_void_p],
     "mt_plan_record_begin": [C.c_void_p],
@@ -164,7 +169,7 @@ def build(verbose: bool = False):
 
 # MT_VERSION of include/mintime_hip.h this binding was written against (tests/test_host_logic.py keeps the two equal; the package
 # itself does not need the header at run time -- it may be copied or installed without the repository's include/ directory)
-ABI_VERSION = 113
+ABI_VERSION = 115
 
 
 def header_version() -> int:

@@ -25,6 +25,10 @@ from . import lib as L
 # bumped by the fused optimizers (optim.py): they update parameters through raw pointers, which torch's version counters do not see
 WEIGHT_EPOCH = [0]
 
+# LayerNorm backward: parameter-gradient column sums folded into the rows kernel as per-block partials (MT_LN_FOLD=0: the second pass
+# over dy / x / dx on the weight-gradient stream)
+LN_FOLD = os.environ.get("MT_LN_FOLD", "1") != "0"
+
 _SEL = (2, 3, 7, 8, 12, 14)      # offsets of w_qkv, w_o (time); w_qkv, w_o (space); net.0 / net.3 weights inside a layer's 16 parameters
 
 
@@ -253,6 +257,16 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
         dx_new = torch.empty_like(dx_cur)
         dx_p = L.planes_empty(M, D, dev)
         x_, st_ = r_["x"], r_["stats"]
+        if LN_FOLD and D <= 512:
+            # the rows kernel also leaves per-block partial column sums; the weight-gradient stream only adds 6 MB of them up
+            nb = lib.mt_layernorm_bwd_rows_blocks(M)
+            part = _new(dev, nb, 3, D)
+            L.check(lib.mt_layernorm_bwd_rows_sums(L.ptr(dxn_), L.ptr(x_), L.ptr(st_), L.ptr(g_), L.ptr(dx_new), L.ptr(dx_cur), M, D,
+                                                   L.ptr(dx_p), L.ptr(part), skip, st), "mt_layernorm_bwd_rows_sums")
+            side.launch(lambda: L.check(lib.mt_layernorm_bwd_cols_reduce(L.ptr(part), nb, D, L.ptr(grads[i_g]), L.ptr(grads[i_g + 1]),
+                                                                         L.ptr(tgt), L.stream_ptr()), "mt_layernorm_bwd_cols_reduce"),
+                        reads=(part,))
+            return dx_new, dx_p
         L.check(lib.mt_layernorm_bwd_rows(L.ptr(dxn_), L.ptr(x_), L.ptr(st_), L.ptr(g_), L.ptr(dx_new), L.ptr(dx_cur), M, D,
                                           L.ptr(dx_p), st), "mt_layernorm_bwd_rows")
         side.launch(lambda: L.check(lib.mt_layernorm_bwd_cols(L.ptr(dxn_), L.ptr(x_), L.ptr(st_), L.ptr(dx_new), L.ptr(grads[i_g]),

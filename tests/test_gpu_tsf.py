@@ -304,7 +304,7 @@ def test_two_graphs_share_the_weight_planes_until_the_weights_change():
             stale.sum().backward()
 
 
-@pytest.mark.parametrize("rows,skip", [(2 * 393, 0), (5 * 393 + 0, 393), (1000, 0)])
+@pytest.mark.parametrize("rows,skip", [(2 * 393, 0), (5 * 393 + 0, 393), (1000, 0), (32 * 393, 393)])
 def test_layernorm_backward_emits_column_sums_of_updated_dx(rows, skip):
     """mt_layernorm_bwd's dx_colsum: the bias gradient of the Linear below (sum over rows of the updated residual-stream
     gradient), with the cls rows (row % skip == 0) left out for the patch embedding."""
@@ -348,6 +348,29 @@ def test_layernorm_backward_emits_column_sums_of_updated_dx(rows, skip):
     assert_close(dg, (dy.double() * xh).sum(0), 1e-4, "dgamma (fused kernel)")
     assert_close(db3, dy.double().sum(0), 1e-4, "dbeta (cols kernel)")
     assert_close(cs3, dx_ref[keep].sum(0), 1e-4, "column sums (cols kernel)")
+    # ... and with the sums folded into the rows kernel as per-block partials + a block-order reduce (the default of the plane path):
+    # dx bit-identical to the rows kernel, sums deterministic (two runs agree to the bit) and accumulated ONTO the targets
+    lib = L.get()
+    nb = lib.mt_layernorm_bwd_rows_blocks(rows)
+    res = []
+    for rep in range(2):
+        dx_f = torch.full((rows, D), float("nan"), device="cuda")
+        part = torch.full((nb, 3, D), float("nan"), device="cuda")
+        dg4, db4, cs4 = torch.ones(D, device="cuda"), torch.ones(D, device="cuda"), torch.ones(D, device="cuda")
+        L.check(lib.mt_layernorm_bwd_rows_sums(L.ptr(dy_d), L.ptr(x_d), L.ptr(stats), L.ptr(gamma_d), L.ptr(dx_f), L.ptr(dx_in), rows, D, None,
+                                               L.ptr(part), skip, L.stream_ptr()), "ln bwd rows + sums")
+        L.check(lib.mt_layernorm_bwd_cols_reduce(L.ptr(part), nb, D, L.ptr(dg4), L.ptr(db4), L.ptr(cs4), L.stream_ptr()), "ln cols reduce")
+        res.append((dx_f, dg4, db4, cs4))
+    dx_f, dg4, db4, cs4 = res[0]
+    assert_close(dx_f, dx_ref, 1e-5, "dx (rows + sums kernel)")
+    assert_close(dg4 - 1.0, (dy.double() * xh).sum(0), 1e-4, "dgamma (folded)")
+    assert_close(db4 - 1.0, dy.double().sum(0), 1e-4, "dbeta (folded)")
+    assert_close(cs4 - 1.0, dx_ref[keep].sum(0), 1e-4, "column sums (folded)")
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1])), "block-order reduce: run-to-run identical"
+    # dx_colsum is optional
+    dg5, db5 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    L.check(lib.mt_layernorm_bwd_cols_reduce(L.ptr(part), nb, D, L.ptr(dg5), L.ptr(db5), None, L.stream_ptr()), "ln cols reduce")
+    assert torch.equal(dg5 + 1.0, dg4) or float((dg5 + 1.0 - dg4).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("B,Fr,ids,ragged", [(2, 8, 2, True), (3, 16, 3, False)])

@@ -359,7 +359,7 @@ def e2e_case(EF, TSF, name, batch, frames, identities, ragged, training, seed):
          training=int(training), seed=seed, **out)
 
 
-def e2e_full_case(EF, TSF, name, batch, frames, identities, seed, rate=0.2):
+def e2e_full_case(EF, TSF, name, batch, frames, identities, seed, rate=0.2, checkpoint_blocks=False):
     """A BASELINE configuration at FULL size (config 2: B = 16, 1 identity; config 3: B = 32, 2 identities), one training step of
     the imported reference in float64 (its exact arithmetic): train-mode BatchNorm, drop-connect `rate`, BCE loss, backward.
     Stored for EVERY parameter of both networks: gradient norm, max |g| and a 256-element strided sample; logits, loss, and the
@@ -367,7 +367,10 @@ def e2e_full_case(EF, TSF, name, batch, frames, identities, seed, rate=0.2):
     on its host (round-4 verdict, weak #9).
     Drop-connect: the reference draws torch.rand([N,1,1,1], dtype=inputs.dtype) per gated block (utils.py:148-150).  The fp64 model
     would draw from the generator's 53-bit stream; torch.rand is wrapped for this run so that those calls draw the float32 values
-    (cast up) -- the values oracle.drop_connect_uniforms(seed, N, rate) replays and the tests feed to the HIP path."""
+    (cast up) -- the values oracle.drop_connect_uniforms(seed, N, rate) replays and the tests feed to the HIP path.
+    checkpoint_blocks: autograd keeps only each MBConv block's input and re-runs the block (the reference's own forward, same RNG
+    state) inside the backward pass -- config 3's 256 crops in float64 do not fit this container's 62 GB otherwise.  The same
+    arithmetic in the same order; the running statistics are sampled right after the forward (the re-runs update them again)."""
     import time
     t0 = time.time()
     cfg = arch.default_tsf_config(channels=1280, num_frames=frames)
@@ -389,17 +392,24 @@ def e2e_full_case(EF, TSF, name, batch, frames, identities, seed, rate=0.2):
             return real_rand(*a, **k).double()
         return real_rand(*a, **k)
 
+    if checkpoint_blocks:
+        from torch.utils.checkpoint import checkpoint
+        for blk in ef._blocks:
+            inner = blk.forward
+            blk.forward = (lambda inner: lambda x, drop_connect_rate=None: checkpoint(
+                inner, x, drop_connect_rate, use_reentrant=False, preserve_rng_state=True))(inner)
     torch.manual_seed(seed)
-    torch.rand = rand32
-    try:
-        feats = ef(vid)
-    finally:
-        torch.rand = real_rand
+    torch.rand = rand32           # stays wrapped until after backward: checkpointed blocks draw again (same restored RNG state)
+    feats = ef(vid)
+    stats_after_forward = {k: v.clone() for k, v in ef.state_dict().items() if "running_" in k}
     logits, _ = tsf(feats.reshape(b, f, *feats.shape[1:]), mask=inp["mask"], identities_mask=inp["identities_mask"],
                     size_embedding=inp["size_embedding"], positions=inp["positions"])
     loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, inp["labels"].reshape(-1, 1).to(dtype))
     print(f"{name}: reference fp64 forward {time.time() - t0:.0f} s", flush=True)
-    loss.backward()
+    try:
+        loss.backward()
+    finally:
+        torch.rand = real_rand
     print(f"{name}: + backward {time.time() - t0:.0f} s", flush=True)
     out = {"logits64": logits, "loss64": loss.detach()}
     for model, mtag in ((ef, "ef."), (tsf, "tsf.")):
@@ -411,9 +421,8 @@ def e2e_full_case(EF, TSF, name, batch, frames, identities, seed, rate=0.2):
             out["gnorm64." + mtag + key] = g.norm()
             out["gabsmax64." + mtag + key] = g.abs().max()
             out["gsample64." + mtag + key] = g[::step][:256].clone()
-    esd = ef.state_dict()
     for key in ("_bn0.running_mean", "_blocks.3._bn1.running_var", "_blocks.10._bn2.running_mean", "_bn1.running_var"):
-        out["stat64." + key] = esd[key].clone()
+        out["stat64." + key] = stats_after_forward[key]
     save(name, input_sum=checksum(inp["videos"]), batch=batch, frames=frames, identities=identities, seed=seed, rate=rate, **out)
 
 
@@ -481,11 +490,13 @@ def main():
         man[f"tsf_c{c}_f{fr}"] = [[k, list(v.shape), str(v.dtype)] for k, v in t.state_dict().items()]
         man[f"tsf_c{c}_f{fr}_no_weight_decay"] = sorted(t.no_weight_decay())
     only = os.environ.get("GOLDEN_ONLY", "")
-    if only in ("full2", "full3"):       # full-size steps: minutes of float64 on the host, tens of GB of autograd state -- on request
+    if only in ("full2", "full3", "full2ck"):       # full-size steps: minutes of float64 on the host, tens of GB of autograd state -- on request
         if only == "full2":
             e2e_full_case(EF, TSF, "e2e_full_config2", batch=16, frames=8, identities=1, seed=4)
         else:
-            e2e_full_case(EF, TSF, "e2e_full_config3", batch=32, frames=8, identities=2, seed=4)
+            e2e_full_case(EF, TSF, "e2e_full_config3", batch=32, frames=8, identities=2, seed=4, checkpoint_blocks=True)
+    if only == "full2ck":                # cross-check of the checkpointed run against the plain one (must reproduce e2e_full_config2.npz)
+        e2e_full_case(EF, TSF, "e2e_full_config2_ck", batch=16, frames=8, identities=1, seed=4, checkpoint_blocks=True)
         return
     if only in ("", "dc"):
         ef_dc_case(EF, "ef_train_dc", n_img=4, seed=3)
