@@ -56,6 +56,30 @@ int stem_wgrad_mfma(const float* du, const float* z, const float* kabc, const vo
 
 enum { MT_ERR_ARG = -1, MT_ERR_LAUNCH = -2, MT_ERR_UNSUPPORTED = -3 };
 
+// BatchNorm partial sums [slots][2][C] (fp64 accumulators fed by one atomic per block and channel).  Default: fp64 atomics -- the
+// order in which blocks arrive shows in the last bits.  Deterministic mode (the ABI's `slots` argument NEGATIVE: |slots| accumulators):
+// every accumulator is two 64-bit INTEGER limbs, `limb` = |slots| * 2 * C doubles apart, and a block's fp32 partial v is added as
+//   limb 0 += trunc(v)                      (exact)
+//   limb 1 += round((v - trunc(v)) * 2^44)   (|error| <= 2^-45 per contribution; up to 2^19 contributions per accumulator)
+// Integer addition is associative: the sums are the same bits whatever the arrival order, with no second pass over the tensor
+// (round 4 re-read every tensor for this: 27 of the deterministic mode's 36 extra ms per step).
+__device__ __forceinline__ void stat_add(double* p, int64_t limb, float v) {
+  if (limb == 0) {
+    atomicAdd(p, (double)v);
+    return;
+  }
+  const float t = truncf(v);
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)(long long)t);
+  atomicAdd(reinterpret_cast<unsigned long long*>(p + limb), (unsigned long long)__float2ll_rn((v - t) * 17592186044416.0f));
+}
+__device__ __forceinline__ double stat_get(const double* p, int64_t limb) {
+  if (limb == 0) return *p;
+  const long long hi = *reinterpret_cast<const long long*>(p), lo = *reinterpret_cast<const long long*>(p + limb);
+  return (double)hi + (double)lo * 5.684341886080801486968994140625e-14;      // 2^-44
+}
+__host__ __device__ __forceinline__ int stat_slots(int slots) { return slots < 0 ? -slots : (slots > 0 ? slots : 1); }
+__host__ __device__ __forceinline__ int64_t stat_limb(int slots, int C) { return slots < 0 ? (int64_t)(-slots) * 2 * C : 0; }
+
 // Work assignment for the persistent, channel-chunked NHWC tile kernels (depthwise conv forward / dgrad / wgrad).
 // A chunk of 16 channels is only 64 B of every pixel, so the chunks of ONE spatial tile must run on the same XCD at about
 // the same time: its L2 then fetches each 128 B line once and serves the neighbouring chunk from cache.  Block b runs on XCD

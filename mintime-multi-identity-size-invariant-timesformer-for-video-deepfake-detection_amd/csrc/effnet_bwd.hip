@@ -59,7 +59,7 @@ __device__ __forceinline__ void reduce_stats(float* red, float4 s1, float4 s2, i
       float v = 0.f;
       for (int p = 0; p < PB; ++p) v += red[(p * CQB + q) * 8 + e];
       const int ch = cqq * 4 + (e & 3), which = e >> 2;
-      atomicAdd(stats + ((int64_t)(blockIdx.x % slots) * 2 + which) * C + ch, (double)v);
+      stat_add(stats + ((int64_t)(blockIdx.x % stat_slots(slots)) * 2 + which) * C + ch, stat_limb(slots, C), v);
     }
   }
 }
@@ -120,7 +120,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   const int c = blockIdx.x * 32 + cl;
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (int i = sg; i < slots; i += 8) { a += stats[((int64_t)i * 2) * C + c]; b += stats[((int64_t)i * 2 + 1) * C + c]; }
+    for (int i = sg; i < stat_slots(slots); i += 8) {
+      a += stat_get(stats + ((int64_t)i * 2) * C + c, stat_limb(slots, C));
+      b += stat_get(stats + ((int64_t)i * 2 + 1) * C + c, stat_limb(slots, C));
+    }
   red[sg][cl][0] = a; red[sg][cl][1] = b;
   __syncthreads();
   if (sg != 0 || c >= C) return;
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
     float v = 0.f;
     for (int sl = 0; sl < NSLOT; ++sl) v += lds[(sl * CQN + q) * 8 + e];
     const int ch = c0 + q * 4 + (e & 3), which = e >> 2;
-    atomicAdd(stats + ((int64_t)(blockIdx.x % slots) * 2 + which) * C + ch, (double)v);
+    stat_add(stats + ((int64_t)(blockIdx.x % stat_slots(slots)) * 2 + which) * C + ch, stat_limb(slots, C), v);
   }
 }
 
@@ -687,7 +690,7 @@ int launch_dw_dgrad_tiled(const float* du, const float* z, const float* kabc, co
   // the fused form keeps K*K tap accumulators per thread across tiles: fewer, longer-lived blocks keep the final atomics rare
   const unsigned bx = xcd_chunk_grid(chunks, ntiles, WG ? 4096 : 8192);
   hipLaunchKernelGGL((dwconv_dgrad_tiled_kernel<K, S, T, ACT, CC, WG>), dim3(bx), dim3(256), lds, s, du, z, kabc, w, zin,
-                     scale_in, shift_in, mi_in, du_in, stats, slots > 0 ? slots : 1, N, H, W, C, Ho, Wo, res_pre, res_post, dw);
+                     scale_in, shift_in, mi_in, du_in, stats, slots != 0 ? slots : 1, N, H, W, C, Ho, Wo, res_pre, res_post, dw);
   return check_launch(WG ? "mt_dwconv_bwd(data + weight, fused)" : "mt_dwconv_bwd(data, tiled)");
 }
 
@@ -818,7 +821,7 @@ extern "C" int mt_bn_act_bwd(const float* din, const float* z, const float* scal
   if (nb > cap) nb = cap;
   hipLaunchKernelGGL(bn_act_bwd_kernel, dim3((unsigned)nb, CQ / CQB), dim3(CQB * PB), (size_t)PB * CQB * 8 * sizeof(float),
                      (hipStream_t)stream, din, z, scale, shift, mean_invstd, gate, dpool, rowscale, dout, stats,
-                     slots > 0 ? slots : 1, rows, C, hw > 0 ? hw : 1, act, CQB, PB);
+                     slots != 0 ? slots : 1, rows, C, hw > 0 ? hw : 1, act, CQB, PB);
   return check_launch("mt_bn_act_bwd");
 }
 

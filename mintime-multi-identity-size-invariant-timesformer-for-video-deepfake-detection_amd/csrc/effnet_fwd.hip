@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
       float v = 0.f;
       for (int sl = 0; sl < NSLOT; ++sl) v += lds[(sl * CQN + q) * 8 + e];
       const int ch = c0 + q * 4 + (e & 3), which = e >> 2;
-      atomic_add_f64(stats + ((int64_t)(blockIdx.x % slots) * 2 + which) * C + ch, (double)v);
+      stat_add(stats + ((int64_t)(blockIdx.x % stat_slots(slots)) * 2 + which) * C + ch, stat_limb(slots, C), v);
     }
   }
 }
@@ -191,7 +191,7 @@ int launch_dw_tiled(const float* zin, const float* scale, const float* shift, co
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(k, dim3(bx), dim3(256), lds, s, zin, scale, shift, w, zout, stats, slots > 0 ? slots : 1, N, H,
+  hipLaunchKernelGGL(k, dim3(bx), dim3(256), lds, s, zin, scale, shift, w, zout, stats, slots != 0 ? slots : 1, N, H,
                      W, C, Ho, Wo, pad0);
   return check_launch("mt_dwconv_fwd(tiled)");
 }
@@ -225,7 +225,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   if (training) {
     double s = 0.0, q = 0.0;
     if (c < C)
-      for (int i = sg; i < slots; i += 8) { s += stats[((int64_t)i * 2) * C + c]; q += stats[((int64_t)i * 2 + 1) * C + c]; }
+      for (int i = sg; i < stat_slots(slots); i += 8) {
+        s += stat_get(stats + ((int64_t)i * 2) * C + c, stat_limb(slots, C));
+        q += stat_get(stats + ((int64_t)i * 2 + 1) * C + c, stat_limb(slots, C));
+      }
     red[sg][cl][0] = s; red[sg][cl][1] = q;
     __syncthreads();
   }

@@ -58,6 +58,52 @@ __global__ __launch_bounds__(256) void bn_act_planes_kernel(const float* __restr
   planes_store8(o, r, c, x);
 }
 
+// The same for NARROW tensors (block outputs: 80-320 channels): the kernel above gives each lane 32 bytes of a row, 64 bytes per row and
+// wavefront -- with 320-1280-byte rows a wavefront's 32 row segments are 32 separate half lines (27-32 us per launch in the step
+// where mt_bn_act_fwd takes 10).  Here a block owns a 32-row block: its rows are ONE contiguous run of memory (read and written
+// with consecutive float4s), the results meet in LDS, and each wavefront then emits whole 1 KB plane blocks from there.
+__global__ __launch_bounds__(256) void bn_act_planes_rows_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const float* __restrict__ res,
+                                                                 float* __restrict__ y, int R, int C, int act,
+                                                                 const float* __restrict__ rowscale, int rows_per_group, PlaneRef o) {
+  extern __shared__ float tile_[];                   // [32][C + 4]
+  const int pitch = C + 4, CQ = C >> 2;
+  const int r0 = blockIdx.x * 32;
+  for (int i = threadIdx.x; i < 32 * CQ; i += 256) {
+    const int rl = i / CQ, cq = i - rl * CQ, r = r0 + rl;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < R) {
+      const int64_t at = (int64_t)r * C + 4 * cq;
+      const float4 v = *reinterpret_cast<const float4*>(z + at);
+      const float4 sc = reinterpret_cast<const float4*>(scale)[cq], sh = reinterpret_cast<const float4*>(shift)[cq];
+      t[0] = fmaf(v.x, sc.x, sh.x); t[1] = fmaf(v.y, sc.y, sh.y); t[2] = fmaf(v.z, sc.z, sh.z); t[3] = fmaf(v.w, sc.w, sh.w);
+      const float g = rowscale ? rowscale[r / rows_per_group] : 1.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (act == 1) t[q] = swish_(t[q]);
+        else if (act == 2) t[q] = fmaxf(t[q], 0.f);
+        if (rowscale) t[q] *= g;
+      }
+      if (res) {
+        const float4 rr = *reinterpret_cast<const float4*>(res + at);
+        t[0] += rr.x; t[1] += rr.y; t[2] += rr.z; t[3] += rr.w;
+      }
+      *reinterpret_cast<float4*>(y + at) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    *reinterpret_cast<float4*>(tile_ + rl * pitch + 4 * cq) = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rl = lane >> 1;
+  for (int cb = wave; cb < o.cb16; cb += 4) {
+    const int c = cb * 16 + (lane & 1) * 8;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = c + e < C ? tile_[rl * pitch + c + e] : 0.f;
+    planes_store8(o, r0 + rl, c, x);
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_swish_gate_planes_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                                    const float* __restrict__ shift, const float* __restrict__ gate,
                                                                    int hw, int R, int C, PlaneRef o) {
@@ -93,6 +139,13 @@ extern "C" int mt_bn_act_fwd_planes(const float* z, const float* scale, const fl
     return fail(MT_ERR_ARG, "mt_bn_act_fwd_planes: 16-byte alignment");
   const int cb16 = (C + 15) >> 4, rp = (rows + 31) & ~31;
   const PlaneRef o{reinterpret_cast<__bf16*>(y_planes), (int64_t)rp * cb16 * 16, cb16, rp};
+  if (C <= 512) {                                     // narrow tensors: one block per 32-row block, coalesced rows, planes from LDS
+    const size_t lds = (size_t)32 * (C + 4) * sizeof(float);
+    (void)ensure_dynamic_lds((const void*)bn_act_planes_rows_kernel, lds);
+    hipLaunchKernelGGL(bn_act_planes_rows_kernel, dim3(rp / 32), dim3(256), lds, (hipStream_t)stream, z, scale, shift, res, y, rows, C, act,
+                       rowscale, rows_per_group > 0 ? rows_per_group : 1, o);
+    return check_launch("mt_bn_act_fwd_planes");
+  }
   hipLaunchKernelGGL(bn_act_planes_kernel, dim3((cb16 + 3) / 4, rp / 32), dim3(256), 0, (hipStream_t)stream, z, scale, shift, res, y,
                      rows, C, act, rowscale, rows_per_group > 0 ? rows_per_group : 1, o);
   return check_launch("mt_bn_act_fwd_planes");

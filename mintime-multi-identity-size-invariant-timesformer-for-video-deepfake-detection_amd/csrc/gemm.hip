@@ -83,7 +83,7 @@ static int gemm_impl(const mt_gemm_desc* d, void* stream) {
   a.c_map = {d->c_map.gin, d->c_map.gout, d->c_map.off};
   a.bias = d->bias; a.R = d->R; a.ldr = d->ldr;
   a.scale = d->scale; a.shift = d->shift; a.gate = d->gate; a.hw = d->hw > 0 ? d->hw : 1;
-  a.C2 = d->C2; a.ldc2 = d->ldc2; a.stats = d->stats; a.stats_slots = d->stats_slots > 0 ? d->stats_slots : 1;
+  a.C2 = d->C2; a.ldc2 = d->ldc2; a.stats = d->stats; a.stats_slots = d->stats_slots != 0 ? d->stats_slots : 1;
   a.n_half = d->n_half; a.k_chunk = 0;
   a.conv = {d->conv_H, d->conv_W, d->conv_C, d->conv_Ho, d->conv_Wo, d->conv_k, d->conv_stride, d->conv_pad, d->conv_act, d->conv_src_u8};
   a.col_sum = d->col_sum;

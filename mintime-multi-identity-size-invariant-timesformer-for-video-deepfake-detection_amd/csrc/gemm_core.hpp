@@ -334,9 +334,9 @@ __device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&a
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         if (lane < 32 && nok) {
-          double* st = p.stats + (int64_t)(blockIdx.x % p.stats_slots) * 2 * p.N;
-          atomicAdd(st + n, (double)s1);
-          atomicAdd(st + p.N + n, (double)s2);
+          double* st = p.stats + (int64_t)(blockIdx.x % stat_slots(p.stats_slots)) * 2 * p.N;
+          stat_add(st + n, stat_limb(p.stats_slots, p.N), s1);
+          stat_add(st + p.N + n, stat_limb(p.stats_slots, p.N), s2);
         }
       }
     }
@@ -437,9 +437,9 @@ __device__ __forceinline__ void gemm_epilogue_body(const GemmArgs& p, f32x16 (&a
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         if (lane < 32 && nok) {
-          double* st = p.stats + (int64_t)(blockIdx.x % p.stats_slots) * 2 * p.N;
-          atomicAdd(st + n, (double)s1);
-          atomicAdd(st + p.N + n, (double)s2);
+          double* st = p.stats + (int64_t)(blockIdx.x % stat_slots(p.stats_slots)) * 2 * p.N;
+          stat_add(st + n, stat_limb(p.stats_slots, p.N), s1);
+          stat_add(st + p.N + n, stat_limb(p.stats_slots, p.N), s2);
         }
       }
     }

@@ -165,7 +165,7 @@ static int gemm_planes_impl(const mt_gemm_planes_desc* d, void* stream) {
   a.a_planes = d->a_planes; a.a_pstride = mt_planes_elems(a_rows, a_cols); a.lda = (a_cols + 15) >> 4;
   a.b_planes = d->b_planes; a.b_pstride = mt_planes_elems(b_rows, b_cols); a.ldb = (b_cols + 15) >> 4;
   a.bias = d->bias; a.R = d->R; a.ldr = d->ldr; a.C2 = d->C2; a.ldc2 = d->ldc2; a.n_half = d->n_half; a.col_sum = d->col_sum;
-  a.hw = 1; a.stats_slots = d->stats_slots > 0 ? d->stats_slots : 1; a.stats = d->stats; a.b_hw = 1; a.e_hw = 1;
+  a.hw = 1; a.stats_slots = d->stats_slots != 0 ? d->stats_slots : 1; a.stats = d->stats; a.b_hw = 1; a.e_hw = 1;
   if (epi == MT_EPI_STATS && !d->stats) return fail(MT_ERR_ARG, "mt_gemm_planes: STATS needs stats");
   if (epi == MT_EPI_GEGLU_BWD)
     if (int rc = det_gemm_colsum_setup(a.det, d->M, d->n_half, d->col_sum, s)) return rc;
@@ -199,6 +199,14 @@ static int gemm_planes_impl(const mt_gemm_planes_desc* d, void* stream) {
     // forward / data-gradient GEMMs sit on the critical queue, the weight gradients they share the matrix cores with do not
     static const int prio = getenv("MT_PLANES_MAIN_PRIO") ? atoi(getenv("MT_PLANES_MAIN_PRIO")) : 0;
     a.wave_prio = prio;
+    static const int stagger = [] {                    // "units[,slots]": units of s_sleep(127) (~4 us) per co-resident slot
+      const char* e = getenv("MT_PLANES_STAGGER");
+      if (!e) return 0;
+      int u = 0, sl = 2;
+      sscanf(e, "%d,%d", &u, &sl);
+      return ((u & 0xff) << 8) | ((sl & 0xff) << 16);
+    }();
+    a.wave_prio |= stagger;
   }
   if (m_tiles >= 32 && n_tiles >= 2 && !getenv("MT_NO_L2_BLOCKING")) {
     const int64_t panel = (int64_t)128 * d->K * 6;   // one column group's B panels: three bf16 planes

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void conv1x1_rows_kernel(ConvArgs p) {
         const int j = ct - w_ct0;
         if (j >= 0 && j < NTW) v += red[((w * NTW + j) * 2 + which) * 32 + c];
       }
-      atomicAdd(p.stats + ((int64_t)(blockIdx.x % p.slots) * 2 + which) * p.Cout + co, (double)v);
+      stat_add(p.stats + ((int64_t)(blockIdx.x % stat_slots(p.slots)) * 2 + which) * p.Cout + co, stat_limb(p.slots, p.Cout), v);
     }
   }
 }
@@ -246,7 +246,7 @@ extern "C" int mt_conv1x1_rows(const float* x, const float* x2, const float* w, 
   if (amode == A_BNBWD && (!c0 || !c1 || !c2 || !x2)) return fail(MT_ERR_ARG, "mt_conv1x1_rows: BN-backward mode needs ka, kb, kc and z");
   if (amode < 0 || amode > 2) return fail(MT_ERR_ARG, "mt_conv1x1_rows: bad mode");
   if (((uintptr_t)x | (uintptr_t)x2) & 15) return fail(MT_ERR_ARG, "mt_conv1x1_rows: 16-byte alignment");
-  ConvArgs a{x, x2, w, ldw, w_transposed ? 1 : 0, c0, c1, c2, res, out, stats, slots > 0 ? slots : 1, rows, Cin, Cout, hw > 0 ? hw : 1};
+  ConvArgs a{x, x2, w, ldw, w_transposed ? 1 : 0, c0, c1, c2, res, out, stats, slots != 0 ? slots : 1, rows, Cin, Cout, hw > 0 ? hw : 1};
   hipStream_t st = (hipStream_t)stream;
   const int kt = (Cin + 31) / 32, nt = (Cout + 31) / 32;
 #define MT_CASE(K_, N_, R_) if (kt == K_ && nt == N_) return launch<K_, N_, R_>(a, amode, st);

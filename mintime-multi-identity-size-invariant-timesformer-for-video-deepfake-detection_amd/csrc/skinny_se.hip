@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void se_stage_kernel(SeArgs p) {
     float v = 0.f;
     for (int l = 0; l < PB; ++l) v += red[(l * CQB + q) * 8 + e];
     const int ch = q * 4 + (e & 3), which = e >> 2;
-    atomicAdd(p.stats + ((int64_t)(blockIdx.x % p.slots) * 2 + which) * p.C + ch, (double)v);
+    stat_add(p.stats + ((int64_t)(blockIdx.x % stat_slots(p.slots)) * 2 + which) * p.C + ch, stat_limb(p.slots, p.C), v);
   }
 }
 
@@ -252,7 +252,7 @@ extern "C" int mt_se_stage_fused(const float* du_p, const float* z_p, const floa
   if (!du_p || !z_p || !kabc_p || !w_p || !z_d || !scale_d || !shift_d) return fail(MT_ERR_ARG, "mt_se_stage_fused: null pointer");
   if (!mt_se_stage_fused_supported(Co, C, hw)) return fail(MT_ERR_UNSUPPORTED, "mt_se_stage_fused: no instance for %d -> %d channels, hw %d", C, Co, hw);
   if (mode == 0 && !dgate) return fail(MT_ERR_ARG, "mt_se_stage_fused: reduction mode needs dgate");
-  if (mode == 1 && (!gate || !dpooled || !mean_invstd_d || !du_d || !stats || slots <= 0))
+  if (mode == 1 && (!gate || !dpooled || !mean_invstd_d || !du_d || !stats || slots == 0))
     return fail(MT_ERR_ARG, "mt_se_stage_fused: activation mode needs gate, dpooled, mean_invstd, du_d and stats");
   if (mode != 0 && mode != 1) return fail(MT_ERR_ARG, "mt_se_stage_fused: bad mode");
   if (rows % hw) return fail(MT_ERR_ARG, "mt_se_stage_fused: rows must be a multiple of hw");

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemArgs p) {
     if (tid < 2 * CO) {
       const int which = tid >> 5, c = tid & 31;
       const float v = red[(0 * 2 + which) * CO + c] + red[(1 * 2 + which) * CO + c] + red[(2 * 2 + which) * CO + c] + red[(3 * 2 + which) * CO + c];
-      atomicAdd(p.stats + ((int64_t)(blockIdx.x % p.slots) * 2 + which) * CO + c, (double)v);
+      stat_add(p.stats + ((int64_t)(blockIdx.x % stat_slots(p.slots)) * 2 + which) * CO + c, stat_limb(p.slots, CO), v);
     }
   }
 }
@@ -159,7 +159,7 @@ extern "C" int mt_stem_conv_fwd(const void* x, int x_is_u8, const float* w, floa
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int padt_h = max((Ho - 1) * 2 + 3 - H, 0), padt_w = max((Wo - 1) * 2 + 3 - W, 0);
   if (padt_h / 2 != padt_w / 2) return fail(MT_ERR_UNSUPPORTED, "mt_stem_conv_fwd: H and W must need the same leading padding");
-  StemArgs a{x, w, z, stats, slots > 0 ? slots : 1, x_is_u8 ? 1 : 0, N, H, W, Ho, Wo, padt_h / 2};
+  StemArgs a{x, w, z, stats, slots != 0 ? slots : 1, x_is_u8 ? 1 : 0, N, H, W, Ho, Wo, padt_h / 2};
   const size_t smem = ((size_t)3 * (W + 2) * 3 + 28 * CO + 8 * CO) * sizeof(float);
   const int64_t items = (int64_t)N * Ho;
   const int blocks = (int)(items < 2048 ? items : 2048);

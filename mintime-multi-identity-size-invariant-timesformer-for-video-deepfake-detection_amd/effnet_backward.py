@@ -72,7 +72,6 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
     run = {"blocks_run": 0, "wgrad_launches": 0, "stem_run": False}
     total_c = arch.STEM_COUT + arch.HEAD_COUT + sum((b.spec.cexp if b.spec.has_expand else 0) + b.spec.cexp + b.spec.cout
                                                     for b in blocks)
-    pool = _StatsPool(dev, total_c)
     tr = 1 if training else 0
     side = L.SideStream(dev)
 
@@ -80,32 +79,52 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
     # streaming fusions that meet their partial sums with LDS / global atomics step aside for the GEMM (split-K slabs), the
     # row-streaming data gradient and the unfused squeeze-excite stage
     det = L.deterministic()
+    pool = _StatsPool(dev, total_c, det)
+    slots = -SLOTS if det else SLOTS       # deterministic mode: BatchNorm-backward sums as integer limbs (csrc/common.hpp stat_add)
     expand_fused, wide_wgrad, se_stream, se_fused = (EXPAND_FUSED and not det, WIDE_WGRAD and not det, SE_STREAM and not det,
                                                      SE_FUSED and not det)
     fused_dw = "0" if det else FUSED_DW
 
     def bn_finalize(bnctx, sums, gidx_gamma, d=None, z=None, rows=0):
-        if det:
-            # deterministic mode: the producers' fused (atomic) sums are discarded and retaken in a fixed order from the stored
-            # gradient d and the forward's pre-normalisation tensor z (csrc/det.hip)
-            L.zero_(sums)
-            L.check(lib.mt_det_bn_sums(L.ptr(d), L.ptr(z), L.ptr(bnctx.mean_invstd), int(rows), bnctx.C, 1, L.ptr(sums), st),
-                    "mt_det_bn_sums")
         kabc = _new(dev, 3, bnctx.C)
-        L.check(lib.mt_bn_bwd_finalize(L.ptr(sums), SLOTS, bnctx.count, L.ptr(P[gidx_gamma]), L.ptr(bnctx.mean_invstd), L.ptr(kabc),
+        L.check(lib.mt_bn_bwd_finalize(L.ptr(sums), slots, bnctx.count, L.ptr(P[gidx_gamma]), L.ptr(bnctx.mean_invstd), L.ptr(kabc),
                                        L.ptr(grads[gidx_gamma]), L.ptr(grads[gidx_gamma + 1]), bnctx.C, tr, st), "mt_bn_bwd_finalize")
         return kabc
 
     def act_bwd(din, z, bnctx, dout, rows, hw, act, gate=None, dpool=None, rowscale=None):
         sums = pool.take(bnctx.C)
         L.check(lib.mt_bn_act_bwd(L.ptr(din), L.ptr(z), L.ptr(bnctx.scale), L.ptr(bnctx.shift), L.ptr(bnctx.mean_invstd), L.ptr(gate),
-                                  L.ptr(dpool), L.ptr(rowscale), L.ptr(dout), L.ptr(sums), SLOTS, rows, bnctx.C, hw, act, st),
+                                  L.ptr(dpool), L.ptr(rowscale), L.ptr(dout), L.ptr(sums), slots, rows, bnctx.C, hw, act, st),
                 "mt_bn_act_bwd")
         return sums
 
-    def conv1x1_bwd(du, z, kabc, w, x_in, rows, cout, cin, gw_idx, need_dx_in, res=None, b_pro=None, epi=None):
+    def conv1x1_bwd(du, z, kabc, w, x_in, rows, cout, cin, gw_idx, need_dx_in, res=None, b_pro=None, epi=None, pl=None):
         """z = x_in . w^T with dz = ka*du+kb*z+kc.  Returns dx_in [rows, cin] (+res) or None.
-        epi = (kind, out, kwargs): the data gradient is not stored but consumed by mt_gemm's SE_RED / ACT_BWD epilogue."""
+        epi = (kind, out, kwargs): the data gradient is not stored but consumed by mt_gemm's SE_RED / ACT_BWD epilogue.
+        pl = {"w_p": weight planes, "x_p": planes of the forward operand or None}: the late stages' plane path -- dz is evaluated ONCE,
+        as planes (mt_bn_bwd_apply_planes), and feeds the data-gradient GEMM (weight planes read along their rows) and, when the
+        forward kept its operand as planes, the weight-gradient GEMM."""
+        if pl is not None and epi is None:
+            dz_p = L.planes_empty(rows, cout, dev)
+            L.check(lib.mt_bn_bwd_apply_planes(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(dz_p), rows, cout, st), "mt_bn_bwd_apply_planes")
+            wdone = False
+            if need[gw_idx] and pl.get("x_p") is not None:
+                run["wgrad_launches"] += 1
+                side.launch(lambda: L.gemm_planes(L.OP_TN, dz_p, pl["x_p"], cout, cin, rows, Cout=grads[gw_idx].view(cout, cin), ldc=cin,
+                                                  epilogue=L.EPI_ATOMIC), reads=(dz_p, pl["x_p"]))
+                wdone = True
+            dx_in = None
+            if need_dx_in:
+                dx_in = _new(dev, rows, cin)
+                if res is not None:
+                    L.gemm_planes(L.OP_NN, dz_p, pl["w_p"], rows, cin, cout, Cout=dx_in, ldc=cin, epilogue=L.EPI_BIAS_RES, R=res, ldr=cin)
+                else:
+                    L.gemm_planes(L.OP_NN, dz_p, pl["w_p"], rows, cin, cout, Cout=dx_in, ldc=cin)
+            if wdone or not need[gw_idx]:
+                return dx_in
+            need_dx_in, keep_dx = False, dx_in           # the weight gradient alone on the kernels below (its operand was not kept as planes)
+        else:
+            keep_dx = None
         kw = {}
         if b_pro is not None:
             kw = dict(b_prologue=L.BPRO_BN_SWISH_GATE, b_scale=b_pro[0], b_shift=b_pro[1], b_gate=b_pro[2], b_hw=b_pro[3])
@@ -140,7 +159,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
                                        epilogue=L.EPI_ATOMIC, split_k=0, A2=z, scale=kabc[0], shift=kabc[1], gate=kabc[2], **kw),
                         reads=reads)
         if not need_dx_in:
-            return None
+            return keep_dx
         if epi is not None:
             for kind, out, kw2 in epi:
                 L.gemm(L.OP_NN, du, w, out, rows, cin, cout, cout, cin, cin, prologue=L.PRO_BN_BWD, epilogue=kind, A2=z,
@@ -167,7 +186,8 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
     du_h = _new(dev, M, arch.HEAD_COUT)
     sums = act_bwd(dfeat, hd["z"], hd["bn"], du_h, M, 1, 1)
     kabc = bn_finalize(hd["bn"], sums, ih + 1, du_h, hd["z"], M)
-    dy = conv1x1_bwd(du_h, hd["z"], kabc, P[ih], hd["y_in"], M, arch.HEAD_COUT, arch.HEAD_CIN, ih, lowest < len(blocks))
+    dy = conv1x1_bwd(du_h, hd["z"], kabc, P[ih], hd["y_in"], M, arch.HEAD_COUT, arch.HEAD_CIN, ih, lowest < len(blocks),
+                     pl=dict(w_p=hd["w_p"], x_p=hd["y_p"]) if hd.get("w_p") is not None else None)
     del du_h
 
     # ---- blocks, last to first
@@ -203,7 +223,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
             def stage(mode, dg, g_, dpo, mi, out, st_):
                 L.check(lib.mt_se_stage_fused(L.ptr(dsrc), L.ptr(rec["z_p"]), L.ptr(kabc_p), L.ptr(P[ix["p"]]), L.ptr(rec["z_d"]),
                                               L.ptr(bn_d.scale), L.ptr(bn_d.shift), mode, L.ptr(dg), L.ptr(g_), L.ptr(dpo), L.ptr(mi),
-                                              L.ptr(out), L.ptr(st_), SLOTS, M_out, s.cout, s.cexp, hw, st), "mt_se_stage_fused")
+                                              L.ptr(out), L.ptr(st_), slots, M_out, s.cout, s.cexp, hw, st), "mt_se_stage_fused")
             L.zero_(dgate)
             stage(0, dgate, None, None, None, None, None)                       # (c+d) d gate
             se_part(4)                                                            # dgate -> dpooled
@@ -227,11 +247,12 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
             sums = pool.take(s.cexp)
             need_save, need[ix["p"]] = need[ix["p"]], False        # the weight gradient was launched by the first call
             conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], True, b_pro=b_pro,
-                        epi=[(L.EPI_ACT_BWD, da, dict(C2=rec["z_d"], ldc2=s.cexp, stats=sums, stats_slots=SLOTS,
+                        epi=[(L.EPI_ACT_BWD, da, dict(C2=rec["z_d"], ldc2=s.cexp, stats=sums, stats_slots=slots,
                                                       epi=(bn_d.scale, bn_d.shift, rec["gate"], dpooled, bn_d.mean_invstd, hw)))])
             need[ix["p"]] = need_save
         else:
-            da = conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], True, b_pro=b_pro)
+            da = conv1x1_bwd(dsrc, rec["z_p"], kabc_p, P[ix["p"]], rec["z_d"], M_out, s.cout, s.cexp, ix["p"], True, b_pro=b_pro,
+                             pl=dict(w_p=rec["wp_p"], x_p=rec["a_p"]) if rec.get("wp_p") is not None else None)
             # (d) squeeze-excite adjoint
             se_part(1, da)                                # dgate -> dpooled: the data path waits for these
             if any(need[se:se + 4]):
@@ -246,7 +267,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         sums_in = pool.take(s.cexp)
         def dw_part(parts, _da=da, _rec=rec, _kabc=kabc_d, _bn=in_bn, _du_in=du_in, _sums=sums_in, _s=s, _ix=ix):
             L.check(lib.mt_dwconv_bwd(L.ptr(_da), L.ptr(_rec["z_d"]), L.ptr(_kabc), L.ptr(P[_ix["d"]]), L.ptr(_rec["dw_in"]),
-                                      L.ptr(_bn.scale), L.ptr(_bn.shift), L.ptr(_bn.mean_invstd), L.ptr(_du_in), L.ptr(_sums), SLOTS,
+                                      L.ptr(_bn.scale), L.ptr(_bn.shift), L.ptr(_bn.mean_invstd), L.ptr(_du_in), L.ptr(_sums), slots,
                                       L.ptr(grads[_ix["d"]]), N, _s.hin, _s.hin, _s.cexp, _s.k, _s.s, parts, 1, None, None, L.stream_ptr()),
                     "mt_dwconv_bwd")
         # algorithmic HBM bytes of the pass: read da, z_d (M_out x cexp each) and the dw input's pre-activation (M_in x cexp: swish'
@@ -274,7 +295,8 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
             # (h,i,j) bn0 + expand conv: z_e = y_in . We^T
             kabc_e = bn_finalize(in_bn, sums_in, ix["e"] + 1, du_in, rec["dw_in"], M_in)
             dy = conv1x1_bwd(du_in, rec["z_e"], kabc_e, P[ix["e"]], rec["y_in"], M_in, s.cexp, s.cin, ix["e"], need_below[bi],
-                             res=dy if s.skip else None)
+                             res=dy if s.skip else None,
+                             pl=dict(w_p=rec["we_p"], x_p=rec["y_p"]) if rec.get("we_p") is not None else None)
         else:
             # block 0: the dw input is the stem's activated output
             kabc0 = bn_finalize(in_bn, sums_in, 1, du_in, rec["dw_in"], M_in)

@@ -10,6 +10,12 @@ from . import lib as L
 SLOTS = 32   # replicated fp64 BatchNorm accumulators (spreads atomic traffic)
 STEM_DIRECT = __import__("os").environ.get("MT_STEM_DIRECT", "1") != "0"    # 0 = the im2col-prologue GEMM
 STREAM_ROWS = int(__import__("os").environ.get("MT_STREAM_ROWS", "100000"))   # 1x1 convs with at least this many rows use the streaming kernels
+# Late stages (14 x 14 and 7 x 7 grids, the head) on plane operands (csrc/effnet_planes.hip, gemm_planes.hpp): expand convolutions
+# whose input grid is at most EF_PLANES_EXPAND_HW wide, project convolutions whose output grid is at most EF_PLANES_PROJECT_HW wide
+# (tools/lab/ef_planes_lab.py: at 14 x 14 the project convolution's producer pass costs what its GEMM saves).  MT_EF_PLANES=0: off.
+EF_PLANES = __import__("os").environ.get("MT_EF_PLANES", "1") != "0"
+EF_PLANES_EXPAND_HW = int(__import__("os").environ.get("MT_EF_PLANES_EXPAND_HW", "14"))
+EF_PLANES_PROJECT_HW = int(__import__("os").environ.get("MT_EF_PLANES_PROJECT_HW", "7"))
 
 
 def _new(dev, *shape):
@@ -39,23 +45,25 @@ class _BNCtx:
 
 
 class _StatsPool:
-    """One zero-filled fp64 buffer per forward, carved into [SLOTS][2][C] accumulators."""
+    """One zero-filled fp64 buffer per forward, carved into [SLOTS][2][C] accumulators.  Deterministic mode (det=True): each
+    accumulator is two 64-bit integer limbs (csrc/common.hpp stat_add: integer atomics add up the same whatever the order the
+    blocks arrive in), [2 limbs][SLOTS][2][C], and the kernels are handed `-SLOTS`."""
 
-    def __init__(self, dev, total_channels):
-        self.buf = L.zeros(total_channels * 2 * SLOTS, torch.float64, dev)
+    def __init__(self, dev, total_channels, det=False):
+        self.limbs = 2 if det else 1
+        self.buf = L.zeros(total_channels * 2 * SLOTS * self.limbs, torch.float64, dev)
         self.off = 0
 
     def take(self, C):
-        v = self.buf[self.off:self.off + 2 * SLOTS * C]
-        self.off += 2 * SLOTS * C
+        n = 2 * SLOTS * C * self.limbs
+        v = self.buf[self.off:self.off + n]
+        self.off += n
         return v
 
 
-def _finalize(lib, st, bn_mod, ctx, count, training, gamma, beta, z=None):
+def _finalize(lib, st, bn_mod, ctx, count, training, gamma, beta, slots=SLOTS):
     ctx.count = float(count)
-    if z is not None:      # deterministic mode: the producer took no statistics; fixed-order sums of the stored tensor (csrc/det.hip)
-        L.check(lib.mt_det_bn_sums(L.ptr(z), None, None, int(count), ctx.C, 0, L.ptr(ctx.stats), st), "mt_det_bn_sums")
-    L.check(lib.mt_bn_finalize(L.ptr(ctx.stats), SLOTS, float(count), L.ptr(gamma), L.ptr(beta), L.ptr(bn_mod.running_mean),
+    L.check(lib.mt_bn_finalize(L.ptr(ctx.stats), slots, float(count), L.ptr(gamma), L.ptr(beta), L.ptr(bn_mod.running_mean),
                                L.ptr(bn_mod.running_var), L.ptr(ctx.scale), L.ptr(ctx.shift), L.ptr(ctx.mean_invstd), ctx.C,
                                bn_mod.eps, bn_mod.momentum, 1 if training else 0, st), "mt_bn_finalize")
     if training:
@@ -71,6 +79,60 @@ def _track(counter):
     if not hasattr(_TLS, "tracked"):
         _TLS.tracked = []
     _TLS.tracked.append(counter)
+
+
+def planes_scope(model, N):
+    """(expand-on-planes?, project-on-planes?) per block + head, for a batch of N crops: the plane GEMM wants >= 512 pixel rows."""
+    on = EF_PLANES and L.gemm_split_enabled()
+    blocks = model._blocks
+    exp = [on and b.spec.has_expand and b.spec.hin <= EF_PLANES_EXPAND_HW and N * b.spec.hin * b.spec.hin >= 512 and b.spec.cin % 4 == 0
+           for b in blocks]
+    proj = [on and b.spec.hout <= EF_PLANES_PROJECT_HW and N * b.spec.hout * b.spec.hout >= 512 for b in blocks]
+    last = blocks[-1].spec
+    head = on and last.hout <= EF_PLANES_EXPAND_HW and N * last.hout * last.hout >= 512
+    return exp, proj, head
+
+
+def weight_planes(model, params, exp, proj, head):
+    """Plane tensors of the 1x1-conv weights that run on plane operands, re-split from the fp32 weights by ONE launch per forward
+    (mt_split_planes_blk_multi; cf. tsf_planes.weight_planes).  Returns {("e", block) | ("p", block) | "head": planes}."""
+    lib = L.get()
+    blocks = model._blocks
+    sel, pos = [], 3
+    for bi, blk in enumerate(blocks):
+        if blk.spec.has_expand:
+            if exp[bi]:
+                sel.append((("e", bi), params[pos], blk.spec.cexp, blk.spec.cin))
+            pos += 3
+        if proj[bi]:
+            sel.append((("p", bi), params[pos + 7], blk.spec.cout, blk.spec.cexp))
+        pos += 10
+    if head:
+        sel.append(("head", params[pos], arch.HEAD_COUT, arch.HEAD_CIN))
+    if not sel:
+        return {}
+    # one cache entry per (weight storage, selection): another batch size selects other convolutions, and a recorded launch plan
+    # (plans.py) keeps reading the table and the plane tensors of the entry it was recorded with
+    ident = tuple((k, w.data_ptr()) for k, w, _, _ in sel)
+    caches = model.__dict__.setdefault("_ef_wplanes_cache", {})
+    if len(caches) > 4 and ident not in caches:
+        caches.pop(next(iter(caches)))
+    cache = caches.get(ident)
+    if cache is None:
+        holder, rows, first = {}, [], 0
+        dev = sel[0][1].device
+        for key, w, r, c in sel:
+            if w.dtype != torch.float32 or not w.is_contiguous() or w.numel() != r * c:
+                raise L.MintimeHipError("plane path needs contiguous fp32 1x1-conv weights")
+            t = L.planes_empty(r, c, dev)
+            holder[key] = t
+            rows.append((w.data_ptr(), t.data_ptr(), r, c, first))
+            first += t.shape[1] * t.shape[2]
+        host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+        cache = caches[ident] = dict(holder=holder, host=host, table=host.to(dev, non_blocking=True), blocks=first, count=len(rows))
+    L.check(lib.mt_split_planes_blk_multi(L.ptr(cache["table"]), cache["count"], cache["blocks"], L.stream_ptr()),
+            "mt_split_planes_blk_multi")       # (L.ptr: a plan being recorded pins the table)
+    return cache["holder"]
 
 
 def _bump_tracked(plan=None):
@@ -114,13 +176,16 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False, pla
     blocks = model._blocks
     total_c = arch.STEM_COUT + arch.HEAD_COUT + sum((b.spec.cexp if b.spec.has_expand else 0) + b.spec.cexp + b.spec.cout
                                                     for b in blocks)
-    pool = _StatsPool(dev, total_c) if training else None
+    det = training and L.deterministic()          # MT_DETERMINISTIC: the producers' statistics as integer limbs (order-independent)
+    pool = _StatsPool(dev, total_c, det) if training else None
     it = iter(params)
-    det = training and L.deterministic()          # MT_DETERMINISTIC: no fused (atomic) statistics, see _finalize
-    epi = L.EPI_STATS if training and not det else L.EPI_STORE
-    sptr = (lambda b_: None) if det or not training else (lambda b_: L.ptr(b_.stats))
-    zdet = (lambda z_: z_) if det else (lambda z_: None)
+    slots = -SLOTS if det else SLOTS
+    epi = L.EPI_STATS if training else L.EPI_STORE
+    sptr = (lambda b_: L.ptr(b_.stats)) if training else (lambda b_: None)
     saved = {"blocks": []} if save else None
+    pl_exp, pl_proj, pl_head = planes_scope(model, N)
+    wpl = weight_planes(model, params, pl_exp, pl_proj, pl_head)
+    y_p = None                   # planes of the current block input y (written by the producing block's bn_act when the next conv wants them)
 
     # ---- stem
     w_stem, g0, b0 = next(it), next(it), next(it)
@@ -131,13 +196,13 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False, pla
     # im2col-prologue GEMM it replaced (K = 27 taps padded to 28) stays the path for crops wider than the kernel's LDS row tile.
     if W <= 512 and H == W and STEM_DIRECT:
         L.check(lib.mt_stem_conv_fwd(L.ptr(x_nhwc), 1 if x_nhwc.dtype == torch.uint8 else 0, L.ptr(w_stem), L.ptr(z),
-                                     sptr(bn), SLOTS, N, H, W, st), "mt_stem_conv_fwd")
+                                     sptr(bn), slots, N, H, W, st), "mt_stem_conv_fwd")
     else:
         wp = _new(dev, arch.STEM_COUT, 28)
         L.check(lib.mt_conv_weight_pack(L.ptr(w_stem), L.ptr(wp), arch.STEM_COUT, 3, 3, 28, 0, st), "mt_conv_weight_pack")
         L.gemm(L.OP_NT, x_nhwc, wp, z, N * Hc * Wc, arch.STEM_COUT, 28, 28, 28, arch.STEM_COUT, prologue=L.PRO_IM2COL, epilogue=epi,
-               stats=bn.stats, stats_slots=SLOTS, conv=(H, W, 3, Hc, Wc, 3, 2, 0, 0, 1 if x_nhwc.dtype == torch.uint8 else 0))
-    _finalize(lib, st, model._bn0, bn, N * Hc * Wc, training, g0, b0, zdet(z))
+               stats=bn.stats, stats_slots=slots, conv=(H, W, 3, Hc, Wc, 3, 2, 0, 0, 1 if x_nhwc.dtype == torch.uint8 else 0))
+    _finalize(lib, st, model._bn0, bn, N * Hc * Wc, training, g0, b0, slots)
     if save:
         saved["stem"] = dict(x=x_nhwc, z=z, bn=bn)
     cur_z, cur_bn = z, bn        # "virtual" activated tensor: swish(bn(z))
@@ -157,12 +222,17 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False, pla
             w_e, g, b = next(it), next(it), next(it)
             bn_e = _BNCtx(dev, s.cexp, training, pool)
             z_e = _new(dev, M_in, s.cexp)
-            if M_in >= STREAM_ROWS and lib.mt_conv1x1_rows_supported(s.cin, s.cexp, 0):   # few channels, very many rows: streaming kernel
+            if pl_exp[bi]:
+                # late stages: y arrives as planes (written by the block above), the weight planes were split at the top
+                L.gemm_planes(L.OP_NT, y_p, wpl[("e", bi)], M_in, s.cexp, s.cin, Cout=z_e, ldc=s.cexp, epilogue=epi, stats=bn_e.stats,
+                              stats_slots=slots)
+                rec.update(y_p=y_p, we_p=wpl[("e", bi)])
+            elif M_in >= STREAM_ROWS and lib.mt_conv1x1_rows_supported(s.cin, s.cexp, 0):   # few channels, very many rows: streaming kernel
                 L.check(lib.mt_conv1x1_rows(L.ptr(y), None, L.ptr(w_e), s.cin, 0, None, None, None, 1, 0, None, L.ptr(z_e),
-                                            sptr(bn_e), SLOTS, M_in, s.cin, s.cexp, st), "mt_conv1x1_rows")
+                                            sptr(bn_e), slots, M_in, s.cin, s.cexp, st), "mt_conv1x1_rows")
             else:
-                L.gemm(L.OP_NT, y, w_e, z_e, M_in, s.cexp, s.cin, s.cin, s.cin, s.cexp, epilogue=epi, stats=bn_e.stats, stats_slots=SLOTS)
-            _finalize(lib, st, blk._bn0, bn_e, M_in, training, g, b, zdet(z_e))
+                L.gemm(L.OP_NT, y, w_e, z_e, M_in, s.cexp, s.cin, s.cin, s.cin, s.cexp, epilogue=epi, stats=bn_e.stats, stats_slots=slots)
+            _finalize(lib, st, blk._bn0, bn_e, M_in, training, g, b, slots)
             rec.update(z_e=z_e, bn_e=bn_e)
             dw_in, dw_bn = z_e, bn_e
         else:
@@ -171,8 +241,8 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False, pla
         bn_d = _BNCtx(dev, s.cexp, training, pool)
         z_d = _new(dev, M_out, s.cexp)
         L.check(lib.mt_dwconv_fwd(L.ptr(dw_in), L.ptr(dw_bn.scale), L.ptr(dw_bn.shift), L.ptr(w_d), L.ptr(z_d), sptr(bn_d),
-                                  SLOTS, N, s.hin, s.hin, s.cexp, s.k, s.s, 1, st), "mt_dwconv_fwd")
-        _finalize(lib, st, blk._bn1, bn_d, M_out, training, g, b, zdet(z_d))
+                                  slots, N, s.hin, s.hin, s.cexp, s.k, s.s, 1, st), "mt_dwconv_fwd")
+        _finalize(lib, st, blk._bn1, bn_d, M_out, training, g, b, slots)
         w_r, b_r, w_x, b_x = next(it), next(it), next(it), next(it)
         pooled, gate = _new(dev, N, s.cexp), _new(dev, N, s.cexp)
         hidden = _new(dev, N, s.cse)          # squeeze pre-activations: the gate kernel reads them (and backward keeps them)
@@ -186,18 +256,33 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False, pla
         w_p, g, b = next(it), next(it), next(it)
         bn_p = _BNCtx(dev, s.cout, training, pool)
         z_p = _new(dev, M_out, s.cout)
-        if M_out >= STREAM_ROWS and lib.mt_conv1x1_rows_supported(s.cexp, s.cout, 1):
+        if pl_proj[bi]:
+            # 7 x 7 stage: the operand swish(bn1(z_d)) * gate written once as planes (kept for the weight gradient), the GEMM only DMAs
+            a_p = L.planes_empty(M_out, s.cexp, dev)
+            L.check(lib.mt_bn_swish_gate_planes(L.ptr(z_d), L.ptr(bn_d.scale), L.ptr(bn_d.shift), L.ptr(gate), hw, L.ptr(a_p), M_out,
+                                                s.cexp, st), "mt_bn_swish_gate_planes")
+            L.gemm_planes(L.OP_NT, a_p, wpl[("p", bi)], M_out, s.cout, s.cexp, Cout=z_p, ldc=s.cout, epilogue=epi, stats=bn_p.stats,
+                          stats_slots=slots)
+            rec.update(a_p=a_p, wp_p=wpl[("p", bi)])
+        elif M_out >= STREAM_ROWS and lib.mt_conv1x1_rows_supported(s.cexp, s.cout, 1):
             L.check(lib.mt_conv1x1_rows(L.ptr(z_d), None, L.ptr(w_p), s.cexp, 0, L.ptr(bn_d.scale), L.ptr(bn_d.shift), L.ptr(gate), hw, 1,
-                                        None, L.ptr(z_p), sptr(bn_p), SLOTS, M_out, s.cexp, s.cout, st), "mt_conv1x1_rows")
+                                        None, L.ptr(z_p), sptr(bn_p), slots, M_out, s.cexp, s.cout, st), "mt_conv1x1_rows")
         else:
             L.gemm(L.OP_NT, z_d, w_p, z_p, M_out, s.cout, s.cexp, s.cexp, s.cexp, s.cout, prologue=L.PRO_BN_SWISH_GATE, epilogue=epi,
-                   scale=bn_d.scale, shift=bn_d.shift, gate=gate, hw=hw, stats=bn_p.stats, stats_slots=SLOTS)
-        _finalize(lib, st, blk._bn2, bn_p, M_out, training, g, b, zdet(z_p))
+                   scale=bn_d.scale, shift=bn_d.shift, gate=gate, hw=hw, stats=bn_p.stats, stats_slots=slots)
+        _finalize(lib, st, blk._bn2, bn_p, M_out, training, g, b, slots)
         # block output: bn2(z_p) [* drop-connect gate] [+ block input]
         dc = dc_gates.get(bi)
         y_new = _new(dev, M_out, s.cout)
-        L.check(lib.mt_bn_act_fwd(L.ptr(z_p), L.ptr(bn_p.scale), L.ptr(bn_p.shift), L.ptr(y if s.skip else None), L.ptr(y_new),
-                                  M_out, s.cout, 0, L.ptr(dc), hw, st), "mt_bn_act_fwd")
+        next_planes = pl_exp[bi + 1] if bi + 1 < len(blocks) else pl_head
+        if next_planes:
+            y_p = L.planes_empty(M_out, s.cout, dev)
+            L.check(lib.mt_bn_act_fwd_planes(L.ptr(z_p), L.ptr(bn_p.scale), L.ptr(bn_p.shift), L.ptr(y if s.skip else None), L.ptr(y_new),
+                                             M_out, s.cout, 0, L.ptr(dc), hw, L.ptr(y_p), st), "mt_bn_act_fwd_planes")
+        else:
+            y_p = None
+            L.check(lib.mt_bn_act_fwd(L.ptr(z_p), L.ptr(bn_p.scale), L.ptr(bn_p.shift), L.ptr(y if s.skip else None), L.ptr(y_new),
+                                      M_out, s.cout, 0, L.ptr(dc), hw, st), "mt_bn_act_fwd")
         if save:
             rec.update(y_in=y, dw_in=dw_in, dw_bn=dw_bn, z_d=z_d, bn_d=bn_d, pooled=pooled, hidden=hidden, gate=gate, z_p=z_p,
                        bn_p=bn_p, dc=dc)
@@ -212,14 +297,18 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False, pla
     M = N * s.hout * s.hout
     bn_h = _BNCtx(dev, arch.HEAD_COUT, training, pool)
     z_h = _new(dev, M, arch.HEAD_COUT)
-    L.gemm(L.OP_NT, y, w_h, z_h, M, arch.HEAD_COUT, arch.HEAD_CIN, arch.HEAD_CIN, arch.HEAD_CIN, arch.HEAD_COUT, epilogue=epi,
-           stats=bn_h.stats, stats_slots=SLOTS)
-    _finalize(lib, st, model._bn1, bn_h, M, training, g, b, zdet(z_h))
+    if pl_head:
+        L.gemm_planes(L.OP_NT, y_p, wpl["head"], M, arch.HEAD_COUT, arch.HEAD_CIN, Cout=z_h, ldc=arch.HEAD_COUT, epilogue=epi,
+                      stats=bn_h.stats, stats_slots=slots)
+    else:
+        L.gemm(L.OP_NT, y, w_h, z_h, M, arch.HEAD_COUT, arch.HEAD_CIN, arch.HEAD_CIN, arch.HEAD_CIN, arch.HEAD_COUT, epilogue=epi,
+               stats=bn_h.stats, stats_slots=slots)
+    _finalize(lib, st, model._bn1, bn_h, M, training, g, b, slots)
     feat = _new(dev, M, arch.HEAD_COUT)
     L.check(lib.mt_bn_act_fwd(L.ptr(z_h), L.ptr(bn_h.scale), L.ptr(bn_h.shift), None, L.ptr(feat), M, arch.HEAD_COUT, 1, None, 1,
                               st), "mt_bn_act_fwd")
     if save:
-        saved["head"] = dict(y_in=y, z=z_h, bn=bn_h)
+        saved["head"] = dict(y_in=y, z=z_h, bn=bn_h, y_p=y_p if pl_head else None, w_p=wpl.get("head"))
     _bump_tracked(plan)
     return feat, saved, ys
 

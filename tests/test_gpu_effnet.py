@@ -349,3 +349,71 @@ def test_streaming_se_stage_matches_fp64(n_img, hw, co, c):
     st = stats.sum(0).cpu()
     assert_close(st[0], ref_du.sum(0), 1e-4, "sum du")
     assert_close(st[1], (ref_du * (zd.double() - mi[0].double()) * mi[1].double()).sum(0), 1e-4, "sum du * xhat")
+
+
+@pytest.mark.parametrize("rows,C,act,with_res,with_gate", [(1000, 80, 0, True, True), (3000, 112, 0, False, False), (777, 320, 1, True, False),
+                                                            (100, 40, 0, True, True), (640, 1280, 1, False, False), (49 * 8, 192, 0, True, True)])
+def test_block_output_as_fp32_and_planes(rows, C, act, with_res, with_gate):
+    """mt_bn_act_fwd_planes (late-stage block output: model.py:117-127 + the operand of the next expand convolution): y is mt_bn_act_fwd's
+    y to the bit, the planes are the exact three-piece split of y, padding rows / columns are zeros."""
+    from mintime_amd import lib as L
+    lib = L.get()
+    g = torch.Generator().manual_seed(rows + C)
+    z = (torch.randn(rows, C, generator=g) * 2).cuda()
+    sc, sh = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    res = torch.randn(rows, C, generator=g).cuda() if with_res else None
+    hw = 49
+    gate = (torch.floor(0.8 + torch.rand((rows + hw - 1) // hw, generator=g)) / 0.8).cuda() if with_gate else None
+    y_ref = torch.empty(rows, C, device="cuda")
+    L.check(lib.mt_bn_act_fwd(L.ptr(z), L.ptr(sc), L.ptr(sh), L.ptr(res), L.ptr(y_ref), rows, C, act, L.ptr(gate), hw, L.stream_ptr()), "bn_act")
+    y = torch.full((rows, C), float("nan"), device="cuda")
+    y_p = L.planes_empty(rows, C, "cuda")
+    y_p.fill_(float("nan"))
+    L.check(lib.mt_bn_act_fwd_planes(L.ptr(z), L.ptr(sc), L.ptr(sh), L.ptr(res), L.ptr(y), rows, C, act, L.ptr(gate), hw, L.ptr(y_p),
+                                     L.stream_ptr()), "bn_act_planes")
+    assert torch.equal(y, y_ref)
+    assert not torch.isnan(y_p.float()).any()
+    full = L.planes_to_float(y_p, y_p.shape[1] * 32, y_p.shape[2] * 16)
+    assert torch.equal(full[:rows, :C], y_ref)
+    assert float(full[rows:].abs().sum()) == 0.0 and float(full[:, C:].abs().sum()) == 0.0
+    zd = z.double() * sc.double() + sh.double()
+    want = zd * torch.sigmoid(zd) if act == 1 else zd
+    if gate is not None:
+        want = want * gate.double()[torch.arange(rows, device="cuda") // hw][:, None]
+    if res is not None:
+        want = want + res.double()
+    assert_close(y, want, 1e-5, "block output vs float64")
+
+
+@pytest.mark.parametrize("n_img,hw,C,Co", [(16, 49, 1152, 192), (8, 196, 672, 112), (3, 49, 480, 80)])
+def test_project_operand_planes_and_the_gemm_on_them(n_img, hw, C, Co):
+    """mt_bn_swish_gate_planes: swish(bn1(z_d)) * gate (model.py:104-116) as planes, and the project convolution on them
+    (mt_gemm_planes with BatchNorm statistics) against mt_gemm's operand prologue and against float64."""
+    from mintime_amd import lib as L
+    from mintime_amd.effnet_engine import SLOTS
+    lib = L.get()
+    rows = n_img * hw
+    g = torch.Generator().manual_seed(C + hw)
+    z = (torch.randn(rows, C, generator=g) * 2).cuda()
+    sc, sh = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    gate = torch.rand(n_img, C, generator=g).cuda()
+    w = (torch.randn(Co, C, generator=g) * 0.05).cuda()
+    a_p = L.planes_empty(rows, C, "cuda")
+    a_p.fill_(float("nan"))
+    L.check(lib.mt_bn_swish_gate_planes(L.ptr(z), L.ptr(sc), L.ptr(sh), L.ptr(gate), hw, L.ptr(a_p), rows, C, L.stream_ptr()), "a planes")
+    zd = z.double() * sc.double() + sh.double()
+    a64 = zd * torch.sigmoid(zd) * gate.double().repeat_interleave(hw, 0)
+    a = L.planes_to_float(a_p, a_p.shape[1] * 32, C)
+    assert_close(a[:rows], a64, 2e-6, "operand planes vs float64")
+    assert float(a[rows:].abs().sum()) == 0.0
+    out = torch.empty(rows, Co, device="cuda")
+    st = torch.zeros(SLOTS * 2 * Co, dtype=torch.float64, device="cuda")
+    L.gemm_planes(L.OP_NT, a_p, L.split_planes_blk(w), rows, Co, C, Cout=out, ldc=Co, epilogue=L.EPI_STATS, stats=st, stats_slots=SLOTS)
+    want = a64 @ w.double().T
+    assert_close(out, want, 2e-5, "project convolution on plane operands vs float64")
+    sums = st.view(SLOTS, 2, Co).sum(0)
+    assert_close(sums[0], want.sum(0), 1e-4, "BatchNorm sum")
+    assert_close(sums[1], (want * want).sum(0), 1e-4, "BatchNorm sum of squares")
+    ref = torch.empty(rows, Co, device="cuda")
+    L.gemm(L.OP_NT, z, w, ref, rows, Co, C, C, C, Co, prologue=L.PRO_BN_SWISH_GATE, scale=sc, shift=sh, gate=gate, hw=hw)
+    assert_close(out, ref, 2e-5, "plane operands vs the operand-prologue GEMM")
