@@ -124,7 +124,7 @@ def cpu_baseline(num_frames, seed, budget_s=20.0):
     return res
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_families.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_families.json")
 _PMC_WARNED = []
 
 
@@ -595,6 +595,11 @@ def main():
                          "traffic": pmc("tsf_wgrad").get("bytes_per_launch"), "traffic_unit": "bytes/launch (family mean)",
                          "traffic_source": pmc("tsf_wgrad").get("source"),
                          "algorithmic_bytes": pmc("tsf_wgrad").get("algorithmic_bytes_per_launch"),
+                         # matrix-pipe counters of the same family from the hash-tied PMC passes (serialised: side stream off):
+                         # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), clock = GRBM_GUI_ACTIVE / 8 / wall
+                         "mfma_busy_frac": pmc("tsf_wgrad").get("mfma_busy_frac"),
+                         "effective_clock_ghz": pmc("tsf_wgrad").get("effective_clock_ghz"),
+                         "mfma_busy_vs_algorithmic": pmc("tsf_wgrad").get("busy_vs_algorithmic"),
                          "launches_timed": n_w, "launches_per_step": n_w // max(a.steps, 1),
                          "avg_launch_us": round(t_w / max(n_w, 1) * 1e6, 1), "flops_per_launch": f_w / max(n_w, 1),
                          "ms_per_step": round(t_w / max(a.steps, 1) * 1e3, 3)},
@@ -604,6 +609,9 @@ def main():
                              **mfma_roofline(f_f / t_f if t_f else None, split_on),
                              "traffic": pmc("tsf_ff1").get("bytes_per_launch"), "traffic_unit": "bytes/launch",
                              "algorithmic_bytes": pmc("tsf_ff1").get("algorithmic_bytes_per_launch"),
+                             "mfma_busy_frac": pmc("tsf_ff1").get("mfma_busy_frac"),
+                             "effective_clock_ghz": pmc("tsf_ff1").get("effective_clock_ghz"),
+                             "mfma_busy_vs_algorithmic": pmc("tsf_ff1").get("busy_vs_algorithmic"),
                              "launches_timed": n_f, "avg_launch_us": round(t_f / max(n_f, 1) * 1e6, 1),
                              "flops_per_launch": f_f / max(n_f, 1)},
         }

@@ -199,14 +199,6 @@ static int gemm_planes_impl(const mt_gemm_planes_desc* d, void* stream) {
     // forward / data-gradient GEMMs sit on the critical queue, the weight gradients they share the matrix cores with do not
     static const int prio = getenv("MT_PLANES_MAIN_PRIO") ? atoi(getenv("MT_PLANES_MAIN_PRIO")) : 0;
     a.wave_prio = prio;
-    static const int stagger = [] {                    // "units[,slots]": units of s_sleep(127) (~4 us) per co-resident slot
-      const char* e = getenv("MT_PLANES_STAGGER");
-      if (!e) return 0;
-      int u = 0, sl = 2;
-      sscanf(e, "%d,%d", &u, &sl);
-      return ((u & 0xff) << 8) | ((sl & 0xff) << 16);
-    }();
-    a.wave_prio |= stagger;
   }
   if (m_tiles >= 32 && n_tiles >= 2 && !getenv("MT_NO_L2_BLOCKING")) {
     const int64_t panel = (int64_t)128 * d->K * 6;   // one column group's B panels: three bf16 planes

@@ -526,20 +526,9 @@ void gemm_planes_kernel(const GemmArgs p) {
     }
   };
 
-  if ((p.wave_prio & 0xff) == 1) __builtin_amdgcn_s_setprio(1);
-  else if ((p.wave_prio & 0xff) == 2) __builtin_amdgcn_s_setprio(2);
-  else if ((p.wave_prio & 0xff) == 3) __builtin_amdgcn_s_setprio(3);
-  if constexpr (!AKM) {
-    // experiment (MT_PLANES_STAGGER=units[,slots]): the blocks that share a CU start out of phase, so that one block's pipeline fill
-    // and epilogue fall into its neighbours' main loops instead of all of them filling / storing at once.  Blocks go round-robin
-    // to the XCDs and, inside an XCD, fill the 32 CUs slot by slot: slot = (blockIdx / 8) / 32.
-    const int stag = (p.wave_prio >> 8) & 0xff;
-    if (stag) {
-      const int nsl = (p.wave_prio >> 16) & 0xff;
-      const int slot = ((blockIdx.x >> 3) >> 5) % (nsl > 0 ? nsl : 2);
-      for (int i = 0; i < slot * stag; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
+  if (p.wave_prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p.wave_prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p.wave_prio == 3) __builtin_amdgcn_s_setprio(3);
   if (MT_PLANES_PRIO == 1) {
     const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));     // HW_ID[3:0] = wave slot on the SIMD
     if (__builtin_amdgcn_readfirstlane(hwid) & 1) __builtin_amdgcn_s_setprio(1);

@@ -315,24 +315,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_sums_kernel(
   meet(ds, 2);
 }
 
-// out_which[c] += sum over blocks (in block order) of partials[b][which][c]; one thread per (which, column), 4 partial chains per
-// thread for memory-level parallelism (added in a fixed order)
-__global__ __launch_bounds__(256) void layernorm_cols_reduce_kernel(const float* __restrict__ partials, int blocks, int D,
-                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                    float* __restrict__ dxsum) {
+// out_which[c] += sum over blocks of partials[b][which][c], in a FIXED order: 64 columns x 16 phases per block (1024 threads), phase p
+// takes blocks p, p + 16, ... in four independent chains (the first version -- 4 phases, one chain -- was 256 dependent loads per
+// thread: 198 us in the step for 6 MB), chains then phases added in index order
+__global__ __launch_bounds__(1024) void layernorm_cols_reduce_kernel(const float* __restrict__ partials, int blocks, int D,
+                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                     float* __restrict__ dxsum) {
   const int which = blockIdx.y;
   float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
   if (!dst) return;
-  // 64 columns per block, 4 block-row phases per column; phase p sums blocks p, p + 4, ...
-  __shared__ float red[4][64];
+  __shared__ float red[16][64];
   const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (c < D)
-    for (int b = ph; b < blocks; b += 4) s += partials[((int64_t)b * 3 + which) * D + c];
-  red[ph][cl] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < D) {
+    const float* src = partials + (int64_t)which * D + c;
+    const int64_t stride = (int64_t)3 * D;
+    int b = ph;
+    for (; b + 48 < blocks; b += 64) {
+      s0 += src[(int64_t)b * stride]; s1 += src[(int64_t)(b + 16) * stride];
+      s2 += src[(int64_t)(b + 32) * stride]; s3 += src[(int64_t)(b + 48) * stride];
+    }
+    for (; b < blocks; b += 16) s0 += src[(int64_t)b * stride];
+  }
+  red[ph][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (ph == 0 && c < D) dst[c] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  if (ph == 0 && c < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cl];
+    dst[c] += t;
+  }
 }
 
 template <int NI>
@@ -537,7 +550,10 @@ __global__ __launch_bounds__(64) void embed_bwd_det_kernel(const float* __restri
 // one block of CLS_W wavefronts per (b,h).  Writes dq (row 0) and INITIALISES dk, dv for every key row of this head with the cls
 // query's contribution; the patch kernels then accumulate on top.  Keys are spread over all lanes of the block for the per-key
 // work and over its wavefronts for the dq reduction.
-constexpr int CLS_W = 16;          // (16 wavefronts: the N keys in two trips of 256 -- with 4 the kernel was a chain of 2 x 7 exposed round trips)
+#ifndef MT_CLS_W
+#define MT_CLS_W 16
+#endif
+constexpr int CLS_W = MT_CLS_W;          // (16 wavefronts: the N keys in two trips of 256 -- with 4 the kernel was a chain of 2 x 7 exposed round trips)
 
 __device__ __forceinline__ float block_reduce(float v, float* red, int wave, int lane, bool is_max) {
   v = is_max ? wave_max(v) : wave_sum(v);
@@ -1448,7 +1464,7 @@ extern "C" int mt_layernorm_bwd_cols_reduce(const float* partials, int blocks, i
                                             void* stream) {
   if (!partials || !dgamma || !dbeta) return fail(MT_ERR_ARG, "mt_layernorm_bwd_cols_reduce: null pointer");
   if (blocks <= 0 || dim <= 0) return fail(MT_ERR_ARG, "mt_layernorm_bwd_cols_reduce: bad shape");
-  hipLaunchKernelGGL(layernorm_cols_reduce_kernel, dim3((dim + 63) / 64, 3), dim3(256), 0, (hipStream_t)stream, partials, blocks, dim,
+  hipLaunchKernelGGL(layernorm_cols_reduce_kernel, dim3((dim + 63) / 64, 3), dim3(1024), 0, (hipStream_t)stream, partials, blocks, dim,
                      dgamma, dbeta, dx_colsum);
   return check_launch("mt_layernorm_bwd_cols_reduce");
 }

@@ -502,7 +502,10 @@ __global__ __launch_bounds__(WPB * 64) void attn_space_fwd_mfma_kernel(const flo
 // one block of CLS_W wavefronts per (b,h): the (scaled) cls query attends to all N keys, padded frames masked (:120, :259-260).
 // Keys are spread over all the block's lanes for the scores (one 256-byte K row per lane) and over its wavefronts for the
 // weighted V sum (lane = d, coalesced rows); one wavefront per (b,h) left 3/4 of the chip idle at B*H = 256.
-constexpr int CLS_W = 16;          // (16 wavefronts: the N keys in two trips of 256 -- with 4 the kernel was a chain of 2 x 7 exposed round trips)
+#ifndef MT_CLS_W
+#define MT_CLS_W 16
+#endif
+constexpr int CLS_W = MT_CLS_W;          // (16 wavefronts: the N keys in two trips of 256 -- with 4 the kernel was a chain of 2 x 7 exposed round trips)
 
 __device__ __forceinline__ float block_reduce(float v, float* red, int wave, int lane, bool is_max) {
   v = is_max ? wave_max(v) : wave_sum(v);

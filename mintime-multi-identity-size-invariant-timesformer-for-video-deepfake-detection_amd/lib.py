@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libmintime_hip.so")
+LIB_PATH = os.environ.get("MT_LIB") or os.path.join(CSRC, "libmintime_hip.so")      # MT_LIB: a lab build of the library
 
 _lib = None
 
