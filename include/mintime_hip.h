@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 115
+#define MT_VERSION 116
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -46,6 +46,9 @@ const char* mt_last_error(void);
  */
 int mt_set_deterministic(int on);
 int mt_get_deterministic(void);
+/* Frees the deterministic mode's workspaces of `stream` on the current device (synchronises that stream): call before destroying a
+ * stream that ran deterministic launches.  The workspaces never grow under stream capture (the entry point fails instead). */
+int mt_det_release(void* stream);
 int mt_det_bn_sums(const float* x, const float* z, const float* mean_invstd, int64_t rows, int C, int mode, double* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -14,16 +14,22 @@ static std::atomic<int>& det_flag() {
 int det_enabled() { return det_flag().load(std::memory_order_relaxed); }
 
 struct Arena { void* p = nullptr; size_t bytes = 0; };
+static std::mutex g_arena_mu;
+static std::map<std::pair<int, hipStream_t>, Arena> g_arenas[2];
 
+// Grown with synchronise + free + allocate on first use.  Never under stream capture: growing is illegal there and would free
+// memory an already captured graph may hold -- the caller gets nullptr (an error at the entry point: run one eager step first so
+// that the workspace has its size, like harness.GraphedEval's warm-up).  Arenas are keyed by (device, stream handle);
+// mt_det_release(stream) frees those of a stream that is about to be destroyed.
 void* det_arena(hipStream_t s, size_t bytes, int slot) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, Arena> arenas2[2];
-  auto& arenas = arenas2[slot & 1];
+  auto& arenas = g_arenas[slot & 1];
   int dev = 0;
   (void)hipGetDevice(&dev);
-  std::lock_guard<std::mutex> g(mu);
+  std::lock_guard<std::mutex> g(g_arena_mu);
   Arena& a = arenas[std::make_pair(dev, s)];
   if (bytes > a.bytes) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
     if (a.p) { (void)hipStreamSynchronize(s); (void)hipFree(a.p); a.p = nullptr; a.bytes = 0; }
     size_t want = bytes + bytes / 2;
     if (want < (size_t)(8 << 20)) want = (size_t)(8 << 20);
@@ -31,6 +37,19 @@ void* det_arena(hipStream_t s, size_t bytes, int slot) {
     a.bytes = want;
   }
   return a.p;
+}
+
+int det_release(hipStream_t s) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> g(g_arena_mu);
+  for (auto& arenas : g_arenas) {
+    auto it = arenas.find(std::make_pair(dev, s));
+    if (it == arenas.end()) continue;
+    if (it->second.p) { (void)hipStreamSynchronize(s); (void)hipFree(it->second.p); }
+    arenas.erase(it);
+  }
+  return 0;
 }
 
 // ---- log reduce: block (g, chunk of W outputs); 256 threads = (256 / W) rank segments x W outputs
@@ -81,7 +100,7 @@ DetScope::DetScope(hipStream_t stream, int groups, int ranks, int p, bool enable
   (void)hipMemsetAsync(log.base, base_zero ? 0 : 0xFF, bbytes, stream);
   on = true;
 }
-static int no_arena() { return fail(MT_ERR_LAUNCH, "deterministic mode: no workspace for the partial-sum log (hipMalloc failed)"); }
+static int no_arena() { return fail(MT_ERR_LAUNCH, "deterministic mode: no workspace for the partial-sum log (hipMalloc failed, or the workspace would have to grow under stream capture)"); }
 int DetScope::reduce_f32(float* out, int g0, int count) { return failed ? no_arena() : (on ? launch_reduce<float>(log, G, out, g0, count, s) : 0); }
 int DetScope::reduce_f64(double* out, int g0, int count) { return failed ? no_arena() : (on ? launch_reduce<double>(log, G, out, g0, count, s) : 0); }
 
@@ -215,3 +234,4 @@ extern "C" int mt_set_deterministic(int on) {
   return 0;
 }
 extern "C" int mt_get_deterministic(void) { return mt::det_enabled(); }
+extern "C" int mt_det_release(void* stream) { return mt::det_release((hipStream_t)stream); }

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "mt_last_error": [],
     "mt_set_deterministic": [C.c_int],
     "mt_get_deterministic": [],
+    "mt_det_release": [C.c_void_p],
     "mt_det_bn_sums": [f32p, f32p, f32p, i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "mt_gemm": [C.POINTER(GemmDesc), C.c_void_p],
     "mt_gemm_set_split": [C.c_int],
@@ -169,7 +170,7 @@ def build(verbose: bool = False):
 
 # MT_VERSION of include/mintime_hip.h this binding was written against (tests/test_host_logic.py keeps the two equal; the package
 # itself does not need the header at run time -- it may be copied or installed without the repository's include/ directory)
-ABI_VERSION = 115
+ABI_VERSION = 116
 
 
 def header_version() -> int:

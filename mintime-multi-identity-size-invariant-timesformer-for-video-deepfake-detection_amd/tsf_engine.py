@@ -413,17 +413,27 @@ def tsf_apply(model, x, mask, identities_mask, size_embedding, positions):
         # sequences on their own streams.  One sequence leaves the matrix cores idle during its LayerNorm / attention / epilogue
         # phases and the tile tails; a second one fills them (measured in-step: two co-running kernels each stretch ~1.4x, not 2x).
         main = torch.cuda.current_stream(x.device)
+        from . import tsf_planes
+        presplit = tsf_planes.eligible(model, (b // chains) * (1 + f * h * w), grad_on)
+        if presplit:
+            # the chains share the weights' operand planes: write them ONCE on the main stream, before the fork (each chain re-writing
+            # them while another chain's GEMMs read them was an unsynchronised -- if value-preserving -- write)
+            tsf_planes.weight_planes(model, model._param_list(), grad_on)
+            model.__dict__["_wplanes_presplit"] = True
         ready = torch.cuda.Event()
         ready.record(main)
         outs = []
-        for ci in range(chains):
-            lo, hi = ci * b // chains, (ci + 1) * b // chains
-            st = _chain_stream(x.device, ci)
-            st.wait_event(ready)
-            x.record_stream(st)
-            with torch.cuda.stream(st):
-                sl = lambda t: None if t is None else t[lo:hi]
-                outs.append(_run_chain(model, x[lo:hi], sl(mask), sl(identities_mask), sl(size_embedding), sl(positions), grad_on))
+        try:
+            for ci in range(chains):
+                lo, hi = ci * b // chains, (ci + 1) * b // chains
+                st = _chain_stream(x.device, ci)
+                st.wait_event(ready)
+                x.record_stream(st)
+                with torch.cuda.stream(st):
+                    sl = lambda t: None if t is None else t[lo:hi]
+                    outs.append(_run_chain(model, x[lo:hi], sl(mask), sl(identities_mask), sl(size_embedding), sl(positions), grad_on))
+        finally:
+            model.__dict__.pop("_wplanes_presplit", None)
         for ci in range(chains):
             main.wait_stream(_chain_stream(x.device, ci))
         for o in outs:

@@ -82,6 +82,8 @@ def weight_planes(model, params, training):
     # (p.data.copy_, dist.broadcast(p.data), a fused optimizer step through raw pointers) cannot leave them stale, and a forward
     # captured into a HIP graph (harness.GraphedEval) holds the split as a node, so its replays read the weights of the replay's time.
     stamp = (tuple(w._version for w in ws), WEIGHT_EPOCH[0])
+    if model.__dict__.get("_wplanes_presplit"):      # MT_TSF_CHAINS: tsf_apply split once, before the chains' streams forked
+        return cache["holder"], cache["serial"]
     L.check(lib.mt_split_planes_blk_multi(L.ptr(cache["table"]), cache["count"], cache["blocks"], L.stream_ptr()),
             "mt_split_planes_blk_multi")             # (L.ptr: a launch plan being recorded pins the table)
     if cache["stamp"] != stamp:                      # the weights changed since the planes were last written: graphs that saved the

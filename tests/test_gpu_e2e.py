@@ -523,13 +523,19 @@ def picked(ef, tsf):
     tp, ep = list(tsf.named_parameters()), [(k, p) for k, p in ef.named_parameters() if not k.startswith("_fc") and not k.endswith("_bn2.bias")]   # _bn2.bias: analytically zero gradient (rounding noise only)
     return tp[:6] + tp[-6:] + tp[40:44] + ep[:6] + ep[-6:] + ep[100:104]
 
-# (a) what this rank computes ALONE on its shard (no reducer, no process group involved)
-cfg, ef0, tsf0 = harness.build_models(seed=3, device="cuda", drop_connect_rate=0.0)
-start = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in (ef0, tsf0)]
-y = harness.forward(ef0, tsf0, shard(0))
-optim.bce_with_logits(y, shard(0)["labels"], None).backward()
-alone = {k: p.grad.detach().cpu().clone() for k, p in picked(ef0, tsf0)}
-mark("alone step done")
+# (a) what this rank computes ALONE on its shard (no reducer, no process group involved).  The ranks take turns: two processes
+# that start their HIP context, load the library's code objects and build models on ONE GPU at the same time are time-sliced against
+# each other in long quanta (111 s for this phase in round 5's first suite run; a few seconds each when they do it one after the other)
+for turn in (0, 1):
+    if rank == turn:
+        cfg, ef0, tsf0 = harness.build_models(seed=3, device="cuda", drop_connect_rate=0.0)
+        start = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in (ef0, tsf0)]
+        y = harness.forward(ef0, tsf0, shard(0))
+        optim.bce_with_logits(y, shard(0)["labels"], None).backward()
+        alone = {k: p.grad.detach().cpu().clone() for k, p in picked(ef0, tsf0)}
+        torch.cuda.synchronize()
+        mark("alone step done")
+    dist.barrier()
 # (b) the data-parallel step, once per reducer, each from the same starting state (one model pair: building it is the slow part)
 ef, tsf = ef0, tsf0
 for mode in ("overlap", "flat"):

@@ -28,6 +28,27 @@ def test_library_exports_every_declared_symbol():
     assert lib.get().mt_version() == lib.header_version() == lib.ABI_VERSION
 
 
+def test_every_launching_entry_point_has_a_recording_thunk():
+    """Launch plans (header section "Launch plans"): csrc/gen_plan.py turns every declaration whose last parameter is `void* stream`
+    into an exported thunk `mt_xxx` around the kernels' own entry point `mti_xxx`; both must be in the library, and the plan API itself
+    must not be wrapped."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_plan", os.path.join(lib.CSRC, "gen_plan.py"))
+    gp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gp)
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mintime_hip.h")).read()
+    launching = [name for ret, name, ps in gp.prototypes(hdr) if ps[-1] == ("void*", "stream") and ret == "int"]
+    assert len(launching) >= 50 and "mt_gemm" in launching and "mt_memset_async" in launching
+    handle = ctypes.CDLL(lib.LIB_PATH)
+    for name in launching:
+        assert hasattr(handle, name) and hasattr(handle, "mti_" + name[3:]), name
+    for name in ("mt_plan_run", "mt_plan_fork", "mt_plan_create", "mt_version"):
+        assert hasattr(handle, name) and not hasattr(handle, "mti_" + name[3:]), name
+    # descriptors are captured by value: the generated thunk copies *d before the closure is made
+    thunks = open(os.path.join(lib.CSRC, "plan_thunks.inc")).read()
+    assert "const auto d_v = *d;" in thunks and "mti_gemm_planes(&d_v, stream)" in thunks
+
+
 def test_errors_are_reported_not_swallowed():
     h = lib.get()
     d = lib.GemmDesc()          # all-null descriptor
