@@ -332,7 +332,8 @@ class _EffNetFunction(torch.autograd.Function):
         if save and not want_blocks:
             stream = torch.cuda.current_stream(x_nhwc.device).cuda_stream
             key = ("ef", tuple(x_nhwc.shape), x_nhwc.dtype, model.training, L.deterministic(), L.gemm_split_enabled(),
-                   float(model.drop_connect_rate), tuple(ctx.needs_input_grad[3:]), stream)
+                   float(model.drop_connect_rate), tuple(ctx.needs_input_grad[3:]), stream,
+                   float(model._bn0.momentum), float(model._bn0.eps))       # (scalars a recorded call holds by value)
             np_, mode = plans.lookup(model, key)
             if mode == "replay" and np_.state_ptrs != plans.state_ptrs(_state_tensors(model, params)):
                 plans.drop(model, np_)                   # parameters / buffers moved (load_state_dict, .to()): record afresh later

@@ -27,6 +27,8 @@ ENABLED = os.environ.get("MT_PLAN", "1") != "0"
 RECORD_AFTER = int(os.environ.get("MT_PLAN_AFTER", "1"))     # eager occurrences of a key before it is recorded
 MAX_PLANS = int(os.environ.get("MT_PLAN_MAX", "2"))          # per module
 
+_REG = weakref.WeakKeyDictionary()   # module -> {key: NetPlan}; kept OUT of the module's __dict__ (plans hold ctypes handles: a
+                                     # copy.deepcopy / pickle of the module must not meet them)
 OWNED = set()                 # storage addresses of plan-owned output buffers (feat, dfeat, logits): consumed in place by the next plan
 ALL = weakref.WeakSet()       # live NetPlans (bench.py reads their probes)
 PROBE_MASK = [0]              # bit t: time the calls tagged t (lib.TAG_*) inside mt_plan_run
@@ -89,7 +91,7 @@ def lookup(model, key):
     """-> (NetPlan | None, 'eager' | 'record' | 'replay')."""
     if not ENABLED or torch.cuda.is_current_stream_capturing():
         return None, "eager"
-    reg = model.__dict__.setdefault("_mt_plans", {})
+    reg = _REG.setdefault(model, {})
     ent = reg.get(key)
     if ent is None:
         if len(reg) >= MAX_PLANS:
@@ -113,7 +115,7 @@ def lookup(model, key):
 
 
 def drop(model, np_):
-    model.__dict__.get("_mt_plans", {}).pop(np_.key, None)
+    _REG.get(model, {}).pop(np_.key, None)
     STATS["dropped"] += 1
 
 
