@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 116
+#define MT_VERSION 117
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -184,6 +184,11 @@ int mt_mul_planes(const float* x, const float* m, void* planes, float* out, int 
 int mt_mul_add(const float* y, const float* m, const float* r, float* out, int64_t n, void* stream);
 int mt_geglu_bwd(const float* dh, const float* m, const float* u, void* du_planes, float* du, int rows, int n_half, void* stream);
 int64_t mt_gemm_planes_workspace_bytes(void);
+/* Persistent form of the fp32-output NT / NN plane GEMMs (MT_EPI_STORE, MT_EPI_BIAS_RES) with more tiles than resident block slots:
+ * blocks_per_cu resident blocks per CU walk their XCD's share of the tile list and issue the next tile's first DMA stage before the
+ * current tile's epilogue.  Same sums in the same order (bit-identical results).  0 = one block per tile (default; MT_PLANES_PERSIST
+ * sets the initial value).  Process-wide like mt_gemm_set_split; returns the previous setting. */
+int mt_gemm_planes_set_persist(int blocks_per_cu);
 
 /* ------------------------------------------------------------------------------------------------
  * Size-Invariant TimeSformer forward, non-GEMM pieces

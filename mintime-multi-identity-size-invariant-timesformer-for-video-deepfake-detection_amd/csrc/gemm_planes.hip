@@ -91,7 +91,19 @@ int cu_count() {
   return c;
 }
 
-template <bool AKM, bool BKM, int EPI, int BAL, bool CPL, bool SK = false>
+// persistent form of the fp32-output forward / data-gradient GEMMs: resident blocks per CU (0 = one block per tile, the default:
+// QKV 122 -> 114 us standalone, the step unchanged -- profiles/README.md round 5).  MT_PLANES_PERSIST sets the initial value.
+int g_persist = -1;
+int persist_blocks() {
+  if (g_persist < 0) {
+    const char* e = getenv("MT_PLANES_PERSIST");
+    g_persist = e ? atoi(e) : 0;
+    if (g_persist < 0 || g_persist > 4) g_persist = 0;
+  }
+  return g_persist;
+}
+
+template <bool AKM, bool BKM, int EPI, int BAL, bool CPL, int SK = 0>
 int launch_planes(const GemmArgs& a, dim3 grid, hipStream_t s) {
   constexpr int ST = 2;
   auto k = gemm_planes_kernel<2, 2, 2, 2, AKM, BKM, EPI, ST, BAL == BAL_PAIR ? 2 : 3, BAL, CPL, SK>;
@@ -105,6 +117,12 @@ int launch_planes(const GemmArgs& a, dim3 grid, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int mt_gemm_planes_set_persist(int blocks_per_cu) {
+  const int prev = persist_blocks();
+  g_persist = blocks_per_cu < 0 || blocks_per_cu > 4 ? 0 : blocks_per_cu;
+  return prev;
+}
 
 extern "C" int64_t mt_gemm_planes_workspace_bytes(void) { return kSkFlagBytes + (int64_t)kSkMaxGrid * 128 * 128 * 4; }
 
@@ -193,7 +211,7 @@ static int gemm_planes_impl(const mt_gemm_planes_desc* d, void* stream) {
     a.k_chunk = chunk; a.xcd_k = 1;
     grid.y = (unsigned)(((d->K + chunk - 1) / chunk + 7) / 8 * 8);
     if (int rc = det_gemm_setup(a.C, a.ldc, a.det_slab, d->M, d->N, (d->K + chunk - 1) / chunk, false, s)) return rc;
-    return launch_planes<true, true, EPI_ATOMIC, BAL_NONE, false>(a, grid, s);
+    return launch_planes<true, true, EPI_ATOMIC, BAL_NONE, false, 0>(a, grid, s);
   }
   {
     // forward / data-gradient GEMMs sit on the critical queue, the weight gradients they share the matrix cores with do not
@@ -227,10 +245,22 @@ static int gemm_planes_impl(const mt_gemm_planes_desc* d, void* stream) {
       a.sk_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(d->sk_workspace) + kSkFlagBytes);
     }
   }
+  // persistent blocks with the next tile's first stage prefetched under the epilogue (gemm_planes.hpp SKM = 2): fp32-output forward /
+  // data-gradient GEMMs with more tiles than resident block slots.  MT_PLANES_PERSIST: 0 = off, N = blocks per CU (default below).
+  if (!sk && !cpl && (epi == MT_EPI_STORE || epi == MT_EPI_BIAS_RES)) {
+    const int per_cu = persist_blocks();
+    const int g = cu_count() * per_cu / 8 * 8;
+    if (per_cu > 0 && g >= 8 && m_tiles * n_tiles > g) {
+      const dim3 pg((unsigned)g, 1, 1);
+      if (op == MT_OP_NT && epi == MT_EPI_STORE) return launch_planes<false, false, EPI_STORE, BAL_PAIR, false, 2>(a, pg, s);
+      if (op == MT_OP_NT && epi == MT_EPI_BIAS_RES) return launch_planes<false, false, EPI_BIAS_RES, BAL_PAIR, false, 2>(a, pg, s);
+      if (op == MT_OP_NN && epi == MT_EPI_STORE) return launch_planes<false, true, EPI_STORE, BAL_PAIR, false, 2>(a, pg, s);
+    }
+  }
 #define PL_COMBO(OP, BKM_, EPI_, CPL_) \
   if (op == OP && epi == EPI_ && cpl == CPL_)                                                       \
-    return sk ? launch_planes<false, BKM_, EPI_, BAL_PAIR, CPL_, true>(a, grid, s)                  \
-              : launch_planes<false, BKM_, EPI_, BAL_PAIR, CPL_, false>(a, grid, s);
+    return sk ? launch_planes<false, BKM_, EPI_, BAL_PAIR, CPL_, 1>(a, grid, s)                     \
+              : launch_planes<false, BKM_, EPI_, BAL_PAIR, CPL_, 0>(a, grid, s);
   PL_COMBO(MT_OP_NT, false, EPI_STORE, false)
   PL_COMBO(MT_OP_NT, false, EPI_BIAS_RES, false)
   PL_COMBO(MT_OP_NT, false, EPI_STATS, false)

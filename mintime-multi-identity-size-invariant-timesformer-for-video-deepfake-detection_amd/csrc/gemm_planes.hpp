@@ -227,7 +227,9 @@ __device__ __forceinline__ void sk_tile_coords(const GemmArgs& p, int t, int& mt
 // GemmArgs for this loop: a_planes / b_planes with a_pstride / b_pstride (elements between planes), lda / ldb = the operand's
 // number of 16-column blocks (C / 16); M, N, K logical; rows past the end are clamped to the last row block (whose padding rows are
 // zeros).
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int EPI, int STAGES, int MINW, int BAL, bool CPL = false, bool SK = false>
+// SKM: 0 = one block per tile, 1 = stream-K (below), 2 = persistent blocks that walk their XCD's share of the tile list and issue
+// the NEXT tile's first stage before the current tile's epilogue (the per-tile pipeline fill that K = 512 problems pay on every tile)
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int EPI, int STAGES, int MINW, int BAL, bool CPL = false, int SKM = 0>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW)
 void gemm_planes_kernel(const GemmArgs p) {
   constexpr int NW = WAVES_M * WAVES_N;
@@ -242,7 +244,9 @@ void gemm_planes_kernel(const GemmArgs p) {
   constexpr int IPW = (PA + PB) / NW;
   static_assert(STAGES >= 2 && STAGES <= 4, "2..4 stages");
   static_assert((!AKM || BM == 128) && (!BKM || BN == 128), "k-major images are laid out for 128-column tiles");
+  constexpr bool SK = SKM == 1, PS = SKM == 2;
   static_assert(!SK || !AKM, "stream-K: forward / data-gradient forms (weight gradients split K over the grid already)");
+  static_assert(!PS || (!AKM && !CPL && STAGES == 2 && EPI != EPI_GEGLU && BAL != BAL_PHASE), "persistent form: NT / NN, fp32 output, ring of two");
   constexpr bool PAIR = BAL == BAL_PAIR, PHASE = BAL == BAL_PHASE;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_pl[];
@@ -536,7 +540,124 @@ void gemm_planes_kernel(const GemmArgs p) {
     if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
   }
 
-  if constexpr (!SK) {
+  if constexpr (PS) {
+    // ---- persistent: block (x, q) of XCD x = blockIdx % 8 takes tiles q, q + Q, ... of that XCD's contiguous share of the tile list
+    // (the L2-blocked order of tile_coords() when group_n > 0), Q = gridDim / 8 blocks per XCD
+    const int Q = gridDim.x >> 3, xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + BM - 1) / BM;
+    int base = 0, cnt;
+    if (p.group_n > 0) {
+      const int qq = m_tiles >> 3, rr = m_tiles & 7;
+      for (int i = 0; i < xcd; ++i) base += (qq + (i < rr ? 1 : 0)) * n_tiles;
+      cnt = (qq + (xcd < rr ? 1 : 0)) * n_tiles;
+    } else {
+      const int T = m_tiles * n_tiles, per = T >> 3, rem = T & 7;
+      base = xcd * per + min(xcd, rem);
+      cnt = per + (xcd < rem ? 1 : 0);
+    }
+    if (q >= cnt) return;
+    const int nk = (p.K + BK - 1) / BK;
+    // DMA pieces of this wave: which operand / plane / piece is tile-independent, the byte offsets are per tile
+    bool is_a[IPW];
+    int pl_[IPW], pc_[IPW];
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const int qj = wave * IPW + j;
+      is_a[j] = qj < PA;
+      const int qx = is_a[j] ? qj : qj - PA;
+      pl_[j] = is_a[j] ? qx / PPA : qx / PPB;
+      pc_[j] = is_a[j] ? qx % PPA : qx % PPB;
+    }
+    auto setup = [&](int mt_, int nt_, unsigned (&voff)[IPW]) {
+      const int m0 = mt_ * BM, n0 = nt_ * BN;
+#pragma unroll
+      for (int j = 0; j < IPW; ++j) {
+        const int64_t pstride = is_a[j] ? p.a_pstride : p.b_pstride;
+        const int64_t cb16 = is_a[j] ? p.lda : p.ldb;
+        const bool kmaj = is_a[j] ? AKM : BKM;
+        int64_t off;
+        if (!kmaj) {
+          const int row = lane >> 1, sl = lane & 1;
+          const int kh = sl ^ ((row >> 3) & 1);
+          int g0 = (is_a[j] ? m0 : n0) + pc_[j] * 32;
+          const int lim = is_a[j] ? p.M : p.N;
+          if (g0 >= lim) g0 = (lim - 1) & ~31;
+          off = pl_[j] * pstride + (int64_t)(g0 >> 5) * cb16 * 512 + row * 16 + kh * 8;
+        } else {
+          const int kl = pc_[j] * 4 + (lane >> 4), s16 = lane & 15;
+          const int seg = (s16 >> 1) ^ (2 * (kl & 3)), half = s16 & 1;
+          int cb = ((is_a[j] ? m0 : n0) >> 4) + seg;
+          const int cbmax = (int)cb16 - 1;
+          cb = cb < cbmax ? cb : cbmax;
+          off = pl_[j] * pstride + (int64_t)cb * 512 + kl * 16 + half * 8;
+        }
+        voff[j] = (unsigned)(off * 2);
+      }
+    };
+    auto issue = [&](const unsigned (&voff)[IPW], int kt, int slot_) {
+      if (MT_PLANES_ABLATE & 1) return;
+      const int kb = kt * BK;
+      const __bf16* as = a_base + (AKM ? ((int64_t)(kb >> 5) * p.lda * 512 + (kb & 31) * 16) : (int64_t)(kb >> 4) * 512);
+      const __bf16* bs = b_base + (BKM ? ((int64_t)(kb >> 5) * p.ldb * 512 + (kb & 31) * 16) : (int64_t)(kb >> 4) * 512);
+      const unsigned dst = lds_base + (unsigned)(slot_ * STAGE);
+#pragma unroll
+      for (int j = 0; j < IPW; ++j) lds_dma16_s(is_a[j] ? as : bs, voff[j], dst + (unsigned)((wave * IPW + j) * 1024));
+    };
+    int i = q, mt_, nt_;
+    sk_tile_coords<BM, BN>(p, base + i, mt_, nt_);
+    unsigned vc[IPW], vn[IPW];
+    setup(mt_, nt_, vc);
+    issue(vc, 0, 0);
+    int slot = 0;
+    while (true) {
+      const int inext = i + Q;
+      const bool has_next = inext < cnt;
+      int mtn = 0, ntn = 0;
+      if (has_next) {
+        sk_tile_coords<BM, BN>(p, base + inext, mtn, ntn);
+        setup(mtn, ntn, vn);
+      }
+#pragma unroll
+      for (int ii = 0; ii < TM; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[ii][jj][r] = 0.f; if constexpr (PAIR) nacc[ii][jj][r] = 0.f; }
+      auto step = [&](int kt, auto odd_c) {
+        wait_vmcnt<0>();                                // this tile's stage kt has landed (and the previous tile's stores are acknowledged)
+        MT_PL_BARRIER();
+        const int nslot = slot ^ 1;
+        if (kt + 1 < nk) issue(vc, kt + 1, nslot);
+        else if (has_next) issue(vn, 0, nslot);         // the next tile's first stage rides under this tile's last step and epilogue
+        Frags f;
+        read_frags(slot, f);
+        mma(f, odd_c, 0u);
+        slot = nslot;
+      };
+      for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, std::false_type{});
+        if (kt + 1 >= nk) break;
+        step(kt + 1, std::true_type{});
+      }
+      if constexpr (PAIR) {
+#pragma unroll
+        for (int ii = 0; ii < TM; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ii][jj][r] -= nacc[ii][jj][r];
+#pragma unroll
+        for (int ii = 0; ii < TM; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < TN; ++jj) asm volatile("" : "+v"(acc[ii][jj]));
+      }
+      epilogue(mt_, nt_);
+      if (!has_next) break;
+      i = inext; mt_ = mtn; nt_ = ntn;
+#pragma unroll
+      for (int j = 0; j < IPW; ++j) vc[j] = vn[j];
+    }
+  } else if constexpr (!SK) {
     int mt_, nt_;
     int k_begin = 0, k_end = p.K;
     int split_idx = blockIdx.y;

@@ -74,6 +74,7 @@ PROTOTYPES = {
     "mt_bn_bwd_apply_planes": [f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "mt_gemm_planes": [C.POINTER(GemmPlanesDesc), C.c_void_p],
     "mt_gemm_planes_workspace_bytes": [],
+    "mt_gemm_planes_set_persist": [C.c_int],
     "mt_mul_planes": [f32p, f32p, C.c_void_p, f32p, C.c_int, C.c_int, C.c_void_p],
     "mt_mul_add": [f32p, f32p, f32p, f32p, i64, C.c_void_p],
     "mt_geglu_bwd": [f32p, f32p, f32p, C.c_void_p, f32p, C.c_int, C.c_int, C.c_void_p],
@@ -170,7 +171,7 @@ def build(verbose: bool = False):
 
 # MT_VERSION of include/mintime_hip.h this binding was written against (tests/test_host_logic.py keeps the two equal; the package
 # itself does not need the header at run time -- it may be copied or installed without the repository's include/ directory)
-ABI_VERSION = 116
+ABI_VERSION = 117
 
 
 def header_version() -> int:

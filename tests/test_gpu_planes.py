@@ -240,6 +240,37 @@ def test_stream_k_matches_one_block_per_tile_and_is_reproducible(op, M, N, K, ep
     assert ws is not None and int(ws[:4096].view(torch.int32).abs().sum()) == 0, "flags must be cleared by their consumers"
 
 
+@pytest.mark.parametrize("op,M,N,K,epi", [(L.OP_NT, 12576, 1536, 512, L.EPI_STORE), (L.OP_NT, 12576, 1536, 520, L.EPI_BIAS_RES),
+                                           (L.OP_NN, 12576, 1024, 1536, L.EPI_STORE), (L.OP_NT, 9000, 640, 48, L.EPI_STORE)])
+def test_persistent_blocks_give_the_same_bits(op, M, N, K, epi):
+    """mt_gemm_planes_set_persist(2): 2 blocks per CU walk the tile list and prefetch the next tile's first stage under the epilogue.
+    Every tile is still summed by one block in the same order: the results are the one-block-per-tile bits (also with a ragged K and
+    with more XCD bands than tiles per band)."""
+    A = _rand(M, K, seed=1)
+    Bm = _rand(N, K, seed=2, scale=0.05) if op == L.OP_NT else _rand(K, N, seed=2, scale=0.05)
+    b, R = _rand(N, seed=3).cuda(), _rand(M, N, seed=4).cuda()
+    a_p, b_p = L.split_planes_blk(A.cuda()), L.split_planes_blk(Bm.cuda())
+    kw = dict(ldc=N, epilogue=epi, bias=b, streamk=False)
+    if epi == L.EPI_BIAS_RES:
+        kw.update(R=R, ldr=N)
+    outs = []
+    lib = L.get()
+    prev = lib.mt_gemm_planes_set_persist(0)
+    try:
+        for per_cu in (0, 2, 1):
+            lib.mt_gemm_planes_set_persist(per_cu)
+            c = torch.full((M, N), float("nan"), device="cuda")
+            L.gemm_planes(op, a_p, b_p, M, N, K, Cout=c, **kw)
+            outs.append(c)
+    finally:
+        lib.mt_gemm_planes_set_persist(prev)
+    ref = (A.double() @ (Bm.double().T if op == L.OP_NT else Bm.double())) + b.cpu().double()
+    if epi == L.EPI_BIAS_RES:
+        ref = ref + R.cpu().double()
+    assert_close(outs[0], ref, TOL, "one block per tile vs fp64")
+    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+
+
 def test_stream_k_under_a_co_running_kernel():
     """The persistent blocks are not all resident when another stream holds CUs: a block only waits for slabs its successors write
     FIRST, so the launch still completes (and gives the same bits)."""
