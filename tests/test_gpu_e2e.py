@@ -37,8 +37,19 @@ def _step(ef, tsf, inp, require_attention=True):
     return features, out
 
 
-@pytest.mark.parametrize("name", ["e2e_cfg1_eval", "e2e_2id_train"])
-def test_step_matches_reference_fixture(name):
+@pytest.mark.parametrize("name,deterministic", [("e2e_cfg1_eval", False), ("e2e_2id_train", False), ("e2e_2id_train", True)])
+def test_step_matches_reference_fixture(name, deterministic):
+    """... and once in deterministic mode (train.py:110; MT_DETERMINISTIC=1): the fixed-order / integer-limb reductions are judged
+    against the reference's float64 pass directly, not only against the default path."""
+    from mintime_amd import lib as L
+    prev = L.set_deterministic(deterministic)
+    try:
+        _check_step_against_fixture(name)
+    finally:
+        L.set_deterministic(prev)
+
+
+def _check_step_against_fixture(name):
     g = golden(name)
     B, Fr, seed, training = int(g["batch"]), int(g["frames"]), int(g["seed"]), bool(g["training"])
     cfg, ef, tsf, _, _ = _models(seed, Fr, training)
