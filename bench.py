@@ -311,7 +311,9 @@ def pin_launch_thread(local_rank, world):
         return None
     try:
         cores = sorted(os.sched_getaffinity(0))
-        per = max(1, len(cores) // world)
+        per = len(cores) // world
+        if per < 8:                  # too few cores to fence off (launch thread, autograd thread, RCCL proxies per rank): leave it to the OS
+            return None
         mine = cores[local_rank * per:(local_rank + 1) * per] or cores
         os.sched_setaffinity(0, mine)
         return [mine[0], mine[-1]]

@@ -546,6 +546,34 @@ __global__ __launch_bounds__(64) void embed_bwd_det_kernel(const float* __restri
   if (cur >= 0) dst[(int64_t)cur * D + col] += run;
 }
 
+// Deterministic mode since round 5: the run walk above is one wavefront per 64 columns over all B N token rows -- 5.9 ms per step at
+// B = 32, on the main queue.  An embedding gradient is an index_add; what makes it order-dependent is floating-point addition.  So the
+// token rows scatter into two-limb INTEGER accumulators (common.hpp stat_add: trunc(v) and round(frac * 2^44) as int64 atomics --
+// associative, hence the same bits whatever order the wavefronts arrive in), one wavefront per token row like the default kernel, and
+// a second pass decodes the table-shaped accumulator and adds it to the gradient.  ~0.3 ms for both tables.
+__global__ __launch_bounds__(256) void embed_bwd_limb_scatter_kernel(const float* __restrict__ dx, const int64_t* __restrict__ positions,
+                                                                    const int* __restrict__ sizes, int B, int N, int n, int F, int D,
+                                                                    int rows, int kind, double* __restrict__ acc, int64_t limb) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= B * N) return;
+  const int b = row / N, t = row - b * N;
+  int64_t idx;
+  if (kind == 1) idx = positions ? positions[row] : (int64_t)t;
+  else idx = (t > 0 && sizes) ? sizes[b * F + (t - 1) / n] : 0;
+  idx = idx < 0 ? 0 : (idx >= rows ? rows - 1 : idx);              // same clamp as the forward (which raised the flag)
+  const float* dr = dx + (int64_t)row * D;
+  for (int i = lane; i < D; i += 64) stat_add(acc + idx * D + i, limb, dr[i]);
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_limb_decode_kernel(const double* __restrict__ acc, int64_t limb, float* __restrict__ dst,
+                                                                   int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const long long hi = *reinterpret_cast<const long long*>(acc + i), lo = *reinterpret_cast<const long long*>(acc + limb + i);
+    if (hi | lo) dst[i] += (float)stat_get(acc + i, limb);
+  }
+}
+
 // ---------------------------------------------------------------------------------------- attention backward: cls query
 // one block of CLS_W wavefronts per (b,h).  Writes dq (row 0) and INITIALISES dk, dv for every key row of this head with the cls
 // query's contribution; the patch kernels then accumulate on top.  Keys are spread over all lanes of the block for the per-key
@@ -1518,10 +1546,31 @@ extern "C" int mt_embed_bwd(const float* dx, float* dcls, float* dpos_emb, float
   if (pos_rows <= 0 || (dsize_emb && size_rows <= 0)) return fail(MT_ERR_ARG, "mt_embed_bwd: empty embedding table");
   const int N = 1 + F * n;
   if (det_enabled()) {
+    hipStream_t s = (hipStream_t)stream;
+    static const bool walk = getenv("MT_DET_EMBED_WALK") != nullptr;        // A/B aid: round 4's run walk for all three gradients
     const int srows = dsize_emb ? size_rows : 1;
-    hipLaunchKernelGGL(embed_bwd_det_kernel, dim3((dim + 63) / 64, 3), dim3(64), 0, (hipStream_t)stream, dx, dcls,
+    // cls token: B ordered adds per column (kind 0 of the walk kernel); the tables: integer-limb scatter + decode
+    hipLaunchKernelGGL(embed_bwd_det_kernel, dim3((dim + 63) / 64, walk ? 3 : 1), dim3(64), 0, s, dx, dcls,
                        dpos_emb, dsize_emb, positions, sizes, B, N, n, F, dim, pos_rows, srows);
-    return check_launch("mt_embed_bwd(deterministic)");
+    int rc = check_launch("mt_embed_bwd(deterministic)");
+    if (rc || walk) return rc;
+    for (int kind = 1; kind <= 2; ++kind) {
+      float* dst = kind == 1 ? dpos_emb : dsize_emb;
+      if (!dst) continue;
+      const int rows = kind == 1 ? pos_rows : srows;
+      const int64_t total = (int64_t)rows * dim;
+      double* acc = reinterpret_cast<double*>(det_arena(s, (size_t)total * 2 * sizeof(double), 1));
+      if (!acc) return fail(MT_ERR_LAUNCH, "deterministic mode: no workspace for the embedding gradient (%lld MB)", (long long)(total * 16 >> 20));
+      if (hipMemsetAsync(acc, 0, (size_t)total * 2 * sizeof(double), s) != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_embed_bwd: memset");
+      hipLaunchKernelGGL(embed_bwd_limb_scatter_kernel, dim3((B * N + 3) / 4), dim3(256), 0, s, dx, positions, sizes, B, N, n, F, dim, rows,
+                         kind, acc, total);
+      int64_t nb = (total + 255) / 256;
+      if (nb > 4096) nb = 4096;
+      hipLaunchKernelGGL(embed_bwd_limb_decode_kernel, dim3((unsigned)nb), dim3(256), 0, s, acc, total, dst, total);
+      rc = check_launch("mt_embed_bwd(deterministic, limbs)");
+      if (rc) return rc;
+    }
+    return 0;
   }
   hipLaunchKernelGGL(embed_bwd_kernel, dim3((B * N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dx, dcls, dpos_emb, dsize_emb,
                      positions, sizes, B, N, n, F, dim, pos_rows, dsize_emb ? size_rows : 1);
