@@ -310,7 +310,8 @@ int mt_layernorm_bwd_rows(const float* dy, const float* x, const float* stats, c
 int mt_layernorm_bwd_cols(const float* dy, const float* x, const float* stats, const float* dx_new, float* dgamma, float* dbeta,
                           float* dx_colsum, int skip_period, int rows, int dim, void* stream);
 
-/* The rows kernel with the parameter-gradient sums folded in: besides dx (and its planes) every block stores one row of
+/* (autograd of PreNorm's nn.LayerNorm, size_invariant_timesformer.py:18-26, as above.)  The rows kernel with the parameter-gradient
+ * sums folded in: besides dx (and its planes) every block stores one row of
  * partials[blocks][3][dim] = its rows' column sums of dy * xhat, dy and dx_new (rows with r % skip_period == 0 left out of the
  * third when skip_period > 0); blocks = mt_layernorm_bwd_rows_blocks(rows).  mt_layernorm_bwd_cols_reduce adds the block rows,
  * in block order (a fixed summation order: deterministic as it is), into dgamma, dbeta and dx_colsum (NULL = skipped) -- 6 MB read at
