@@ -415,7 +415,11 @@ def stub_main(a, rank, world):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    mine = torch.tensor([1e3 * dt / a.steps, float(rank)], dtype=torch.float64)       # the per-rank gather of main(), on CPU ranks
+    per_rank = [mine]
     if world > 1:
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -425,7 +429,9 @@ def stub_main(a, rank, world):
                           "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                           "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f32", "data": "stub", "config": {"workload": "stub", "parallelism": f"dp{world}",
-                                                                        "checksum": float(y.sum().item())}}), flush=True)
+                                                                        "checksum": float(y.sum().item()),
+                                                                        "per_rank": {"ms_per_step": [round(float(r[0]), 3) for r in per_rank],
+                                                                                     "rank": [int(r[1]) for r in per_rank]}}}), flush=True)
 
 
 def main():

@@ -433,6 +433,23 @@ def test_bench_self_launches_multi_rank_and_prints_one_json_line_last():
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["parallelism"] == "dp2"
     assert d["config"]["checksum"] == 1024 * 2.0 * (1 + 2)          # both ranks took part in the all-reduce
+    pr = d["config"]["per_rank"]                                     # every rank's own readings reach the line (all_gather)
+    assert pr["rank"] == [0, 1] and len(pr["ms_per_step"]) == 2 and all(v > 0 for v in pr["ms_per_step"])
+
+
+def test_launch_threads_get_disjoint_core_slices_only_when_there_are_enough_cores(monkeypatch):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pinned = {}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: pinned.setdefault("cores", sorted(cores)), raising=False)
+    assert bench.pin_launch_thread(0, 1) is None and not pinned                  # one rank: nothing to fence off
+    assert bench.pin_launch_thread(3, 8) == [24, 31] and pinned["cores"] == list(range(24, 32))
+    pinned.clear()
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)), raising=False)
+    assert bench.pin_launch_thread(3, 8) is None and not pinned                  # 2 cores per rank: left to the OS
 
 
 def test_bench_drops_pmc_counters_measured_on_other_sources(tmp_path, monkeypatch):
