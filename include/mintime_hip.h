@@ -36,7 +36,7 @@ const char* mt_last_error(void);
  * gradients run after run.  Slower (the bench line's `deterministic` leg has the cost).  Returns 0 / the current setting.
  * mt_det_bn_sums: BatchNorm sums in fixed order from a stored tensor x [rows][C] into stats[0 .. 2C) (fp64, +=): mode 0 = sum x,
  * sum x^2 (forward batch statistics); mode 1 = sum x, sum x * (z - mean) * invstd (backward; mean_invstd = [2][C]).  The engines call
- * it instead of the producers' fused statistics when the switch is on (Xception; round 4's EfficientNet).
+ * it instead of the producers' fused statistics when the switch is on (round 4's engines; kept as an entry point, no longer on the path).
  * BatchNorm statistics without the second pass (EfficientNet since version 115): every entry point that takes a BatchNorm accumulator
  * (`double* stats, int slots`, or `stats` / `stats_slots` of a GEMM descriptor) accepts a NEGATIVE slot count: |slots| accumulators,
  * each held as two 64-bit INTEGER limbs |slots| * 2 * C doubles apart (stats must hold 2 * |slots| * 2 * C zeroed doubles): a block's

@@ -69,11 +69,10 @@ def _total_channels(model):
     return c
 
 
-def _finalize(lib, bn_mod, ctx, count, training, gamma, beta, z=None):
+def _finalize(lib, bn_mod, ctx, count, training, gamma, beta, slots=SLOTS):
+    """slots < 0 (deterministic mode): the producers' statistics are integer limbs (csrc/common.hpp stat_add, effnet_engine._StatsPool)."""
     ctx.count = float(count)
-    if z is not None:      # deterministic mode: fixed-order sums of the stored tensor instead of the producer's fused atomics
-        L.check(lib.mt_det_bn_sums(L.ptr(z), None, None, int(count), ctx.C, 0, L.ptr(ctx.stats), L.stream_ptr()), "mt_det_bn_sums")
-    L.check(lib.mt_bn_finalize(L.ptr(ctx.stats), SLOTS, float(count), L.ptr(gamma), L.ptr(beta), L.ptr(bn_mod.running_mean),
+    L.check(lib.mt_bn_finalize(L.ptr(ctx.stats), slots, float(count), L.ptr(gamma), L.ptr(beta), L.ptr(bn_mod.running_mean),
                                L.ptr(bn_mod.running_var), L.ptr(ctx.scale), L.ptr(ctx.shift), L.ptr(ctx.mean_invstd), ctx.C,
                                bn_mod.eps, bn_mod.momentum, 1 if training else 0, L.stream_ptr()), "mt_bn_finalize")
     if training:
@@ -84,10 +83,11 @@ def xception_forward(model, x, params, training, save):
     lib = L.get()
     dev = x.device
     N, H, W, _ = x.shape
-    pool = _StatsPool(dev, _total_channels(model)) if training else None
-    consts = _Consts(dev)
     det = training and L.deterministic()
-    epi = L.EPI_STATS if training and not det else L.EPI_STORE
+    pool = _StatsPool(dev, _total_channels(model), det) if training else None
+    consts = _Consts(dev)
+    slots = -SLOTS if det else SLOTS          # deterministic mode: BatchNorm sums as integer limbs -- order-independent, no second pass
+    epi = L.EPI_STATS if training else L.EPI_STORE
     planes_on = XC_PLANES and L.gemm_split_enabled()
     it = iter(params)
     saved = {"x": x, "blocks": [], "consts": consts} if save else None
@@ -104,8 +104,8 @@ def xception_forward(model, x, params, training, save):
         ctx = _BNCtx(dev, Cout, training, pool)
         z = _new(dev, M, Cout)
         L.gemm(L.OP_NT, src.t, wp, z, M, Cout, K, K, K, Cout, prologue=L.PRO_IM2COL, epilogue=epi, scale=src.scale, shift=src.shift,
-               stats=ctx.stats, stats_slots=SLOTS, conv=(Hh, Ww, Cc, Ho, Wo, k, s_, p_, src.act, 1 if u8 else 0))
-        _finalize(lib, bn_mod, ctx, M, training, gamma, beta, z if det else None)
+               stats=ctx.stats, stats_slots=slots, conv=(Hh, Ww, Cc, Ho, Wo, k, s_, p_, src.act, 1 if u8 else 0))
+        _finalize(lib, bn_mod, ctx, M, training, gamma, beta, slots)
         return z, ctx
 
     def sep_unit(src, act, w_dw, w_pw, co, bn_mod, gamma, beta):
@@ -125,12 +125,12 @@ def xception_forward(model, x, params, training, save):
             # gradient and weight gradient read the same plane tensors by LDS-DMA (728 -> 728 over 100 352 rows: 0.81 -> 0.58 ms)
             d_p = L.split_planes_blk(d, M, ci)
             w_p = L.split_planes_blk(w_pw.view(co, ci), co, ci)
-            L.gemm_planes(L.OP_NT, d_p, w_p, M, co, ci, Cout=z, ldc=co, epilogue=epi, stats=ctx.stats, stats_slots=SLOTS)
+            L.gemm_planes(L.OP_NT, d_p, w_p, M, co, ci, Cout=z, ldc=co, epilogue=epi, stats=ctx.stats, stats_slots=slots)
             if save:
                 d = None                                   # backward reads d through its planes only
         else:
-            L.gemm(L.OP_NT, d, w_pw, z, M, co, ci, ci, ci, co, epilogue=epi, stats=ctx.stats, stats_slots=SLOTS)
-        _finalize(lib, bn_mod, ctx, M, training, gamma, beta, z if det else None)
+            L.gemm(L.OP_NT, d, w_pw, z, M, co, ci, ci, ci, co, epilogue=epi, stats=ctx.stats, stats_slots=slots)
+        _finalize(lib, bn_mod, ctx, M, training, gamma, beta, slots)
         rec = dict(src=src, eff=eff, sc=sc, sh=sh, d=d, d_p=d_p, w_p=w_p, z=z, bn=ctx, ci=ci, co=co, H=Hh) if save else None
         return _Src(z, co, Hh, ctx.scale, ctx.shift, NONE, ctx), rec
 
@@ -200,7 +200,9 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
     P = list(params)
     grads, flat_grads = L.zero_grads(P, with_flat=True)
     consts = saved["consts"]
-    pool = _StatsPool(dev, 2 * _total_channels(model) + 4096)
+    det = L.deterministic()
+    slots = -SLOTS if det else SLOTS          # (see xception_forward)
+    pool = _StatsPool(dev, 2 * _total_channels(model) + 4096, det)
     tr = 1 if training else 0
     side = L.SideStream(dev)
     # parameter index map
@@ -221,19 +223,14 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
     def bn_sums(g, z, ctx, rows, act=0, dout=None):
         sums = pool.take(ctx.C)
         L.check(lib.mt_bn_act_bwd(L.ptr(g), L.ptr(z), L.ptr(ctx.scale), L.ptr(ctx.shift), L.ptr(ctx.mean_invstd), None, None, None,
-                                  L.ptr(dout), L.ptr(sums), SLOTS, rows, ctx.C, 1, act, L.stream_ptr()), "mt_bn_act_bwd")
+                                  L.ptr(dout), L.ptr(sums), slots, rows, ctx.C, 1, act, L.stream_ptr()), "mt_bn_act_bwd")
         return sums
 
-    det = L.deterministic()
-
     def bn_kabc(ctx, sums, gi, d, z, rows):
-        """(d, z, rows): the gradient w.r.t. the BatchNorm's output and its input tensor -- deterministic mode retakes the sums from them."""
-        if det:
-            sums.zero_()
-            L.check(lib.mt_det_bn_sums(L.ptr(d), L.ptr(z), L.ptr(ctx.mean_invstd), int(rows), ctx.C, 1, L.ptr(sums), L.stream_ptr()),
-                    "mt_det_bn_sums")
+        """(d, z, rows): the gradient w.r.t. the BatchNorm's output and its input tensor (round 4's deterministic mode retook the sums
+        from them; they are integer limbs now)."""
         kabc = _new(dev, 3, ctx.C)
-        L.check(lib.mt_bn_bwd_finalize(L.ptr(sums), SLOTS, ctx.count, L.ptr(P[gi]), L.ptr(ctx.mean_invstd), L.ptr(kabc), L.ptr(grads[gi]),
+        L.check(lib.mt_bn_bwd_finalize(L.ptr(sums), slots, ctx.count, L.ptr(P[gi]), L.ptr(ctx.mean_invstd), L.ptr(kabc), L.ptr(grads[gi]),
                                        L.ptr(grads[gi + 1]), ctx.C, tr, L.stream_ptr()), "mt_bn_bwd_finalize")
         return kabc
 
@@ -271,7 +268,7 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
 
         def dw_part(parts):
             L.check(lib.mt_dwconv_bwd(L.ptr(dd), L.ptr(dd), L.ptr(kid), L.ptr(w_dw), L.ptr(src.t), L.ptr(rec["sc"]), L.ptr(rec["sh"]),
-                                      L.ptr(src.bn.mean_invstd) if has_bn else None, L.ptr(du_in), L.ptr(sums_in), SLOTS,
+                                      L.ptr(src.bn.mean_invstd) if has_bn else None, L.ptr(du_in), L.ptr(sums_in), slots,
                                       L.ptr(grads[pi]), N, Hh, Hh, ci, 3, 1, parts, rec["eff"], L.ptr(res_pre), L.ptr(res_post),
                                       L.stream_ptr()), "mt_dwconv_bwd")
         side.launch(lambda: dw_part(1), reads=(dd, kid, src.t, rec["sc"], rec["sh"]))
