@@ -49,6 +49,51 @@ def test_every_launching_entry_point_has_a_recording_thunk():
     assert "const auto d_v = *d;" in thunks and "mti_gemm_planes(&d_v, stream)" in thunks
 
 
+def test_launch_plan_registry_state_machine(monkeypatch):
+    """plans.lookup: a key runs eagerly the first time it is seen, is recorded the second time, replays afterwards; while a planned
+    forward's autograd node is alive the plan's static buffers are taken (a second forward goes eager); at most MT_PLAN_MAX plans per
+    module, the oldest idle one makes room; the registry lives outside the module (deepcopy / pickle never meet a ctypes handle)."""
+    import copy
+    import gc
+    import pickle
+    from mintime_amd import plans
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(plans, "ENABLED", True)
+    monkeypatch.setattr(plans, "MAX_PLANS", 2)
+    monkeypatch.setattr(plans, "RECORD_AFTER", 1)
+    m = torch.nn.Linear(2, 2)
+    assert plans.lookup(m, "a") == (None, "eager")
+    np_a, mode = plans.lookup(m, "a")
+    assert mode == "record" and np_a is not None
+    np_a.fwd = object()                                   # (the engine stores the recorded L.Plan here)
+    assert plans.lookup(m, "a") == (np_a, "replay")
+    tok = np_a.begin()                                    # a planned forward whose backward has not run yet
+    before = plans.STATS["eager_in_flight"]
+    assert plans.lookup(m, "a") == (None, "eager") and plans.STATS["eager_in_flight"] == before + 1
+    del tok
+    gc.collect()                                          # the autograd node died: the buffers are free again
+    assert plans.lookup(m, "a") == (np_a, "replay")
+    np_a.begin()
+    np_a.release()                                        # ... or the backward ran
+    assert plans.lookup(m, "a")[1] == "replay"
+    plans.lookup(m, "b")
+    np_b, mode = plans.lookup(m, "b")
+    assert mode == "record"
+    np_b.fwd = object()
+    tok_b = np_b.begin()
+    assert plans.lookup(m, "c") == (None, "eager")        # third key: evicts the oldest IDLE plan ("a"), then counts its first sighting
+    assert plans.lookup(m, "a") == (None, "eager")        # ... "a" starts over (and "b", in flight, stayed)
+    assert plans.lookup(m, "b") == (None, "eager") and np_b.in_flight
+    del tok_b
+    np_b.broken = True                                    # a recording that raised: that key stays eager
+    gc.collect()
+    assert plans.lookup(m, "b") == (None, "eager")
+    assert "_mt_plans" not in m.__dict__
+    pickle.loads(pickle.dumps(copy.deepcopy(m)))          # nothing plan-related travels with the module
+    monkeypatch.setattr(plans, "ENABLED", False)
+    assert plans.lookup(m, "a") == (None, "eager")
+
+
 def test_errors_are_reported_not_swallowed():
     h = lib.get()
     d = lib.GemmDesc()          # all-null descriptor
