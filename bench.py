@@ -321,7 +321,7 @@ def pin_launch_thread(local_rank, world):
         return None
 
 
-def other_config_leg(config, dev, steps=5, warm=6):
+def other_config_leg(config, dev, steps=6, warm=10):
     """Another single-GPU BASELINE configuration timed in the same process (the driver's line carries config 3 as `value`; configs 2
     and 5 ride along so that they are driver-timed too): fresh models, `warm` untimed steps (they also grow the caching allocator's
     pools: the first steps of a large configuration on a warm box pay fresh hipMallocs), then `steps` timed steps."""
