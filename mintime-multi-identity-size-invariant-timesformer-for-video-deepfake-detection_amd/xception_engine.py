@@ -79,6 +79,47 @@ def _finalize(lib, bn_mod, ctx, count, training, gamma, beta, slots=SLOTS):
         _track(bn_mod.num_batches_tracked)
 
 
+class _WeightPlanes:
+    """Plane tensors of the pointwise-conv weights that run on plane operands.  The first forward splits them one by one and registers
+    them; every later forward re-splits all of them with ONE mt_split_planes_blk_multi launch (33 launches per step before)."""
+
+    def __init__(self):
+        self.items = {}          # weight data_ptr -> (weight, planes, co, ci)
+        self.table = None
+        self.fresh = False
+
+    def begin(self, lib):
+        self.fresh = False
+        if self.table is None:
+            return
+        if any(w.data_ptr() != k for k, (w, _, _, _) in self.items.items()):       # a weight moved: start over
+            self.items, self.table = {}, None
+            return
+        L.check(lib.mt_split_planes_blk_multi(L.ptr(self.table), len(self.items), self.blocks, L.stream_ptr()),
+                "mt_split_planes_blk_multi")
+        self.fresh = True
+
+    def get(self, w_pw, co, ci):
+        ent = self.items.get(w_pw.data_ptr())
+        if ent is not None and self.fresh and ent[0] is w_pw:
+            return ent[1]
+        planes = L.split_planes_blk(w_pw.view(co, ci), co, ci)
+        self.items[w_pw.data_ptr()] = (w_pw, planes, co, ci)
+        self.table = None
+        return planes
+
+    def end(self, dev):
+        if self.table is not None or not self.items:
+            return
+        rows, first = [], 0
+        for k, (w, pl, co, ci) in self.items.items():
+            rows.append((k, pl.data_ptr(), co, ci, first))
+            first += pl.shape[1] * pl.shape[2]
+        self.host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+        self.table = self.host.to(dev, non_blocking=True)
+        self.blocks = first
+
+
 def xception_forward(model, x, params, training, save):
     lib = L.get()
     dev = x.device
@@ -89,6 +130,9 @@ def xception_forward(model, x, params, training, save):
     slots = -SLOTS if det else SLOTS          # deterministic mode: BatchNorm sums as integer limbs -- order-independent, no second pass
     epi = L.EPI_STATS if training else L.EPI_STORE
     planes_on = XC_PLANES and L.gemm_split_enabled()
+    wplanes = model.__dict__.setdefault("_xc_wplanes", _WeightPlanes())
+    if planes_on:
+        wplanes.begin(lib)
     it = iter(params)
     saved = {"x": x, "blocks": [], "consts": consts} if save else None
 
@@ -124,7 +168,7 @@ def xception_forward(model, x, params, training, save):
             # wide pointwise convolutions on plane operands (csrc/gemm_planes.hpp): d and the weight are split once; forward, data
             # gradient and weight gradient read the same plane tensors by LDS-DMA (728 -> 728 over 100 352 rows: 0.81 -> 0.58 ms)
             d_p = L.split_planes_blk(d, M, ci)
-            w_p = L.split_planes_blk(w_pw.view(co, ci), co, ci)
+            w_p = wplanes.get(w_pw, co, ci)
             L.gemm_planes(L.OP_NT, d_p, w_p, M, co, ci, Cout=z, ldc=co, epilogue=epi, stats=ctx.stats, stats_slots=slots)
             if save:
                 d = None                                   # backward reads d through its planes only
@@ -189,6 +233,8 @@ def xception_forward(model, x, params, training, save):
             "mt_bn_act_fwd")
     if save:
         saved["tail"] = tail
+    if planes_on:
+        wplanes.end(dev)
     _bump_tracked()
     return feat, saved, cur.H
 
