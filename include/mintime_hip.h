@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 117
+#define MT_VERSION 118
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -465,6 +465,18 @@ int mt_maxpool_add_fwd(const float* z, const float* scale, const float* shift, c
 /* du (pre-zeroed, [N,H,W,C]) += dy routed to each window's arg-max of z*scale+shift. */
 int mt_maxpool_bwd(const float* dy, const float* z, const float* scale, const float* shift, float* du, int N, int H,
                    int W, int C, void* stream);
+/* The block tail with the adjoint's routing recorded (training): also writes arg [N,Ho,Wo,C] uint8 = the window position kh*3+kw of each
+ * window's arg-max (first maximum in row-major order, like torch; 255 = none) and zmax = the raw z there.  The BatchNorm-backward sums of
+ * the pooled unit are then sums over the POOLED tensors (S1 = sum dy, S2 = sum dy * xhat(zmax): mt_bn_act_bwd on dy / zmax), and the
+ * routed gradient is a gather with one writer per element -- no zero fill, no atomics, bit-identical run to run:
+ *   mt_maxpool_bwd_arg: du [N,H,W,C] = dy routed (every element written);
+ *   mt_maxpool_bn_bwd_apply_planes: dz = ka*du + kb*z + kc with du routed on the fly, written as a plane tensor (mt_gemm_planes operand);
+ *     du never exists in memory (replaces zero fill + mt_maxpool_bwd + the full-resolution sums pass + mt_bn_bwd_apply_planes). */
+int mt_maxpool_add_fwd_arg(const float* z, const float* scale, const float* shift, const float* zs, const float* scale_s,
+                           const float* shift_s, float* y, uint8_t* arg, float* zmax, int N, int H, int W, int C, void* stream);
+int mt_maxpool_bwd_arg(const float* dy, const uint8_t* arg, float* du, int N, int H, int W, int C, void* stream);
+int mt_maxpool_bn_bwd_apply_planes(const float* dy, const uint8_t* arg, const float* z, const float* kabc, void* planes, int N, int H,
+                                   int W, int C, void* stream);
 /* dz = ka*du + kb*z + kc materialised (dense conv2's data gradient is itself an im2col GEMM over dz). */
 int mt_bn_bwd_apply(const float* du, const float* z, const float* kabc, float* dz, int64_t rows, int C, void* stream);
 

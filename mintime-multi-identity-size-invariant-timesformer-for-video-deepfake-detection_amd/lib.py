@@ -117,6 +117,9 @@ PROTOTYPES = {
     "mt_conv_weight_unpack_grad": [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_maxpool_add_fwd": [f32p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_maxpool_bwd": [f32p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_maxpool_add_fwd_arg": [f32p] * 7 + [C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_maxpool_bwd_arg": [f32p, C.c_void_p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_maxpool_bn_bwd_apply_planes": [f32p, C.c_void_p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_bn_bwd_apply": [f32p, f32p, f32p, f32p, i64, C.c_int, C.c_void_p],
     "mt_conv1x1_rows_supported": [C.c_int, C.c_int, C.c_int],
     "mt_conv1x1_rows": [f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p, C.c_void_p, C.c_int, C.c_int64,
@@ -171,7 +174,7 @@ def build(verbose: bool = False):
 
 # MT_VERSION of include/mintime_hip.h this binding was written against (tests/test_host_logic.py keeps the two equal; the package
 # itself does not need the header at run time -- it may be copied or installed without the repository's include/ directory)
-ABI_VERSION = 117
+ABI_VERSION = 118
 
 
 def header_version() -> int:

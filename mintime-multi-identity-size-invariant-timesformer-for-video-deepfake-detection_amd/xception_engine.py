@@ -16,6 +16,7 @@ RELU, NONE = 2, 0
 # pointwise convolutions with at least this many input channels run on plane operands (MT_XC_PLANES=0: the in-kernel-split loop)
 XC_PLANES = __import__("os").environ.get("MT_XC_PLANES", "1") != "0"
 PLANES_MIN_C = int(__import__("os").environ.get("MT_XC_PLANES_MIN_C", "256"))
+POOL_ARG = __import__("os").environ.get("MT_XC_POOL_ARG", "1") != "0"      # 0: the adjoint of the max-pool as an arg-max scatter (round 4)
 
 
 def _new(dev, *shape):
@@ -209,8 +210,18 @@ def xception_forward(model, x, params, training, save):
             Ho = (Hin - 1) // 2 + 1
             z_s, bn_s = conv_im2col(inp, w_s.view(cout, cin), cout, cin, (Hin, Hin, cin, Ho, Ho, 1, 2, 0), blk.skipbn, g_s, b_s)
             y = _new(dev, N * Ho * Ho, cout)
-            L.check(lib.mt_maxpool_add_fwd(L.ptr(src.t), L.ptr(src.scale), L.ptr(src.shift), L.ptr(z_s), L.ptr(bn_s.scale),
-                                           L.ptr(bn_s.shift), L.ptr(y), N, Hin, Hin, cout, L.stream_ptr()), "mt_maxpool_add_fwd")
+            if save and POOL_ARG:
+                # the adjoint's routing is recorded here (1 byte + the raw arg-max value per pooled element): backward never builds the
+                # full-resolution routed gradient by atomics, and takes the pooled unit's BatchNorm sums from the pooled tensors
+                arg = torch.empty(N * Ho * Ho, cout, dtype=torch.uint8, device=dev)
+                zmax = _new(dev, N * Ho * Ho, cout)
+                L.check(lib.mt_maxpool_add_fwd_arg(L.ptr(src.t), L.ptr(src.scale), L.ptr(src.shift), L.ptr(z_s), L.ptr(bn_s.scale),
+                                                   L.ptr(bn_s.shift), L.ptr(y), L.ptr(arg), L.ptr(zmax), N, Hin, Hin, cout, L.stream_ptr()),
+                        "mt_maxpool_add_fwd_arg")
+                brec.update(arg=arg, zmax=zmax)
+            else:
+                L.check(lib.mt_maxpool_add_fwd(L.ptr(src.t), L.ptr(src.scale), L.ptr(src.shift), L.ptr(z_s), L.ptr(bn_s.scale),
+                                               L.ptr(bn_s.shift), L.ptr(y), N, Hin, Hin, cout, L.stream_ptr()), "mt_maxpool_add_fwd")
             brec.update(z_s=z_s, bn_s=bn_s, Ho=Ho)
             cur = _Src(y, cout, Ho)
         else:
@@ -280,12 +291,19 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
                                        L.ptr(grads[gi + 1]), ctx.C, tr, L.stream_ptr()), "mt_bn_bwd_finalize")
         return kabc
 
-    def unit_backward(rec, pi, g, sums, res_pre=None, res_post=None):
+    def unit_backward(rec, pi, g, sums, res_pre=None, res_post=None, pooled=None):
         """g = gradient w.r.t. this unit's BatchNorm output (sums already accumulated when `sums` is given).
+        pooled = (dy, arg, zmax, Ho) instead of g: the unit feeds the block's max-pool and the gradient is dy routed by `arg`.
         Returns (gradient w.r.t. the source's affine output [activation derivative applied], its BN sums or None)."""
         ci, co, Hh = rec["ci"], rec["co"], rec["H"]
         M = N * Hh * Hh
-        if sums is None:
+        if pooled is not None:
+            p_dy, p_arg, p_zmax, p_Ho = pooled
+            sums = bn_sums(p_dy, p_zmax, rec["bn"], N * p_Ho * p_Ho)      # sum du = sum dy, sum du xhat = sum dy xhat(arg-max)
+            if rec["d_p"] is None:
+                g = _new(dev, M, co)
+                L.check(lib.mt_maxpool_bwd_arg(L.ptr(p_dy), L.ptr(p_arg), L.ptr(g), N, Hh, Hh, co, L.stream_ptr()), "mt_maxpool_bwd_arg")
+        elif sums is None:
             sums = bn_sums(g, rec["z"], rec["bn"], M)
         kabc = bn_kabc(rec["bn"], sums, pi + 2, g, rec["z"], M)
         w_dw, w_pw = P[pi], P[pi + 1]
@@ -294,8 +312,12 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
         if rec["d_p"] is not None:
             # plane operands: dz = ka g + kb z + kc is evaluated ONCE, as planes, and feeds both gradient GEMMs
             dz_p = L.planes_empty(M, co, dev)
-            L.check(lib.mt_bn_bwd_apply_planes(L.ptr(g), L.ptr(rec["z"]), L.ptr(kabc), L.ptr(dz_p), M, co, L.stream_ptr()),
-                    "mt_bn_bwd_apply_planes")
+            if pooled is not None:
+                L.check(lib.mt_maxpool_bn_bwd_apply_planes(L.ptr(p_dy), L.ptr(p_arg), L.ptr(rec["z"]), L.ptr(kabc), L.ptr(dz_p), N, Hh, Hh, co,
+                                                           L.stream_ptr()), "mt_maxpool_bn_bwd_apply_planes")
+            else:
+                L.check(lib.mt_bn_bwd_apply_planes(L.ptr(g), L.ptr(rec["z"]), L.ptr(kabc), L.ptr(dz_p), M, co, L.stream_ptr()),
+                        "mt_bn_bwd_apply_planes")
             side.launch(lambda: L.gemm_planes(L.OP_TN, dz_p, rec["d_p"], co, ci, M, Cout=grads[pi + 1].view(co, ci), ldc=ci,
                                               epilogue=L.EPI_ATOMIC), reads=(dz_p, rec["d_p"]))
             L.gemm_planes(L.OP_NN, dz_p, rec["w_p"], M, ci, co, Cout=dd, ldc=ci)
@@ -359,16 +381,21 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
             else:
                 res_post = d_skip         # the skip conv consumed the raw block input, the first unit relu(input)
             # main path: y += maxpool(bn(z_last))
-            du_last = torch.zeros(N * Hin * Hin, cout, dtype=torch.float32, device=dev)
-            L.check(lib.mt_maxpool_bwd(L.ptr(dy), L.ptr(last["z"]), L.ptr(last["bn"].scale), L.ptr(last["bn"].shift), L.ptr(du_last), N,
-                                       Hin, Hin, cout, L.stream_ptr()), "mt_maxpool_bwd")
-            g, sums = du_last, None
+            pooled = None
+            if "arg" in brec:
+                g, sums, pooled = None, None, (dy, brec["arg"], brec["zmax"], Ho)
+            else:
+                du_last = torch.zeros(N * Hin * Hin, cout, dtype=torch.float32, device=dev)
+                L.check(lib.mt_maxpool_bwd(L.ptr(dy), L.ptr(last["z"]), L.ptr(last["bn"].scale), L.ptr(last["bn"].shift), L.ptr(du_last), N,
+                                           Hin, Hin, cout, L.stream_ptr()), "mt_maxpool_bwd")
+                g, sums = du_last, None
         else:
-            g, sums = dy, None
+            g, sums, pooled = dy, None, None
             res_post = dy                 # identity skip: y = bn(z_last) + inp
         for u in reversed(range(len(units))):
             first = u == 0
-            g, sums = unit_backward(units[u], bm["units"][u], g, sums, res_pre if first else None, res_post if first else None)
+            g, sums = unit_backward(units[u], bm["units"][u], g, sums, res_pre if first else None, res_post if first else None,
+                                    pooled if u == len(units) - 1 else None)
         # for block1 the result is the gradient w.r.t. bn2's output (sums accumulated); otherwise w.r.t. the previous block's y
         dy = g
         bn2_sums = sums

@@ -108,3 +108,79 @@ def test_uint8_crops_are_ingested_directly():
         outs.append((f.detach().clone(), model.conv1.weight.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0])
     assert_close(outs[1][1], outs[0][1], 1e-5, "conv1 weight gradient (split-K atomics order only)")
+
+
+@pytest.mark.parametrize("N,H,C", [(3, 19, 128), (2, 28, 728), (2, 7, 64)])
+def test_max_pool_adjoint_from_the_recorded_arg_max(N, H, C):
+    """Block tail (xception.py:64-79) with the routing recorded in the forward: y is the plain kernel's, arg / zmax are torch's
+    max_pool2d indices and the raw z there, the routed gradient is torch's max_pool2d backward (one writer per element: the same bits
+    on every launch), the pooled BatchNorm sums equal the full-resolution ones, and the fused BatchNorm-backward + routing writes the
+    planes of ka du + kb z + kc."""
+    from mintime_amd import lib as L
+    lib = L.get()
+    g = torch.Generator().manual_seed(N * 1000 + H)
+    Ho = (H - 1) // 2 + 1
+    z = torch.randn(N, H, H, C, generator=g).cuda()
+    z[0, :4, :4] = z[0, 0, 0]                                            # ties: the first maximum in window order wins
+    # some negative gammas; powers of two, so that z * scale is exact and torch's (unfused) affine rounds like the kernels' fma
+    sc = torch.tensor([0.5, 1.0, 2.0])[torch.randint(0, 3, (C,), generator=g)] * torch.where(torch.rand(C, generator=g) < 0.2, -1.0, 1.0)
+    sc, sh = sc.cuda(), torch.randn(C, generator=g).cuda()
+    zs, ss, hs = torch.randn(N, Ho, Ho, C, generator=g).cuda(), torch.rand(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    y0, y1, zmax = (torch.empty(N, Ho, Ho, C, device="cuda") for _ in range(3))
+    arg = torch.empty(N, Ho, Ho, C, dtype=torch.uint8, device="cuda")
+    st = L.stream_ptr()
+    L.check(lib.mt_maxpool_add_fwd(L.ptr(z), L.ptr(sc), L.ptr(sh), L.ptr(zs), L.ptr(ss), L.ptr(hs), L.ptr(y0), N, H, H, C, st), "fwd")
+    L.check(lib.mt_maxpool_add_fwd_arg(L.ptr(z), L.ptr(sc), L.ptr(sh), L.ptr(zs), L.ptr(ss), L.ptr(hs), L.ptr(y1), L.ptr(arg), L.ptr(zmax),
+                                       N, H, H, C, st), "fwd_arg")
+    assert torch.equal(y0, y1)
+    u = (z * sc + sh).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    pooled, idx = torch.nn.functional.max_pool2d(u, 3, 2, 1, return_indices=True)
+    ih, iw = idx // H, idx % H
+    oh = torch.arange(Ho, device="cuda").view(1, 1, Ho, 1)
+    ow = torch.arange(Ho, device="cuda").view(1, 1, 1, Ho)
+    k_ref = (ih - 2 * oh + 1) * 3 + (iw - 2 * ow + 1)
+    assert torch.equal(arg.permute(0, 3, 1, 2).long(), k_ref)
+    assert torch.equal(zmax.permute(0, 3, 1, 2), z.permute(0, 3, 1, 2).reshape(N, C, H * H).gather(2, idx.view(N, C, -1)).view(N, C, Ho, Ho))
+    dy = torch.randn(N, Ho, Ho, C, generator=g).cuda()
+    pooled.backward(dy.permute(0, 3, 1, 2))
+    du_ref = u.grad.permute(0, 2, 3, 1).contiguous()
+    du = torch.full((N, H, H, C), 7.0, device="cuda")
+    L.check(lib.mt_maxpool_bwd_arg(L.ptr(dy), L.ptr(arg), L.ptr(du), N, H, H, C, st), "bwd_arg")
+    assert_close(du, du_ref, 1e-6, "routed gradient vs torch")
+    du2 = torch.full((N, H, H, C), 7.0, device="cuda")
+    L.check(lib.mt_maxpool_bwd_arg(L.ptr(dy), L.ptr(arg), L.ptr(du2), N, H, H, C, st), "bwd_arg")
+    assert torch.equal(du, du2)
+    old = torch.zeros(N, H, H, C, device="cuda")
+    L.check(lib.mt_maxpool_bwd(L.ptr(dy), L.ptr(z), L.ptr(sc), L.ptr(sh), L.ptr(old), N, H, H, C, st), "bwd")
+    assert_close(du, old, 1e-6, "routed gradient vs the arg-max scatter")
+    # BatchNorm-backward sums: pooled tensors vs full resolution
+    mi = torch.stack([z.mean((0, 1, 2)), 1.0 / z.var((0, 1, 2), unbiased=False).add(1e-5).sqrt()]).contiguous()
+    sums = []
+    for d_, z_, rows in ((dy, zmax, N * Ho * Ho), (du, z, N * H * H)):
+        s_ = torch.zeros(32, 2, C, dtype=torch.float64, device="cuda")
+        L.check(lib.mt_bn_act_bwd(L.ptr(d_), L.ptr(z_), L.ptr(sc), L.ptr(sh), L.ptr(mi), None, None, None, None, L.ptr(s_), 32, rows, C, 1, 0,
+                                  st), "sums")
+        sums.append(s_.sum(0))
+    assert_close(sums[0], sums[1], 1e-5, "sum du, sum du xhat: pooled vs full resolution")
+    # fused BatchNorm-backward affine + routing, as planes
+    kabc = torch.randn(3, C, generator=g).cuda()
+    dz = torch.empty(N * H * H, C, device="cuda")
+    L.check(lib.mt_bn_bwd_apply(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(dz), N * H * H, C, st), "apply")
+    p = L.planes_empty(N * H * H, C, "cuda")
+    p.fill_(7.0)
+    L.check(lib.mt_maxpool_bn_bwd_apply_planes(L.ptr(dy), L.ptr(arg), L.ptr(z), L.ptr(kabc), L.ptr(p), N, H, H, C, st), "apply_planes")
+    assert torch.equal(p, L.split_planes_blk(dz, N * H * H, C))
+
+
+def test_training_step_is_the_same_with_the_arg_max_scatter(monkeypatch):
+    """MT_XC_POOL_ARG=0 (round 4's adjoint: zero fill + atomics + full-resolution sums) and the default give the same gradients."""
+    from mintime_amd import xception_engine as XE
+    grads = []
+    for on in (True, False):
+        monkeypatch.setattr(XE, "POOL_ARG", on)
+        model, _ = _model(5, True)
+        f = model(_input(2, 7).cuda())
+        (f * torch.linspace(-1, 1, f.numel(), device="cuda").view_as(f)).sum().backward()
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    for k in grads[0]:
+        assert_close(grads[0][k], grads[1][k], 2e-4, k)
