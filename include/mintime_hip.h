@@ -240,6 +240,11 @@ int mt_stem_conv_fwd(const void* x, int x_is_u8, const float* w, float* z, doubl
  * act 2 = relu / 0 = none: Xception SeparableConv2d.conv1 (xception.py:21,25).  w torch layout [C,1,k,k]. */
 int mt_dwconv_fwd(const float* zin, const float* scale, const float* shift, const float* w, float* zout,
                   double* stats, int slots, int N, int H, int W, int C, int k, int stride, int act, void* stream);
+/* The same convolution with the output written as a plane tensor ([N*Ho*Wo rows][C columns], mt_planes_elems; padding zeroed) and
+ * nowhere else: Xception's SeparableConv2d (xception.py:17-27) feeds its depthwise output to the pointwise convolution only, which
+ * runs on mt_gemm_planes -- the fp32 tensor and the mt_split_planes_blk pass over it are not needed. */
+int mt_dwconv_fwd_planes(const float* zin, const float* scale, const float* shift, const float* w, void* planes, int N, int H,
+                         int W, int C, int k, int stride, int act, void* stream);
 
 /* nn.BatchNorm2d bookkeeping (model.py:51-52,62,72,86,174,202): training!=0 -> batch statistics from `stats`
  * (count = N*H*W), running-stat update with `momentum` (unbiased variance); else running statistics.

@@ -20,6 +20,7 @@
 //   mt_bn_act_fwd       _bn2 (+ residual, model.py:117-127) and the head's _bn1 + swish (model.py:286)
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
+#include "planes.hpp"
 #include <stdlib.h>
 
 using namespace mt;
@@ -57,7 +58,7 @@ template <int K, int S, int T, int ACT, int CC>
 __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restrict__ zin, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ w,
                                                            float* __restrict__ zout, double* __restrict__ stats, int slots,
-                                                           int N, int H, int W, int C, int Ho, int Wo, int pad0) {
+                                                           int N, int H, int W, int C, int Ho, int Wo, int pad0, PlaneRef po) {
   constexpr int CQN = CC / 4, NSLOT = 256 / CQN;
   constexpr int IH = (T - 1) * S + K;
   constexpr int IWP = IH | 1;
@@ -155,7 +156,16 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
             acc.x = fmaf(a.x, ww.x, acc.x); acc.y = fmaf(a.y, ww.y, acc.y);
             acc.z = fmaf(a.z, ww.z, acc.z); acc.w = fmaf(a.w, ww.w, acc.w);
           }
-        *reinterpret_cast<float4*>(zout + (((int64_t)n * Ho + oh) * Wo + ow) * C + c0 + cq * 4) = acc;
+        if (po.p) {
+          // the output as operand planes (Xception: the pointwise convolution that follows reads nothing else); the thread that owns
+          // the last channels also zeroes the padding columns of the last 16-column block
+          const int row = (n * Ho + oh) * Wo + ow, c = c0 + cq * 4;
+          planes_store4(po, row, c, acc.x, acc.y, acc.z, acc.w);
+          if (c + 4 == C)
+            for (int cz = C; cz < po.cb16 * 16; cz += 4) planes_store4(po, row, cz, 0.f, 0.f, 0.f, 0.f);
+        } else {
+          *reinterpret_cast<float4*>(zout + (((int64_t)n * Ho + oh) * Wo + ow) * C + c0 + cq * 4) = acc;
+        }
         s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
         s2.x += acc.x * acc.x; s2.y += acc.y * acc.y; s2.z += acc.z * acc.z; s2.w += acc.w * acc.w;
       }
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
 
 template <int K, int S, int T, int ACT, int CC>
 int launch_dw_tiled(const float* zin, const float* scale, const float* shift, const float* w, float* zout, double* stats, int slots,
-                    int N, int H, int W, int C, int Ho, int Wo, int pad0, hipStream_t s) {
+                    int N, int H, int W, int C, int Ho, int Wo, int pad0, hipStream_t s, const PlaneRef& po) {
   constexpr int IH = (T - 1) * S + K;
   constexpr int IWP = IH | 1;
   size_t lds = (size_t)(IH * IWP * CC + (K > 3 ? K * K * CC : 0)) * sizeof(float);
@@ -192,20 +202,20 @@ int launch_dw_tiled(const float* zin, const float* scale, const float* shift, co
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(k, dim3(bx), dim3(256), lds, s, zin, scale, shift, w, zout, stats, slots != 0 ? slots : 1, N, H,
-                     W, C, Ho, Wo, pad0);
+                     W, C, Ho, Wo, pad0, po);
   return check_launch("mt_dwconv_fwd(tiled)");
 }
 
 template <int K, int S, int ACT>
 int launch_dw_tiled_any(const float* zin, const float* scale, const float* shift, const float* w, float* zout, double* stats,
-                        int slots, int N, int H, int W, int C, int Ho, int Wo, int pad0, hipStream_t s) {
+                        int slots, int N, int H, int W, int C, int Ho, int Wo, int pad0, hipStream_t s, const PlaneRef& po) {
   const bool t14 = Ho >= 14;
   if (C % 16 == 0) {
-    if (t14) return launch_dw_tiled<K, S, 14, ACT, 16>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s);
-    return launch_dw_tiled<K, S, 7, ACT, 16>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s);
+    if (t14) return launch_dw_tiled<K, S, 14, ACT, 16>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s, po);
+    return launch_dw_tiled<K, S, 7, ACT, 16>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s, po);
   }
-  if (t14) return launch_dw_tiled<K, S, 14, ACT, 8>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s);
-  return launch_dw_tiled<K, S, 7, ACT, 8>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s);
+  if (t14) return launch_dw_tiled<K, S, 14, ACT, 8>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s, po);
+  return launch_dw_tiled<K, S, 7, ACT, 8>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s, po);
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm finalize
@@ -421,26 +431,48 @@ int pick_cqb(int CQ) {
 namespace {
 template <int K, int S>
 int launch_dw(const float* zin, const float* scale, const float* shift, const float* w, float* zout, double* stats, int slots,
-              int N, int H, int W, int C, int act, hipStream_t s) {
+              int N, int H, int W, int C, int act, hipStream_t s, const PlaneRef& po) {
   const int Ho = (H + S - 1) / S, Wo = (W + S - 1) / S;
   const int pad = max((Ho - 1) * S + K - H, 0) / 2;              // TF-SAME pad-before
-  if (act == 1) return launch_dw_tiled_any<K, S, 1>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s);
-  if (act == 2) return launch_dw_tiled_any<K, S, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s);
-  return launch_dw_tiled_any<K, S, 0>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s);
+  if (act == 1) return launch_dw_tiled_any<K, S, 1>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s, po);
+  if (act == 2) return launch_dw_tiled_any<K, S, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s, po);
+  return launch_dw_tiled_any<K, S, 0>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, s, po);
+}
+
+int dwconv_fwd(const float* zin, const float* scale, const float* shift, const float* w, float* zout, double* stats, int slots, int N,
+               int H, int W, int C, int k, int stride, int act, hipStream_t s, const PlaneRef& po, const char* who) {
+  if (C & 7) return fail(MT_ERR_ARG, "%s: C must be a multiple of 8 (got %d)", who, C);
+  if (act < 0 || act > 2) return fail(MT_ERR_ARG, "%s: act must be 0, 1 or 2", who);
+  if (k == 3 && stride == 1) return launch_dw<3, 1>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s, po);
+  if (k == 3 && stride == 2) return launch_dw<3, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s, po);
+  if (k == 5 && stride == 1) return launch_dw<5, 1>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s, po);
+  if (k == 5 && stride == 2) return launch_dw<5, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s, po);
+  return fail(MT_ERR_UNSUPPORTED, "%s: k=%d stride=%d unsupported", who, k, stride);
 }
 }  // namespace
 
 extern "C" int mt_dwconv_fwd(const float* zin, const float* scale, const float* shift, const float* w, float* zout,
                              double* stats, int slots, int N, int H, int W, int C, int k, int stride, int act, void* stream) {
   if (!zin || !scale || !shift || !w || !zout) return fail(MT_ERR_ARG, "mt_dwconv_fwd: null pointer");
-  if (C & 7) return fail(MT_ERR_ARG, "mt_dwconv_fwd: C must be a multiple of 8 (got %d)", C);
-  if (act < 0 || act > 2) return fail(MT_ERR_ARG, "mt_dwconv_fwd: act must be 0, 1 or 2");
+  return dwconv_fwd(zin, scale, shift, w, zout, stats, slots, N, H, W, C, k, stride, act, (hipStream_t)stream, PlaneRef{nullptr, 0, 0, 0},
+                    "mt_dwconv_fwd");
+}
+
+extern "C" int mt_dwconv_fwd_planes(const float* zin, const float* scale, const float* shift, const float* w, void* planes, int N, int H,
+                                    int W, int C, int k, int stride, int act, void* stream) {
+  if (!zin || !scale || !shift || !w || !planes) return fail(MT_ERR_ARG, "mt_dwconv_fwd_planes: null pointer");
+  if ((uintptr_t)planes & 15) return fail(MT_ERR_ARG, "mt_dwconv_fwd_planes: planes must be 16-byte aligned");
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const int64_t rows = (int64_t)N * Ho * Wo;
+  if (rows > INT32_MAX - 32) return fail(MT_ERR_ARG, "mt_dwconv_fwd_planes: too many rows");
+  const int cb16 = (C + 15) >> 4, rp = ((int)rows + 31) & ~31;
+  const PlaneRef po{reinterpret_cast<__bf16*>(planes), (int64_t)rp * cb16 * 16, cb16, rp};
   hipStream_t s = (hipStream_t)stream;
-  if (k == 3 && stride == 1) return launch_dw<3, 1>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
-  if (k == 3 && stride == 2) return launch_dw<3, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
-  if (k == 5 && stride == 1) return launch_dw<5, 1>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
-  if (k == 5 && stride == 2) return launch_dw<5, 2>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, act, s);
-  return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_fwd: k=%d stride=%d unsupported", k, stride);
+  if (rp != rows)        // the padding rows of the last 32-row block: zero the block, the kernel then writes its real rows
+    for (int pl = 0; pl < 3; ++pl)
+      if (hipMemsetAsync(po.p + pl * po.pstride + (int64_t)(rp / 32 - 1) * cb16 * 512, 0, (size_t)cb16 * 512 * sizeof(__bf16), s) != hipSuccess)
+        return fail(MT_ERR_LAUNCH, "mt_dwconv_fwd_planes: memset failed");
+  return dwconv_fwd(zin, scale, shift, w, nullptr, nullptr, 1, N, H, W, C, k, stride, act, s, po, "mt_dwconv_fwd_planes");
 }
 
 extern "C" int mt_bn_finalize(const double* stats, int slots, double count, const float* gamma, const float* beta,

@@ -87,6 +87,7 @@ PROTOTYPES = {
     "mt_stem_conv_fwd": [C.c_void_p, C.c_int, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_dwconv_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_int, C.c_void_p],
+    "mt_dwconv_fwd_planes": [f32p] * 4 + [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p],
     "mt_bn_finalize": [C.c_void_p, C.c_int, C.c_double, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_float,
                        C.c_float, C.c_int, C.c_void_p],
     "mt_se_pool_parts": [C.c_int, C.c_int, C.c_int],

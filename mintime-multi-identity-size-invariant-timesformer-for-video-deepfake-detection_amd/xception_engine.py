@@ -16,6 +16,7 @@ RELU, NONE = 2, 0
 # pointwise convolutions with at least this many input channels run on plane operands (MT_XC_PLANES=0: the in-kernel-split loop)
 XC_PLANES = __import__("os").environ.get("MT_XC_PLANES", "1") != "0"
 PLANES_MIN_C = int(__import__("os").environ.get("MT_XC_PLANES_MIN_C", "256"))
+DW_PLANES = __import__("os").environ.get("MT_XC_DW_PLANES", "1") != "0"   # 0: depthwise output as fp32 + mt_split_planes_blk (round 4)
 POOL_ARG = __import__("os").environ.get("MT_XC_POOL_ARG", "1") != "0"      # 0: the adjoint of the max-pool as an arg-max scatter (round 4)
 
 
@@ -159,21 +160,29 @@ def xception_forward(model, x, params, training, save):
         M = N * Hh * Hh
         sc, sh = (src.scale, src.shift) if src.scale is not None else consts.ident(ci)
         eff = RELU if (act == RELU or src.act == RELU) else NONE
-        d = _new(dev, M, ci)
-        L.check(lib.mt_dwconv_fwd(L.ptr(src.t), L.ptr(sc), L.ptr(sh), L.ptr(w_dw), L.ptr(d), None, SLOTS, N, Hh, Hh, ci, 3, 1, eff,
-                                  L.stream_ptr()), "mt_dwconv_fwd")
         ctx = _BNCtx(dev, co, training, pool)
         z = _new(dev, M, co)
-        d_p = w_p = None
+        d = d_p = w_p = None
         if planes_on and ci >= PLANES_MIN_C and M >= 512:
-            # wide pointwise convolutions on plane operands (csrc/gemm_planes.hpp): d and the weight are split once; forward, data
-            # gradient and weight gradient read the same plane tensors by LDS-DMA (728 -> 728 over 100 352 rows: 0.81 -> 0.58 ms)
-            d_p = L.split_planes_blk(d, M, ci)
+            # wide pointwise convolutions on plane operands (csrc/gemm_planes.hpp): forward, data gradient and weight gradient read
+            # the same plane tensors by LDS-DMA (728 -> 728 over 100 352 rows: 0.81 -> 0.58 ms).  The weight is split once per
+            # forward; the depthwise kernel writes its output as planes and nowhere else (DW_PLANES; round 4: fp32 + a split pass)
+            d_p = L.planes_empty(M, ci, dev)
+            if DW_PLANES:
+                L.check(lib.mt_dwconv_fwd_planes(L.ptr(src.t), L.ptr(sc), L.ptr(sh), L.ptr(w_dw), L.ptr(d_p), N, Hh, Hh, ci, 3, 1, eff,
+                                                 L.stream_ptr()), "mt_dwconv_fwd_planes")
+            else:
+                d = _new(dev, M, ci)
+                L.check(lib.mt_dwconv_fwd(L.ptr(src.t), L.ptr(sc), L.ptr(sh), L.ptr(w_dw), L.ptr(d), None, SLOTS, N, Hh, Hh, ci, 3, 1, eff,
+                                          L.stream_ptr()), "mt_dwconv_fwd")
+                L.split_planes_blk(d, M, ci, out=d_p)
+                d = None                                   # backward reads d through its planes only
             w_p = wplanes.get(w_pw, co, ci)
             L.gemm_planes(L.OP_NT, d_p, w_p, M, co, ci, Cout=z, ldc=co, epilogue=epi, stats=ctx.stats, stats_slots=slots)
-            if save:
-                d = None                                   # backward reads d through its planes only
         else:
+            d = _new(dev, M, ci)
+            L.check(lib.mt_dwconv_fwd(L.ptr(src.t), L.ptr(sc), L.ptr(sh), L.ptr(w_dw), L.ptr(d), None, SLOTS, N, Hh, Hh, ci, 3, 1, eff,
+                                      L.stream_ptr()), "mt_dwconv_fwd")
             L.gemm(L.OP_NT, d, w_pw, z, M, co, ci, ci, ci, co, epilogue=epi, stats=ctx.stats, stats_slots=slots)
         _finalize(lib, bn_mod, ctx, M, training, gamma, beta, slots)
         rec = dict(src=src, eff=eff, sc=sc, sh=sh, d=d, d_p=d_p, w_p=w_p, z=z, bn=ctx, ci=ci, co=co, H=Hh) if save else None

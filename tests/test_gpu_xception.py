@@ -184,3 +184,22 @@ def test_training_step_is_the_same_with_the_arg_max_scatter(monkeypatch):
         grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
     for k in grads[0]:
         assert_close(grads[0][k], grads[1][k], 2e-4, k)
+
+
+@pytest.mark.parametrize("N,H,C,act", [(3, 14, 728, 2), (2, 7, 1536, 0), (5, 28, 256, 2), (1, 19, 264, 2)])
+def test_depthwise_output_as_planes(N, H, C, act):
+    """mt_dwconv_fwd_planes writes exactly the planes mt_split_planes_blk makes of mt_dwconv_fwd's output, padding rows (N*H*W not
+    a multiple of 32) and padding columns (728 = 45.5 sixteen-column blocks) zeroed."""
+    from mintime_amd import lib as L
+    lib = L.get()
+    g = torch.Generator().manual_seed(C + H)
+    zin = torch.randn(N * H * H, C, generator=g).cuda()
+    sc, sh = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    w = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).cuda()
+    d = torch.empty(N * H * H, C, device="cuda")
+    st = L.stream_ptr()
+    L.check(lib.mt_dwconv_fwd(L.ptr(zin), L.ptr(sc), L.ptr(sh), L.ptr(w), L.ptr(d), None, 32, N, H, H, C, 3, 1, act, st), "fwd")
+    p = L.planes_empty(N * H * H, C, "cuda")
+    p.fill_(7.0)
+    L.check(lib.mt_dwconv_fwd_planes(L.ptr(zin), L.ptr(sc), L.ptr(sh), L.ptr(w), L.ptr(p), N, H, H, C, 3, 1, act, st), "fwd_planes")
+    assert torch.equal(p, L.split_planes_blk(d, N * H * H, C))

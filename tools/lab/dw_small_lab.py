@@ -35,6 +35,12 @@ def one(tag, N, H, C, k, stride, act, res=False):
     s = L.stream_ptr()
     t_f = timeit(lambda: L.check(lib.mt_dwconv_fwd(L.ptr(zin), L.ptr(sc), L.ptr(sh), L.ptr(w), L.ptr(zout), L.ptr(st), SLOTS, N, H, H, C, k,
                                                    stride, act, s), "fwd"))
+    t_fp = t_sp = float("nan")
+    if stride == 1:
+        pl = L.planes_empty(Mo, C, "cuda")
+        t_fp = timeit(lambda: L.check(lib.mt_dwconv_fwd_planes(L.ptr(zin), L.ptr(sc), L.ptr(sh), L.ptr(w), L.ptr(pl), N, H, H, C, k, stride, act,
+                                                               s), "fwd_planes"))
+        t_sp = timeit(lambda: L.split_planes_blk(zout, Mo, C, out=pl))
     du = torch.randn(Mo, C, device="cuda")
     kabc = torch.randn(3, C, device="cuda")
     du_in = torch.empty(Mi, C, device="cuda")
@@ -48,7 +54,7 @@ def one(tag, N, H, C, k, stride, act, res=False):
     t_w = timeit(lambda: bwd(1))
     b_i, b_o = Mi * C * 4, Mo * C * 4
     gb = lambda b, t: b / t / 1e3
-    print(f"{tag:28s} fwd {t_f:7.1f} us {gb(b_i + b_o, t_f):6.0f} GB/s | dgrad {t_d:7.1f} us {gb(2 * b_o + (3 if res else 2) * b_i, t_d):6.0f} GB/s | "
+    print(f"{tag:28s} fwd {t_f:7.1f} us {gb(b_i + b_o, t_f):6.0f} GB/s (+ split {t_sp:6.1f}; as planes {t_fp:6.1f}) | dgrad {t_d:7.1f} us {gb(2 * b_o + (3 if res else 2) * b_i, t_d):6.0f} GB/s | "
           f"wgrad {t_w:7.1f} us {gb(2 * b_o + b_i, t_w):6.0f} GB/s")
 
 
