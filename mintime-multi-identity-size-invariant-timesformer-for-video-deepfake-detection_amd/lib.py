@@ -556,9 +556,17 @@ class SideStream:
 
     _streams = {}
 
-    def __init__(self, device, enabled=True, name=""):
+    def __init__(self, device, enabled=True, name="", hold=False):
+        """hold: instead of record_stream, the tensors a side launch reads are kept alive by this object and dropped in HOST order
+        at `release_point()`s, two points behind, after the main stream has been made to wait for the side stream's progress
+        up to there.  record_stream hands a block back only once the allocator has seen the side event complete: with the host
+        running steps ahead of the device (no per-step sync) every step then takes fresh memory for all such tensors, and a large
+        configuration grows its pools until hipMalloc fails and the allocator frees everything and retries, every step (BASELINE
+        config 5: 127 -> 253 GiB reserved in 12 steps, then 1.4 s / step instead of 0.2)."""
         self.enabled = enabled and os.environ.get("MT_SIDE_STREAM", "1") != "0"
         self.device = device
+        self.hold = hold and os.environ.get("MT_SIDE_HOLD", "1") != "0"
+        self.held, self.epochs = [], []
         if self.enabled:
             key = str(device) + name                 # name: a further low-priority stream (deferred weight gradients)
             if key not in SideStream._streams:
@@ -586,15 +594,32 @@ class SideStream:
         ready = torch.cuda.Event()
         ready.record(main)
         self.stream.wait_event(ready)
-        for t in reads:
-            if t is not None:
-                t.record_stream(self.stream)
+        if self.hold:
+            self.held.append(reads)
+        else:
+            for t in reads:
+                if t is not None:
+                    t.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             fn()
         done = torch.cuda.Event()
         done.record(self.stream)
         self.pending.append(done)
         return done
+
+    def release_point(self, depth=2):
+        """hold mode: what the side launches since the previous point read may be freed once the main stream waits for the side
+        stream's position NOW; that wait is issued `depth` points later (by then it costs nothing) and the tensors are dropped then."""
+        if not (self.enabled and self.hold) or recording() is not None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self.epochs.append((ev, self.held))
+        self.held = []
+        while len(self.epochs) > depth:
+            ev0, held0 = self.epochs.pop(0)
+            torch.cuda.current_stream(self.device).wait_event(ev0)
+            held0.clear()
 
     def wait(self, event=None):
         """Make the current (main) stream wait for one side launch, or for all of them."""
@@ -610,3 +635,4 @@ class SideStream:
             else:
                 main.wait_event(self.pending[-1])    # the side stream is in order: its last launch implies all earlier ones
         self.pending = []
+        self.held, self.epochs = [], []              # joined: everything the side stream read may go back to the main stream's pool

@@ -270,7 +270,7 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
     slots = -SLOTS if det else SLOTS          # (see xception_forward)
     pool = _StatsPool(dev, 2 * _total_channels(model) + 4096, det)
     tr = 1 if training else 0
-    side = L.SideStream(dev)
+    side = L.SideStream(dev, hold=True)
     # parameter index map
     pos = 6
     bmap = []
@@ -409,6 +409,7 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
         dy = g
         bn2_sums = sums
         brec.clear()
+        side.release_point()
 
     # ---- conv2 / conv1
     z1, z2, bn1, bn2, s1 = saved["z1"], saved["z2"], saved["bn1"], saved["bn2"], saved["s1"]
@@ -417,9 +418,12 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
     k2 = bn_kabc(bn2, bn2_sums, 4, dy, z2, M2)
     dwp2 = torch.zeros(64, 288, dtype=torch.float32, device=dev)
     geom2 = (H1, H1, 32, H2, H2, 3, 1, 0, RELU)
-    L.gemm(L.OP_TN, dy, z1, dwp2, 64, 288, M2, 64, 288, 288, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC, split_k=0, A2=z2, scale=k2[0],
-           shift=k2[1], gate=k2[2], b_prologue=L.BPRO_IM2COL, b_scale=bn1.scale, b_shift=bn1.shift, conv=geom2)
-    L.check(lib.mt_conv_weight_unpack_grad(L.ptr(dwp2), L.ptr(grads[3]), 64, 32, 3, 288, L.stream_ptr()), "mt_conv_weight_unpack_grad")
+
+    def conv2_wgrad():      # 6 M rows x (64 x 288): 9 ms, beside conv2's data gradient and conv1's weight gradient on the main stream
+        L.gemm(L.OP_TN, dy, z1, dwp2, 64, 288, M2, 64, 288, 288, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC, split_k=0, A2=z2, scale=k2[0],
+               shift=k2[1], gate=k2[2], b_prologue=L.BPRO_IM2COL, b_scale=bn1.scale, b_shift=bn1.shift, conv=geom2)
+        L.check(lib.mt_conv_weight_unpack_grad(L.ptr(dwp2), L.ptr(grads[3]), 64, 32, 3, 288, L.stream_ptr()), "mt_conv_weight_unpack_grad")
+    side.launch(conv2_wgrad, reads=(dy, z1, z2, k2, dwp2, bn1.scale, bn1.shift))
     dz2 = _new(dev, M2, 64)
     L.check(lib.mt_bn_bwd_apply(L.ptr(dy), L.ptr(z2), L.ptr(k2), L.ptr(dz2), M2, 64, L.stream_ptr()), "mt_bn_bwd_apply")
     # data gradient of conv2 = "full" correlation of dz2 with the flipped kernel: im2col(dz2, pad 2) . W2flip^T
