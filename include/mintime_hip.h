@@ -382,6 +382,12 @@ int mt_dwconv_bwd(const float* du, const float* z, const float* kabc, const floa
                   int parts, int act, const float* res_pre, const float* res_post, void* stream);
 /* act as in mt_dwconv_fwd; stats_in/mean_invstd_in may both be NULL.  du_in = (dgrad + res_pre) * act'(.) + res_post: gradients of
  * other consumers of the activated (res_pre) or raw (res_post) input tensor (Xception skip paths), either may be NULL. */
+/* The same with res_pre / res_post given at half resolution, [N, ceil(H/2), ceil(W/2), C]: the gradient that a stride-2 1x1
+ * convolution (Xception's skip path, xception.py:36-40) sends to the even (ih, iw) positions of its input; stride must be 1. */
+int mt_dwconv_bwd_res2(const float* du, const float* z, const float* kabc, const float* w, const float* zin,
+                       const float* scale_in, const float* shift_in, const float* mean_invstd_in, float* du_in,
+                       double* stats_in, int slots, float* dw, int N, int H, int W, int C, int k, int stride,
+                       int parts, int act, const float* res_pre, const float* res_post, void* stream);
 
 /* _conv_stem weight gradient (accumulated, torch layout [32,3,3,3]); x [N,H,W,3]. */
 int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N,

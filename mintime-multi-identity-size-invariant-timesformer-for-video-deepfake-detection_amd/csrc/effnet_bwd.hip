@@ -511,12 +511,15 @@ int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, co
 //   dW[kh,kw] = sum over input pixels of a_in[iy,ix] * dz[(iy+P-kh)/S, (ix+P-kw)/S]  -- exactly the taps the data gradient gathers),
 // so du, z and the dw input are streamed once instead of once per kernel (the separate weight-gradient kernel re-reads all three:
 // 10 of the EfficientNet step's 88 GB).  Per-thread tap accumulators persist across the block's tiles; reduced through LDS at the end.
+thread_local int g_res_stride = 1;      // set by mt_dwconv_bwd_res2 around its call (one more kernel argument, no new instantiations)
+
 template <int K, int S, int T, int ACT, int CC, bool WG = false>
 __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
     const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ w,
     const float* __restrict__ zin, const float* __restrict__ scale_in, const float* __restrict__ shift_in,
     const float* __restrict__ mi_in, float* __restrict__ du_in, double* __restrict__ stats, int slots, int N, int H, int W,
-    int C, int Ho, int Wo, const float* __restrict__ res_pre, const float* __restrict__ res_post, float* __restrict__ dw) {
+    int C, int Ho, int Wo, const float* __restrict__ res_pre, const float* __restrict__ res_post, float* __restrict__ dw,
+    int res_stride) {
   constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
   constexpr int CQN = CC / 4, NSLOT = 256 / CQN;
   constexpr int OT = (T - 1 + K - 1) / S + 2;       // output rows/cols a T-wide input tile can touch (upper bound)
@@ -631,9 +634,13 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
             if constexpr (WG) wacc[kh * K + kw] = fma4(dzv, ain, wacc[kh * K + kw]);
           }
         }
-        if (res_pre) acc = add4(acc, ld4(res_pre + off));       // another consumer of the same activated tensor
+        // res_stride 2: the residual gradient comes from a stride-2 1x1 convolution (Xception's skip path): it exists at even
+        // (ih, iw) only, as [N, ceil(H/2), ceil(W/2), C] -- no zero-filled full-resolution copy of it is made
+        const bool r_on = res_stride == 1 || !((ih | iw) & 1);
+        const int64_t roff = res_stride == 1 ? off : (((int64_t)n * ((H + 1) >> 1) + (ih >> 1)) * ((W + 1) >> 1) + (iw >> 1)) * C + c;
+        if (res_pre && r_on) acc = add4(acc, ld4(res_pre + roff));       // another consumer of the same activated tensor
         float4 d = mul4(acc, dact4<ACT>(u));
-        if (res_post) d = add4(d, ld4(res_post + off));         // a consumer of the raw (pre-activation) tensor
+        if (res_post && r_on) d = add4(d, ld4(res_post + roff));         // a consumer of the raw (pre-activation) tensor
         st4(du_in + off, d);
         const float4 xh = f4((zz.x - mean.x) * istd.x, (zz.y - mean.y) * istd.y, (zz.z - mean.z) * istd.z, (zz.w - mean.w) * istd.w);
         s1 = add4(s1, d);
@@ -690,7 +697,8 @@ int launch_dw_dgrad_tiled(const float* du, const float* z, const float* kabc, co
   // the fused form keeps K*K tap accumulators per thread across tiles: fewer, longer-lived blocks keep the final atomics rare
   const unsigned bx = xcd_chunk_grid(chunks, ntiles, WG ? 4096 : 8192);
   hipLaunchKernelGGL((dwconv_dgrad_tiled_kernel<K, S, T, ACT, CC, WG>), dim3(bx), dim3(256), lds, s, du, z, kabc, w, zin,
-                     scale_in, shift_in, mi_in, du_in, stats, slots != 0 ? slots : 1, N, H, W, C, Ho, Wo, res_pre, res_post, dw);
+                     scale_in, shift_in, mi_in, du_in, stats, slots != 0 ? slots : 1, N, H, W, C, Ho, Wo, res_pre, res_post, dw,
+                     g_res_stride);
   return check_launch(WG ? "mt_dwconv_bwd(data + weight, fused)" : "mt_dwconv_bwd(data, tiled)");
 }
 
@@ -903,6 +911,18 @@ extern "C" int mt_dwconv_bwd(const float* du, const float* z, const float* kabc,
   if (k == 5 && stride == 1) return launch_dw_bwd<5, 1>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
   if (k == 5 && stride == 2) return launch_dw_bwd<5, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
   return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd: k=%d stride=%d unsupported", k, stride);
+}
+
+extern "C" int mt_dwconv_bwd_res2(const float* du, const float* z, const float* kabc, const float* w, const float* zin,
+                                  const float* scale_in, const float* shift_in, const float* mean_invstd_in, float* du_in,
+                                  double* stats_in, int slots, float* dw, int N, int H, int W, int C, int k, int stride, int parts,
+                                  int act, const float* res_pre, const float* res_post, void* stream) {
+  if (stride != 1) return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd_res2: stride 1 only");
+  g_res_stride = 2;
+  const int rc = mt_dwconv_bwd(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, k, stride,
+                               parts, act, res_pre, res_post, stream);
+  g_res_stride = 1;
+  return rc;
 }
 
 extern "C" int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N,

@@ -114,6 +114,8 @@ PROTOTYPES = {
     "mt_se_scratch_floats": [C.c_int, C.c_int, C.c_int],
     "mt_dwconv_bwd": [f32p] * 9 + [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_int, f32p, f32p, C.c_void_p],
+    "mt_dwconv_bwd_res2": [f32p] * 9 + [C.c_void_p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                           C.c_int, f32p, f32p, C.c_void_p],
     "mt_conv_weight_pack": [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_conv_weight_unpack_grad": [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_maxpool_add_fwd": [f32p] * 7 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],

@@ -17,6 +17,7 @@ RELU, NONE = 2, 0
 XC_PLANES = __import__("os").environ.get("MT_XC_PLANES", "1") != "0"
 PLANES_MIN_C = int(__import__("os").environ.get("MT_XC_PLANES_MIN_C", "256"))
 DW_PLANES = __import__("os").environ.get("MT_XC_DW_PLANES", "1") != "0"   # 0: depthwise output as fp32 + mt_split_planes_blk (round 4)
+SKIP_HALF = __import__("os").environ.get("MT_XC_SKIP_HALF", "1") != "0"    # 0: the skip path's data gradient scattered into a zeroed full-size tensor
 POOL_ARG = __import__("os").environ.get("MT_XC_POOL_ARG", "1") != "0"      # 0: the adjoint of the max-pool as an arg-max scatter (round 4)
 
 
@@ -300,9 +301,10 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
                                        L.ptr(grads[gi + 1]), ctx.C, tr, L.stream_ptr()), "mt_bn_bwd_finalize")
         return kabc
 
-    def unit_backward(rec, pi, g, sums, res_pre=None, res_post=None, pooled=None):
+    def unit_backward(rec, pi, g, sums, res_pre=None, res_post=None, pooled=None, res_half=False):
         """g = gradient w.r.t. this unit's BatchNorm output (sums already accumulated when `sums` is given).
         pooled = (dy, arg, zmax, Ho) instead of g: the unit feeds the block's max-pool and the gradient is dy routed by `arg`.
+        res_half: res_pre / res_post are at half resolution (the stride-2 skip convolution's data gradient, even positions only).
         Returns (gradient w.r.t. the source's affine output [activation derivative applied], its BN sums or None)."""
         ci, co, Hh = rec["ci"], rec["co"], rec["H"]
         M = N * Hh * Hh
@@ -344,10 +346,10 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
         du_in = _new(dev, M, ci)
 
         def dw_part(parts):
-            L.check(lib.mt_dwconv_bwd(L.ptr(dd), L.ptr(dd), L.ptr(kid), L.ptr(w_dw), L.ptr(src.t), L.ptr(rec["sc"]), L.ptr(rec["sh"]),
-                                      L.ptr(src.bn.mean_invstd) if has_bn else None, L.ptr(du_in), L.ptr(sums_in), slots,
-                                      L.ptr(grads[pi]), N, Hh, Hh, ci, 3, 1, parts, rec["eff"], L.ptr(res_pre), L.ptr(res_post),
-                                      L.stream_ptr()), "mt_dwconv_bwd")
+            fn = lib.mt_dwconv_bwd_res2 if res_half else lib.mt_dwconv_bwd
+            L.check(fn(L.ptr(dd), L.ptr(dd), L.ptr(kid), L.ptr(w_dw), L.ptr(src.t), L.ptr(rec["sc"]), L.ptr(rec["sh"]),
+                       L.ptr(src.bn.mean_invstd) if has_bn else None, L.ptr(du_in), L.ptr(sums_in), slots, L.ptr(grads[pi]), N, Hh, Hh, ci,
+                       3, 1, parts, rec["eff"], L.ptr(res_pre), L.ptr(res_post), L.stream_ptr()), "mt_dwconv_bwd")
         side.launch(lambda: dw_part(1), reads=(dd, kid, src.t, rec["sc"], rec["sh"]))
         dw_part(2)
         return du_in, sums_in
@@ -381,10 +383,14 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
             d_small = _new(dev, Mo, cin)
             L.gemm(L.OP_NN, dy, P[bm["skip"]].view(cout, cin), d_small, Mo, cin, cout, cout, cin, cin, prologue=L.PRO_BN_BWD,
                    A2=brec["z_s"], scale=ks[0], shift=ks[1], gate=ks[2])
-            # scatter to the strided positions (2oh, 2ow) of an input-sized zero tensor
-            d_skip = torch.zeros(N, Hin, Hin, cin, dtype=torch.float32, device=dev)
-            d_skip[:, ::2, ::2, :] = d_small.view(N, Ho, Ho, cin)
-            d_skip = d_skip.view(N * Hin * Hin, cin)
+            # it lands on the even positions (2oh, 2ow) of the block input: the first unit's depthwise adjoint adds it from the
+            # half-resolution tensor (SKIP_HALF; round 4 scattered it into an input-sized zero tensor first)
+            if SKIP_HALF:
+                d_skip = d_small
+            else:
+                d_skip = torch.zeros(N, Hin, Hin, cin, dtype=torch.float32, device=dev)
+                d_skip[:, ::2, ::2, :] = d_small.view(N, Ho, Ho, cin)
+                d_skip = d_skip.view(N * Hin * Hin, cin)
             if inp.bn is not None or inp.act == RELU:
                 res_pre = d_skip          # the skip conv consumed the same activated tensor as the first unit
             else:
@@ -404,7 +410,7 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
         for u in reversed(range(len(units))):
             first = u == 0
             g, sums = unit_backward(units[u], bm["units"][u], g, sums, res_pre if first else None, res_post if first else None,
-                                    pooled if u == len(units) - 1 else None)
+                                    pooled if u == len(units) - 1 else None, res_half=first and stride != 1 and SKIP_HALF)
         # for block1 the result is the gradient w.r.t. bn2's output (sums accumulated); otherwise w.r.t. the previous block's y
         dy = g
         bn2_sums = sums

@@ -172,12 +172,14 @@ def test_max_pool_adjoint_from_the_recorded_arg_max(N, H, C):
     assert torch.equal(p, L.split_planes_blk(dz, N * H * H, C))
 
 
-def test_training_step_is_the_same_with_the_arg_max_scatter(monkeypatch):
-    """MT_XC_POOL_ARG=0 (round 4's adjoint: zero fill + atomics + full-resolution sums) and the default give the same gradients."""
+@pytest.mark.parametrize("knob", ["POOL_ARG", "DW_PLANES", "SKIP_HALF"])
+def test_training_step_is_the_same_with_the_round_4_form(monkeypatch, knob):
+    """MT_XC_POOL_ARG=0 (max-pool adjoint: zero fill + atomics + full-resolution sums), MT_XC_DW_PLANES=0 (depthwise output as fp32 +
+    a split pass), MT_XC_SKIP_HALF=0 (skip-path gradient scattered into a zeroed full-size tensor) give the default's gradients."""
     from mintime_amd import xception_engine as XE
     grads = []
     for on in (True, False):
-        monkeypatch.setattr(XE, "POOL_ARG", on)
+        monkeypatch.setattr(XE, knob, on)
         model, _ = _model(5, True)
         f = model(_input(2, 7).cuda())
         (f * torch.linspace(-1, 1, f.numel(), device="cuda").view_as(f)).sum().backward()
