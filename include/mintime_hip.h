@@ -234,6 +234,9 @@ int mt_head_fwd(const float* x, const float* gamma, const float* beta, const flo
  * w in torch layout [32,3,3,3]; W <= 512.  Streaming MFMA kernel (stem_fwd.hip): one output row per block and pass. */
 int mt_stem_conv_fwd(const void* x, int x_is_u8, const float* w, float* z, double* stats, int slots, int N, int H, int W,
                      void* stream);
+/* The same kernel without padding (Conv2d(3, 32, 3, 2, 0): Xception's conv1, xception.py:135): z [N,(H-3)/2+1,(W-3)/2+1,32]. */
+int mt_stem_conv_fwd_valid(const void* x, int x_is_u8, const float* w, float* z, double* stats, int slots, int N, int H, int W,
+                           void* stream);
 
 /* Depthwise conv (k 3|5, stride 1|2, TF-SAME padding; for k3 s1 that is pad 1) applied to act(zin*scale+shift);
  * act 1 = swish: EfficientNet _depthwise_conv on swish(bn(z)) (model.py:98-103);
@@ -392,6 +395,9 @@ int mt_dwconv_bwd_res2(const float* du, const float* z, const float* kabc, const
 /* _conv_stem weight gradient (accumulated, torch layout [32,3,3,3]); x [N,H,W,3]. */
 int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N,
                        int H, int W, void* stream);   /* x fp32 or (x_is_u8) uint8 */
+/* ... of the unpadded stride-2 3x3 convolution (Xception's conv1); du, z [N,(H-3)/2+1,(W-3)/2+1,32]. */
+int mt_stem_conv_wgrad_valid(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N,
+                             int H, int W, void* stream);
 
 /* Weight gradient of a 1x1 convolution with few channels and very many rows (MBConv expand / project convs of stages 1-4,
  * efficientnet_pytorch/model.py:93-104 under train.py:371):  dw[Cout,Cin] += sum_r (ka*du+kb*z+kc)[r,Cout] * a[r,Cin] with

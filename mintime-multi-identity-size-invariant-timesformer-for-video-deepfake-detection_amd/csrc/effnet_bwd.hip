@@ -925,15 +925,26 @@ extern "C" int mt_dwconv_bwd_res2(const float* du, const float* z, const float* 
   return rc;
 }
 
-extern "C" int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N,
-                                  int H, int W, void* stream) {
+static int stem_conv_wgrad(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N, int H, int W,
+                           bool valid, void* stream) {
   if (!du || !z || !kabc || !x || !dw) return fail(MT_ERR_ARG, "mt_stem_conv_wgrad: null pointer");
-  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-  const int padt = max((Ho - 1) * 2 + 3 - H, 0);
+  if (valid && (H < 3 || W < 3)) return fail(MT_ERR_ARG, "mt_stem_conv_wgrad_valid: crops of at least 3 x 3");
+  const int Ho = valid ? (H - 3) / 2 + 1 : (H + 1) / 2, Wo = valid ? (W - 3) / 2 + 1 : (W + 1) / 2;
+  const int padt = valid ? 0 : max((Ho - 1) * 2 + 3 - H, 0);
   // (deterministic mode takes the outer-product kernel: the MFMA form meets its row groups with LDS atomics)
   if (Wo <= 128 && !det_enabled()) return stem_wgrad_mfma(du, z, kabc, x, x_is_u8, dw, N, H, W, Ho, Wo, padt / 2, (hipStream_t)stream);
   DetScope det((hipStream_t)stream, 1, 1024, 32 * 27, true, true);
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, du, z, kabc, x, x_is_u8, dw, N, H, W, Ho, Wo, padt / 2, det.log);
   const int rc = check_launch("mt_stem_conv_wgrad");
   return rc ? rc : det.reduce_f32(dw);
+}
+
+extern "C" int mt_stem_conv_wgrad(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N,
+                                  int H, int W, void* stream) {
+  return stem_conv_wgrad(du, z, kabc, x, x_is_u8, dw, N, H, W, false, stream);
+}
+
+extern "C" int mt_stem_conv_wgrad_valid(const float* du, const float* z, const float* kabc, const void* x, int x_is_u8, float* dw, int N,
+                                        int H, int W, void* stream) {
+  return stem_conv_wgrad(du, z, kabc, x, x_is_u8, dw, N, H, W, true, stream);
 }

@@ -151,13 +151,15 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemArgs p) {
 
 }  // namespace
 
-extern "C" int mt_stem_conv_fwd(const void* x, int x_is_u8, const float* w, float* z, double* stats, int slots, int N, int H, int W,
-                                void* stream) {
+static int stem_conv_fwd(const void* x, int x_is_u8, const float* w, float* z, double* stats, int slots, int N, int H, int W, bool valid,
+                         void* stream) {
   if (!x || !w || !z) return fail(MT_ERR_ARG, "mt_stem_conv_fwd: null pointer");
   if (N <= 0 || H <= 0 || W <= 0 || W > MAXW || (int64_t)N * H > (1 << 30))
     return fail(MT_ERR_ARG, "mt_stem_conv_fwd: crops of 1..%d columns, N*H < 2^30", MAXW);
-  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-  const int padt_h = max((Ho - 1) * 2 + 3 - H, 0), padt_w = max((Wo - 1) * 2 + 3 - W, 0);
+  if (valid && (H < 3 || W < 3)) return fail(MT_ERR_ARG, "mt_stem_conv_fwd_valid: crops of at least 3 x 3");
+  // TF-SAME: ceil(H / 2) outputs, the missing rows / columns are zeros; valid (padding 0): floor((H - 3) / 2) + 1 outputs, no padding
+  const int Ho = valid ? (H - 3) / 2 + 1 : (H + 1) / 2, Wo = valid ? (W - 3) / 2 + 1 : (W + 1) / 2;
+  const int padt_h = valid ? 0 : max((Ho - 1) * 2 + 3 - H, 0), padt_w = valid ? 0 : max((Wo - 1) * 2 + 3 - W, 0);
   if (padt_h / 2 != padt_w / 2) return fail(MT_ERR_UNSUPPORTED, "mt_stem_conv_fwd: H and W must need the same leading padding");
   StemArgs a{x, w, z, stats, slots != 0 ? slots : 1, x_is_u8 ? 1 : 0, N, H, W, Ho, Wo, padt_h / 2};
   const size_t smem = ((size_t)3 * (W + 2) * 3 + 28 * CO + 8 * CO) * sizeof(float);
@@ -166,4 +168,14 @@ extern "C" int mt_stem_conv_fwd(const void* x, int x_is_u8, const float* w, floa
   if (3 * W * 3 <= 8 * 256) hipLaunchKernelGGL(stem_mfma_kernel<8>, dim3(blocks), dim3(256), smem, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(stem_mfma_kernel<(MAXW * 9 + 255) / 256>, dim3(blocks), dim3(256), smem, (hipStream_t)stream, a);
   return check_launch("mt_stem_conv_fwd");
+}
+
+extern "C" int mt_stem_conv_fwd(const void* x, int x_is_u8, const float* w, float* z, double* stats, int slots, int N, int H, int W,
+                                void* stream) {
+  return stem_conv_fwd(x, x_is_u8, w, z, stats, slots, N, H, W, false, stream);
+}
+
+extern "C" int mt_stem_conv_fwd_valid(const void* x, int x_is_u8, const float* w, float* z, double* stats, int slots, int N, int H, int W,
+                                      void* stream) {
+  return stem_conv_fwd(x, x_is_u8, w, z, stats, slots, N, H, W, true, stream);
 }

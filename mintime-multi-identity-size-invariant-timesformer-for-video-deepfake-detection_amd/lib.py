@@ -85,6 +85,7 @@ PROTOTYPES = {
                     C.c_void_p, C.c_void_p],
     "mt_head_fwd": [f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "mt_stem_conv_fwd": [C.c_void_p, C.c_int, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_stem_conv_fwd_valid": [C.c_void_p, C.c_int, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_dwconv_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_int, C.c_void_p],
     "mt_dwconv_fwd_planes": [f32p] * 4 + [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p],
@@ -141,6 +142,7 @@ PROTOTYPES = {
     "mt_se_stage_fused": [f32p] * 7 + [C.c_int] + [f32p] * 5 + [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_conv1x1_bwd_fused": [f32p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "mt_stem_conv_wgrad": [f32p] * 4 + [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "mt_stem_conv_wgrad_valid": [f32p] * 4 + [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_bn_act_fwd_planes": [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_void_p, C.c_void_p],
     "mt_bn_swish_gate_planes": [f32p, f32p, f32p, f32p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "mt_plan_create": [C.POINTER(C.c_void_p)],

@@ -17,6 +17,7 @@ RELU, NONE = 2, 0
 XC_PLANES = __import__("os").environ.get("MT_XC_PLANES", "1") != "0"
 PLANES_MIN_C = int(__import__("os").environ.get("MT_XC_PLANES_MIN_C", "256"))
 DW_PLANES = __import__("os").environ.get("MT_XC_DW_PLANES", "1") != "0"   # 0: depthwise output as fp32 + mt_split_planes_blk (round 4)
+XC_STEM = __import__("os").environ.get("MT_XC_STEM", "1") != "0"             # 0: conv1 as an im2col GEMM (round 4)
 SKIP_HALF = __import__("os").environ.get("MT_XC_SKIP_HALF", "1") != "0"    # 0: the skip path's data gradient scattered into a zeroed full-size tensor
 POOL_ARG = __import__("os").environ.get("MT_XC_POOL_ARG", "1") != "0"      # 0: the adjoint of the max-pool as an arg-max scatter (round 4)
 
@@ -192,8 +193,17 @@ def xception_forward(model, x, params, training, save):
     # ---- conv1 (3x3 s2 p0, 3 -> 32) and conv2 (3x3 s1 p0, 32 -> 64) as im2col GEMMs
     w1, g1, b1, w2, g2, b2 = next(it), next(it), next(it), next(it), next(it), next(it)
     H1 = (H - 3) // 2 + 1
-    wp1 = pack(w1, 32, 3, 3, 28)
-    z1, bn1 = conv_im2col(_Src(x, 3, H), wp1, 32, 28, (H, W, 3, H1, H1, 3, 2, 0), model.bn1, g1, b1, u8=x.dtype == torch.uint8)
+    if XC_STEM and W <= 512:
+        # conv1 = the EfficientNet stem's streaming MFMA kernel without padding (K = 27 is far too short for the im2col GEMM: 4.3 ms
+        # against 0.5 at 512 crops); reads uint8 crops as well
+        bn1 = _BNCtx(dev, 32, training, pool)
+        z1 = _new(dev, N * H1 * H1, 32)
+        L.check(lib.mt_stem_conv_fwd_valid(L.ptr(x), 1 if x.dtype == torch.uint8 else 0, L.ptr(w1), L.ptr(z1), L.ptr(bn1.stats) if training
+                                           else None, slots, N, H, W, L.stream_ptr()), "mt_stem_conv_fwd_valid")
+        _finalize(lib, model.bn1, bn1, N * H1 * H1, training, g1, b1, slots)
+    else:
+        wp1 = pack(w1, 32, 3, 3, 28)
+        z1, bn1 = conv_im2col(_Src(x, 3, H), wp1, 32, 28, (H, W, 3, H1, H1, 3, 2, 0), model.bn1, g1, b1, u8=x.dtype == torch.uint8)
     s1 = _Src(z1, 32, H1, bn1.scale, bn1.shift, RELU, bn1)
     H2 = H1 - 2
     wp2 = pack(w2, 64, 32, 3, 288)
@@ -439,11 +449,15 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
     L.gemm(L.OP_NT, dz2, wp2t, da1, M1, 32, 576, 576, 576, 32, prologue=L.PRO_IM2COL, conv=(H2, H2, 64, H1, H1, 3, 1, 2, NONE))
     du1 = _new(dev, M1, 32)
     k1 = bn_kabc(bn1, bn_sums(da1, z1, bn1, M1, act=RELU, dout=du1), 1, du1, z1, M1)
-    dwp1 = torch.zeros(32, 28, dtype=torch.float32, device=dev)
-    L.gemm(L.OP_TN, du1, saved["x"], dwp1, 32, 28, M1, 32, 28, 28, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC, split_k=0, A2=z1,
-           scale=k1[0], shift=k1[1], gate=k1[2], b_prologue=L.BPRO_IM2COL,
-           conv=(H, W, 3, H1, H1, 3, 2, 0, NONE, 1 if saved["x"].dtype == torch.uint8 else 0))
-    L.check(lib.mt_conv_weight_unpack_grad(L.ptr(dwp1), L.ptr(grads[0]), 32, 3, 3, 28, L.stream_ptr()), "mt_conv_weight_unpack_grad")
+    if XC_STEM and W <= 512:
+        L.check(lib.mt_stem_conv_wgrad_valid(L.ptr(du1), L.ptr(z1), L.ptr(k1), L.ptr(saved["x"]), 1 if saved["x"].dtype == torch.uint8 else 0,
+                                             L.ptr(grads[0]), N, H, W, L.stream_ptr()), "mt_stem_conv_wgrad_valid")
+    else:
+        dwp1 = torch.zeros(32, 28, dtype=torch.float32, device=dev)
+        L.gemm(L.OP_TN, du1, saved["x"], dwp1, 32, 28, M1, 32, 28, 28, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC, split_k=0, A2=z1,
+               scale=k1[0], shift=k1[1], gate=k1[2], b_prologue=L.BPRO_IM2COL,
+               conv=(H, W, 3, H1, H1, 3, 2, 0, NONE, 1 if saved["x"].dtype == torch.uint8 else 0))
+        L.check(lib.mt_conv_weight_unpack_grad(L.ptr(dwp1), L.ptr(grads[0]), 32, 3, 3, 28, L.stream_ptr()), "mt_conv_weight_unpack_grad")
     side.wait()
     L.grads_ready(model, P, flat_grads)
     return [g_ if need else None for need, g_ in zip(need_dparams, grads)]

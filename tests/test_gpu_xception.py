@@ -235,3 +235,31 @@ def test_side_stream_hold_mode_frees_in_host_order():
     assert wu() is None
     torch.cuda.synchronize()
     assert out.tolist() == [2.0] * 4
+
+
+@pytest.mark.parametrize("N,H,u8", [(3, 224, False), (2, 37, True), (2, 64, False)])
+def test_conv1_on_the_stem_kernels_without_padding(N, H, u8):
+    """Xception's conv1 = Conv2d(3, 32, 3, 2, 0) (xception.py:135) on the EfficientNet stem's kernels with no padding: output, its
+    BatchNorm sums and the weight gradient of dz = ka du + kb z + kc against torch in float64 (odd and even sizes, uint8 crops)."""
+    from mintime_amd import lib as L
+    lib = L.get()
+    g = torch.Generator().manual_seed(H)
+    x = torch.randint(0, 256, (N, H, H, 3), generator=g).to(torch.uint8 if u8 else torch.float32).cuda()
+    w = (torch.randn(32, 3, 3, 3, generator=g) * 0.2).cuda()
+    Ho = (H - 3) // 2 + 1
+    z = torch.full((N, Ho, Ho, 32), 7.0, device="cuda")
+    stats = torch.zeros(32, 2, 32, dtype=torch.float64, device="cuda")
+    st = L.stream_ptr()
+    L.check(lib.mt_stem_conv_fwd_valid(L.ptr(x), int(u8), L.ptr(w), L.ptr(z), L.ptr(stats), 32, N, H, H, st), "fwd")
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), stride=2).permute(0, 2, 3, 1)
+    assert_close(z, ref, 1e-5, "conv1 output")
+    assert_close(stats.sum(0)[0], ref.sum((0, 1, 2)), 1e-5, "sum z")
+    assert_close(stats.sum(0)[1], (ref * ref).sum((0, 1, 2)), 1e-5, "sum z^2")
+    du = torch.randn(N, Ho, Ho, 32, generator=g).cuda()
+    kabc = torch.randn(3, 32, generator=g).cuda()
+    dw = torch.zeros(32, 3, 3, 3, device="cuda")
+    L.check(lib.mt_stem_conv_wgrad_valid(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(x), int(u8), L.ptr(dw), N, H, H, st), "wgrad")
+    dz = kabc[0].double() * du.double() + kabc[1].double() * z.double() + kabc[2].double()
+    wd = w.double().requires_grad_(True)
+    (torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wd, stride=2) * dz.permute(0, 3, 1, 2)).sum().backward()
+    assert_close(dw, wd.grad, 2e-5, "conv1 weight gradient")
