@@ -17,5 +17,10 @@ python bench.py --steps 20 --warmup 5 > $out/r05_bench_b32_line.json 2>$out/benc
 python bench.py --config 2 --steps 10 --warmup 5 --no-cpu-baseline > $out/r05_bench_config2_b16_line.json 2>/dev/null
 python bench.py --config 5 --steps 5 --warmup 3 --no-cpu-baseline > $out/r05_bench_config5_xs_line.json 2>/dev/null
 python bench.py --ragged --steps 10 --warmup 5 --no-cpu-baseline --no-extras > $out/r05_bench_b32_ragged_line.json 2>/dev/null
+rm -rf $out/c5_stats
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5_stats -o c5 -- python $GRAFT_REPO_ROOT/bench.py --config 5 --steps 4 --warmup 5 --no-cpu-baseline --no-extras > $out/r05_bench_config5_xs_line_under_rocprof.json 2>$out/c5_rocprof.err)
+python tools/step_timeline.py $(find $out/c5_stats -name "*kernel_trace.csv") > $out/r05_config5_in_step_timeline.txt 2>&1
+cp $(find $out/c5_stats -name "*kernel_stats.csv" | head -1) $out/r05_config5_kernel_stats.csv 2>/dev/null
+rm -rf $out/c5_stats $out/bench_stats
 ls -la $out | head -40
 tail -c 600 $out/r05_bench_b32_line.json
