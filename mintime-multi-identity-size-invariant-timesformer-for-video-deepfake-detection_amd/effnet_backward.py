@@ -73,7 +73,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
     total_c = arch.STEM_COUT + arch.HEAD_COUT + sum((b.spec.cexp if b.spec.has_expand else 0) + b.spec.cexp + b.spec.cout
                                                     for b in blocks)
     tr = 1 if training else 0
-    side = L.SideStream(dev)
+    side = L.SideStream(dev, hold=True)     # (eager launches; a recording plan pins what the side stream reads itself)
 
     # deterministic mode (MT_DETERMINISTIC / lib.set_deterministic): only kernels whose reductions have a fixed-order form -- the
     # streaming fusions that meet their partial sums with LDS / global atomics step aside for the GEMM (split-K slabs), the
@@ -312,6 +312,7 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         del du_in
         if not keep_saved:
             rec.clear()
+        side.release_point()
 
     side.wait()
     if need_dx:

@@ -243,7 +243,7 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
         idx -= k
         return idx
 
-    side = L.SideStream(dev)
+    side = L.SideStream(dev, hold=True)     # (eager launches; a recording plan pins what the side stream reads itself)
 
     def wgrad(a_p, b_p, out, M_, N_, bias_src=None, bias_out=None):
         """dW[M_, N_] += A^T B over the M token rows, on the side stream (+ an optional bias column sum of an fp32 tensor)."""
@@ -348,6 +348,7 @@ def tsf_backward_planes(model, feat, aux, params, dims, saved, dlogits, need_dfe
             dx2, dx_p = ln_bwd(dxn, r, g, dx2, i0, tgt, skip)
             if not keep_saved:
                 r.clear()
+        side.release_point()
 
     # ---- embeddings + patch embedding (row-mapped operands: the fp32 GEMM family)
     i0 = take(5)
