@@ -17,6 +17,7 @@ RELU, NONE = 2, 0
 XC_PLANES = __import__("os").environ.get("MT_XC_PLANES", "1") != "0"
 PLANES_MIN_C = int(__import__("os").environ.get("MT_XC_PLANES_MIN_C", "256"))
 DW_PLANES = __import__("os").environ.get("MT_XC_DW_PLANES", "1") != "0"   # 0: depthwise output as fp32 + mt_split_planes_blk (round 4)
+CONV2_WGRAD_SIDE = float(__import__("os").environ.get("MT_XC_CONV2_WGRAD_SIDE", "0.7"))   # share of conv2's weight gradient on the side stream
 XC_STEM = __import__("os").environ.get("MT_XC_STEM", "1") != "0"             # 0: conv1 as an im2col GEMM (round 4)
 SKIP_HALF = __import__("os").environ.get("MT_XC_SKIP_HALF", "1") != "0"    # 0: the skip path's data gradient scattered into a zeroed full-size tensor
 POOL_ARG = __import__("os").environ.get("MT_XC_POOL_ARG", "1") != "0"      # 0: the adjoint of the max-pool as an arg-max scatter (round 4)
@@ -435,11 +436,16 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
     dwp2 = torch.zeros(64, 288, dtype=torch.float32, device=dev)
     geom2 = (H1, H1, 32, H2, H2, 3, 1, 0, RELU)
 
-    def conv2_wgrad():      # 6 M rows x (64 x 288): 9 ms, beside conv2's data gradient and conv1's weight gradient on the main stream
-        L.gemm(L.OP_TN, dy, z1, dwp2, 64, 288, M2, 64, 288, 288, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC, split_k=0, A2=z2, scale=k2[0],
-               shift=k2[1], gate=k2[2], b_prologue=L.BPRO_IM2COL, b_scale=bn1.scale, b_shift=bn1.shift, conv=geom2)
-        L.check(lib.mt_conv_weight_unpack_grad(L.ptr(dwp2), L.ptr(grads[3]), 64, 32, 3, 288, L.stream_ptr()), "mt_conv_weight_unpack_grad")
-    side.launch(conv2_wgrad, reads=(dy, z1, z2, k2, dwp2, bn1.scale, bn1.shift))
+    def conv2_wgrad(n0, n1):      # images [n0, n1): 6 M rows x (64 x 288) in all, 9 ms
+        r0, r1 = n0 * H2 * H2, n1 * H2 * H2
+        L.gemm(L.OP_TN, dy[r0:r1], z1[n0 * H1 * H1:n1 * H1 * H1], dwp2, 64, 288, r1 - r0, 64, 288, 288, prologue=L.PRO_BN_BWD,
+               epilogue=L.EPI_ATOMIC, split_k=0, A2=z2[r0:r1], scale=k2[0], shift=k2[1], gate=k2[2], b_prologue=L.BPRO_IM2COL,
+               b_scale=bn1.scale, b_shift=bn1.shift, conv=geom2)
+    # most of it on the side stream, beside conv2's data gradient and conv1's weight gradient; the rest after those on the main stream,
+    # so that both queues end together (the whole of it on either queue leaves the other idle for 3-9 ms at the end of the step)
+    # (deterministic mode: every split-K GEMM of this backward stays on the side stream -- they share the slab arena in stream order)
+    n_side = N if (not side.enabled or det) else max(1, min(N, int(round(N * CONV2_WGRAD_SIDE))))
+    side.launch(lambda: conv2_wgrad(0, n_side), reads=(dy, z1, z2, k2, dwp2, bn1.scale, bn1.shift))
     dz2 = _new(dev, M2, 64)
     L.check(lib.mt_bn_bwd_apply(L.ptr(dy), L.ptr(z2), L.ptr(k2), L.ptr(dz2), M2, 64, L.stream_ptr()), "mt_bn_bwd_apply")
     # data gradient of conv2 = "full" correlation of dz2 with the flipped kernel: im2col(dz2, pad 2) . W2flip^T
@@ -458,7 +464,10 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
                scale=k1[0], shift=k1[1], gate=k1[2], b_prologue=L.BPRO_IM2COL,
                conv=(H, W, 3, H1, H1, 3, 2, 0, NONE, 1 if saved["x"].dtype == torch.uint8 else 0))
         L.check(lib.mt_conv_weight_unpack_grad(L.ptr(dwp1), L.ptr(grads[0]), 32, 3, 3, 28, L.stream_ptr()), "mt_conv_weight_unpack_grad")
+    if n_side < N:
+        conv2_wgrad(n_side, N)
     side.wait()
+    L.check(lib.mt_conv_weight_unpack_grad(L.ptr(dwp2), L.ptr(grads[3]), 64, 32, 3, 288, L.stream_ptr()), "mt_conv_weight_unpack_grad")
     L.grads_ready(model, P, flat_grads)
     return [g_ if need else None for need, g_ in zip(need_dparams, grads)]
 
