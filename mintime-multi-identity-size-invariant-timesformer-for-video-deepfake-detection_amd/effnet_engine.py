@@ -132,7 +132,32 @@ def weight_planes(model, params, exp, proj, head):
         cache = caches[ident] = dict(holder=holder, host=host, table=host.to(dev, non_blocking=True), blocks=first, count=len(rows))
     L.check(lib.mt_split_planes_blk_multi(L.ptr(cache["table"]), cache["count"], cache["blocks"], L.stream_ptr()),
             "mt_split_planes_blk_multi")       # (L.ptr: a plan being recorded pins the table)
+    weight_planes_touch(model, cache, [w for _, w, _, _ in sel])
     return cache["holder"]
+
+
+def weight_planes_touch(model, cache=None, ws=None):
+    """A new serial when the weights changed since the planes were last written (cf. tsf_planes.weight_planes): graphs that saved
+    an older serial must not run their backward on the re-split planes.  A replayed forward (the split launch is in the plan)
+    calls this with no arguments for the bookkeeping alone.  Returns the serial the forward's planes carry, None without planes."""
+    from .tsf_planes import WEIGHT_EPOCH
+    st = model.__dict__.setdefault("_ef_wplanes_state", dict(serial=0, stamp=None, ws=None))
+    if ws is not None:
+        st["ws"], st["ident"] = ws, id(cache)
+    if st["ws"] is None:
+        return None
+    stamp = (tuple(w._version for w in st["ws"]), tuple(w.data_ptr() for w in st["ws"]), st["ident"], WEIGHT_EPOCH[0])
+    if stamp != st["stamp"]:
+        st["serial"] += 1
+        st["stamp"] = stamp
+    return st["serial"]
+
+
+def check_weight_serial(model, saved):
+    ser = saved.get("w_serial")
+    if ser is not None and model.__dict__.get("_ef_wplanes_state", {}).get("serial") != ser:
+        raise RuntimeError("EfficientNet: the 1x1-conv weights were updated between this graph's forward and its backward (their "
+                           "operand planes were rewritten by a later forward): run backward before the optimizer step")
 
 
 def _bump_tracked(plan=None):
@@ -309,6 +334,7 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False, pla
                               st), "mt_bn_act_fwd")
     if save:
         saved["head"] = dict(y_in=y, z=z_h, bn=bn_h, y_p=y_p if pl_head else None, w_p=wpl.get("head"))
+        saved["w_serial"] = model.__dict__.get("_ef_wplanes_state", {}).get("serial") if wpl else None
     _bump_tracked(plan)
     return feat, saved, ys
 
@@ -367,6 +393,8 @@ class _EffNetFunction(torch.autograd.Function):
             if np_.extra.get("gates") is not None:
                 np_.extra["gates"].copy_(_dc_gates(model, N, x_nhwc.device)[1])
             plans.run(np_.fwd)
+            if np_.extra["saved"].get("w_serial") is not None:
+                np_.extra["saved"]["w_serial"] = weight_planes_touch(model)       # the split launch is in the plan
             if np_.extra.get("tracked"):
                 torch._foreach_add_(np_.extra["tracked"], 1)
         ctx.plan, ctx.token = np_, np_.begin()
@@ -381,6 +409,7 @@ class _EffNetFunction(torch.autograd.Function):
         from . import plans
         from .effnet_backward import effnet_backward, LAST_RUN
         np_ = ctx.plan
+        check_weight_serial(ctx.model, ctx.saved)
         dfeat = dfeat.contiguous()
         need_dx, need_dp = ctx.needs_input_grad[2], ctx.needs_input_grad[3:]
         if np_ is None:
@@ -413,7 +442,8 @@ class _EffNetFunction(torch.autograd.Function):
             dx, dparams = None, plans.fresh_aliases(np_.extra["grads"])
         ctx.saved = None
         if np_ is not None:
-            np_.release()
+            np_.release(ctx.token)
+            ctx.token = None
         return (None, None, dx) + tuple(dparams)
 
 

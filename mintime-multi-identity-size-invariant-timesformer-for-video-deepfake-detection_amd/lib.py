@@ -579,6 +579,15 @@ class SideStream:
             self.stream = SideStream._streams[key]
         self.pending = []
 
+    def __del__(self):
+        # hold mode on an error path: a backward that raised between a launch and wait() drops this object with tensors the side
+        # stream may still be reading; make the main stream wait for the side stream BEFORE those references go back to its pool
+        try:
+            if self.enabled and self.hold and (self.held or self.epochs):
+                torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        except Exception:
+            pass
+
     def launch(self, fn, reads=()):
         """Run fn() on the side stream once everything enqueued so far on the current stream is done."""
         if not self.enabled:

@@ -49,6 +49,7 @@ class NetPlan:
         self.bwd = None
         self.broken = False
         self.in_flight = False
+        self.live = None           # weak reference to the token of the forward that currently owns the static buffers
         self.inputs = {}           # name -> static tensor the recorded calls read
         self.state_ptrs = None
         self.stream = None
@@ -58,21 +59,30 @@ class NetPlan:
     def begin(self):
         tok = _Token()
         self.in_flight = True
-        weakref.finalize(tok, _release, weakref.ref(self))
+        self.live = weakref.ref(tok)
+        weakref.finalize(tok, _release, weakref.ref(self), id(tok))
         return tok
 
-    def release(self):
-        self.in_flight = False
+    def release(self, token=None):
+        """The forward that holds `token` is done with the static buffers.  Only the LIVE token may clear `in_flight`: the token of
+        step N sits on its autograd node and can die during step N+1, after begin() has handed the buffers to the new forward
+        (a stale release there would let a second same-key forward replay over activations a pending backward still needs)."""
+        if token is None or (self.live is not None and self.live() is token):
+            self.in_flight = False
+            self.live = None
 
     def __del__(self):
         for p in self.extra.get("owned", ()):
             OWNED.discard(p)
 
 
-def _release(ref):
+def _release(ref, tok_id):
+    """Finalizer of a token: clears `in_flight` only when no newer forward has taken the plan since (the dead token's weak
+    reference is the one stored in `live`: it now reads None; a newer token's reads the newer token)."""
     np_ = ref()
-    if np_ is not None:
+    if np_ is not None and np_.live is not None and np_.live() is None:
         np_.in_flight = False
+        np_.live = None
 
 
 def own(np_, *tensors):
@@ -93,12 +103,19 @@ def lookup(model, key):
         return None, "eager"
     reg = _REG.setdefault(model, {})
     ent = reg.get(key)
+    if ent is not None:
+        reg[key] = reg.pop(key)           # most recently used last: eviction below takes the least recently used idle plan
     if ent is None:
         if len(reg) >= MAX_PLANS:
             victim = next((k for k, v in reg.items() if not v.in_flight), None)
             if victim is None:
                 return None, "eager"
-            reg.pop(victim)
+            if reg.pop(victim).fwd is not None:
+                STATS["rerecord_risk"] = STATS.get("rerecord_risk", 0) + 1
+                if STATS["rerecord_risk"] == 8:       # a workload cycling through more keys than MT_PLAN_MAX re-records (and re-pins) forever
+                    import warnings
+                    warnings.warn("mintime_amd.plans: recorded launch plans keep being evicted (more distinct shapes / modes per module "
+                                  f"than MT_PLAN_MAX={MAX_PLANS}); raise MT_PLAN_MAX or set MT_PLAN=0")
             STATS["dropped"] += 1
         ent = reg[key] = NetPlan(key)
     if ent.broken:

@@ -322,7 +322,9 @@ class _TSFFunction(torch.autograd.Function):
         if np_ is not None:
             ctx.plan, ctx.token = np_, np_.begin()
             ctx.aux, ctx.saved, ctx.feat = np_.extra["aux"], np_.extra["saved"], np_.extra["feat"]
-            logits, s_att, t_att = (None if t is None else t.detach() for t in (logits, s_att, t_att))
+            # the user-facing outputs are small ([B, classes], two [(B H), 1, N] maps): hand out copies, so that a caller who keeps
+            # predictions on the device across steps does not see the next replay write over them (the eager path returns fresh tensors)
+            logits, s_att, t_att = (None if t is None else t.clone() for t in (logits, s_att, t_att))
         outs = [logits]
         if model.require_attention:
             ctx.mark_non_differentiable(s_att, t_att)
@@ -373,7 +375,8 @@ class _TSFFunction(torch.autograd.Function):
             dparams = plans.fresh_aliases(np_.extra["grads"])
         ctx.saved = None
         if np_ is not None:
-            np_.release()
+            np_.release(ctx.token)
+            ctx.token = None
         return (None, None, None, dfeat) + tuple(dparams)
 
 

@@ -92,6 +92,8 @@ class _WeightPlanes:
         self.items = {}          # weight data_ptr -> (weight, planes, co, ci)
         self.table = None
         self.fresh = False
+        self.serial, self.stamp = 0, None     # see tsf_planes.weight_planes: graphs that saved an older serial must not run their
+                                              # backward on planes a later forward re-split from updated weights
 
     def begin(self, lib):
         self.fresh = False
@@ -112,6 +114,16 @@ class _WeightPlanes:
         self.items[w_pw.data_ptr()] = (w_pw, planes, co, ci)
         self.table = None
         return planes
+
+    def touch(self):
+        """A new serial when the weights changed since the planes were last written (version counters; the fused optimizers that
+        write through raw pointers bump tsf_planes.WEIGHT_EPOCH)."""
+        from .tsf_planes import WEIGHT_EPOCH
+        stamp = (tuple(w._version for w, _, _, _ in self.items.values()), tuple(self.items), WEIGHT_EPOCH[0])
+        if stamp != self.stamp:
+            self.serial += 1
+            self.stamp = stamp
+        return self.serial
 
     def end(self, dev):
         if self.table is not None or not self.items:
@@ -267,12 +279,17 @@ def xception_forward(model, x, params, training, save):
         saved["tail"] = tail
     if planes_on:
         wplanes.end(dev)
+        if save:
+            saved["w_serial"] = wplanes.touch()
     _bump_tracked()
     return feat, saved, cur.H
 
 
 def xception_backward(model, params, saved, shape, training, dfeat, need_dparams):
     lib = L.get()
+    if "w_serial" in saved and model.__dict__["_xc_wplanes"].serial != saved["w_serial"]:
+        raise RuntimeError("Xception: the pointwise weights were updated between this graph's forward and its backward (their operand "
+                           "planes were rewritten by a later forward): run backward before the optimizer step")
     dev = dfeat.device
     N, H, W = shape
     P = list(params)

@@ -389,9 +389,20 @@ def aggregate_attentions(attentions, heads, num_frames, frames_per_identity, sca
 # --------------------------------------------------------------------------------------------
 # PARITY PIN (partial): slot assignment (sort + assign_slots) is pinned against the reference's
 # DeepFakesDataset.get_sorted_identities run on throw-away directory trees (tests/golden/slots.json, made by
-# tools/make_golden.py).  The per-clip tensor construction (build_clip_tensors) is PARITY UNPINNED: __getitem__ /
-# generate_masks call cv2.imread / cv2.VideoCapture / albumentations, which are not installed here and may not be faked, so
-# it is restated from the source lines cited below and tested against hand-derived cases only.
+# tools/make_golden.py), and the size-embedding constants (RANGE_SIZE, SIZE_EMB_DICT) against the imported module's
+# (tests/golden/f1_constants.json).  The per-clip tensor construction (build_clip_tensors) is PARITY UNPINNED, and it cannot be
+# pinned in this container.  The exact lines that block it:
+#   deepfakes_dataset.py  __getitem__ (:191-339) is ONE function; between the slot assignment (:216) and the integer tail
+#       (mask :280-284, identities_mask :313-320, positions :323-330) it calls cv2.VideoCapture(...).get(3|4) (:250-252: the video
+#       area every size bucket is a ratio of), cv2.imread (:257: the face's shape) and the albumentations transform object
+#       (:299-308: `transform(image=..., image1=...)`, built from IsotropicResize / PadIfNeeded / Resize at :57-108).
+#   predict.py  generate_masks (:254-352) takes the crops in memory, but still calls cv2.VideoCapture(video_path).get (:286-288)
+#       for the video area and create_val_transform(...)(image=...) (:321-325) before its integer tail (:329-345); the module's
+#       own imports (:2-29: cv2, facenet_pytorch, albumentations, preprocessing.face_detector) are placeholders at best.
+# Neither cv2 nor albumentations is installed, there is no network, and giving their calls BEHAVIOUR (a VideoCapture that answers
+# get(3), a transform that returns its inputs) would be writing a stand-in for a library -- an oracle pinned against that pins
+# nothing.  The integer tail has no function boundary of its own in either file, so it cannot be called on pre-built lists.
+# It is therefore restated from the source lines cited below and tested against hand-derived cases (tests/test_sequence_builder.py).
 
 _RANGE_SIZE = 5
 SIZE_EMB_DICT = [(1 + i * _RANGE_SIZE, (i + 1) * _RANGE_SIZE) if i != 0 else (0, _RANGE_SIZE) for i in range(20)]   # :30-31

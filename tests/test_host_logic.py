@@ -76,6 +76,18 @@ def test_launch_plan_registry_state_machine(monkeypatch):
     np_a.begin()
     np_a.release()                                        # ... or the backward ran
     assert plans.lookup(m, "a")[1] == "replay"
+    # a stale token must not free buffers a NEWER forward has taken: the token of step N lives on its autograd node and can die
+    # during step N+1 (reference-style loop: `loss` is rebound after the next forward has begun)
+    tok_old = np_a.begin()
+    np_a.release(tok_old)                                 # backward of step N
+    tok_new = np_a.begin()                                # forward of step N+1
+    del tok_old
+    gc.collect()                                          # step N's graph dies now
+    assert np_a.in_flight and plans.lookup(m, "a") == (None, "eager")
+    np_a.release(object())                                # a release carrying a token that is not the live one: ignored
+    assert np_a.in_flight
+    np_a.release(tok_new)
+    assert not np_a.in_flight and plans.lookup(m, "a") == (np_a, "replay")
     plans.lookup(m, "b")
     np_b, mode = plans.lookup(m, "b")
     assert mode == "record"

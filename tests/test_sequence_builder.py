@@ -22,6 +22,20 @@ def _slot_cases():
         return json.load(fh)
 
 
+def test_size_embedding_constants_match_reference():
+    """RANGE_SIZE / SIZE_EMB_DICT of the imported deepfakes_dataset module (tools/make_golden.py slots_case) against the oracle's and
+    the product's tables: 20 buckets, (0..5), (6..10), ... (96..100)."""
+    with open(os.path.join(GOLDEN, "f1_constants.json")) as fh:
+        ref = json.load(fh)
+    assert [list(t) for t in O.SIZE_EMB_DICT] == ref["SIZE_EMB_DICT"] and O._RANGE_SIZE == ref["RANGE_SIZE"]
+    assert len(ref["SIZE_EMB_DICT"]) == 20 and ref["SIZE_EMB_DICT"][0] == [0, 5] and ref["SIZE_EMB_DICT"][-1] == [96, 100]
+    # the oracle's bucket rule agrees with the reference's table on every integer ratio 0..100 (the device builder is compared with
+    # the oracle bit for bit in the GPU test below)
+    for ratio in range(101):
+        want = next(i for i, (a, b) in enumerate(ref["SIZE_EMB_DICT"]) if a <= ratio <= b) + 1
+        assert O.size_bucket(ratio, 1, 200, 1, "predict") == want, ratio      # face area = ratio, video area = 200 * 1 / 2 = 100
+
+
 def test_oracle_slot_assignment_matches_reference():
     for r in _slot_cases():
         s = O.sort_identities([(i, 0, c) for i, c in enumerate(r["counts"])], 1, r["max_identities"])

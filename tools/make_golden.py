@@ -324,6 +324,13 @@ def slots_case(name):
     with open(os.path.join(OUT, name + ".json"), "w") as fh:
         json.dump(rows, fh)
     print(f"wrote {name}.json ({len(rows)} cases)")
+    # the module-level constants of the size embedding (deepfakes_dataset.py:30-31): what CAN be read off the imported reference
+    # of the per-clip tensor rules -- the rest of __getitem__ (:216-339) sits behind cv2.VideoCapture (:250), cv2.imread (:257)
+    # and the albumentations transform call (:299-308) and cannot be run here (oracle/mintime_oracle.py, f1 header)
+    with open(os.path.join(OUT, "f1_constants.json"), "w") as fh:
+        json.dump(dict(RANGE_SIZE=int(ds_mod.RANGE_SIZE), SIZE_EMB_DICT=[[int(a), int(b)] for a, b in ds_mod.SIZE_EMB_DICT],
+                       MODES=list(ds_mod.MODES)), fh)
+    print("wrote f1_constants.json")
 
 
 def e2e_case(EF, TSF, name, batch, frames, identities, ragged, training, seed):
