@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MT_VERSION 118
+#define MT_VERSION 119
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -243,6 +243,15 @@ int mt_stem_conv_fwd_valid(const void* x, int x_is_u8, const float* w, float* z,
  * act 2 = relu / 0 = none: Xception SeparableConv2d.conv1 (xception.py:21,25).  w torch layout [C,1,k,k]. */
 int mt_dwconv_fwd(const float* zin, const float* scale, const float* shift, const float* w, float* zout,
                   double* stats, int slots, int N, int H, int W, int C, int k, int stride, int act, void* stream);
+/* MBConv expand + depthwise in one kernel (efficientnet_pytorch/model.py:93-103: _expand_conv -> _bn0 -> swish -> _depthwise_conv):
+ * y [N,H,W,cin] is the BLOCK input, we [C,cin] the expand weight, scale/shift the folded _bn0; the kernel rebuilds its 16-channel
+ * chunk of the expanded tensor as y . we^T on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32) while staging its tile, so the
+ * expanded tensor -- the widest of the network, 6x the block input -- is neither written nor read (csrc/rc.hpp).  In train mode its
+ * BatchNorm statistics come from mt_conv1x1_rows with out = NULL (statistics only).  Instances: mt_dwconv_rc_supported
+ * (EfficientNet-B0 blocks 1-3: the 112^2 and 56^2 grids); act is swish.  zout / stats as mt_dwconv_fwd. */
+int mt_dwconv_rc_supported(int cin, int C, int k, int stride, int H);
+int mt_dwconv_fwd_rc(const float* y, const float* we, int cin, const float* scale, const float* shift, const float* w, float* zout,
+                     double* stats, int slots, int N, int H, int W, int C, int k, int stride, void* stream);
 /* The same convolution with the output written as a plane tensor ([N*Ho*Wo rows][C columns], mt_planes_elems; padding zeroed) and
  * nowhere else: Xception's SeparableConv2d (xception.py:17-27) feeds its depthwise output to the pointwise convolution only, which
  * runs on mt_gemm_planes -- the fp32 tensor and the mt_split_planes_blk pass over it are not needed. */
@@ -383,6 +392,12 @@ int mt_dwconv_bwd(const float* du, const float* z, const float* kabc, const floa
                   const float* scale_in, const float* shift_in, const float* mean_invstd_in, float* du_in,
                   double* stats_in, int slots, float* dw, int N, int H, int W, int C, int k, int stride,
                   int parts, int act, const float* res_pre, const float* res_post, void* stream);
+/* The adjoint of mt_dwconv_fwd_rc: `zin` of mt_dwconv_bwd is replaced by the block input y [N,H,W,cin] and the expand weight we
+ * [C,cin]; the depthwise input's pre-activation is rebuilt in the kernel (csrc/rc.hpp).  parts = 1 (dw) or 2 (du_in + sums); act is
+ * swish.  du_in is the gradient w.r.t. the expand convolution's BatchNorm output -- what mt_conv1x1_bwd_fused consumes. */
+int mt_dwconv_bwd_rc(const float* du, const float* z, const float* kabc, const float* w, const float* y, const float* we, int cin,
+                     const float* scale_in, const float* shift_in, const float* mean_invstd_in, float* du_in, double* stats_in,
+                     int slots, float* dw, int N, int H, int W, int C, int k, int stride, int parts, void* stream);
 /* act as in mt_dwconv_fwd; stats_in/mean_invstd_in may both be NULL.  du_in = (dgrad + res_pre) * act'(.) + res_post: gradients of
  * other consumers of the activated (res_pre) or raw (res_post) input tensor (Xception skip paths), either may be NULL. */
 /* The same with res_pre / res_post given at half resolution, [N, ceil(H/2), ceil(W/2), C]: the gradient that a stride-2 1x1
@@ -437,9 +452,10 @@ int mt_conv1x1_wgrad_wide(const float* du, const float* z, const float* kabc, co
  * their data gradients, efficientnet_pytorch/model.py:93-118): out[rows,Cout] = a[rows,Cin] . W^T (+ res), with
  *   amode 0: a = x;   1: a = swish(c0*x + c1) * c2[row / hw]  (c2 = SE gate [rows/hw, Cin]);   2: a = c0*x + c1*x2 + c2 (BatchNorm backward).
  * w is [Cout, ldw] (w_transposed = 0) or the forward weight [Cin, ldw] used transposed (w_transposed = 1, data gradient).
- * stats (optional) receives the BatchNorm sums of `out` like MT_EPI_STATS.  mt_conv1x1_rows_supported tells whether this kernel is
+ * stats (optional) receives the BatchNorm sums of `out` like MT_EPI_STATS; out may be NULL when stats is given (statistics only).  mt_conv1x1_rows_supported tells whether this kernel is
  * the measured better choice for a channel pair and mode (otherwise use mt_gemm). */
 int mt_conv1x1_rows_supported(int Cin, int Cout, int amode);
+int mt_conv1x1_rows_instance(int Cin, int Cout);      /* an instance exists (whether or not it is the better choice) */
 int mt_conv1x1_rows(const float* x, const float* x2, const float* w, int ldw, int w_transposed, const float* c0, const float* c1,
                     const float* c2, int hw, int amode, const float* res, float* out, double* stats, int slots, int64_t rows,
                     int Cin, int Cout, void* stream);

@@ -10,6 +10,7 @@
 //   * swish'(u) = sig(u)*(1+u*(1-sig(u))) is recomputed from z (utils.py:70-75 saves only the input as well).
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
+#include "rc.hpp"
 #include "det.hpp"
 #include <stdlib.h>
 
@@ -17,7 +18,7 @@ using namespace mt;
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   /* v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division: the swish kernels are VALU-bound */
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float dswishf_(float u) { const float s = sigmoidf_(u); return s * (1.0f + u * (1.0f - s)); }
 
@@ -351,11 +352,13 @@ __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__
 // and the dz tile are built ONCE per tile in LDS (swish / BN-backward affine evaluated once per element instead of once per
 // tap); thread (cq, kh, ps) then accumulates the K taps of kernel row kh for channel quad cq over its share of the pixels.
 // Accumulators persist across the block's tiles -> one atomic per (channel, tap) per block.
-template <int K, int S, int T, int ACT, int CC>
+// RC = Cin > 0: zin is the block input y [N,H,W,Cin]; the depthwise input chunk is rebuilt as y . We^T while staging (rc.hpp).
+template <int K, int S, int T, int ACT, int CC, int RC = 0>
 __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
     const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ zin,
     const float* __restrict__ scale_in, const float* __restrict__ shift_in, float* __restrict__ dw, int N, int H, int W, int C,
-    int Ho, int Wo, const DetLog det) {
+    int Ho, int Wo, const DetLog det, const float* __restrict__ we) {
+  static_assert(RC == 0 || CC == 16, "the recompute yields 16-channel chunks");
   constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
   constexpr int CQN = CC / 4;
   constexpr int IH = (T - 1) * S + K;
@@ -376,7 +379,13 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
 
   // per-thread BN vectors for the loader role (channel quad = tid & 3)
   const float4 ka = ld4(kabc + c0 + cq * 4), kb = ld4(kabc + C + c0 + cq * 4), kc = ld4(kabc + 2 * C + c0 + cq * 4);
-  const float4 sc = ld4(scale_in + c0 + cq * 4), sh = ld4(shift_in + c0 + cq * 4);
+  // staging role of the input tile: plain = (slot, cq); RC = the MFMA result layout (pixel lane & 15 of the wavefront's group, quad lane >> 4)
+  const int lane = tid & 63;
+  const int f_q = RC ? (lane >> 4) : cq, f_slot = RC ? ((tid >> 6) * 16 + (lane & 15)) : tid / CQN;
+  const float4 sc = ld4(scale_in + c0 + f_q * 4), sh = ld4(shift_in + c0 + f_q * 4);
+  constexpr int RCW = RC ? RC : 8;
+  RcFrag<RCW> wfrag;
+  if constexpr (RC > 0) rc_load<RCW>(wfrag, we + (int64_t)(c0 + (lane & 15)) * RC, lane);
 
   float4 acc[K];
 #pragma unroll
@@ -388,7 +397,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
   constexpr int NL = (IH * IH + NSL - 1) / NSL, ND = (T * T + NSL - 1) / NSL;
   static_assert(NL <= 32 && ND <= 32, "validity masks are 32 bits");
   const int slot = tid / CQN;
-  float4 pre[NL], pdu[ND], pz[ND];
+  float4 pre[RC ? 1 : NL], pdu[ND], pz[ND];
+  RcFrag<RCW> ypre[RC ? NL : 1];
   unsigned pre_ok = 0, pd_ok = 0;
   auto fetch = [&](int64_t tile) {
     const int tx = (int)(tile % tx_n);
@@ -397,15 +407,17 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
     const int n = (int)(t2 / ty_n);
     const int oh0 = ty * T, ow0 = tx * T;
     const int ih0 = oh0 * S - P, iw0 = ow0 * S - P;
-    const float* img = zin + (int64_t)n * H * W * C + c0 + cq * 4;
+    const float* img = RC ? zin + (int64_t)n * H * W * RC : zin + (int64_t)n * H * W * C + c0 + cq * 4;
     pre_ok = 0; pd_ok = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int pix = slot + i * NSL;
+      const int pix = f_slot + i * NSL;
       const int iy = pix / IH, ix = pix - iy * IH;
       const int ih = ih0 + iy, iw = iw0 + ix;
       if (pix < IH * IH && ih >= 0 && ih < H && iw >= 0 && iw < W) pre_ok |= 1u << i;
-      pre[i] = ld4(img + ((int64_t)min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1)) * C);
+      const int64_t poff = (int64_t)min(max(ih, 0), H - 1) * W + min(max(iw, 0), W - 1);
+      if constexpr (RC > 0) rc_load<RCW>(ypre[i], img + poff * RC, lane);
+      else pre[i] = ld4(img + poff * C);
     }
     const int64_t obase = (int64_t)n * Ho * Wo * C + c0 + cq * 4;
 #pragma unroll
@@ -425,12 +437,15 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
     __syncthreads();                              // previous tile fully consumed
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int pix = slot + i * NSL;
+      const int pix = f_slot + i * NSL;
+      float4 zraw;
+      if constexpr (RC > 0) zraw = rc_mma<RCW>(wfrag, ypre[i]);       // (all lanes: the MFMA runs outside the range test)
+      else zraw = pre[i];
       if (pix < IH * IH) {
         const int iy = pix / IH, ix = pix - iy * IH;
-        const float4 v = act4<ACT>(fma4(pre[i], sc, sh));
+        const float4 v = act4<ACT>(fma4(zraw, sc, sh));
         const bool ok = (pre_ok >> i) & 1u;
-        st4(a_t + (iy * IWP + ix) * CC + cq * 4, f4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f));
+        st4(a_t + (iy * IWP + ix) * CC + f_q * 4, f4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f));
       }
     }
 #pragma unroll
@@ -479,9 +494,10 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
   }
 }
 
-template <int K, int S, int T, int ACT, int CC>
+template <int K, int S, int T, int ACT, int CC, int RC = 0>
 int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, const float* zin, const float* scale_in,
-                          const float* shift_in, float* dw, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+                          const float* shift_in, float* dw, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s,
+                          const float* we = nullptr) {
   constexpr int IH = (T - 1) * S + K;
   constexpr int IWP = IH | 1;
   constexpr int CQN = CC / 4;
@@ -492,13 +508,13 @@ int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, co
   const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((Ho + T - 1) / T) * ((Wo + T - 1) / T);
   const unsigned bx = xcd_chunk_grid(chunks, ntiles, 4096);
-  auto k = dwconv_wgrad_tiled_kernel<K, S, T, ACT, CC>;
+  auto k = dwconv_wgrad_tiled_kernel<K, S, T, ACT, CC, RC>;
   if (lds > 48 * 1024) {
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
   DetScope det(s, chunks, (int)((bx >> 3) / chunks) * 8, CC * K * K);     // ranks = first tiles of a chunk's blocks (xcd_chunk_tile)
-  hipLaunchKernelGGL(k, dim3(bx), dim3(256), lds, s, du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, det.log);
+  hipLaunchKernelGGL(k, dim3(bx), dim3(256), lds, s, du, z, kabc, zin, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, det.log, we);
   const int rc = check_launch("mt_dwconv_bwd(weight, tiled)");
   return rc ? rc : det.reduce_f32(dw);
 }
@@ -513,13 +529,16 @@ int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, co
 // 10 of the EfficientNet step's 88 GB).  Per-thread tap accumulators persist across the block's tiles; reduced through LDS at the end.
 thread_local int g_res_stride = 1;      // set by mt_dwconv_bwd_res2 around its call (one more kernel argument, no new instantiations)
 
-template <int K, int S, int T, int ACT, int CC, bool WG = false>
+// RC = Cin > 0: zin is the block input y [N,H,W,Cin]; the tile's raw depthwise input chunk z = y . We^T is rebuilt into an LDS tile
+// (rc.hpp) next to the dz tile and the gather reads it from there (the plain form loads it from global memory inside the gather).
+template <int K, int S, int T, int ACT, int CC, bool WG = false, int RC = 0>
 __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
     const float* __restrict__ du, const float* __restrict__ z, const float* __restrict__ kabc, const float* __restrict__ w,
     const float* __restrict__ zin, const float* __restrict__ scale_in, const float* __restrict__ shift_in,
     const float* __restrict__ mi_in, float* __restrict__ du_in, double* __restrict__ stats, int slots, int N, int H, int W,
     int C, int Ho, int Wo, const float* __restrict__ res_pre, const float* __restrict__ res_post, float* __restrict__ dw,
-    int res_stride) {
+    int res_stride, const float* __restrict__ we) {
+  static_assert(RC == 0 || CC == 16, "the recompute yields 16-channel chunks");
   constexpr int P = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
   constexpr int CQN = CC / 4, NSLOT = 256 / CQN;
   constexpr int OT = (T - 1 + K - 1) / S + 2;       // output rows/cols a T-wide input tile can touch (upper bound)
@@ -538,6 +557,13 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
   // 3x3 weights in registers; 5x5 (25 float4 = 100 VGPRs) in LDS behind the dz tile, read as broadcasts
   constexpr bool WLDS = K > 3;
   float* w_t = lds + OT * OTP * CC;
+  float* z_t = w_t + (WLDS ? K * K * CC : 0);        // RC: raw input chunk of the tile, [T*T][CC]
+  constexpr int RCW = RC ? RC : 8;
+  constexpr int NLZ = (T * T + 63) / 64;
+  const int lane = tid & 63;
+  const int f_q = lane >> 4, f_slot = (tid >> 6) * 16 + (lane & 15);      // RC staging role (MFMA result layout)
+  RcFrag<RCW> wfrag, ypre[RC ? NLZ : 1];
+  if constexpr (RC > 0) rc_load<RCW>(wfrag, we + (int64_t)(c0 + (lane & 15)) * RC, lane);
   float4 wt[WLDS ? 1 : K * K];
   if constexpr (WLDS) {
     if (slot == 0)
@@ -585,6 +611,15 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
       pdu[i] = ld4(du + off);
       pz[i] = ld4(z + off);
     }
+    if constexpr (RC > 0) {
+      const float* img = zin + (int64_t)n * H * W * RC;
+#pragma unroll
+      for (int i = 0; i < NLZ; ++i) {
+        const int pix = f_slot + i * 64;
+        const int iy = pix / T, ix = pix - iy * T;
+        rc_load<RCW>(ypre[i], img + ((int64_t)min(ih0 + iy, H - 1) * W + min(iw0 + ix, W - 1)) * RC, lane);
+      }
+    }
   };
   int64_t tile = tile0;
   if (tile < ntiles) fetch(tile);
@@ -602,6 +637,14 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
         st4(lds + (oy * OTP + ox) * CC + cq * 4, f4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f));
       }
     }
+    if constexpr (RC > 0) {
+#pragma unroll
+      for (int i = 0; i < NLZ; ++i) {
+        const int pix = f_slot + i * 64;
+        const float4 zq = rc_mma<RCW>(wfrag, ypre[i]);                 // (all lanes)
+        if (pix < T * T) st4(z_t + pix * CC + f_q * 4, zq);
+      }
+    }
     __syncthreads();
     if (tile + tile_stride < ntiles) fetch(tile + tile_stride);
     for (int p = slot; p < T * T; p += NSLOT) {
@@ -610,7 +653,9 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
       if (ih < H && iw < W) {
         float4 acc = f4(0, 0, 0, 0);
         const int64_t off = (((int64_t)n * H + ih) * W + iw) * C + c;
-        const float4 zz = ld4(zin + off);
+        float4 zz;
+        if constexpr (RC > 0) zz = ld4(z_t + p * CC + cq * 4);
+        else zz = ld4(zin + off);
         const float4 u = fma4(zz, sc, sh);
         float4 ain = f4(0, 0, 0, 0);
         if constexpr (WG) ain = act4<ACT>(u);       // the depthwise conv's input at this pixel
@@ -681,24 +726,29 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
   }
 }
 
-template <int K, int S, int T, int ACT, int CC, bool WG = false>
+template <int K, int S, int T, int ACT, int CC, bool WG = false, int RC = 0>
 int launch_dw_dgrad_tiled(const float* du, const float* z, const float* kabc, const float* w, const float* zin,
                           const float* scale_in, const float* shift_in, const float* mi_in, float* du_in, double* stats, int slots,
                           int N, int H, int W, int C, int Ho, int Wo, const float* res_pre, const float* res_post, hipStream_t s,
-                          float* dw = nullptr) {
+                          float* dw = nullptr, const float* we = nullptr) {
   constexpr int OT = (T - 1 + K - 1) / S + 2;
   constexpr int OTP = OT | 1;
   constexpr int CQN = CC / 4, NSLOT = 256 / CQN;
-  size_t lds = (size_t)(OT * OTP * CC + (K > 3 ? K * K * CC : 0)) * sizeof(float);
+  size_t lds = (size_t)(OT * OTP * CC + (K > 3 ? K * K * CC : 0) + (RC ? T * T * CC : 0)) * sizeof(float);
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);
   if (WG && lds < (size_t)NSLOT * CQN * K * 4 * sizeof(float)) lds = (size_t)NSLOT * CQN * K * 4 * sizeof(float);
   const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((H + T - 1) / T) * ((W + T - 1) / T);
   // the fused form keeps K*K tap accumulators per thread across tiles: fewer, longer-lived blocks keep the final atomics rare
   const unsigned bx = xcd_chunk_grid(chunks, ntiles, WG ? 4096 : 8192);
-  hipLaunchKernelGGL((dwconv_dgrad_tiled_kernel<K, S, T, ACT, CC, WG>), dim3(bx), dim3(256), lds, s, du, z, kabc, w, zin,
+  auto kfn = dwconv_dgrad_tiled_kernel<K, S, T, ACT, CC, WG, RC>;
+  if (lds > 48 * 1024) {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), lds);
+    if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(kfn, dim3(bx), dim3(256), lds, s, du, z, kabc, w, zin,
                      scale_in, shift_in, mi_in, du_in, stats, slots != 0 ? slots : 1, N, H, W, C, Ho, Wo, res_pre, res_post, dw,
-                     g_res_stride);
+                     g_res_stride, we);
   return check_launch(WG ? "mt_dwconv_bwd(data + weight, fused)" : "mt_dwconv_bwd(data, tiled)");
 }
 
@@ -911,6 +961,38 @@ extern "C" int mt_dwconv_bwd(const float* du, const float* z, const float* kabc,
   if (k == 5 && stride == 1) return launch_dw_bwd<5, 1>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
   if (k == 5 && stride == 2) return launch_dw_bwd<5, 2>(du, z, kabc, w, zin, scale_in, shift_in, mean_invstd_in, du_in, stats_in, slots, dw, N, H, W, C, parts, act, res_pre, res_post, s);
   return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd: k=%d stride=%d unsupported", k, stride);
+}
+
+// The adjoint with the depthwise input rebuilt from the block input (rc.hpp): instances as in effnet_fwd.hip (MT_DW_RC_INSTANCES).
+#define MT_DW_RC_INSTANCES(X) X(3, 2, 16, 14) X(3, 1, 24, 14) X(5, 2, 24, 7)       /* (k, stride, Cin, weight-gradient tile) */
+extern "C" int mt_dwconv_rc_supported(int cin, int C, int k, int stride, int H);
+
+extern "C" int mt_dwconv_bwd_rc(const float* du, const float* z, const float* kabc, const float* w, const float* y, const float* we,
+                                int cin, const float* scale_in, const float* shift_in, const float* mean_invstd_in, float* du_in,
+                                double* stats_in, int slots, float* dw, int N, int H, int W, int C, int k, int stride, int parts,
+                                void* stream) {
+  if (!du || !z || !kabc || !y || !we || !scale_in || !shift_in) return fail(MT_ERR_ARG, "mt_dwconv_bwd_rc: null pointer");
+  if (((uintptr_t)y | (uintptr_t)we) & 15) return fail(MT_ERR_ARG, "mt_dwconv_bwd_rc: y and we must be 16-byte aligned");
+  if (parts != 1 && parts != 2) return fail(MT_ERR_ARG, "mt_dwconv_bwd_rc: parts must be 1 (weight) or 2 (data)");
+  if (parts == 1 && !dw) return fail(MT_ERR_ARG, "mt_dwconv_bwd_rc: weight part needs dw");
+  if (parts == 2 && (!w || !du_in)) return fail(MT_ERR_ARG, "mt_dwconv_bwd_rc: data part needs w and du_in");
+  if (parts == 2 && ((stats_in == nullptr) != (mean_invstd_in == nullptr))) return fail(MT_ERR_ARG, "mt_dwconv_bwd_rc: stats_in and mean_invstd_in go together");
+  if (stride == 2 && ((H & 1) || (W & 1))) return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd_rc: stride 2 needs even H, W");
+  if (!mt_dwconv_rc_supported(cin, C, k, stride, H))
+    return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd_rc: no instance for k=%d stride=%d Cin=%d C=%d H=%d", k, stride, cin, C, H);
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  hipStream_t s = (hipStream_t)stream;
+#define MT_CASE(K_, S_, CIN_, T_)                                                                                               \
+  if (k == K_ && stride == S_ && cin == CIN_) {                                                                                 \
+    if (parts == 1)                                                                                                             \
+      return launch_dw_wgrad_tiled<K_, S_, T_, 1, 16, CIN_>(du, z, kabc, y, scale_in, shift_in, dw, N, H, W, C, Ho, Wo, s, we); \
+    return launch_dw_dgrad_tiled<K_, S_, 14, 1, 16, false, CIN_>(du, z, kabc, w, y, scale_in, shift_in, mean_invstd_in, du_in, \
+                                                                  stats_in, slots, N, H, W, C, Ho, Wo, nullptr, nullptr, s,    \
+                                                                  nullptr, we);                                                 \
+  }
+  MT_DW_RC_INSTANCES(MT_CASE)
+#undef MT_CASE
+  return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_bwd_rc: no instance");
 }
 
 extern "C" int mt_dwconv_bwd_res2(const float* du, const float* z, const float* kabc, const float* w, const float* zin,

@@ -21,13 +21,14 @@
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
 #include "planes.hpp"
+#include "rc.hpp"
 #include <stdlib.h>
 
 using namespace mt;
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   /* v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division: the swish kernels are VALU-bound */
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 
 __device__ __forceinline__ float4 bn_swish4(float4 z, float4 sc, float4 sh) {
@@ -54,11 +55,15 @@ __device__ __forceinline__ float4 act_affine4(float4 z, float4 sc, float4 sh) {
 
 // ACT: input activation applied after the per-channel affine (0 none, 1 swish [EfficientNet], 2 relu [Xception]).
 // CC : channels per block (16, or 8 for channel counts like Xception's 728 that are not multiples of 16).
-template <int K, int S, int T, int ACT, int CC>
+// RC : 0 = zin is the conv's raw input [N,H,W,C]; Cin > 0 = zin is the BLOCK input y [N,H,W,Cin] and the raw input chunk is rebuilt
+//      as y . We^T while the tile is staged (rc.hpp; we = the expand weight [C, Cin]) -- the expanded tensor is not read.
+template <int K, int S, int T, int ACT, int CC, int RC = 0>
 __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restrict__ zin, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ w,
                                                            float* __restrict__ zout, double* __restrict__ stats, int slots,
-                                                           int N, int H, int W, int C, int Ho, int Wo, int pad0, PlaneRef po) {
+                                                           int N, int H, int W, int C, int Ho, int Wo, int pad0, PlaneRef po,
+                                                           const float* __restrict__ we) {
+  static_assert(RC == 0 || CC == 16, "the recompute yields 16-channel chunks");
   constexpr int CQN = CC / 4, NSLOT = 256 / CQN;
   constexpr int IH = (T - 1) * S + K;
   constexpr int IWP = IH | 1;
@@ -95,9 +100,16 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
   constexpr int NSL = 256 / CQN;                           // pixels covered per pass of the block
   constexpr int NL = (IH * IH + NSL - 1) / NSL;            // float4 slots per thread
   static_assert(NL <= 32, "validity mask is 32 bits");
-  const float4 sc_q = *reinterpret_cast<const float4*>(scale + c0 + cq * 4);
-  const float4 sh_q = *reinterpret_cast<const float4*>(shift + c0 + cq * 4);
-  float4 pre[NL];
+  // staging role: (pixel slot, channel quad) of the element this thread brings into the LDS tile.  Plain: the compute role's.
+  // RC: the MFMA result layout -- lane l of a wavefront holds pixel (l & 15) of its 16-pixel group, channel quad l >> 4.
+  const int lane = tid & 63;
+  const int f_q = RC ? (lane >> 4) : cq, f_slot = RC ? ((tid >> 6) * 16 + (lane & 15)) : slot;
+  const float4 sc_q = *reinterpret_cast<const float4*>(scale + c0 + f_q * 4);
+  const float4 sh_q = *reinterpret_cast<const float4*>(shift + c0 + f_q * 4);
+  constexpr int RCW = RC ? RC : 8;
+  RcFrag<RCW> wfrag, ypre[RC ? NL : 1];
+  if constexpr (RC > 0) rc_load<RCW>(wfrag, we + (int64_t)(c0 + (lane & 15)) * RC, lane);
+  float4 pre[RC ? 1 : NL];
   unsigned pre_ok = 0;
   auto fetch = [&](int64_t tile) {
     const int tx = (int)(tile % tx_n);
@@ -105,16 +117,17 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
     const int ty = (int)(t2 % ty_n);
     const int n = (int)(t2 / ty_n);
     const int ih0 = ty * T * S - pad0, iw0 = tx * T * S - pad0;
-    const float* img = zin + (int64_t)n * H * W * C + c0 + cq * 4;
+    const float* img = RC ? zin + (int64_t)n * H * W * RC : zin + (int64_t)n * H * W * C + c0 + cq * 4;
     pre_ok = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int pix = slot + i * NSL;
+      const int pix = f_slot + i * NSL;
       const int iy = pix / IH, ix = pix - iy * IH;
       const int ih = ih0 + iy, iw = iw0 + ix;
       if (pix < IH * IH && ih >= 0 && ih < H && iw >= 0 && iw < W) pre_ok |= 1u << i;
       const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
-      pre[i] = *reinterpret_cast<const float4*>(img + ((int64_t)ihc * W + iwc) * C);
+      if constexpr (RC > 0) rc_load<RCW>(ypre[i], img + ((int64_t)ihc * W + iwc) * RC, lane);
+      else pre[i] = *reinterpret_cast<const float4*>(img + ((int64_t)ihc * W + iwc) * C);
     }
   };
   int64_t tile = tile0;
@@ -128,12 +141,15 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int pix = slot + i * NSL;
+      const int pix = f_slot + i * NSL;
+      float4 zraw;
+      if constexpr (RC > 0) zraw = rc_mma<RCW>(wfrag, ypre[i]);       // (all lanes: the MFMA runs outside the range test)
+      else zraw = pre[i];
       if (pix < IH * IH) {
         const int iy = pix / IH, ix = pix - iy * IH;
-        const float4 a = act_affine4<ACT>(pre[i], sc_q, sh_q);
+        const float4 a = act_affine4<ACT>(zraw, sc_q, sh_q);
         const bool ok = (pre_ok >> i) & 1u;
-        *reinterpret_cast<float4*>(lds + (iy * IWP + ix) * CC + cq * 4) =
+        *reinterpret_cast<float4*>(lds + (iy * IWP + ix) * CC + f_q * 4) =
             make_float4(ok ? a.x : 0.f, ok ? a.y : 0.f, ok ? a.z : 0.f, ok ? a.w : 0.f);
       }
     }
@@ -186,9 +202,10 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
   }
 }
 
-template <int K, int S, int T, int ACT, int CC>
+template <int K, int S, int T, int ACT, int CC, int RC = 0>
 int launch_dw_tiled(const float* zin, const float* scale, const float* shift, const float* w, float* zout, double* stats, int slots,
-                    int N, int H, int W, int C, int Ho, int Wo, int pad0, hipStream_t s, const PlaneRef& po) {
+                    int N, int H, int W, int C, int Ho, int Wo, int pad0, hipStream_t s, const PlaneRef& po,
+                    const float* we = nullptr) {
   constexpr int IH = (T - 1) * S + K;
   constexpr int IWP = IH | 1;
   size_t lds = (size_t)(IH * IWP * CC + (K > 3 ? K * K * CC : 0)) * sizeof(float);
@@ -196,13 +213,13 @@ int launch_dw_tiled(const float* zin, const float* scale, const float* shift, co
   const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((Ho + T - 1) / T) * ((Wo + T - 1) / T);
   const unsigned bx = xcd_chunk_grid(chunks, ntiles, 8192);
-  auto k = dwconv_tiled_kernel<K, S, T, ACT, CC>;
+  auto k = dwconv_tiled_kernel<K, S, T, ACT, CC, RC>;
   if (lds > 48 * 1024) {
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds);
     if (e != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_dwconv_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(k, dim3(bx), dim3(256), lds, s, zin, scale, shift, w, zout, stats, slots != 0 ? slots : 1, N, H,
-                     W, C, Ho, Wo, pad0, po);
+                     W, C, Ho, Wo, pad0, po, we);
   return check_launch("mt_dwconv_fwd(tiled)");
 }
 
@@ -456,6 +473,35 @@ extern "C" int mt_dwconv_fwd(const float* zin, const float* scale, const float* 
   if (!zin || !scale || !shift || !w || !zout) return fail(MT_ERR_ARG, "mt_dwconv_fwd: null pointer");
   return dwconv_fwd(zin, scale, shift, w, zout, stats, slots, N, H, W, C, k, stride, act, (hipStream_t)stream, PlaneRef{nullptr, 0, 0, 0},
                     "mt_dwconv_fwd");
+}
+
+// instances of the recompute form: (k, stride, Cin, output tile) of EfficientNet-B0's blocks 1-3 (the expanded tensors of the 112^2 /
+// 56^2 grids).  5x5 stride 2 takes 7 x 7 tiles: a 14 x 14 tile's 31 x 31 halo is 16 operand fragments of prefetch per thread (occupancy 1).
+#define MT_DW_RC_INSTANCES(X) X(3, 2, 16, 14) X(3, 1, 24, 14) X(5, 2, 24, 7)
+
+extern "C" int mt_dwconv_rc_supported(int cin, int C, int k, int stride, int H) {
+  if (C <= 0 || (C & 15) || (H + stride - 1) / stride < 14) return 0;
+#define MT_CASE(K_, S_, CIN_, T_) if (k == K_ && stride == S_ && cin == CIN_) return 1;
+  MT_DW_RC_INSTANCES(MT_CASE)
+#undef MT_CASE
+  return 0;
+}
+
+extern "C" int mt_dwconv_fwd_rc(const float* y, const float* we, int cin, const float* scale, const float* shift, const float* w,
+                                float* zout, double* stats, int slots, int N, int H, int W, int C, int k, int stride, void* stream) {
+  if (!y || !we || !scale || !shift || !w || !zout) return fail(MT_ERR_ARG, "mt_dwconv_fwd_rc: null pointer");
+  if (((uintptr_t)y | (uintptr_t)we) & 15) return fail(MT_ERR_ARG, "mt_dwconv_fwd_rc: y and we must be 16-byte aligned");
+  if (!mt_dwconv_rc_supported(cin, C, k, stride, H))
+    return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_fwd_rc: no instance for k=%d stride=%d Cin=%d C=%d H=%d", k, stride, cin, C, H);
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const int pad = max((Ho - 1) * stride + k - H, 0) / 2;
+  const PlaneRef po{nullptr, 0, 0, 0};
+#define MT_CASE(K_, S_, CIN_, T_)                                                                                              \
+  if (k == K_ && stride == S_ && cin == CIN_)                                                                                  \
+    return launch_dw_tiled<K_, S_, T_, 1, 16, CIN_>(y, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad, (hipStream_t)stream, po, we);
+  MT_DW_RC_INSTANCES(MT_CASE)
+#undef MT_CASE
+  return fail(MT_ERR_UNSUPPORTED, "mt_dwconv_fwd_rc: no instance");
 }
 
 extern "C" int mt_dwconv_fwd_planes(const float* zin, const float* scale, const float* shift, const float* w, void* planes, int N, int H,

@@ -19,7 +19,7 @@ using namespace mt;
 
 namespace {
 
-__device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   /* v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division: the swish kernels are VALU-bound */
 __device__ __forceinline__ float swish_(float x) { return x * sigmoid_(x); }      // (the formula of effnet_fwd.hip / gemm_core.hpp)
 
 __global__ __launch_bounds__(256) void bn_act_planes_kernel(const float* __restrict__ z, const float* __restrict__ scale,

@@ -162,14 +162,14 @@ struct GemmArgs {
   int xcd_k;                            // split-K weight gradients: every XCD owns whole K-ranges (gemm_split.hpp), grid = (tiles, splits % 8 == 0)
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   /* v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division: the swish kernels are VALU-bound */
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float dswish_gemm_(float u) { const float s = sigmoidf_(u); return s * (1.0f + u * (1.0f - s)); }
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 rounding level) -- libm's erff costs ~3x the VALU slots,
 // and the GEGLU epilogues evaluate it 64x per lane while no MFMA of that wave is in flight.
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = 1.0f / fmaf(0.3275911f, ax, 1.0f);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));     // v_rcp_f32 (1 ulp; the series itself is good to 1.5e-7)
   float y = fmaf(1.061405429f, t, -1.453152027f);
   y = fmaf(y, t, 1.421413741f);
   y = fmaf(y, t, -0.284496736f);
@@ -189,7 +189,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 __device__ __forceinline__ void gelu_erf_both(float x, float& gelu, float& grad) {
   const float z = x * 0.70710678118654752440f;
   const float az = fabsf(z);
-  const float t = 1.0f / fmaf(0.3275911f, az, 1.0f);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
   float y = fmaf(1.061405429f, t, -1.453152027f);
   y = fmaf(y, t, 1.421413741f);
   y = fmaf(y, t, -0.284496736f);

@@ -33,7 +33,7 @@ struct ConvArgs {
   int64_t rows; int Cin, Cout, hw;
 };
 
-__device__ __forceinline__ float swish_f(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float swish_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }   /* v_rcp_f32 (1 ulp), see effnet_fwd.hip sigmoidf_ */
 
 // KT = 32-wide k tiles (Cin <= 32 KT), NT = 32-wide output column tiles, R = rows per chunk (one 32-row tile per wavefront at
 // R = 128, two wavefronts per row tile at R = 64)
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void conv1x1_rows_kernel(ConvArgs p) {
           if (row < p.rows) {
             float v = acc[j][r];
             if (p.res) v += p.res[row * p.Cout + co];
-            p.out[row * p.Cout + co] = v;
+            if (p.out) p.out[row * p.Cout + co] = v;        // out == NULL: BatchNorm statistics of the product only
             s1[j] += v; s2[j] = fmaf(v, v, s2[j]);
           }
         }
@@ -228,6 +228,9 @@ static bool rows_instance(int Cin, int Cout) {
   return false;
 }
 
+// does mt_conv1x1_rows have an instance for this channel pair at all?  (mt_conv1x1_rows_supported: is it the better choice)
+extern "C" int mt_conv1x1_rows_instance(int Cin, int Cout) { return rows_instance(Cin, Cout) ? 1 : 0; }
+
 // is the streaming kernel the better choice for this conv?  (amode as in mt_conv1x1_rows)
 extern "C" int mt_conv1x1_rows_supported(int Cin, int Cout, int amode) {
   if (!rows_instance(Cin, Cout)) return 0;
@@ -240,7 +243,7 @@ extern "C" int mt_conv1x1_rows_supported(int Cin, int Cout, int amode) {
 extern "C" int mt_conv1x1_rows(const float* x, const float* x2, const float* w, int ldw, int w_transposed, const float* c0,
                                const float* c1, const float* c2, int hw, int amode, const float* res, float* out, double* stats,
                                int slots, int64_t rows, int Cin, int Cout, void* stream) {
-  if (!x || !w || !out) return fail(MT_ERR_ARG, "mt_conv1x1_rows: null pointer");
+  if (!x || !w || (!out && !stats)) return fail(MT_ERR_ARG, "mt_conv1x1_rows: null pointer");
   if (!rows_instance(Cin, Cout)) return fail(MT_ERR_UNSUPPORTED, "mt_conv1x1_rows: no instance for %d -> %d channels", Cin, Cout);
   if (amode == A_GATE && (!c0 || !c1 || !c2 || hw <= 0)) return fail(MT_ERR_ARG, "mt_conv1x1_rows: gate mode needs scale, shift, gate, hw");
   if (amode == A_BNBWD && (!c0 || !c1 || !c2 || !x2)) return fail(MT_ERR_ARG, "mt_conv1x1_rows: BN-backward mode needs ka, kb, kc and z");

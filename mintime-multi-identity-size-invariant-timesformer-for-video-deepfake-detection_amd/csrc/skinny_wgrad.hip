@@ -33,7 +33,7 @@ struct WgradArgs {
 
 enum { A_PLAIN = 0, A_GATE = 1, A_STEM = 2 };
 
-__device__ __forceinline__ float swish_f(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float swish_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }   /* v_rcp_f32 (1 ulp), see effnet_fwd.hip sigmoidf_ */
 // component-wise on purpose: `c ? a : zero4` on the structs makes the compiler select between two stack slots
 __device__ __forceinline__ float4 keep_if(bool c, const float4& a) { return make_float4(c ? a.x : 0.f, c ? a.y : 0.f, c ? a.z : 0.f, c ? a.w : 0.f); }
 

@@ -34,7 +34,7 @@ struct WideArgs {
   int nslab, nsplit; int64_t chunks_per_split;
 };
 
-__device__ __forceinline__ float swish_w(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float swish_w(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }   /* v_rcp_f32 (1 ulp), see effnet_fwd.hip sigmoidf_ */
 
 constexpr int R = 32;                      // rows per chunk
 constexpr int SLAB = 128;                  // columns of C per block

@@ -266,6 +266,12 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         du_in = _new(dev, M_in, s.cexp)
         sums_in = pool.take(s.cexp)
         def dw_part(parts, _da=da, _rec=rec, _kabc=kabc_d, _bn=in_bn, _du_in=du_in, _sums=sums_in, _s=s, _ix=ix):
+            if _rec.get("rc"):        # the depthwise input's pre-activation is rebuilt from the block input (csrc/rc.hpp)
+                L.check(lib.mt_dwconv_bwd_rc(L.ptr(_da), L.ptr(_rec["z_d"]), L.ptr(_kabc), L.ptr(P[_ix["d"]]), L.ptr(_rec["y_in"]),
+                                             L.ptr(_rec["w_e"]), _s.cin, L.ptr(_bn.scale), L.ptr(_bn.shift), L.ptr(_bn.mean_invstd),
+                                             L.ptr(_du_in), L.ptr(_sums), slots, L.ptr(grads[_ix["d"]]), N, _s.hin, _s.hin, _s.cexp,
+                                             _s.k, _s.s, parts, L.stream_ptr()), "mt_dwconv_bwd_rc")
+                return
             L.check(lib.mt_dwconv_bwd(L.ptr(_da), L.ptr(_rec["z_d"]), L.ptr(_kabc), L.ptr(P[_ix["d"]]), L.ptr(_rec["dw_in"]),
                                       L.ptr(_bn.scale), L.ptr(_bn.shift), L.ptr(_bn.mean_invstd), L.ptr(_du_in), L.ptr(_sums), slots,
                                       L.ptr(grads[_ix["d"]]), N, _s.hin, _s.hin, _s.cexp, _s.k, _s.s, parts, 1, None, None, L.stream_ptr()),
@@ -273,28 +279,37 @@ def effnet_backward(model, params, saved, shape, training, dfeat, need_dx, need_
         # algorithmic HBM bytes of the pass: read da, z_d (M_out x cexp each) and the dw input's pre-activation (M_in x cexp: swish'
         # for the data gradient, swish for the weight gradient), write du_in (M_in x cexp)
         need_du_in = need_below[bi] or (s.has_expand and any(need[ix["e"]:ix["e"] + 3]))
+        dw_src = rec["y_in"] if rec.get("rc") else rec["dw_in"]          # what the kernels read on the input side
+        # algorithmic bytes with the recompute: the block input (cin channels) instead of the expanded pre-activation
+        dw_bytes = (4.0 * (s.cexp * (2 * M_out + M_in) + s.cin * M_in) if rec.get("rc") else 4.0 * s.cexp * (2 * M_out + 2 * M_in))
         if not need_du_in or not need[ix["d"]]:
             # a frozen neighbour: only the half that something trainable still needs
             if need[ix["d"]]:
                 run["wgrad_launches"] += 1
-                side.launch(lambda: dw_part(1), reads=(da, rec["z_d"], kabc_d, rec["dw_in"], in_bn.scale, in_bn.shift))
+                side.launch(lambda: dw_part(1), reads=(da, rec["z_d"], kabc_d, dw_src, in_bn.scale, in_bn.shift))
             if need_du_in:
-                L.timed("dwconv_dgrad", lambda: dw_part(2), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
-        elif fused_dw == "1" or (fused_dw == "3" and s.k == 3):
+                L.timed("dwconv_dgrad", lambda: dw_part(2), dw_bytes)
+        elif not rec.get("rc") and (fused_dw == "1" or (fused_dw == "3" and s.k == 3)):
             run["wgrad_launches"] += 1
             # data AND weight gradient in one pass over da / z_d / the dw input (the separate weight-gradient kernel re-read all three)
             L.timed("dwconv_dgrad", lambda: dw_part(3), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
         else:
             run["wgrad_launches"] += 1
-            side.launch(lambda: dw_part(1), reads=(da, rec["z_d"], kabc_d, rec["dw_in"], in_bn.scale, in_bn.shift))
-            L.timed("dwconv_dgrad", lambda: dw_part(2), 4.0 * s.cexp * (2 * M_out + 2 * M_in))
+            side.launch(lambda: dw_part(1), reads=(da, rec["z_d"], kabc_d, dw_src, in_bn.scale, in_bn.shift))
+            L.timed("dwconv_dgrad", lambda: dw_part(2), dw_bytes)
         del da
         if not need_du_in:
             dy = None
         elif s.has_expand:
             # (h,i,j) bn0 + expand conv: z_e = y_in . We^T
             kabc_e = bn_finalize(in_bn, sums_in, ix["e"] + 1, du_in, rec["dw_in"], M_in)
-            dy = conv1x1_bwd(du_in, rec["z_e"], kabc_e, P[ix["e"]], rec["y_in"], M_in, s.cexp, s.cin, ix["e"], need_below[bi],
+            z_e = rec["z_e"]
+            if z_e is None and not (expand_fused and need[ix["e"]] and need_below[bi] and M_in >= 100000
+                                    and lib.mt_conv1x1_bwd_fused_supported(s.cexp, s.cin)):
+                # recompute form, but this pass takes a branch that reads the expanded pre-activation (a frozen neighbour): rebuild it
+                z_e = _new(dev, M_in, s.cexp)
+                L.gemm(L.OP_NT, rec["y_in"], P[ix["e"]], z_e, M_in, s.cexp, s.cin, s.cin, s.cin, s.cexp)
+            dy = conv1x1_bwd(du_in, z_e, kabc_e, P[ix["e"]], rec["y_in"], M_in, s.cexp, s.cin, ix["e"], need_below[bi],
                              res=dy if s.skip else None,
                              pl=dict(w_p=rec["we_p"], x_p=rec["y_p"]) if rec.get("we_p") is not None else None)
         else:

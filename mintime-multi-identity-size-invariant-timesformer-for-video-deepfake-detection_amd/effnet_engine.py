@@ -13,6 +13,14 @@ STREAM_ROWS = int(__import__("os").environ.get("MT_STREAM_ROWS", "100000"))   # 
 # Late stages (14 x 14 and 7 x 7 grids, the head) on plane operands (csrc/effnet_planes.hip, gemm_planes.hpp): expand convolutions
 # whose input grid is at most EF_PLANES_EXPAND_HW wide, project convolutions whose output grid is at most EF_PLANES_PROJECT_HW wide
 # (tools/lab/ef_planes_lab.py: at 14 x 14 the project convolution's producer pass costs what its GEMM saves).  MT_EF_PLANES=0: off.
+# Early stages (blocks 1-3: 112^2 / 56^2 grids): expand convolution recomputed inside the depthwise kernels from the 16- / 24-channel
+# block input (csrc/rc.hpp) -- the 6x wider expanded tensor is never written (forward) nor read (depthwise forward, data and weight
+# gradient); in train mode its BatchNorm statistics come from a statistics-only pass over the block input.  Measured (round 6,
+# profiles/r06_expand_recompute_ab.txt): HBM-side traffic of the extractor step 76.7 -> 70.1 GB, kernel time 22.3 -> 23.3 ms, step
+# +0.4 ms -- the depthwise kernels are bound by instruction issue at 2-3 wavefronts per SIMD (VALU 50-60 % busy), not by the bytes
+# the recompute removes, and it adds MFMA + staging work to them.  OFF by default; MT_EF_RC=1 switches it on (parity-tested).
+EF_RC = __import__("os").environ.get("MT_EF_RC", "0") != "0"
+EF_RC_MIN_ROWS = int(__import__("os").environ.get("MT_EF_RC_ROWS", "100000"))    # pixel rows from which the recompute form is used
 EF_PLANES = __import__("os").environ.get("MT_EF_PLANES", "1") != "0"
 EF_PLANES_EXPAND_HW = int(__import__("os").environ.get("MT_EF_PLANES_EXPAND_HW", "14"))
 EF_PLANES_PROJECT_HW = int(__import__("os").environ.get("MT_EF_PLANES_PROJECT_HW", "7"))
@@ -246,8 +254,14 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False, pla
         if s.has_expand:
             w_e, g, b = next(it), next(it), next(it)
             bn_e = _BNCtx(dev, s.cexp, training, pool)
-            z_e = _new(dev, M_in, s.cexp)
-            if pl_exp[bi]:
+            rc_on = (EF_RC and not L.deterministic() and M_in >= EF_RC_MIN_ROWS and w_e.data_ptr() % 16 == 0
+                     and lib.mt_dwconv_rc_supported(s.cin, s.cexp, s.k, s.s, s.hin) and lib.mt_conv1x1_rows_instance(s.cin, s.cexp))
+            z_e = None if rc_on else _new(dev, M_in, s.cexp)
+            if rc_on:
+                if training:      # BatchNorm statistics of the expanded tensor without the tensor: the product is formed and summed, not stored
+                    L.check(lib.mt_conv1x1_rows(L.ptr(y), None, L.ptr(w_e), s.cin, 0, None, None, None, 1, 0, None, None,
+                                                sptr(bn_e), slots, M_in, s.cin, s.cexp, st), "mt_conv1x1_rows")
+            elif pl_exp[bi]:
                 # late stages: y arrives as planes (written by the block above), the weight planes were split at the top
                 L.gemm_planes(L.OP_NT, y_p, wpl[("e", bi)], M_in, s.cexp, s.cin, Cout=z_e, ldc=s.cexp, epilogue=epi, stats=bn_e.stats,
                               stats_slots=slots)
@@ -258,15 +272,20 @@ def effnet_forward(model, x_nhwc, params, training, save, want_blocks=False, pla
             else:
                 L.gemm(L.OP_NT, y, w_e, z_e, M_in, s.cexp, s.cin, s.cin, s.cin, s.cexp, epilogue=epi, stats=bn_e.stats, stats_slots=slots)
             _finalize(lib, st, blk._bn0, bn_e, M_in, training, g, b, slots)
-            rec.update(z_e=z_e, bn_e=bn_e)
+            rec.update(z_e=z_e, bn_e=bn_e, rc=rc_on, w_e=w_e)
             dw_in, dw_bn = z_e, bn_e
         else:
+            rc_on = False
             dw_in, dw_bn = cur_z, cur_bn
         w_d, g, b = next(it), next(it), next(it)
         bn_d = _BNCtx(dev, s.cexp, training, pool)
         z_d = _new(dev, M_out, s.cexp)
-        L.check(lib.mt_dwconv_fwd(L.ptr(dw_in), L.ptr(dw_bn.scale), L.ptr(dw_bn.shift), L.ptr(w_d), L.ptr(z_d), sptr(bn_d),
-                                  slots, N, s.hin, s.hin, s.cexp, s.k, s.s, 1, st), "mt_dwconv_fwd")
+        if rc_on:
+            L.check(lib.mt_dwconv_fwd_rc(L.ptr(y), L.ptr(w_e), s.cin, L.ptr(dw_bn.scale), L.ptr(dw_bn.shift), L.ptr(w_d), L.ptr(z_d),
+                                         sptr(bn_d), slots, N, s.hin, s.hin, s.cexp, s.k, s.s, st), "mt_dwconv_fwd_rc")
+        else:
+            L.check(lib.mt_dwconv_fwd(L.ptr(dw_in), L.ptr(dw_bn.scale), L.ptr(dw_bn.shift), L.ptr(w_d), L.ptr(z_d), sptr(bn_d),
+                                      slots, N, s.hin, s.hin, s.cexp, s.k, s.s, 1, st), "mt_dwconv_fwd")
         _finalize(lib, st, blk._bn1, bn_d, M_out, training, g, b, slots)
         w_r, b_r, w_x, b_x = next(it), next(it), next(it), next(it)
         pooled, gate = _new(dev, N, s.cexp), _new(dev, N, s.cexp)

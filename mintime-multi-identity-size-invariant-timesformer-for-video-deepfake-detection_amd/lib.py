@@ -89,6 +89,9 @@ PROTOTYPES = {
     "mt_dwconv_fwd": [f32p, f32p, f32p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_int, C.c_void_p],
     "mt_dwconv_fwd_planes": [f32p] * 4 + [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p],
+    "mt_dwconv_rc_supported": [C.c_int] * 5,
+    "mt_dwconv_fwd_rc": [f32p, f32p, C.c_int, f32p, f32p, f32p, f32p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p],
+    "mt_dwconv_bwd_rc": [f32p] * 6 + [C.c_int] + [f32p] * 4 + [C.c_void_p, C.c_int, f32p] + [C.c_int] * 7 + [C.c_void_p],
     "mt_bn_finalize": [C.c_void_p, C.c_int, C.c_double, f32p, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_float,
                        C.c_float, C.c_int, C.c_void_p],
     "mt_se_pool_parts": [C.c_int, C.c_int, C.c_int],
@@ -126,6 +129,7 @@ PROTOTYPES = {
     "mt_maxpool_bn_bwd_apply_planes": [f32p, C.c_void_p, f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "mt_bn_bwd_apply": [f32p, f32p, f32p, f32p, i64, C.c_int, C.c_void_p],
     "mt_conv1x1_rows_supported": [C.c_int, C.c_int, C.c_int],
+    "mt_conv1x1_rows_instance": [C.c_int, C.c_int],
     "mt_conv1x1_rows": [f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p, C.c_void_p, C.c_int, C.c_int64,
                         C.c_int, C.c_int, C.c_void_p],
     "mt_bce_logits": [f32p, f32p, C.c_float, f32p, f32p, C.c_int, C.c_void_p],
@@ -179,7 +183,7 @@ def build(verbose: bool = False):
 
 # MT_VERSION of include/mintime_hip.h this binding was written against (tests/test_host_logic.py keeps the two equal; the package
 # itself does not need the header at run time -- it may be copied or installed without the repository's include/ directory)
-ABI_VERSION = 118
+ABI_VERSION = 119
 
 
 def header_version() -> int:

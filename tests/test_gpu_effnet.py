@@ -61,6 +61,45 @@ def test_block_outputs_match_oracle(training):
     assert_close(feat, ref, REL_TOL, "features vs oracle")
 
 
+@pytest.mark.parametrize("n,training", [(3, True), (9, True), (2, False)])
+def test_expand_recompute_matches_stored_expansion(n, training, monkeypatch):
+    """Blocks 1-3 with the expand convolution rebuilt inside the depthwise kernels (csrc/rc.hpp: the expanded tensor is never in
+    memory; BatchNorm statistics from a statistics-only pass) against the same network with the expanded tensor stored: features,
+    every parameter gradient and the running statistics.  n = 9 puts block 1 above the row count at which the expand convolution's
+    backward runs as the fused streaming kernel (no z needed); below it the backward rebuilds z with one GEMM -- both are covered.
+    The two forms differ by the summation order of a 16- / 24-term dot product (1 ulp of z)."""
+    from mintime_amd import effnet_engine as E
+    monkeypatch.setattr(E, "EF_RC_MIN_ROWS", 0)
+    x = _input(n, 5).cuda()
+    gen = torch.Generator().manual_seed(11)
+    wts = torch.randn(n, 1280, 7, 7, generator=gen).cuda()
+    out = {}
+    for rc in (False, True):
+        monkeypatch.setattr(E, "EF_RC", rc)
+        model, _ = _model(5, training)
+        if training:
+            feat = model(x)
+            (feat * wts).sum().backward()
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        else:
+            with torch.no_grad():
+                feat = model(x)
+            grads = {}
+        stats = {k: v.detach().clone() for k, v in model.state_dict().items() if "running_" in k}
+        out[rc] = (feat.detach().clone(), grads, stats)
+    ran = [b for b in model._blocks if b.spec.has_expand and E.L.get().mt_dwconv_rc_supported(b.spec.cin, b.spec.cexp, b.spec.k, b.spec.s, b.spec.hin)]
+    assert len(ran) == 3                      # blocks 1, 2, 3
+    assert_close(out[True][0], out[False][0], 2e-5, "features, recompute vs stored")
+    assert set(out[True][1]) == set(out[False][1])
+    for k in out[False][1]:
+        ref = out[False][1][k]
+        if k.endswith("_bn2.bias") and float(ref.norm()) < 1e-3 * float(out[False][1][k.replace(".bias", ".weight")].norm()):
+            continue      # analytically zero (the train-mode BatchNorm behind the next 1x1 conv removes a per-channel shift): rounding noise
+        assert_close(out[True][1][k], ref, 1e-4, f"grad {k}, recompute vs stored")
+    for k in out[False][2]:
+        assert_close(out[True][2][k], out[False][2][k], 2e-5, f"{k}, recompute vs stored")
+
+
 def test_nchw_contiguous_input_is_accepted():
     g = golden("ef_eval")
     model, _ = _model(int(g["seed"]), False)
