@@ -490,7 +490,12 @@ def main():
     opt = harness.make_optimizer(cfg, ef, tsf)
     batch = harness.device_batch(B, frames, wl["ids"], seed=rank, device=dev, ragged=a.ragged)
     # buckets in the order backward finishes them: the TimeSformer's 48 M gradients all-reduce under the EfficientNet backward
-    reducer = (ddp.OverlappedGradReducer([tsf, ef], force=a.force_reducer)
+    # ... and only the rows of the TimeSformer's two 21 MB embedding-gradient tables that the data can index go on the wire: positions
+    # reach F * 49, size buckets 20 (synth.clip_inputs / sequence.py keep the reference's ranges: deepfakes_dataset.py:259-263,324-329)
+    live_rows = {tsf.pos_emb.weight: frames * 49 + 1}
+    if getattr(tsf, "enable_size_emb", False):
+        live_rows[tsf.size_emb.weight] = 21
+    reducer = (ddp.OverlappedGradReducer([tsf, ef], force=a.force_reducer, live_rows=live_rows)
                if world > 1 or a.force_reducer else None)
     reducer_path = "none" if reducer is None else "overlapped"
 
@@ -602,6 +607,9 @@ def main():
                          **mfma_roofline(f_w / t_w if t_w else None, split_on),
                          "traffic": pmc("tsf_wgrad").get("bytes_per_launch"), "traffic_unit": "bytes/launch (family mean)",
                          "traffic_source": pmc("tsf_wgrad").get("source"),
+                         # the counter fields of this object and of roofline_ff1 / roofline_hbm are NOT measured in this run: they are read
+                         # from profiles/*_pmc_families.json (hash-tied to csrc/), collected with the weight-gradient stream off
+                         "pmc_mode": "serialised (side stream off), committed file, hash-tied to csrc/" if pmc("tsf_wgrad") else None,
                          "algorithmic_bytes": pmc("tsf_wgrad").get("algorithmic_bytes_per_launch"),
                          # matrix-pipe counters of the same family from the hash-tied PMC passes (serialised: side stream off):
                          # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), clock = GRBM_GUI_ACTIVE / 8 / wall

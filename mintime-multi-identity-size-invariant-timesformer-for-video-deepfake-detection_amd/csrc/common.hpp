@@ -91,7 +91,20 @@ __device__ __forceinline__ void xcd_chunk_tile(int chunks, int& chunk, int64_t& 
   stride = (int64_t)((gridDim.x >> 3) / chunks) * 8;
 }
 
+// (n, ty, tx) of a tile index in an [N][ty_n][tx_n] grid, in 32-bit unsigned arithmetic.  A 64-bit division by a run-time value is a
+// ~100-instruction scalar sequence, and the tile kernels decompose a tile index twice per tile: 1300 of the 2200 instructions of the
+// 3x3 depthwise data-gradient kernel were exactly that (round 6; the kernels are bound by instruction issue, not by bytes).  Tile
+// counts are far below 2^31 (xcd_chunk_grid refuses more).
+__device__ __forceinline__ void tile_nyx(int64_t tile, int ty_n, int tx_n, int& n, int& ty, int& tx) {
+  const unsigned t = (unsigned)tile, t2 = t / (unsigned)tx_n;
+  tx = (int)(t - t2 * (unsigned)tx_n);
+  const unsigned nn = t2 / (unsigned)ty_n;
+  ty = (int)(t2 - nn * (unsigned)ty_n);
+  n = (int)nn;
+}
+
 inline unsigned xcd_chunk_grid(int chunks, int64_t ntiles, int target_blocks) {
+  if (ntiles >= ((int64_t)1 << 31)) return 0;      // (a zero grid makes the launch fail loudly: tile_nyx works in 32 bits)
   int64_t per_xcd = target_blocks / (8 * chunks);
   const int64_t need = (ntiles + 7) / 8;
   if (per_xcd > need) per_xcd = need;

@@ -401,10 +401,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(
   RcFrag<RCW> ypre[RC ? NL : 1];
   unsigned pre_ok = 0, pd_ok = 0;
   auto fetch = [&](int64_t tile) {
-    const int tx = (int)(tile % tx_n);
-    const int64_t t2 = tile / tx_n;
-    const int ty = (int)(t2 % ty_n);
-    const int n = (int)(t2 / ty_n);
+    int n, ty, tx;
+    tile_nyx(tile, ty_n, tx_n, n, ty, tx);
     const int oh0 = ty * T, ow0 = tx * T;
     const int ih0 = oh0 * S - P, iw0 = ow0 * S - P;
     const float* img = RC ? zin + (int64_t)n * H * W * RC : zin + (int64_t)n * H * W * C + c0 + cq * 4;
@@ -586,10 +584,8 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
   float4 pdu[ND], pz[ND];
   unsigned pd_ok = 0;
   auto lows = [&](int64_t tile, int& n, int& ih0, int& iw0, int& oh_lo, int& ow_lo) {
-    const int tx = (int)(tile % tx_n);
-    const int64_t t2 = tile / tx_n;
-    const int ty = (int)(t2 % ty_n);
-    n = (int)(t2 / ty_n);
+    int ty, tx;
+    tile_nyx(tile, ty_n, tx_n, n, ty, tx);
     ih0 = ty * T; iw0 = tx * T;
     // first output row/col reachable from this tile: ceil((ih0 + P - (K-1)) / S), possibly negative
     const int nh = ih0 + P - (K - 1), nw = iw0 + P - (K - 1);

@@ -112,10 +112,8 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
   float4 pre[RC ? 1 : NL];
   unsigned pre_ok = 0;
   auto fetch = [&](int64_t tile) {
-    const int tx = (int)(tile % tx_n);
-    const int64_t t2 = tile / tx_n;
-    const int ty = (int)(t2 % ty_n);
-    const int n = (int)(t2 / ty_n);
+    int n, ty, tx;
+    tile_nyx(tile, ty_n, tx_n, n, ty, tx);
     const int ih0 = ty * T * S - pad0, iw0 = tx * T * S - pad0;
     const float* img = RC ? zin + (int64_t)n * H * W * RC : zin + (int64_t)n * H * W * C + c0 + cq * 4;
     pre_ok = 0;
@@ -133,10 +131,8 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
   int64_t tile = tile0;
   if (tile < ntiles) fetch(tile);
   for (; tile < ntiles; tile += tile_stride) {
-    const int tx = (int)(tile % tx_n);
-    const int64_t t2 = tile / tx_n;
-    const int ty = (int)(t2 % ty_n);
-    const int n = (int)(t2 / ty_n);
+    int n, ty, tx;
+    tile_nyx(tile, ty_n, tx_n, n, ty, tx);
     const int oh0 = ty * T, ow0 = tx * T;
     __syncthreads();
 #pragma unroll

@@ -92,9 +92,17 @@ class OverlappedGradReducer:
         loss.backward(); reducer.allreduce(); optimizer.step()
     """
 
-    def __init__(self, buckets, group=None, force=False, broadcast_init=True):
+    def __init__(self, buckets, group=None, force=False, broadcast_init=True, live_rows=None):
+        """live_rows: {parameter: n} -- only the first n rows of that (embedding-table) parameter ever receive gradient: the rest
+        of its gradient is exactly zero on every rank and is left out of the collective.  The TimeSformer's two tables are
+        [num_frames * channels + 1, dim] = 21 MB each (the reference's (sic) sizing, size_invariant_timesformer.py:172-180) while
+        positions only reach F * 49 and size buckets 20 (deepfakes_dataset.py:259-263,324-329): 42 of the bucket's 234 MB.  The
+        bound is the caller's data contract; the first `LIVE_ROW_CHECKS` engine launches verify that the skipped rows are zero."""
         self.group = group
         self.sync = True
+        self.live_rows = {id(p): int(n) for p, n in (live_rows or {}).items()}
+        self._segments = {}
+        self._live_checks_left = self.LIVE_ROW_CHECKS
         if broadcast_init:
             broadcast_module_state(buckets, group)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -118,6 +126,36 @@ class OverlappedGradReducer:
                     for p in b:
                         p.register_post_accumulate_grad_hook(self._make_hook(bi))
 
+    LIVE_ROW_CHECKS = 2
+
+    def _flat_segments(self, bi, params, flat):
+        """Contiguous [start, end) ranges of an engine's flat gradient buffer that go on the wire: everything but the dead rows of
+        the `live_rows` parameters (carving rule of lib.zero_grads: every view starts on a multiple of 4 floats)."""
+        key = (bi, flat.numel(), tuple(id(p) for p in params))
+        if key not in self._segments:
+            segs, dead, off = [], [], 0
+
+            def add(a, b):
+                if b <= a:
+                    return
+                if segs and segs[-1][1] >= a:
+                    segs[-1][1] = max(segs[-1][1], b)
+                else:
+                    segs.append([a, b])
+            for p in params:
+                size = p.numel()
+                padded = (size + 3) // 4 * 4
+                n = self.live_rows.get(id(p))
+                if n is not None and p.dim() >= 1 and 0 <= n < p.shape[0]:
+                    live_end = off + n * (size // p.shape[0])
+                    add(off, live_end)
+                    dead.append((live_end, off + size))
+                else:
+                    add(off, min(off + padded, flat.numel()))          # (the alignment padding -- zeros -- rides along)
+                off += padded
+            self._segments[key] = ([tuple(s_) for s_ in segs], dead)
+        return self._segments[key]
+
     # ---- engine-backed buckets ------------------------------------------------------------------------------------
     def _make_engine_hook(self, bi):
         def hook(params, flat):
@@ -129,15 +167,25 @@ class OverlappedGradReducer:
                 # and that contribution would never be reduced.  Drain the collective so memory stays sane, then refuse.
                 for work, _, back in self.pending:
                     if work is not None and back is not None and back[0] == "engine" and back[1] == bi:
-                        work.wait()
+                        for w_ in (work if isinstance(work, list) else [work]):
+                            w_.wait()
                 raise RuntimeError("OverlappedGradReducer: backward ran twice before allreduce(); wrap all but the last "
                                    "micro-batch in `with reducer.no_sync():` to accumulate gradients")
             # gradients that already exist (accumulated under no_sync) are ADDED to by autograd after this hook returns: leave
             # such a bucket to the synchronous path in allreduce()
             if any(p.grad is not None for p in params):
                 return
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.pending.append((work, flat, ("engine", bi, params)))
+            segs, dead = self._flat_segments(bi, params, flat) if self.live_rows else ([(0, flat.numel())], [])
+            if dead and self._live_checks_left > 0:
+                self._live_checks_left -= 1
+                if any(bool(flat[a:b].any()) for a, b in dead):
+                    raise RuntimeError("OverlappedGradReducer: a parameter's gradient is non-zero beyond its `live_rows` bound; "
+                                       "the bound does not hold for this data")
+            if len(segs) == 1 and segs[0] == (0, flat.numel()):
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                work = [dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for a, b in segs]
+            self.pending.append((work, flat, ("engine", bi, params, segs)))
             self.launched[bi] = True
             self.stats["overlapped_launches"] += 1
             self.stats["in_place"] += 1
@@ -234,12 +282,17 @@ class OverlappedGradReducer:
             ev[0].record()
         for work, flat, back in self.pending:
             if work is not None:
-                work.wait()
-            flat.mul_(1.0 / self.world)
+                for w_ in (work if isinstance(work, list) else [work]):
+                    w_.wait()
+            if back is not None and back[0] == "engine" and isinstance(work, list):
+                for a, b in back[3]:                                      # (the dead rows are zeros: nothing to scale)
+                    flat[a:b].mul_(1.0 / self.world)
+            else:
+                flat.mul_(1.0 / self.world)
             if back is not None and back[0] == "copy":
                 torch._foreach_copy_(back[1], back[2])
             elif back is not None:                                        # engine bucket: p.grad must still alias the buffer
-                _, bi, params = back
+                _, bi, params = back[:3]
                 base = flat.untyped_storage().data_ptr()
                 stale = [(p, v) for p, v in zip(params, self._views_like_zero_grads(params, flat))
                          if p.grad is not None and p.grad.untyped_storage().data_ptr() != base]

@@ -387,6 +387,16 @@ def test_config5_train_mode_step_vs_fp64_oracle():
     oloss = O.bce_with_logits(ologits, inp["labels"])
     oloss.backward()
     print(f"oracle fp64 config-5 step (64 crops) on the host: {time.time() - t0:.1f} s")
+    # the same oracle in float32: how far fp32 arithmetic ITSELF lands from fp64 for each tensor (ReLU / max-pool decisions that
+    # rounding flips) -- the per-tensor floor the HIP path is held to below
+    t0 = time.time()
+    f_xc = {k: (t.clone().requires_grad_("running_" not in k) if t.is_floating_point() else t.clone()) for k, t in xc_sd.items()}
+    f_tsf = {k: t.clone().requires_grad_(True) for k, t in tsf_sd.items()}
+    ffeat = O.xception_forward(f_xc, vid.float(), training=True)
+    flogits = O.tsf_forward(f_tsf, cfg, ffeat.reshape(B, F, 2048, 7, 7), inp["mask"], inp["identities_mask"], inp["size_embedding"],
+                            inp["positions"])
+    O.bce_with_logits(flogits, inp["labels"]).backward()
+    print(f"oracle fp32 config-5 step on the host: {time.time() - t0:.1f} s")
 
     assert_close(feats.reshape(B * F, 2048, 7, 7), ofeat.detach(), REL_TOL, "Xception features (train-mode BN)")
     assert_close(out, ologits.detach(), REL_TOL, "logits")          # per tensor: max|d| <= 1e-3 max|ref| (north_star)
@@ -414,9 +424,82 @@ def test_config5_train_mode_step_vs_fp64_oracle():
     # fp32 run is this far from its fp64 run)
     for k in ("conv4.pointwise.weight", "bn4.weight"):
         assert errs[k] <= 3 * REL_TOL, (k, errs[k])
-    assert max(errs.values()) <= 2e-2, errs
+    # EVERY Xception gradient, each against its own floor: 3e-3 + 2 x (the fp32 oracle's distance from the fp64 oracle for that
+    # tensor).  (Rounds 2-5 gated eleven tensors at a blanket 2e-2.)
+    worst_x, floors = (0.0, ""), {}
+    for k, p in xc.named_parameters():
+        ref = o_xc[k].grad
+        if p.grad is None or ref is None:
+            assert p.grad is None and ref is None, k
+            continue
+        den = float(ref.norm().clamp_min(1e-30))
+        floors[k] = float((f_xc[k].grad.double() - ref).norm()) / den
+        e = float((p.grad.cpu().double() - ref).norm()) / den
+        assert e <= 3 * REL_TOL + 2 * floors[k], f"grad {k}: rel-L2 {e:.3e} > 3e-3 + 2 x fp32 floor {floors[k]:.3e}"
+        if e > worst_x[0]:
+            worst_x = (e, k)
+    print("config 5 train step: worst Xception gradient", worst_x, "fp32-oracle floor there", floors.get(worst_x[1]),
+          "largest floor", max(floors.values()))
     # running statistics moved (momentum 0.1, torch defaults of models/xception.py) and the counters were bumped
     assert int(dict(xc.named_buffers())["bn1.num_batches_tracked"]) == 1
+
+
+def test_config5_full_size_equals_eight_quarter_steps():
+    """BASELINE config 5 at FULL size (B = 32 clips x 16 slots = 512 crops, 3 identities [7,5,4]) through a size-independent
+    property: with eval-mode BatchNorm no operation couples clips, so one step on the 32 clips must equal eight steps on 4 clips each
+    -- same features and logits, and the gradients of the 32-clip mean loss = the mean of the eight 4-clip gradients.  The 512-crop
+    launch geometry (1.5 GB tensors, other split-K / chunk choices than the 64-crop oracle test) is what bench.py --config 5 times.
+    Then one TRAIN-mode step at full size: finite loss / gradients / running statistics, loss within reach of the eval one."""
+    from mintime_amd import harness
+    B, F, seed = 32, 16, 5
+    cfg, xc, tsf = harness.build_models_xs(F, seed=seed, device="cuda")
+    xc.eval()
+    batch = harness.device_batch(B, F, 3, seed=seed, device="cuda")
+    params = list(xc.parameters()) + list(tsf.parameters())
+
+    def run(bt):
+        for p_ in params:
+            p_.grad = None
+        y = harness.forward(xc, tsf, bt)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(y, bt["labels"].reshape(-1, 1))
+        loss.backward()
+        return y.detach().clone(), float(loss.detach()), [None if p_.grad is None else p_.grad.detach().clone() for p_ in params]
+
+    y_full, loss_full, g_full = run(batch)
+    ys, acc = [], None
+    for q in range(8):
+        sl = slice(4 * q, 4 * q + 4)
+        y_q, _, g_q = run({k: v[sl] for k, v in batch.items()})
+        ys.append(y_q)
+        acc = g_q if acc is None else [a if b is None else (b if a is None else a + b) for a, b in zip(acc, g_q)]
+    y_cat = torch.cat(ys)
+    assert y_cat.shape == y_full.shape == (B, 1)
+    e_y = float((y_cat - y_full).abs().max() / y_full.abs().max())
+    print("config 5 full size: logits 32 clips vs 8 x 4 clips, max rel diff", e_y, "bit-equal" if torch.equal(y_cat, y_full) else "")
+    assert e_y <= 2e-6
+    worst = (0.0, "")
+    names = [k for k, _ in xc.named_parameters()] + [k for k, _ in tsf.named_parameters()]
+    for k, gf, ga in zip(names, g_full, acc):
+        if gf is None or ga is None:
+            assert gf is None and ga is None, k
+            continue
+        ga = ga / 8.0
+        den = float(gf.norm())
+        if den == 0.0:
+            assert float(ga.abs().max()) == 0.0, k
+            continue
+        e = float((ga - gf).norm()) / den
+        if e > worst[0]:
+            worst = (e, k)
+        # split-K ranges, atomic orders and chunk counts differ between the two geometries: rounding-level differences only
+        assert e <= 2e-5, f"grad {k}: 32-clip step vs mean of eight 4-clip steps, rel-L2 {e:.3e}"
+    print("config 5 full size: worst gradient difference", worst)
+    # train-mode BatchNorm at full size (what bench.py --config 5 runs): everything finite
+    xc.train()
+    y_t, loss_t, g_t = run(batch)
+    assert bool(torch.isfinite(y_t).all()) and loss_t == loss_t and abs(loss_t - loss_full) < 0.5
+    assert all(bool(torch.isfinite(g_).all()) for g_ in g_t if g_ is not None)
+    assert all(bool(torch.isfinite(b_).all()) for b_ in xc.buffers() if b_.is_floating_point())
 
 
 def test_native_bce_and_fused_sgd_match_torch():

@@ -67,7 +67,8 @@ def test_expand_recompute_matches_stored_expansion(n, training, monkeypatch):
     memory; BatchNorm statistics from a statistics-only pass) against the same network with the expanded tensor stored: features,
     every parameter gradient and the running statistics.  n = 9 puts block 1 above the row count at which the expand convolution's
     backward runs as the fused streaming kernel (no z needed); below it the backward rebuilds z with one GEMM -- both are covered.
-    The two forms differ by the summation order of a 16- / 24-term dot product (1 ulp of z)."""
+    The two forms differ by the summation order of a 16- / 24-term dot product (1 ulp of z), carried through 16 blocks of
+    train-mode BatchNorm: 1e-4 is 10x below the parity gate."""
     from mintime_amd import effnet_engine as E
     monkeypatch.setattr(E, "EF_RC_MIN_ROWS", 0)
     x = _input(n, 5).cuda()
@@ -89,7 +90,7 @@ def test_expand_recompute_matches_stored_expansion(n, training, monkeypatch):
         out[rc] = (feat.detach().clone(), grads, stats)
     ran = [b for b in model._blocks if b.spec.has_expand and E.L.get().mt_dwconv_rc_supported(b.spec.cin, b.spec.cexp, b.spec.k, b.spec.s, b.spec.hin)]
     assert len(ran) == 3                      # blocks 1, 2, 3
-    assert_close(out[True][0], out[False][0], 2e-5, "features, recompute vs stored")
+    assert_close(out[True][0], out[False][0], 1e-4, "features, recompute vs stored")
     assert set(out[True][1]) == set(out[False][1])
     for k in out[False][1]:
         ref = out[False][1][k]
@@ -97,7 +98,7 @@ def test_expand_recompute_matches_stored_expansion(n, training, monkeypatch):
             continue      # analytically zero (the train-mode BatchNorm behind the next 1x1 conv removes a per-channel shift): rounding noise
         assert_close(out[True][1][k], ref, 1e-4, f"grad {k}, recompute vs stored")
     for k in out[False][2]:
-        assert_close(out[True][2][k], out[False][2][k], 2e-5, f"{k}, recompute vs stored")
+        assert_close(out[True][2][k], out[False][2][k], 1e-4, f"{k}, recompute vs stored")
 
 
 def test_nchw_contiguous_input_is_accepted():

@@ -387,6 +387,80 @@ def test_engine_level_bucket_hooks_world_size_2_gloo():
         assert torch.equal(a, b)
 
 
+class _EngineEmbed(_EngineLike):
+    """An engine with an embedding-like table whose gradient only touches its first rows (the TimeSformer's pos_emb / size_emb:
+    [num_frames * channels + 1, dim] tables of which F * 49 + 1 / 21 rows are ever indexed)."""
+
+    def __init__(self, live):
+        super().__init__([(6,), (40, 4), (5,), (30, 4), (3,)], 3)
+        self.live = live
+
+    def forward(self, x):
+        model = self
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, *params):
+                ctx.save_for_backward(x)
+                return x * sum(p.sum() for p in params)
+
+            @staticmethod
+            def backward(ctx, gout):
+                (x,) = ctx.saved_tensors
+                params = list(model.ps)
+                grads, flat = lib.zero_grads(params, with_flat=True)
+                for p, gr in zip(params, grads):
+                    rows = model.live.get(id(p))
+                    (gr if rows is None else gr[:rows]).add_(float((gout * x).sum()))
+                lib.grads_ready(model, params, flat)
+                return (gout * sum(p.sum() for p in params).detach(),) + tuple(grads)
+
+        return Fn.apply(x, *self.ps)
+
+
+def _live_rows_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    for tag, declare in (("full", False), ("live", True), ("wrong", True)):
+        net = _EngineEmbed({})
+        ps = list(net.parameters())
+        net.live = {id(ps[1]): 3, id(ps[3]): 7} if tag != "wrong" else {id(ps[1]): 5, id(ps[3]): 7}    # rows the backward really touches
+        red = ddp.OverlappedGradReducer([net], live_rows={ps[1]: 3, ps[3]: 7} if declare else None)
+        try:
+            net(torch.full((3,), float(rank + 1))).sum().backward()
+            red.allreduce()
+            res[tag] = ([p.grad.clone() for p in ps], dict(red.stats), list(red._segments.values()))
+        except RuntimeError as e:
+            res[tag] = str(e)
+            for w_, _, _ in red.pending:
+                for x_ in (w_ if isinstance(w_, list) else [w_]):
+                    x_.wait()
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_live_rows_of_embedding_tables_world_size_2_gloo():
+    """SURVEY 8(e) / round-5 verdict item 8: only the live rows of the TimeSformer's embedding-gradient tables go on the wire.  Same
+    averaged gradients as the full all-reduce; the wire ranges skip the dead rows; a bound the data violates is refused loudly."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 36500 + (os.getpid() % 2000)
+    mp.spawn(_live_rows_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    for a, b, c, d in zip(r0["full"][0], r0["live"][0], r1["full"][0], r1["live"][0]):
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    assert torch.allclose(r0["live"][0][1][:3], torch.full((3, 4), 4.5)) and not r0["live"][0][1][3:].any()     # mean of 3 and 6; dead rows zero
+    (segs, dead), = r0["live"][2]
+    # flat layout: 6 -> [0, 8); table 40 x 4 at 8: live [8, 20), dead [20, 168); 5 -> [168, 176); table 30 x 4 at 176: live [176, 204), dead [204, 296); 3 -> [296, 300)
+    assert segs == [(0, 20), (168, 204), (296, 300)] and dead == [(20, 168), (204, 296)]
+    assert sum(b - a for a, b in segs) == 60 and r0["live"][1]["overlapped_launches"] == 1
+    assert "live_rows" in r0["wrong"] and "live_rows" in r1["wrong"]
+
+
 class _EngineLikeOptional(_EngineLike):
     """An engine whose parameter list has an empty slot (SizeInvariantTimeSformer._param_list() puts None where size_emb would
     be when enable-size-emb is False): the None is handed to lib.zero_grads / lib.grads_ready exactly like tsf_backward does."""

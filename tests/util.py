@@ -46,3 +46,11 @@ def dropout_multipliers(g, batch, tokens, dim):
             bits = np.unpackbits(g[f"keep.{li}.{kind}"])[:batch * tokens * width]
             out[(li, kind)] = torch.from_numpy(bits.astype(np.float32)).reshape(batch, tokens, width) / (1.0 - p)
     return out
+
+
+def probe_vector(name, n, seed=0):
+    """Fixed pseudo-random weights r in [-1, 1) for the whole-tensor checksum pair (sum g, sum g*r) of a parameter gradient:
+    numpy Philox keyed by (seed, crc32(name)) -- the same vector in tools/make_golden.py (reference side) and in the GPU tests."""
+    import zlib
+    rng = np.random.Generator(np.random.Philox(key=[int(seed), zlib.crc32(name.encode())]))
+    return rng.uniform(-1.0, 1.0, int(n))

@@ -428,6 +428,10 @@ def e2e_full_case(EF, TSF, name, batch, frames, identities, seed, rate=0.2, chec
             out["gnorm64." + mtag + key] = g.norm()
             out["gabsmax64." + mtag + key] = g.abs().max()
             out["gsample64." + mtag + key] = g[::step][:256].clone()
+            # whole-tensor checksum pair: every element is weighted (a tile-local defect between the 256 samples moves these)
+            from tests.util import probe_vector
+            out["gsum64." + mtag + key] = g.sum()
+            out["gdot64." + mtag + key] = (g * torch.from_numpy(probe_vector(mtag + key, g.numel(), seed))).sum()
     for key in ("_bn0.running_mean", "_blocks.3._bn1.running_var", "_blocks.10._bn2.running_mean", "_bn1.running_var"):
         out["stat64." + key] = stats_after_forward[key]
     save(name, input_sum=checksum(inp["videos"]), batch=batch, frames=frames, identities=identities, seed=seed, rate=rate, **out)
