@@ -10,6 +10,15 @@ from mintime_amd import arch, synth, EfficientNet, SizeInvariantTimeSformer
 from oracle import mintime_oracle as O
 from tests.util import REL_TOL, assert_close, golden, rel_err
 
+# Gradient gates.  north_star states 1e-3 for OUTPUTS (REL_TOL: logits, features, loss, attentions' per-tensor gate); gradients had
+# been gated at 2-3x that.  Round 6 measured every comparison of this file on an MI355X (MT_TEST_VERBOSE=1, gpurun_out/r06_e2e_verbose.log)
+# and set each gate to ~2x the worst case seen (DESIGN.md section 4 lists the measurements):
+GRAD_TOL_EF = 6e-4          # EfficientNet parameter gradients, every size: worst 2.6e-4 (config 2, live fp64 oracle), 3.0e-4 (config 3 fixture)
+GRAD_TOL_TSF = 4e-4         # TimeSformer gradients behind the EfficientNet: worst 1.9e-4
+GRAD_TOL_TSF_XS = 2e-3      # ... behind the train-mode Xception (config 5, ReLU / max-pool decisions upstream): worst 1.0e-3
+GRAD_TOL_SLICE = 8e-4       # 256-element gradient slices of the small fixtures: worst 3.5e-4
+ATT_TOL = 3e-4              # cls attention maps: worst 1.1e-4
+
 pytestmark = pytest.mark.gpu
 
 
@@ -62,8 +71,8 @@ def _check_step_against_fixture(name):
     # that by up to 8e-3 on the train-mode case (tools/make_golden.py: e2e_case) -- more than this path does.
     assert_close(y_pred, g["logits64"], REL_TOL, "logits")
     assert_close(loss, g["loss64"], REL_TOL, "loss")
-    assert_close(s_att, g["space_att64"], 2 * REL_TOL, "space attention")
-    assert_close(t_att, g["time_att64"], 2 * REL_TOL, "time attention")
+    assert_close(s_att, g["space_att64"], ATT_TOL, "space attention")
+    assert_close(t_att, g["time_att64"], ATT_TOL, "time attention")
     assert_close(features.mean(dim=(0, 1, 3, 4)), g["feat_mean64"], REL_TOL, "feature mean")
     ours_vs_exact = rel_err(y_pred, g["logits64"])
     ref32_vs_exact = rel_err(g["logits"], g["logits64"])
@@ -74,8 +83,8 @@ def _check_step_against_fixture(name):
             if k.startswith("gnorm64." + tag):
                 key = k[len("gnorm64." + tag):]
                 assert named[key].grad is not None, key
-                assert_close(named[key].grad.norm(), g[k], 2 * REL_TOL, k)
-                assert_close(named[key].grad.reshape(-1)[:256], g["gslice64." + tag + key], 3 * REL_TOL, "gslice " + k)
+                assert_close(named[key].grad.norm(), g[k], GRAD_TOL_TSF, k)                      # (norms: worst 4.5e-5)
+                assert_close(named[key].grad.reshape(-1)[:256], g["gslice64." + tag + key], GRAD_TOL_SLICE, "gslice " + k)
 
 
 # The full-size steps are judged against committed float64 runs of the imported reference (test_full_size_training_step_vs_reference_
@@ -115,7 +124,7 @@ def test_effnet_backward_all_parameters_vs_oracle(training):
             wn = float(dict(ef.named_parameters())[k.replace(".bias", ".weight")].grad.norm())
             assert float(p.grad.norm()) < 1e-3 * wn and float(ref.norm()) < 1e-3 * wn, k
             continue
-        worst = max(worst, assert_close(p.grad, ref, 3 * REL_TOL, "grad " + k))
+        worst = max(worst, assert_close(p.grad, ref, GRAD_TOL_EF, "grad " + k))          # (worst measured here: 2.3e-5)
     print("worst relative gradient error", worst)
 
 
@@ -162,7 +171,7 @@ def test_config3_full_size_training_step_vs_oracle(B, ids, tag):
         if float(ref.abs().max()) == 0.0:
             assert float(p.grad.abs().max()) == 0.0, k
         else:
-            worst = max(worst, assert_close(p.grad, ref, 2 * REL_TOL, "tsf grad " + k))
+            worst = max(worst, assert_close(p.grad, ref, GRAD_TOL_TSF, "tsf grad " + k))
     for k, p in ef.named_parameters():
         if k.startswith("_fc"):
             continue
@@ -172,7 +181,7 @@ def test_config3_full_size_training_step_vs_oracle(B, ids, tag):
             if float(ref.norm()) < 1e-3 * wn:       # analytically zero (see test_effnet_backward_all_parameters_vs_oracle)
                 assert float(p.grad.norm()) < 1e-3 * wn, k
                 continue
-        worst = max(worst, assert_close(p.grad, ref, 3 * REL_TOL, "ef grad " + k))
+        worst = max(worst, assert_close(p.grad, ref, GRAD_TOL_EF, "ef grad " + k))
     print(tag, "full size: worst relative gradient error", worst)
 
 
@@ -217,8 +226,8 @@ def test_full_size_training_step_vs_reference_fixture(name, B, ids):
     esd = ef.state_dict()
     for key in [k[len("stat64."):] for k in g.files if k.startswith("stat64.")]:
         assert_close(esd[key], torch.from_numpy(g["stat64." + key]), REL_TOL, "running statistic " + key)
-    worst, n = 0.0, 0
-    for tag, model, tol in (("tsf.", tsf, 2 * REL_TOL), ("ef.", ef, 3 * REL_TOL)):
+    worst, n, worst_c, worst_s, n_c = 0.0, 0, 0.0, 0.0, 0
+    for tag, model, tol in (("tsf.", tsf, GRAD_TOL_EF), ("ef.", ef, GRAD_TOL_EF)):      # (sample / norm / checksum errors: worst 3.0e-4 / 3.7e-4)
         named = dict(model.named_parameters())
         for key in [k[len("gnorm64." + tag):] for k in g.files if k.startswith("gnorm64." + tag)]:
             got = named[key].grad.detach().double().cpu().reshape(-1)
@@ -238,8 +247,25 @@ def test_full_size_training_step_vs_reference_fixture(name, B, ids):
             assert err <= tol and nerr <= tol, f"{tag}{key}: sample error {err:.2e}, norm error {nerr:.2e} (tolerance {tol:.0e})"
             worst = max(worst, err, nerr)
             n += 1
+            if "gdot64." + tag + key in g.files:
+                # whole-tensor checksum pair of the reference's gradient: sum g and sum g*r for the fixed pseudo-random r of
+                # tests/util.probe_vector -- EVERY element is weighted, so a tile-local defect that sits between the 256 samples and
+                # moves the norm by less than the gate still shows here.  Normalised so that an error vector d with random signs
+                # gives |d . r| / (rms(r) |g|) ~ |sum d| / |g| ~ |d| / |g| (the relative L2 error).
+                from tests.util import probe_vector
+                r = torch.from_numpy(probe_vector(tag + key, got.numel(), int(g["seed"])))
+                cdot = abs(float((got * r).sum()) - float(g["gdot64." + tag + key])) / (0.57735 * ref_norm)
+                csum = abs(float(got.sum()) - float(g["gsum64." + tag + key])) / ref_norm
+                assert cdot <= 8e-4, f"{tag}{key}: checksum sum(g*r) off by {cdot:.2e} |g|"          # (worst measured 3.7e-4)
+                # sum g adds a SYSTEMATIC error coherently (sqrt(numel) x the random-sign case): it is the bias detector
+                assert csum <= 1e-2, f"{tag}{key}: checksum sum(g) off by {csum:.2e} |g|"             # (worst measured 4.8e-3)
+                worst_c = max(worst_c, cdot)
+                worst_s = max(worst_s, csum)
+                n_c += 1
     assert n > 300
-    print(f"{name}: {n} parameter gradients within {worst:.2e} of the reference's float64 step")
+    print(f"{name}: {n} parameter gradients within {worst:.2e} of the reference's float64 step; whole-tensor checksums of {n_c}: "
+          f"sum(g*r) within {worst_c:.2e} |g|, sum(g) within {worst_s:.2e} |g|")
+    assert n_c == n or n_c == 0
 
 
 def test_hip_graph_replay_matches_eager_eval():
@@ -346,7 +372,7 @@ def test_config5_xception_timesformer_step_vs_oracle():
     tsf_named = dict(tsf.named_parameters())
     for k in ("to_patch_embedding.weight", "pos_emb.weight", "layers.0.0.fn.to_qkv.weight", "layers.4.1.fn.to_out.0.weight",
               "layers.8.2.fn.net.0.weight", "to_out.1.weight"):
-        assert_close(tsf_named[k].grad, o_tsf[k].grad, 3 * REL_TOL, "grad " + k)
+        assert_close(tsf_named[k].grad, o_tsf[k].grad, REL_TOL, "grad " + k)               # (worst measured: 4.8e-4)
     xc_named = dict(xc.named_parameters())
     for k in ("conv4.pointwise.weight", "block12.rep.4.pointwise.weight", "block6.rep.1.conv1.weight", "block1.skip.weight",
               "conv1.weight"):
@@ -409,7 +435,7 @@ def test_config5_train_mode_step_vs_fp64_oracle():
         if float(ref.abs().max()) == 0.0:
             assert float(p.grad.abs().max()) == 0.0, k
             continue
-        worst = max(worst, assert_close(p.grad, ref, 3 * REL_TOL, "grad " + k))
+        worst = max(worst, assert_close(p.grad, ref, GRAD_TOL_TSF_XS, "grad " + k))
     print("config 5 train step: worst TimeSformer gradient error", worst)
     xc_named = dict(xc.named_parameters())
     errs = {}
@@ -763,10 +789,10 @@ def test_partially_frozen_extractor_matches_oracle_and_skips_frozen_work(unfreez
         n_train += 1
         if k.endswith("_bn2.bias"):
             continue                       # analytically zero under train-mode BN (see test_effnet_backward_all_parameters_vs_oracle)
-        assert_close(p.grad, eo[k].grad, 3 * REL_TOL, "grad " + k)
+        assert_close(p.grad, eo[k].grad, GRAD_TOL_EF, "grad " + k)
     for k, p in tsf.named_parameters():
         if float(to[k].grad.abs().max()) > 0:
-            assert_close(p.grad, to[k].grad, 3 * REL_TOL, "tsf grad " + k)
+            assert_close(p.grad, to[k].grad, GRAD_TOL_TSF, "tsf grad " + k)
     if unfreeze == 0:
         # nothing in the extractor is trainable: its backward never runs, the TimeSformer skips the feature gradient
         assert n_train == 0 and EB.LAST_RUN["blocks_run"] == -1
@@ -800,4 +826,4 @@ def test_frozen_backbone_step_like_train_py():
     assert_close(y, yo, REL_TOL, "logits")
     for k, p in tsf.named_parameters():
         if float(to[k].grad.abs().max()) > 0:
-            assert_close(p.grad, to[k].grad, 3 * REL_TOL, "tsf grad " + k)
+            assert_close(p.grad, to[k].grad, GRAD_TOL_TSF, "tsf grad " + k)
