@@ -103,6 +103,12 @@ __device__ __forceinline__ void tile_nyx(int64_t tile, int ty_n, int tx_n, int& 
   n = (int)nn;
 }
 
+// rows / hw for a uniform row index: 32-bit when it fits (a 64-bit division by a run-time value is a ~100-instruction scalar sequence,
+// paid once per 64- / 128-row chunk by the streaming kernels)
+__device__ __forceinline__ int64_t div_rows(int64_t r, int hw) {
+  return (r >> 32) ? r / hw : (int64_t)((unsigned)r / (unsigned)hw);
+}
+
 inline unsigned xcd_chunk_grid(int chunks, int64_t ntiles, int target_blocks) {
   if (ntiles >= ((int64_t)1 << 31)) return 0;      // (a zero grid makes the launch fail loudly: tile_nyx works in 32 bits)
   int64_t per_xcd = target_blocks / (8 * chunks);

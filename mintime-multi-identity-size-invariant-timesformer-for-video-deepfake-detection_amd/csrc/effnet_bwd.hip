@@ -753,7 +753,8 @@ int launch_dw_bwd_tiled_any(const float* du, const float* z, const float* kabc, 
                             const float* shift_in, const float* mi_in, float* du_in, double* stats, int slots, float* dw, int N, int H,
                             int W, int C, int Ho, int Wo, int parts, const float* res_pre, const float* res_post, hipStream_t s) {
   int rc = 0;
-  const bool t14o = Ho >= 14, t14i = H >= 14;
+  static const int t7_mask = getenv("MT_DW_T7") ? atoi(getenv("MT_DW_T7")) : 0;       // lab: bit 1 = 7 x 7 tiles in the data gradient, bit 2 = in the weight gradient
+  const bool t14o = Ho >= 14 && !(t7_mask & 4), t14i = H >= 14 && !(t7_mask & 2);
   if (parts == 3) {       // one pass over du / z / the dw input for both gradients
     if (C % 16 == 0) return t14i ? launch_dw_dgrad_tiled<K, S, 14, ACT, 16, true>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, res_pre, res_post, s, dw)
                                  : launch_dw_dgrad_tiled<K, S, 7, ACT, 16, true>(du, z, kabc, w, zin, scale_in, shift_in, mi_in, du_in, stats, slots, N, H, W, C, Ho, Wo, res_pre, res_post, s, dw);

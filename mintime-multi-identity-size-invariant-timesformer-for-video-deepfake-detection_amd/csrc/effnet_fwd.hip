@@ -222,7 +222,8 @@ int launch_dw_tiled(const float* zin, const float* scale, const float* shift, co
 template <int K, int S, int ACT>
 int launch_dw_tiled_any(const float* zin, const float* scale, const float* shift, const float* w, float* zout, double* stats,
                         int slots, int N, int H, int W, int C, int Ho, int Wo, int pad0, hipStream_t s, const PlaneRef& po) {
-  const bool t14 = Ho >= 14;
+  static const int t7_mask = getenv("MT_DW_T7") ? atoi(getenv("MT_DW_T7")) : 0;       // lab: bit 0 = 7 x 7 tiles in the forward kernel
+  const bool t14 = Ho >= 14 && !(t7_mask & 1);
   if (C % 16 == 0) {
     if (t14) return launch_dw_tiled<K, S, 14, ACT, 16>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s, po);
     return launch_dw_tiled<K, S, 7, ACT, 16>(zin, scale, shift, w, zout, stats, slots, N, H, W, C, Ho, Wo, pad0, s, po);

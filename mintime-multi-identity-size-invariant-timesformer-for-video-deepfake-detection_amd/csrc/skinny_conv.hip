@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void conv1x1_rows_kernel(ConvArgs p) {
     const int left = (int)((p.rows - r0) < R ? (p.rows - r0) : R);
     int64_t img0 = 0;
     int rem0 = 0;
-    if constexpr (AMODE == A_GATE) { img0 = r0 / p.hw; rem0 = (int)(r0 - img0 * p.hw); }
+    if constexpr (AMODE == A_GATE) { img0 = div_rows(r0, p.hw); rem0 = (int)(r0 - img0 * p.hw); }
 #pragma unroll
     for (int i = 0; i < VA; ++i) {
       if (ar[i] < 0) continue;

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void se_stage_kernel(SeArgs p) {
   for (int64_t chunk = c_lo; chunk < c_hi; ++chunk) {
     const int64_t r0 = chunk * R;
     const int left = (int)((p.rows - r0) < R ? (p.rows - r0) : R);
-    const int64_t img = r0 / p.hw;                   // hw % R == 0: a chunk lies inside one image
+    const int64_t img = div_rows(r0, p.hw);                   // hw % R == 0: a chunk lies inside one image
     if (MODE == MODE_RED && img != cur_img) {
       if (cur_img >= 0) flush_gate();
       cur_img = img;

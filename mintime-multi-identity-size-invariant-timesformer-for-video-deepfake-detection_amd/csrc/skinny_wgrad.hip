@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
     if constexpr (GATE) {
-      const int64_t img0 = r0 / p.hw;                      // uniform: one division per chunk
+      const int64_t img0 = div_rows(r0, p.hw);                      // uniform: one division per chunk
       const int rem0 = (int)(r0 - img0 * p.hw);
 #pragma unroll
       for (int i = 0; i < VA; ++i) {

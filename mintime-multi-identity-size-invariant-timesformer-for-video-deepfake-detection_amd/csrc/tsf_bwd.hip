@@ -478,6 +478,50 @@ __global__ void head_bwd_kernel(const float* __restrict__ dlogits, const float* 
   }
 }
 
+// The same with one block per clip (default mode): the single block above walks the B clips one after the other with six block barriers
+// each -- 70 us at B = 32 on the head of the backward pass, where nothing else can run yet.  Parameter gradients meet in atomics.
+__global__ void head_bwd_clips_kernel(const float* __restrict__ dlogits, const float* __restrict__ x, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, const float* __restrict__ w, float* __restrict__ dx,
+                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dw,
+                                      float* __restrict__ dbias, int B, int N, int D, int C, float eps) {
+  __shared__ float red[2][16];
+  const int i = threadIdx.x, b = blockIdx.x;
+  const int lane = i & 63, wv = i >> 6, nw = blockDim.x >> 6;
+  auto block_sum2 = [&](float a, float c, float& oa, float& oc) {
+    a = wave_sum(a); c = wave_sum(c);
+    __syncthreads();
+    if (lane == 0) { red[0][wv] = a; red[1][wv] = c; }
+    __syncthreads();
+    float sa = 0.f, sc = 0.f;
+    for (int k = 0; k < nw; ++k) { sa += red[0][k]; sc += red[1][k]; }
+    oa = sa; oc = sc;
+  };
+  const float gi = gamma[i], bi = beta[i];
+  const float xv = x[(int64_t)b * N * D + i];
+  float s, dummy;
+  block_sum2(xv, 0.f, s, dummy);
+  const float mean = s / (float)D;
+  float ss;
+  block_sum2((xv - mean) * (xv - mean), 0.f, ss, dummy);
+  const float rstd = rsqrtf(ss / (float)D + eps);
+  const float xh = (xv - mean) * rstd;
+  const float xn = xh * gi + bi;
+  float dxn = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float dl = dlogits[b * C + c];
+    dxn += dl * w[(int64_t)c * D + i];
+    atomicAdd(dw + (int64_t)c * D + i, dl * xn);
+  }
+  atomicAdd(dgamma + i, dxn * xh);
+  atomicAdd(dbeta + i, dxn);
+  const float gy = dxn * gi;
+  float c1, c2;
+  block_sum2(gy, gy * xh, c1, c2);
+  c1 /= (float)D; c2 /= (float)D;
+  dx[(int64_t)b * N * D + i] = rstd * (gy - c1 - xh * c2);
+  if (i < C) atomicAdd(dbias + i, dlogits[b * C + i]);
+}
+
 // ---------------------------------------------------------------------------------------- embeddings backward
 // dcls += sum_b dx[b,0]; dpos[positions[b,t]] += dx[b,t]; dsize[size idx] += dx[b,t]   (atomics; tables pre-zeroed)
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dcls,
@@ -499,6 +543,45 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     if (t == 0 && dcls) atomicAdd(dcls + i, v);
     if (dpos) atomicAdd(dpos + pi * D + i, v);
     if (dsize) atomicAdd(dsize + (int64_t)si * D + i, v);
+  }
+}
+
+// One block per (clip, frame slot): the n tokens of a slot share their size row, so the block sums them in registers and issues ONE
+// atomic per column for it (the row-per-wavefront kernel above sends B N D atomics at ~21 live rows: 600 adds per address); position
+// rows differ per token and keep one atomic each.  Block (b, 0) also carries the cls row.
+__global__ __launch_bounds__(256) void embed_bwd_slots_kernel(const float* __restrict__ dx, float* __restrict__ dcls,
+                                                              float* __restrict__ dpos, float* __restrict__ dsize,
+                                                              const int64_t* __restrict__ positions, const int* __restrict__ sizes,
+                                                              int B, int N, int n, int F, int D, int pos_rows, int size_rows) {
+  const int b = blockIdx.x / F, f = blockIdx.x - b * F;
+  int si = sizes ? sizes[b * F + f] : 0;
+  si = si < 0 ? 0 : (si >= size_rows ? size_rows - 1 : si);
+  const int row0 = b * N + 1 + f * n;
+  for (int i = threadIdx.x; i < D; i += 256) {
+    float acc = 0.f;
+#pragma unroll 7
+    for (int t = 0; t < n; ++t) {
+      const int row = row0 + t;
+      const float v = dx[(int64_t)row * D + i];
+      acc += v;
+      if (dpos) {
+        int64_t pi = positions ? positions[row] : (int64_t)(1 + f * n + t);
+        pi = pi < 0 ? 0 : (pi >= pos_rows ? pos_rows - 1 : pi);
+        atomicAdd(dpos + pi * D + i, v);
+      }
+    }
+    if (dsize) atomicAdd(dsize + (int64_t)si * D + i, acc);
+    if (f == 0) {                                      // the cls token of this clip: position row as given, size row 0
+      const int row = b * N;
+      const float v = dx[(int64_t)row * D + i];
+      if (dcls) atomicAdd(dcls + i, v);
+      if (dpos) {
+        int64_t pi = positions ? positions[row] : 0;
+        pi = pi < 0 ? 0 : (pi >= pos_rows ? pos_rows - 1 : pi);
+        atomicAdd(dpos + pi * D + i, v);
+      }
+      if (dsize) atomicAdd(dsize + i, v);
+    }
   }
 }
 
@@ -1535,8 +1618,12 @@ extern "C" int mt_head_bwd(const float* dlogits, const float* x, const float* ga
     return fail(MT_ERR_ARG, "mt_head_bwd: null pointer");
   if (dim > 1024 || (dim & 63)) return fail(MT_ERR_ARG, "mt_head_bwd: dim %d unsupported (multiple of 64, <= 1024)", dim);
   if (classes > dim) return fail(MT_ERR_ARG, "mt_head_bwd: classes > dim");
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(1), dim3(dim), 0, (hipStream_t)stream, dlogits, x, gamma, beta, w, dx, dgamma, dbeta, dw,
-                     dbias, B, N, dim, classes, eps);
+  if (det_enabled() || B < 2)
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(1), dim3(dim), 0, (hipStream_t)stream, dlogits, x, gamma, beta, w, dx, dgamma, dbeta, dw,
+                       dbias, B, N, dim, classes, eps);
+  else
+    hipLaunchKernelGGL(head_bwd_clips_kernel, dim3(B), dim3(dim), 0, (hipStream_t)stream, dlogits, x, gamma, beta, w, dx, dgamma, dbeta,
+                       dw, dbias, B, N, dim, classes, eps);
   return check_launch("mt_head_bwd");
 }
 
@@ -1572,8 +1659,13 @@ extern "C" int mt_embed_bwd(const float* dx, float* dcls, float* dpos_emb, float
     }
     return 0;
   }
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((B * N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dx, dcls, dpos_emb, dsize_emb,
-                     positions, sizes, B, N, n, F, dim, pos_rows, dsize_emb ? size_rows : 1);
+  static const bool rows_form = getenv("MT_EMBED_BWD_ROWS") != nullptr;        // A/B aid: the row-per-wavefront kernel
+  if (rows_form || F * n + 1 != N)
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((B * N + 3) / 4), dim3(256), 0, (hipStream_t)stream, dx, dcls, dpos_emb, dsize_emb,
+                       positions, sizes, B, N, n, F, dim, pos_rows, dsize_emb ? size_rows : 1);
+  else
+    hipLaunchKernelGGL(embed_bwd_slots_kernel, dim3(B * F), dim3(256), 0, (hipStream_t)stream, dx, dcls, dpos_emb, dsize_emb,
+                       positions, sizes, B, N, n, F, dim, pos_rows, dsize_emb ? size_rows : 1);
   return check_launch("mt_embed_bwd");
 }
 

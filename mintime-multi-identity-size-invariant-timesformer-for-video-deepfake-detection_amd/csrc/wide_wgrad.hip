@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512) void wgrad_wide_kernel(WideArgs p) {
       }
       const float* xc = p.x + c0 + acl;
       const float* gc = p.gate + c0 + acl;
-      const int64_t img0 = r0 / p.hw;                        // uniform: one division per chunk
+      const int64_t img0 = div_rows(r0, p.hw);                        // uniform: one division per chunk
       const int rem0 = (int)(r0 - img0 * p.hw);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
