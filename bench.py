@@ -124,7 +124,7 @@ def cpu_baseline(num_frames, seed, budget_s=20.0):
     return res
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_families.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_families.json")
 _PMC_WARNED = []
 
 
@@ -489,6 +489,8 @@ def main():
         cfg, ef, tsf = harness.build_models(frames, seed=0, device=dev)          # train-mode BN + drop-connect 0.2 (train.py:157)
     opt = harness.make_optimizer(cfg, ef, tsf)
     batch = harness.device_batch(B, frames, wl["ids"], seed=rank, device=dev, ragged=a.ragged)
+    if os.environ.get("MT_BENCH_SE_DEVICE"):        # lab: size_embedding already on the device (the reference's callers keep it on the host)
+        batch["size_embedding"] = batch["size_embedding"].to(dev)
     # buckets in the order backward finishes them: the TimeSformer's 48 M gradients all-reduce under the EfficientNet backward
     # ... and only the rows of the TimeSformer's two 21 MB embedding-gradient tables that the data can index go on the wire: positions
     # reach F * 49, size buckets 20 (synth.clip_inputs / sequence.py keep the reference's ranges: deepfakes_dataset.py:259-263,324-329)

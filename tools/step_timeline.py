@@ -7,7 +7,9 @@ from collections import defaultdict
 ap = argparse.ArgumentParser()
 ap.add_argument("csv")
 ap.add_argument("--start", default="stem_mfma_kernel", help="substring of the kernel that starts a step (the stem kernel)")
-ap.add_argument("--steps-from-end", type=int, default=2)
+ap.add_argument("--steps-from-end", type=int, default=6,
+                help="which step of the trace: bench.py ends with three enqueue-timing steps that follow a synchronize (the host is not "
+                     "ahead there and its launch latency shows as device idle); 6 from the end lies inside the timed region")
 ap.add_argument("--top", type=int, default=40, help="symbols listed per queue")
 a = ap.parse_args()
 rows = sorted(csv.DictReader(open(a.csv)), key=lambda r: int(r["Start_Timestamp"]))
