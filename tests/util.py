@@ -8,6 +8,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # north_star tolerance: outputs within 1e-3 relative, fp32.
 REL_TOL = 1e-3
+# gradient gate of the kernel-level / small-fixture tests: ~4x the worst case measured over every comparison of test_gpu_tsf.py,
+# test_gpu_effnet.py and test_gpu_xception.py on an MI355X (4.4e-5, round 6); the full-size gates live in test_gpu_e2e.py
+GRAD_TOL_UNIT = 2e-4
 
 
 def golden(name):
