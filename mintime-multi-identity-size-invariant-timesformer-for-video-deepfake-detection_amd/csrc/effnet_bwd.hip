@@ -521,10 +521,14 @@ int launch_dw_wgrad_tiled(const float* du, const float* z, const float* kabc, co
 // One block = one 16-channel chunk, grid-strided over T x T INPUT tiles.  dz = ka*du+kb*z+kc over the output positions
 // the tile's taps can reach is built once in LDS; thread (cq, slot) then gathers its input pixels' taps from LDS,
 // applies swish' of the input-side BatchNorm and accumulates that BatchNorm's backward sums in registers.
-// WG = true also accumulates the depthwise WEIGHT gradient in the same pass (input-centric form of the same sum:
+// WG = true also produces the depthwise WEIGHT gradient from the same tile (input-centric form of the same sum:
 //   dW[kh,kw] = sum over input pixels of a_in[iy,ix] * dz[(iy+P-kh)/S, (ix+P-kw)/S]  -- exactly the taps the data gradient gathers),
 // so du, z and the dw input are streamed once instead of once per kernel (the separate weight-gradient kernel re-reads all three:
-// 10 of the EfficientNet step's 88 GB).  Per-thread tap accumulators persist across the block's tiles; reduced through LDS at the end.
+// 10.5 of the EfficientNet step's 79 GB, and evaluates swish and the BatchNorm-backward affine a second time).  Two phases per tile
+// (round 6): the gather leaves a_in = act(u) of its pixels in an LDS tile; after a barrier the threads change role to (channel quad,
+// kernel row kh, pixel share) like the stand-alone weight-gradient kernel and walk a_in x dz out of LDS with K float4 accumulators each
+// (rounds 2-5 kept K*K accumulators per gather thread: 216-254 VGPRs, two wavefronts per SIMD, slower than the two kernels).
+// Accumulators persist across the block's tiles; reduced through LDS at the end, one atomic per (channel, tap) and block.
 thread_local int g_res_stride = 1;      // set by mt_dwconv_bwd_res2 around its call (one more kernel argument, no new instantiations)
 
 // RC = Cin > 0: zin is the block input y [N,H,W,Cin]; the tile's raw depthwise input chunk z = y . We^T is rebuilt into an LDS tile
@@ -574,9 +578,13 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
   }
   const float4 ka = ld4(kabc + c), kb = ld4(kabc + C + c), kc = ld4(kabc + 2 * C + c);
   float4 s1 = f4(0, 0, 0, 0), s2 = s1;
-  float4 wacc[WG ? K * K : 1];
+  // WG: phase-2 role (cq2, kh2, ps2) and its K tap accumulators; a_t = activated input of the tile's pixels, [T*T][CC]
+  float* a_t = z_t + (RC ? T * T * CC : 0);
+  constexpr int PS2 = NSLOT / K;
+  const int r2 = tid / CQN, kh2 = r2 % K, ps2 = r2 / K;
+  float4 wacc[WG ? K : 1];
 #pragma unroll
-  for (int i = 0; i < (WG ? K * K : 1); ++i) wacc[i] = f4(0, 0, 0, 0);
+  for (int i = 0; i < (WG ? K : 1); ++i) wacc[i] = f4(0, 0, 0, 0);
   // Software pipeline: du / z of the outputs reachable from the block's NEXT tile are in flight while the current tile is
   // gathered out of LDS (prefetching the tile's own raw inputs as well cost more in registers than it hid).  Unconditional loads on clamped addresses + a validity mask.
   constexpr int ND = (OT * OT + NSLOT - 1) / NSLOT;
@@ -646,6 +654,9 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
     for (int p = slot; p < T * T; p += NSLOT) {
       const int iy = p / T, ix = p - iy * T;
       const int ih = ih0 + iy, iw = iw0 + ix;
+      if constexpr (WG) {
+        if (!(ih < H && iw < W)) st4(a_t + p * CC + cq * 4, f4(0, 0, 0, 0));      // pixels past the image edge contribute nothing
+      }
       if (ih < H && iw < W) {
         float4 acc = f4(0, 0, 0, 0);
         const int64_t off = (((int64_t)n * H + ih) * W + iw) * C + c;
@@ -653,8 +664,7 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
         if constexpr (RC > 0) zz = ld4(z_t + p * CC + cq * 4);
         else zz = ld4(zin + off);
         const float4 u = fma4(zz, sc, sh);
-        float4 ain = f4(0, 0, 0, 0);
-        if constexpr (WG) ain = act4<ACT>(u);       // the depthwise conv's input at this pixel
+        if constexpr (WG) st4(a_t + p * CC + cq * 4, act4<ACT>(u));       // the depthwise conv's input at this pixel, for phase 2
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
           const int ohn = ih + P - kh;
@@ -672,7 +682,6 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
             else ww = wt[kh * K + kw];
             const float4 dzv = ld4(lds + (oy * OTP + ox) * CC + cq * 4);
             acc = fma4(dzv, ww, acc);
-            if constexpr (WG) wacc[kh * K + kw] = fma4(dzv, ain, wacc[kh * K + kw]);
           }
         }
         // res_stride 2: the residual gradient comes from a stride-2 1x1 convolution (Xception's skip path): it exists at even
@@ -688,24 +697,45 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
         s2 = fma4(d, xh, s2);
       }
     }
+    if constexpr (WG) {
+      // phase 2: weight gradient of this tile out of LDS (a_t x dz tile), K taps of kernel row kh2 per thread
+      __syncthreads();
+      if (ps2 < PS2) {
+        const int ohb = ih0 + P - kh2;                  // output row index (times S) reached from input row ih0 + iy through tap row kh2
+        for (int p = ps2; p < T * T; p += PS2) {
+          const int iy = p / T, ix = p - iy * T;
+          const int ohn = ohb + iy;
+          if (ohn < 0 || (S == 2 && (ohn & 1))) continue;
+          const int oy = ohn / S - oh_lo;
+          const float4 a = ld4(a_t + p * CC + cq * 4);
+          const float* drow = lds + (oy * OTP) * CC + cq * 4;
+          const int owb = iw0 + ix + P;
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            const int own = owb - kw;
+            if (own < 0 || (S == 2 && (own & 1))) continue;
+            wacc[kw] = fma4(ld4(drow + (own / S - ow_lo) * CC), a, wacc[kw]);
+          }
+        }
+      }
+    }
   }
   if constexpr (WG) {
-    // weight gradient: sum the per-thread tap accumulators over the block's NSLOT pixel slots, one kernel row at a time
-    // (K taps x NSLOT x CQN float4 fit the tile buffer), then one atomic per (channel, tap) per block
+    // sum the accumulators over the PS2 pixel shares through LDS, then one atomic per (channel, tap) per block
+    __syncthreads();
+    float* red = lds;                               // [PS2][K(kh)][CQN(cq)][K(kw)] float4
+    if (ps2 < PS2) {
 #pragma unroll
-    for (int kh = 0; kh < K; ++kh) {
-      __syncthreads();
-#pragma unroll
-      for (int kw = 0; kw < K; ++kw) st4(lds + ((slot * CQN + cq) * K + kw) * 4, wacc[kh * K + kw]);
-      __syncthreads();
-      if (tid < CQN * K) {
-        const int kw = tid % K, q = tid / K;
-        float4 t = f4(0, 0, 0, 0);
-        for (int sl = 0; sl < NSLOT; ++sl) t = add4(t, ld4(lds + ((sl * CQN + q) * K + kw) * 4));
-        const int ch = c0 + q * 4, tp = kh * K + kw;
-        atomicAdd(dw + (ch + 0) * K * K + tp, t.x); atomicAdd(dw + (ch + 1) * K * K + tp, t.y);
-        atomicAdd(dw + (ch + 2) * K * K + tp, t.z); atomicAdd(dw + (ch + 3) * K * K + tp, t.w);
-      }
+      for (int kw = 0; kw < K; ++kw) st4(red + (((ps2 * K + kh2) * CQN + cq) * K + kw) * 4, wacc[kw]);
+    }
+    __syncthreads();
+    if (tid < K * CQN * K) {                        // (kh, cq, kw)
+      const int kw = tid % K, q = (tid / K) % CQN, khh = tid / (CQN * K);
+      float4 t = f4(0, 0, 0, 0);
+      for (int g = 0; g < PS2; ++g) t = add4(t, ld4(red + (((g * K + khh) * CQN + q) * K + kw) * 4));
+      const int ch = c0 + q * 4, tp = khh * K + kw;
+      atomicAdd(dw + (ch + 0) * K * K + tp, t.x); atomicAdd(dw + (ch + 1) * K * K + tp, t.y);
+      atomicAdd(dw + (ch + 2) * K * K + tp, t.z); atomicAdd(dw + (ch + 3) * K * K + tp, t.w);
     }
   }
   if (!stats) return;
@@ -730,9 +760,9 @@ int launch_dw_dgrad_tiled(const float* du, const float* z, const float* kabc, co
   constexpr int OT = (T - 1 + K - 1) / S + 2;
   constexpr int OTP = OT | 1;
   constexpr int CQN = CC / 4, NSLOT = 256 / CQN;
-  size_t lds = (size_t)(OT * OTP * CC + (K > 3 ? K * K * CC : 0) + (RC ? T * T * CC : 0)) * sizeof(float);
+  size_t lds = (size_t)(OT * OTP * CC + (K > 3 ? K * K * CC : 0) + (RC ? T * T * CC : 0) + (WG ? T * T * CC : 0)) * sizeof(float);
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);
-  if (WG && lds < (size_t)NSLOT * CQN * K * 4 * sizeof(float)) lds = (size_t)NSLOT * CQN * K * 4 * sizeof(float);
+  if (WG && lds < (size_t)(NSLOT / K) * K * CQN * K * 4 * sizeof(float)) lds = (size_t)(NSLOT / K) * K * CQN * K * 4 * sizeof(float);
   const int chunks = C / CC;
   const int64_t ntiles = (int64_t)N * ((H + T - 1) / T) * ((W + T - 1) / T);
   // the fused form keeps K*K tap accumulators per thread across tiles: fewer, longer-lived blocks keep the final atomics rare

@@ -101,6 +101,55 @@ def test_expand_recompute_matches_stored_expansion(n, training, monkeypatch):
         assert_close(out[True][2][k], out[False][2][k], 1e-4, f"{k}, recompute vs stored")
 
 
+@pytest.mark.parametrize("k,s,H,C,N", [(3, 1, 28, 48, 3), (3, 2, 28, 32, 2), (5, 1, 14, 32, 3), (5, 2, 28, 48, 2), (5, 1, 7, 64, 5),
+                                       (3, 1, 7, 24, 3), (3, 1, 112, 32, 1)])
+def test_fused_depthwise_backward_equals_the_two_kernels(k, s, H, C, N):
+    """mt_dwconv_bwd parts = 3 (data AND weight gradient from one pass over du / z / the depthwise input: the gather leaves the
+    activated input of its tile in LDS, a second phase walks it against the dz tile) against parts = 2 + parts = 1 (the two
+    stand-alone kernels): du_in bit-identical (same arithmetic), BatchNorm-backward sums and the weight gradient within summation
+    order.  Odd tile counts, image edges (H = 7: one partial tile; 28 / 14: 2 x 2 and 1 x 1 tiles of 14) and 8-channel chunks (C = 24)."""
+    from mintime_amd import lib as L
+    lib = L.get()
+    g = torch.Generator().manual_seed(k * 100 + s * 10 + H)
+    Ho = (H + s - 1) // s
+    dev = "cuda"
+    du = torch.randn(N * Ho * Ho, C, generator=g).to(dev)
+    z = torch.randn(N * Ho * Ho, C, generator=g).to(dev)
+    zin = torch.randn(N * H * H, C, generator=g).to(dev)
+    kabc = (torch.rand(3, C, generator=g) + 0.5).to(dev)
+    w = torch.randn(C, 1, k, k, generator=g).to(dev)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    mi = torch.stack([torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5]).to(dev)
+    slots = 8
+
+    def run(parts_list):
+        du_in = torch.full((N * H * H, C), float("nan"), device=dev)
+        stats = torch.zeros(slots, 2, C, dtype=torch.float64, device=dev)
+        dw = torch.zeros(C, 1, k, k, device=dev)
+        for parts in parts_list:
+            L.check(lib.mt_dwconv_bwd(L.ptr(du), L.ptr(z), L.ptr(kabc), L.ptr(w), L.ptr(zin), L.ptr(sc), L.ptr(sh), L.ptr(mi),
+                                      L.ptr(du_in), L.ptr(stats), slots, L.ptr(dw), N, H, H, C, k, s, parts, 1, None, None,
+                                      L.stream_ptr()), "mt_dwconv_bwd")
+        torch.cuda.synchronize()
+        return du_in, stats.sum(0), dw
+
+    a_du, a_st, a_dw = run([2, 1])
+    b_du, b_st, b_dw = run([3])
+    assert torch.equal(a_du, b_du)
+    assert_close(b_st, a_st, 1e-5, "BatchNorm-backward sums, fused vs separate")
+    assert_close(b_dw, a_dw, 2e-5, "depthwise weight gradient, fused vs separate")
+    # and the weight gradient against its definition in float64 (autograd of the same convolution)
+    a_in = (zin.double() * sc.double() + sh.double())
+    a_in = (a_in * torch.sigmoid(a_in)).view(N, H, H, C).permute(0, 3, 1, 2)
+    pad_total = max((Ho - 1) * s + k - H, 0)
+    a_pad = torch.nn.functional.pad(a_in, (pad_total // 2, pad_total - pad_total // 2, pad_total // 2, pad_total - pad_total // 2))
+    wd = w.double().clone().requires_grad_(True)
+    out = torch.nn.functional.conv2d(a_pad, wd, stride=s, groups=C)
+    dz = (kabc[0].double() * du.double() + kabc[1].double() * z.double() + kabc[2].double()).view(N, Ho, Ho, C).permute(0, 3, 1, 2)
+    out.backward(dz)
+    assert_close(b_dw, wd.grad, 2e-4, "depthwise weight gradient vs float64 autograd")
+
+
 def test_nchw_contiguous_input_is_accepted():
     g = golden("ef_eval")
     model, _ = _model(int(g["seed"]), False)
