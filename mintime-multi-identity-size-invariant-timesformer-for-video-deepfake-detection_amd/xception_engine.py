@@ -137,7 +137,8 @@ class _WeightPlanes:
         self.blocks = first
 
 
-def xception_forward(model, x, params, training, save):
+def xception_forward(model, x, params, training, save, plan=None):
+    """plan: the plans.NetPlan being recorded (it keeps the tracked counters for its replays)."""
     lib = L.get()
     dev = x.device
     N, H, W, _ = x.shape
@@ -281,11 +282,13 @@ def xception_forward(model, x, params, training, save):
         wplanes.end(dev)
         if save:
             saved["w_serial"] = wplanes.touch()
-    _bump_tracked()
+    _bump_tracked(plan)
     return feat, saved, cur.H
 
 
-def xception_backward(model, params, saved, shape, training, dfeat, need_dparams):
+def xception_backward(model, params, saved, shape, training, dfeat, need_dparams, keep_saved=False, plan=None):
+    """keep_saved: the activation records belong to a launch plan (plans.py) and stay for its next replay; plan: the NetPlan whose
+    backward phase is being recorded (it keeps the flat gradient buffer)."""
     lib = L.get()
     if "w_serial" in saved and model.__dict__["_xc_wplanes"].serial != saved["w_serial"]:
         raise RuntimeError("Xception: the pointwise weights were updated between this graph's forward and its backward (their operand "
@@ -442,7 +445,8 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
         # for block1 the result is the gradient w.r.t. bn2's output (sums accumulated); otherwise w.r.t. the previous block's y
         dy = g
         bn2_sums = sums
-        brec.clear()
+        if not keep_saved:
+            brec.clear()
         side.release_point()
 
     # ---- conv2 / conv1
@@ -450,7 +454,7 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
     H1, H2 = saved["H1"], saved["H2"]
     M1, M2 = N * H1 * H1, N * H2 * H2
     k2 = bn_kabc(bn2, bn2_sums, 4, dy, z2, M2)
-    dwp2 = torch.zeros(64, 288, dtype=torch.float32, device=dev)
+    dwp2 = L.zeros((64, 288), torch.float32, dev)          # (a fill of the library: a recorded phase re-issues it)
     geom2 = (H1, H1, 32, H2, H2, 3, 1, 0, RELU)
 
     def conv2_wgrad(n0, n1):      # images [n0, n1): 6 M rows x (64 x 288) in all, 9 ms
@@ -485,20 +489,71 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
         conv2_wgrad(n_side, N)
     side.wait()
     L.check(lib.mt_conv_weight_unpack_grad(L.ptr(dwp2), L.ptr(grads[3]), 64, 32, 3, 288, L.stream_ptr()), "mt_conv_weight_unpack_grad")
+    if plan is not None:
+        plan.extra["flat_grads"] = flat_grads
     L.grads_ready(model, P, flat_grads)
     return [g_ if need else None for need, g_ in zip(need_dparams, grads)]
 
 
+def _plannable():
+    """The recorded form covers the default kernels only: the lab alternatives issue torch fills / scatters a recording cannot see."""
+    return SKIP_HALF and POOL_ARG and XC_STEM and XC_PLANES and DW_PLANES and XC_PLAN
+
+
+XC_PLAN = __import__("os").environ.get("MT_XC_PLAN", "1") != "0"      # 0: the Xception phases are never recorded (launch plans, plans.py)
+
+
 class _XceptionFunction(torch.autograd.Function):
+    """Forward / backward of the extractor; like effnet_engine._EffNetFunction the two launch sequences are recorded into the library
+    the second time a (shape, mode) key is seen and re-issued from C afterwards (plans.py): ~750 ctypes launches per step become 2."""
+
     @staticmethod
     def forward(ctx, model, x_nhwc, *params):
+        from . import plans
         model, grad_on = model
         save = grad_on and any(ctx.needs_input_grad)      # see tsf_engine._TSFFunction.forward
-        feat, saved, ho = xception_forward(model, x_nhwc, params, model.training, save)
-        ctx.model, ctx.saved, ctx.params, ctx.training = model, saved, params, model.training
         N, H, W, _ = x_nhwc.shape
         ctx.shape = (N, H, W)
-        return feat
+        ctx.model, ctx.params, ctx.training = model, params, model.training
+        ctx.plan = ctx.token = None
+        np_, mode = None, "eager"
+        if save and _plannable() and W <= 512 and L.gemm_split_enabled():
+            stream = torch.cuda.current_stream(x_nhwc.device).cuda_stream
+            key = ("xc", tuple(x_nhwc.shape), x_nhwc.dtype, model.training, L.deterministic(), tuple(ctx.needs_input_grad[2:]), stream,
+                   float(model.bn1.momentum), float(model.bn1.eps))
+            np_, mode = plans.lookup(model, key)
+            if mode == "replay" and np_.state_ptrs != plans.state_ptrs(list(params) + list(model.buffers())):
+                plans.drop(model, np_)                   # parameters / buffers moved: record afresh later
+                np_, mode = None, "eager"
+        if mode == "eager":
+            feat, saved, ho = xception_forward(model, x_nhwc, params, model.training, save)
+            ctx.saved = saved
+            return feat
+        if mode == "record":
+            np_.stream = stream
+            x_s = plans.static_input(np_, "x", x_nhwc)
+            pl = L.Plan()
+            try:
+                with pl:
+                    feat, saved, _ = xception_forward(model, x_s, params, model.training, True, plan=np_)
+            except Exception:
+                np_.broken = True
+                raise
+            np_.fwd = pl
+            np_.extra.update(saved=saved, feat=feat)
+            np_.state_ptrs = plans.state_ptrs(list(params) + list(model.buffers()))
+            plans.own(np_, feat)
+            plans.STATS["recorded"] += 1
+        else:
+            plans.refresh_input(np_, "x", x_nhwc)
+            plans.run(np_.fwd)
+            if "w_serial" in np_.extra["saved"]:
+                np_.extra["saved"]["w_serial"] = model.__dict__["_xc_wplanes"].touch()      # the split launch is in the plan
+            if np_.extra.get("tracked"):
+                torch._foreach_add_(np_.extra["tracked"], 1)
+        ctx.plan, ctx.token = np_, np_.begin()
+        ctx.saved = np_.extra["saved"]
+        return np_.extra["feat"].detach()
 
     @staticmethod
     def backward(ctx, dfeat):
@@ -507,9 +562,43 @@ class _XceptionFunction(torch.autograd.Function):
                                "released after the first pass (retain_graph is not supported by the HIP engine)")
         if ctx.needs_input_grad[1]:
             raise NotImplementedError("gradient w.r.t. the input crops is not part of the MINTIME training path")
-        dparams = xception_backward(ctx.model, ctx.params, ctx.saved, ctx.shape, ctx.training, dfeat.contiguous(),
-                                    ctx.needs_input_grad[2:])
+        from . import plans
+        np_ = ctx.plan
+        if "w_serial" in ctx.saved and ctx.model.__dict__["_xc_wplanes"].serial != ctx.saved["w_serial"]:
+            raise RuntimeError("Xception: the pointwise weights were updated between this graph's forward and its backward (their operand "
+                               "planes were rewritten by a later forward): run backward before the optimizer step")
+        dfeat = dfeat.contiguous()
+        need = ctx.needs_input_grad[2:]
+        if np_ is None:
+            dparams = xception_backward(ctx.model, ctx.params, ctx.saved, ctx.shape, ctx.training, dfeat, need)
+        elif (plans.grads_exist(ctx.params) or torch.cuda.current_stream(dfeat.device).cuda_stream != np_.stream
+              or torch.cuda.is_current_stream_capturing()):
+            # existing gradients are ADDED to by autograd (they alias the plan's gradient buffer): eager sequence over the plan's
+            # saved activations, which stay for the next replay
+            plans.STATS["eager_accumulate"] += 1
+            dparams = xception_backward(ctx.model, ctx.params, ctx.saved, ctx.shape, ctx.training, dfeat, need, keep_saved=True)
+        elif np_.bwd is None:
+            d_s = plans.static_input(np_, "dfeat", dfeat)
+            pl = L.Plan()
+            try:
+                with pl:
+                    dparams = xception_backward(ctx.model, ctx.params, ctx.saved, ctx.shape, ctx.training, d_s, need, keep_saved=True,
+                                                plan=np_)
+            except Exception:
+                np_.broken = True
+                raise
+            np_.bwd = pl
+            np_.extra.update(grads=list(dparams))
+            dparams = plans.fresh_aliases(dparams)
+        else:
+            plans.refresh_input(np_, "dfeat", dfeat)
+            plans.run(np_.bwd)
+            L.grads_ready(ctx.model, list(ctx.params), np_.extra["flat_grads"])
+            dparams = plans.fresh_aliases(np_.extra["grads"])
         ctx.saved = None
+        if np_ is not None:
+            np_.release(ctx.token)
+            ctx.token = None
         return (None, None) + tuple(dparams)
 
 

@@ -191,3 +191,29 @@ def test_plan_is_dropped_when_parameters_move(plan_switch):
     loss = harness.train_step(ef, tsf, opt2, batch)
     torch.cuda.synchronize()
     assert plans.STATS["dropped"] == dropped + 2 and bool(torch.isfinite(loss))
+
+
+def _train_xs(n_steps, plan_on, B=1, F=16):
+    plans.ENABLED = plan_on
+    cfg, xc, tsf = harness.build_models_xs(F, seed=3, device="cuda")
+    opt = harness.make_optimizer(cfg, xc, tsf)
+    losses = []
+    for i in range(n_steps):
+        batch = harness.device_batch(B, F, 3, seed=i, device="cuda", ragged=i % 2 == 1)
+        losses.append(harness.train_step(xc, tsf, opt, batch).detach().clone())
+    torch.cuda.synchronize()
+    return torch.stack(losses), _state(xc, tsf)
+
+
+def test_planned_xception_training_is_bit_identical_to_eager(det_mode, plan_switch):
+    """BASELINE config 5's extractor under launch plans (round 6): 5 training steps of Xception + TimeSformer (1 clip x 16 slots, fresh
+    inputs each step, train-mode BatchNorm) -- step 1 eager, step 2 recorded, steps 3-5 replayed -- give exactly the losses, parameters
+    and running statistics of 5 eager steps in deterministic mode."""
+    before = dict(plans.STATS)
+    l_p, s_p = _train_xs(5, True)
+    assert plans.STATS["recorded"] - before["recorded"] == 2              # Xception + TimeSformer
+    assert plans.STATS["replayed"] - before["replayed"] == 3 * 4            # 3 replayed steps x 4 phases
+    l_e, s_e = _train_xs(5, False)
+    assert torch.equal(l_p, l_e), (l_p, l_e)
+    diff = [k for k in s_e if not torch.equal(s_e[k], s_p[k])]
+    assert not diff, f"{len(diff)} of {len(s_e)} state tensors differ between planned and eager training, e.g. {diff[:5]}"
