@@ -150,6 +150,24 @@ def test_fused_depthwise_backward_equals_the_two_kernels(k, s, H, C, N):
     assert_close(b_dw, wd.grad, 2e-4, "depthwise weight gradient vs float64 autograd")
 
 
+def test_engine_with_fused_depthwise_backward(monkeypatch):
+    """MT_DW_FUSED=1 (every depthwise layer's data + weight gradient from one pass) through the whole extractor: every parameter
+    gradient against the default two-kernel path."""
+    from mintime_amd import effnet_backward as EB
+    x = _input(3, 6).cuda()
+    wts = torch.randn(3, 1280, 7, 7, generator=torch.Generator().manual_seed(2)).cuda()
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setattr(EB, "FUSED_DW", mode)
+        model, _ = _model(6, True)
+        (model(x) * wts).sum().backward()
+        out[mode] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    for k, ref in out["0"].items():
+        if k.endswith("_bn2.bias") and float(ref.norm()) < 1e-3 * float(out["0"][k.replace(".bias", ".weight")].norm()):
+            continue
+        assert_close(out["1"][k], ref, GRAD_TOL_UNIT, f"grad {k}, fused vs two kernels")
+
+
 def test_nchw_contiguous_input_is_accepted():
     g = golden("ef_eval")
     model, _ = _model(int(g["seed"]), False)
