@@ -300,7 +300,8 @@ finals = []
 for overlapped in (False, True):
     cfg, ef, tsf = harness.build_models(seed=3, device="cuda", drop_connect_rate=0.0)
     opt = harness.make_optimizer(cfg, ef, tsf)
-    red = ddp.OverlappedGradReducer([tsf, ef], force=True) if overlapped else None
+    live = {tsf.pos_emb.weight: 8 * 49 + 1, tsf.size_emb.weight: 21}        # what bench.py declares: only these rows go on the wire
+    red = ddp.OverlappedGradReducer([tsf, ef], force=True, live_rows=live) if overlapped else None
     for step in range(3):
         batch = harness.device_batch(2, seed=step)
         loss = harness.train_step(ef, tsf, opt, batch, red)
@@ -665,7 +666,7 @@ for mode in ("overlap", "flat"):
         p.grad = None
     opt = harness.make_optimizer(cfg, ef, tsf)
     if mode == "overlap":
-        red = ddp.OverlappedGradReducer([tsf, ef])
+        red = ddp.OverlappedGradReducer([tsf, ef], live_rows={tsf.pos_emb.weight: 8 * 49 + 1, tsf.size_emb.weight: 21})
     else:
         red = ddp.GradAllReducer(list(ef.parameters()) + list(tsf.parameters()))
     loss = harness.train_step(ef, tsf, opt, shard(0), red)
