@@ -10,6 +10,7 @@
 //   * swish'(u) = sig(u)*(1+u*(1-sig(u))) is recomputed from z (utils.py:70-75 saves only the input as well).
 #include "../../include/mintime_hip.h"
 #include "common.hpp"
+#include <type_traits>
 #include "rc.hpp"
 #include "det.hpp"
 #include <stdlib.h>
@@ -556,8 +557,9 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
   const int c = c0 + cq * 4;
   const float4 sc = ld4(scale_in + c), sh = ld4(shift_in + c);
   const float4 mean = mi_in ? ld4(mi_in + c) : f4(0, 0, 0, 0), istd = mi_in ? ld4(mi_in + C + c) : f4(0, 0, 0, 0);
-  // 3x3 weights in registers; 5x5 (25 float4 = 100 VGPRs) in LDS behind the dz tile, read as broadcasts
-  constexpr bool WLDS = K > 3;
+  // weights in LDS behind the dz tile, read as broadcasts, for 5x5 (25 float4 = 100 VGPRs) and for stride 1 (the rolled kernel-row
+  // loop below; 3x3 stride 1 with its 36 weight registers sat at 188 VGPRs = two wavefronts per SIMD); 3x3 stride 2 keeps registers
+  constexpr bool WLDS = K > 3 || S == 1;
   float* w_t = lds + OT * OTP * CC;
   float* z_t = w_t + (WLDS ? K * K * CC : 0);        // RC: raw input chunk of the tile, [T*T][CC]
   constexpr int RCW = RC ? RC : 8;
@@ -651,6 +653,7 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
     }
     __syncthreads();
     if (tile + tile_stride < ntiles) fetch(tile + tile_stride);
+#pragma unroll 1
     for (int p = slot; p < T * T; p += NSLOT) {
       const int iy = p / T, ix = p - iy * T;
       const int ih = ih0 + iy, iw = iw0 + ix;
@@ -665,24 +668,54 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
         else zz = ld4(zin + off);
         const float4 u = fma4(zz, sc, sh);
         if constexpr (WG) st4(a_t + p * CC + cq * 4, act4<ACT>(u));       // the depthwise conv's input at this pixel, for phase 2
+        // The taps are read WITHOUT per-tap range tests: the dz tile holds every output position the tile's taps can reach, zero
+        // where that lies outside the image (rows / columns from oh_lo / ow_lo on, negative ones included), so the K*K LDS reads of
+        // a pixel are independent and go out back to back.  (Rounds 2-5 skipped "negative" taps one by one: every ds_read sat in its
+        // own exec-masked branch behind an s_waitcnt lgkmcnt(0) -- K*K serial LDS round trips per pixel.)
+        int wq = cq * 4;
+        if constexpr (WLDS) asm volatile("" : "+v"(wq));      // (opaque per pixel: hoisted out of the pixel loop the 25 weight quads are 100 VGPRs)
+        auto tap = [&](int kh, int kw, int oy, int ox) {
+          float4 ww;
+          if constexpr (WLDS) ww = ld4(w_t + (kh * K + kw) * CC + wq);
+          else ww = wt[kh * K + kw];
+          acc = fma4(ld4(lds + (oy * OTP + ox) * CC + cq * 4), ww, acc);
+        };
+        if constexpr (S == 1) {
+          const int oy0 = ih + P - oh_lo, ox0 = iw + P - ow_lo;          // tap (kh, kw) meets dz[oy0 - kh][ox0 - kw]
+          if constexpr (WLDS) {
+            // 5x5: weights come from LDS; a ROLLED loop over kernel rows keeps one row (5 + 5 reads) in flight -- unrolled, the compiler
+            // hoists all 50 reads of a pixel and the kernel needs 256 VGPRs (one wavefront per SIMD)
+#pragma unroll 1
+            for (int kh = 0; kh < K; ++kh) {
 #pragma unroll
-        for (int kh = 0; kh < K; ++kh) {
-          const int ohn = ih + P - kh;
-          if (S == 2 && (ohn & 1)) continue;
-          const int oy = ohn / S - oh_lo;          // ohn may be negative only when the row is out of range -> zero row in LDS
-          if (ohn < 0) continue;
+              for (int kw = 0; kw < K; ++kw) tap(kh, kw, oy0 - kh, ox0 - kw);
+            }
+          } else {
 #pragma unroll
-          for (int kw = 0; kw < K; ++kw) {
-            const int own = iw + P - kw;
-            if (S == 2 && (own & 1)) continue;
-            if (own < 0) continue;
-            const int ox = own / S - ow_lo;
-            float4 ww;
-            if constexpr (WLDS) ww = ld4(w_t + (kh * K + kw) * CC + cq * 4);
-            else ww = wt[kh * K + kw];
-            const float4 dzv = ld4(lds + (oy * OTP + ox) * CC + cq * 4);
-            acc = fma4(dzv, ww, acc);
+            for (int kh = 0; kh < K; ++kh) {
+#pragma unroll
+              for (int kw = 0; kw < K; ++kw) tap(kh, kw, oy0 - kh, ox0 - kw);
+              __builtin_amdgcn_sched_barrier(0);      // one kernel row of reads in flight
+            }
           }
+        } else {
+          // stride 2: only the taps with kh = (ih + P) mod 2, kw = (iw + P) mod 2 (mod 2) meet an output; (ih + P - kh) is even there,
+          // so the arithmetic shift divides exactly, also below zero
+          const int ph = (ih + P) & 1, pw = (iw + P) & 1;
+          const int oyb = ((ih + P - ph) >> 1) - oh_lo, oxb = ((iw + P - pw) >> 1) - ow_lo;
+          auto taps = [&](auto PH, auto PW) {
+            constexpr int ph_ = decltype(PH)::value, pw_ = decltype(PW)::value;
+#pragma unroll
+            for (int kh = ph_; kh < K; kh += 2) {
+#pragma unroll
+              for (int kw = pw_; kw < K; kw += 2) tap(kh, kw, oyb - (kh - ph_) / 2, oxb - (kw - pw_) / 2);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          };
+          using I0 = std::integral_constant<int, 0>;
+          using I1 = std::integral_constant<int, 1>;
+          if (ph == 0) { if (pw == 0) taps(I0{}, I0{}); else taps(I0{}, I1{}); }
+          else { if (pw == 0) taps(I1{}, I0{}); else taps(I1{}, I1{}); }
         }
         // res_stride 2: the residual gradient comes from a stride-2 1x1 convolution (Xception's skip path): it exists at even
         // (ih, iw) only, as [N, ceil(H/2), ceil(W/2), C] -- no zero-filled full-resolution copy of it is made
@@ -760,7 +793,7 @@ int launch_dw_dgrad_tiled(const float* du, const float* z, const float* kabc, co
   constexpr int OT = (T - 1 + K - 1) / S + 2;
   constexpr int OTP = OT | 1;
   constexpr int CQN = CC / 4, NSLOT = 256 / CQN;
-  size_t lds = (size_t)(OT * OTP * CC + (K > 3 ? K * K * CC : 0) + (RC ? T * T * CC : 0) + (WG ? T * T * CC : 0)) * sizeof(float);
+  size_t lds = (size_t)(OT * OTP * CC + ((K > 3 || S == 1) ? K * K * CC : 0) + (RC ? T * T * CC : 0) + (WG ? T * T * CC : 0)) * sizeof(float);
   if (lds < 256 * 8 * sizeof(float)) lds = 256 * 8 * sizeof(float);
   if (WG && lds < (size_t)(NSLOT / K) * K * CQN * K * 4 * sizeof(float)) lds = (size_t)(NSLOT / K) * K * CQN * K * 4 * sizeof(float);
   const int chunks = C / CC;
