@@ -735,19 +735,26 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_tiled_kernel(
       __syncthreads();
       if (ps2 < PS2) {
         const int ohb = ih0 + P - kh2;                  // output row index (times S) reached from input row ih0 + iy through tap row kh2
+#pragma unroll 1
         for (int p = ps2; p < T * T; p += PS2) {
           const int iy = p / T, ix = p - iy * T;
           const int ohn = ohb + iy;
-          if (ohn < 0 || (S == 2 && (ohn & 1))) continue;
-          const int oy = ohn / S - oh_lo;
+          if (S == 2 && (ohn & 1)) continue;
           const float4 a = ld4(a_t + p * CC + cq * 4);
-          const float* drow = lds + (oy * OTP) * CC + cq * 4;
+          const float* drow = lds + (((ohn >> (S - 1)) - oh_lo) * OTP) * CC + cq * 4;     // (even below zero: the shift divides exactly)
           const int owb = iw0 + ix + P;
+          if constexpr (S == 1) {                       // unconditional reads (zero halo in the dz tile), all K in flight
 #pragma unroll
-          for (int kw = 0; kw < K; ++kw) {
-            const int own = owb - kw;
-            if (own < 0 || (S == 2 && (own & 1))) continue;
-            wacc[kw] = fma4(ld4(drow + (own / S - ow_lo) * CC), a, wacc[kw]);
+            for (int kw = 0; kw < K; ++kw) wacc[kw] = fma4(ld4(drow + (owb - kw - ow_lo) * CC), a, wacc[kw]);
+          } else {
+            const int pw = owb & 1, oxb = ((owb - pw) >> 1) - ow_lo;
+            if (pw == 0) {
+#pragma unroll
+              for (int kw = 0; kw < K; kw += 2) wacc[kw] = fma4(ld4(drow + (oxb - kw / 2) * CC), a, wacc[kw]);
+            } else {
+#pragma unroll
+              for (int kw = 1; kw < K; kw += 2) wacc[kw] = fma4(ld4(drow + (oxb - (kw - 1) / 2) * CC), a, wacc[kw]);
+            }
           }
         }
       }

@@ -6,9 +6,11 @@ from . import lib as L
 from .effnet_engine import SLOTS, STREAM_ROWS, _StatsPool
 
 
-# measured in-step: the fused pass (6.9 ms/step on the critical main stream) loses to data gradient (5.0 ms, main) + weight gradient on the
-# side stream, which has slack during the EfficientNet backward: 65.5 vs 64.1 ms/step.  Kept selectable for single-stream use.
-FUSED_DW = __import__("os").environ.get("MT_DW_FUSED", "0")      # "1": every layer, "3": the 3x3 layers only, "0": off
+# Depthwise data AND weight gradient from one pass over du / z / the depthwise input (csrc/effnet_bwd.hip, WG = true): the gather leaves
+# the activated input tile in LDS, the threads change role and walk it against the dz tile.  Rounds 2-5 measured every fused form
+# slower than the two kernels on two streams; with the branch-free tap reads of round 6 it wins for the 3x3 layers (one box, serialised
+# extractor 21.82 -> 21.35 ms, step 44.99 -> 44.43 ms; all layers: 21.34 / 44.60): "3" = the 3x3 layers (default), "1" = every layer, "0" = off.
+FUSED_DW = __import__("os").environ.get("MT_DW_FUSED", "3")
 # Squeeze-excite stage of the reverse walk without the project conv's data gradient `da` in memory: the GEMM  dz_p . W_project  is
 # run twice and consumed in its accumulators (MT_EPI_SE_RED: d gate; MT_EPI_ACT_BWD: du of the depthwise BatchNorm + its sums).
 # 3 passes over a block's expanded tensor (read z_d, read z_d, write du_d) instead of 6 (write da | read da, z_d | read da, z_d,

@@ -381,8 +381,11 @@ def xception_backward(model, params, saved, shape, training, dfeat, need_dparams
             L.check(fn(L.ptr(dd), L.ptr(dd), L.ptr(kid), L.ptr(w_dw), L.ptr(src.t), L.ptr(rec["sc"]), L.ptr(rec["sh"]),
                        L.ptr(src.bn.mean_invstd) if has_bn else None, L.ptr(du_in), L.ptr(sums_in), slots, L.ptr(grads[pi]), N, Hh, Hh, ci,
                        3, 1, parts, rec["eff"], L.ptr(res_pre), L.ptr(res_post), L.stream_ptr()), "mt_dwconv_bwd")
-        side.launch(lambda: dw_part(1), reads=(dd, kid, src.t, rec["sc"], rec["sh"]))
-        dw_part(2)
+        if XC_DW_FUSED and not det:
+            dw_part(3)            # data + weight gradient from one pass (effnet_backward.FUSED_DW; deterministic mode keeps the logged weight-gradient kernel)
+        else:
+            side.launch(lambda: dw_part(1), reads=(dd, kid, src.t, rec["sc"], rec["sh"]))
+            dw_part(2)
         return du_in, sums_in
 
     # ---- tail: feat = bn4(z4); conv4 consumes relu(bn3(z3)); conv3 consumes y12 (no relu)
@@ -500,6 +503,7 @@ def _plannable():
     return SKIP_HALF and POOL_ARG and XC_STEM and XC_PLANES and DW_PLANES and XC_PLAN
 
 
+XC_DW_FUSED = __import__("os").environ.get("MT_XC_DW_FUSED", "1") != "0"   # depthwise data + weight gradient in one kernel (all of Xception's are 3x3 stride 1): config 5 200.0 -> 193.5 ms; 0 = two kernels on two streams
 XC_PLAN = __import__("os").environ.get("MT_XC_PLAN", "1") != "0"      # 0: the Xception phases are never recorded (launch plans, plans.py)
 
 
