@@ -26,6 +26,10 @@
 
 using namespace mt;
 
+#ifndef MT_DW_FWD_ROLL5
+#define MT_DW_FWD_ROLL5 1
+#endif
+
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   /* v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division: the swish kernels are VALU-bound */
@@ -78,6 +82,7 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
   // 3x3 weights live in registers; the 25 float4 of a 5x5 would cost 100 VGPRs on top of the prefetch registers (occupancy 1),
   // so they sit in LDS behind the input tile ([K*K][CC], read as 4 broadcast addresses per wavefront)
   constexpr bool WLDS = K > 3;
+  constexpr bool ROLL5 = MT_DW_FWD_ROLL5;
   float* w_t = lds + IH * IWP * CC;
   float4 wt[WLDS ? 1 : K * K];
   {
@@ -157,8 +162,7 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
       if (oh < Ho && ow < Wo) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* base = lds + ((oy * S) * IWP + ox * S) * CC + cq * 4;
-#pragma unroll
-        for (int kh = 0; kh < K; ++kh)
+        auto row = [&](int kh) {
 #pragma unroll
           for (int kw = 0; kw < K; ++kw) {
             const float4 a = *reinterpret_cast<const float4*>(base + (kh * IWP + kw) * CC);
@@ -168,6 +172,14 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(const float* __restri
             acc.x = fmaf(a.x, ww.x, acc.x); acc.y = fmaf(a.y, ww.y, acc.y);
             acc.z = fmaf(a.z, ww.z, acc.z); acc.w = fmaf(a.w, ww.w, acc.w);
           }
+        };
+        if constexpr (WLDS && ROLL5) {
+#pragma unroll 1
+          for (int kh = 0; kh < K; ++kh) row(kh);         // 5x5: one kernel row (5 + 5 LDS reads) in flight -- see effnet_bwd.hip K7
+        } else {
+#pragma unroll
+          for (int kh = 0; kh < K; ++kh) row(kh);
+        }
         if (po.p) {
           // the output as operand planes (Xception: the pointwise convolution that follows reads nothing else); the thread that owns
           // the last channels also zeroes the padding columns of the last 16-column block
