@@ -109,6 +109,24 @@ __device__ __forceinline__ int64_t div_rows(int64_t r, int hw) {
   return (r >> 32) ? r / hw : (int64_t)((unsigned)r / (unsigned)hw);
 }
 
+// floor(n / d) for 0 <= n < 2^31 and a run-time d >= 1 as one v_mul_hi_u32 + one shift: with l = ceil(log2 d) and
+// M = floor(2^(31+l) / d) + 1 (< 2^32),  n M / 2^(31+l) = n/d + e,  0 < e < 2^-l <= 1/d,  so the floor is exact.  hipcc expands a
+// 32-bit division by a run-time value into ~35 VALU instructions; the im2col prologues (gemm_core.hpp) did six per 16-byte gather.
+struct FastDiv {
+  uint32_t mul;       // 0: d == 1
+  int sh;             // l - 1
+  __device__ __forceinline__ int div(int n) const { return mul ? (int)(__umulhi((uint32_t)n, mul) >> sh) : n; }
+};
+inline FastDiv fast_div_of(int d) {
+  FastDiv f{0u, 0};
+  if (d <= 1) return f;
+  int l = 0;
+  while (((int64_t)1 << l) < d) ++l;
+  f.mul = (uint32_t)((((uint64_t)1 << (31 + l)) / (uint64_t)d) + 1);
+  f.sh = l - 1;
+  return f;
+}
+
 inline unsigned xcd_chunk_grid(int chunks, int64_t ntiles, int target_blocks) {
   if (ntiles >= ((int64_t)1 << 31)) return 0;      // (a zero grid makes the launch fail loudly: tile_nyx works in 32 bits)
   int64_t per_xcd = target_blocks / (8 * chunks);

@@ -9,10 +9,13 @@ using namespace mt;
 
 namespace {
 
-enum { CFG_BIG = 0, CFG_MID = 1, CFG_NARROW = 2, CFG_SMALL = 3 };
+enum { CFG_BIG = 0, CFG_MID = 1, CFG_NARROW = 2, CFG_SMALL = 3, CFG_WG64 = 4 };
 
 struct Cfg { int bm, bn, threads; };
-constexpr Cfg kCfg[4] = {{128, 128, 256}, {128, 64, 256}, {256, 32, 256}, {64, 64, 256}};
+// CFG_WG64: the weight gradient of a dense 3x3 convolution with <= 64 output channels and 9 x 32 gathered columns (Xception's conv2,
+// reference models/xception.py:164: out[64][288] over 11 M pixel rows): ONE 64 x 288 tile per K range (six wavefronts, 32 x 96 each)
+// -- the 128 x 64 tile computed 64 rows of zeros and re-read the dy / z operand pair once per column tile (5x).
+constexpr Cfg kCfg[5] = {{128, 128, 256}, {128, 64, 256}, {256, 32, 256}, {64, 64, 256}, {64, 288, 384}};
 
 // Tile choice.  Replaying every GEMM of a B = 32 training step alone under each configuration (round-1 tuning script; results: profiles/r01_gemm_tile_config_sweep.txt, 70
 // shapes) favours 64x64 tiles almost everywhere, but inside the real step -- where the weight-gradient GEMMs of a second stream
@@ -51,6 +54,14 @@ int launch(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
       if constexpr (EPI == EPI_GEGLU) return fail(MT_ERR_UNSUPPORTED, "GEGLU needs a 128-column tile");
       else hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, AL, BL, PRO, EPI, BPRO>), grid, dim3(256), 0, s, a);
       break;
+    case CFG_WG64:
+      if constexpr ((BPRO == BPRO_IM2COL || BPRO == BPRO_IM2COL_ANY) && EPI == EPI_ATOMIC) {
+        static const bool two = getenv("MT_CONV_WG64") && atoi(getenv("MT_CONV_WG64")) == 2;
+        if (two) hipLaunchKernelGGL((gemm_kernel<2, 3, 1, 3, AL, BL, PRO, EPI, BPRO, 2>), grid, dim3(384), 0, s, a);
+        else hipLaunchKernelGGL((gemm_kernel<2, 3, 1, 3, AL, BL, PRO, EPI, BPRO>), grid, dim3(384), 0, s, a);
+      }
+      else return fail(MT_ERR_UNSUPPORTED, "the 64 x 288 tile is the im2col weight gradient's");
+      break;
 
   }
   return check_launch("mt_gemm");
@@ -85,7 +96,7 @@ static int gemm_impl(const mt_gemm_desc* d, void* stream) {
   a.scale = d->scale; a.shift = d->shift; a.gate = d->gate; a.hw = d->hw > 0 ? d->hw : 1;
   a.C2 = d->C2; a.ldc2 = d->ldc2; a.stats = d->stats; a.stats_slots = d->stats_slots != 0 ? d->stats_slots : 1;
   a.n_half = d->n_half; a.k_chunk = 0;
-  a.conv = {d->conv_H, d->conv_W, d->conv_C, d->conv_Ho, d->conv_Wo, d->conv_k, d->conv_stride, d->conv_pad, d->conv_act, d->conv_src_u8};
+  a.conv = conv_desc_of(d->conv_H, d->conv_W, d->conv_C, d->conv_Ho, d->conv_Wo, d->conv_k, d->conv_stride, d->conv_pad, d->conv_act, d->conv_src_u8);
   a.col_sum = d->col_sum;
   a.b_planes = d->b_planes; a.b_pstride = d->b_plane_stride;
   a.a_planes = nullptr; a.a_pstride = 0; a.c_planes = nullptr; a.c_pstride = 0; a.ldcp = 0; a.sk_ws = nullptr; a.sk_flags = nullptr; a.sk_on = 0; a.wave_prio = 0;
@@ -136,7 +147,10 @@ static int gemm_impl(const mt_gemm_desc* d, void* stream) {
     rc = try_launch_dma(d, a, s);
     if (rc <= 0) return rc;
   }
-  const int cfg = pick_cfg(d->op, d->M, d->N, d->prologue, d->epilogue);
+  int cfg = pick_cfg(d->op, d->M, d->N, d->prologue, d->epilogue);
+  static const bool wg64_off = getenv("MT_CONV_WG64") && atoi(getenv("MT_CONV_WG64")) == 0;      // lab: 0 = the 128 x 64 tile
+  if (d->op == MT_OP_TN && d->b_prologue == MT_BPRO_IM2COL && d->epilogue == MT_EPI_ATOMIC && d->M <= 64 && d->N > 192 && d->N <= 288 && !wg64_off)
+    cfg = CFG_WG64;
   const int m_tiles = (d->M + kCfg[cfg].bm - 1) / kCfg[cfg].bm;
   const int n_tiles = (d->N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
   dim3 grid(m_tiles * n_tiles, 1, 1);
@@ -153,6 +167,8 @@ static int gemm_impl(const mt_gemm_desc* d, void* stream) {
     grid.x = 8 * max_rows * n_tiles;
   }
 
+  // im2col prologues: the granule form (gemm_core.hpp) for float images with C % 4 == 0 and k <= 5, else the per-element gather
+  const bool im_granule = (d->conv_C & 3) == 0 && !d->conv_src_u8 && d->conv_k * d->conv_k <= 32 && !getenv("MT_IM2COL_ANY");
 #define COMBO(OP, AL, BL, PRO, EPI)                                                        \
   if (d->op == OP && d->prologue == PRO && d->epilogue == EPI)                             \
     return launch<AL, BL, PRO, EPI>(cfg, a, grid, s);
@@ -184,7 +200,8 @@ static int gemm_impl(const mt_gemm_desc* d, void* stream) {
     }
     if (d->b_prologue == MT_BPRO_IM2COL) {
       if (d->prologue == MT_PRO_BN_BWD && d->epilogue == MT_EPI_ATOMIC)
-        return launch<LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_ATOMIC, BPRO_IM2COL>(cfg, a, grid, s);
+        return im_granule ? launch<LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_ATOMIC, BPRO_IM2COL>(cfg, a, grid, s)
+                          : launch<LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_BN_BWD, EPI_ATOMIC, BPRO_IM2COL_ANY>(cfg, a, grid, s);
       return fail(MT_ERR_UNSUPPORTED, "mt_gemm TN: im2col B prologue only with BN_BWD/ATOMIC");
     }
     COMBO(MT_OP_TN, LAYOUT_KMAJOR, LAYOUT_KMAJOR, PRO_NONE, EPI_ATOMIC)
@@ -211,8 +228,12 @@ static int gemm_impl(const mt_gemm_desc* d, void* stream) {
   COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_NONE, EPI_GEGLU_BWD)   // FF data gradient over a transposed weight: the fallback of the split loop's instance
   COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_BN_SWISH_GATE, EPI_STATS)
   COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_BN_SWISH_GATE, EPI_STORE)
-  COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_IM2COL, EPI_STORE)
-  COMBO(MT_OP_NT, LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_IM2COL, EPI_STATS)
+  if (d->op == MT_OP_NT && d->prologue == MT_PRO_IM2COL && d->epilogue == MT_EPI_STORE)
+    return im_granule ? launch<LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_IM2COL, EPI_STORE>(cfg, a, grid, s)
+                      : launch<LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_IM2COL_ANY, EPI_STORE>(cfg, a, grid, s);
+  if (d->op == MT_OP_NT && d->prologue == MT_PRO_IM2COL && d->epilogue == MT_EPI_STATS)
+    return im_granule ? launch<LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_IM2COL, EPI_STATS>(cfg, a, grid, s)
+                      : launch<LAYOUT_KCONTIG, LAYOUT_KCONTIG, PRO_IM2COL_ANY, EPI_STATS>(cfg, a, grid, s);
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_STORE)
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_ACCUM)
   COMBO(MT_OP_NN, LAYOUT_KCONTIG, LAYOUT_KMAJOR, PRO_NONE, EPI_GEGLU_BWD)

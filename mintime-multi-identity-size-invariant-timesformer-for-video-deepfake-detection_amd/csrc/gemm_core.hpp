@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "common.hpp"
 #include "det.hpp"
 
 #ifndef MT_BK
@@ -45,10 +46,12 @@ enum : int {
                            //     (dense k x k convolution / strided 1x1 as a GEMM; m = (n,oh,ow), k = (kh,kw,ci); no im2col buffer)
   PRO_BN_BWD = 4,          // a = ka[c]*A[.] + kb[c]*A2[.] + kc[c]   (BatchNorm backward folded into the operand load:
                            //     A = d(bn output), A2 = z (bn input); ka,kb,kc = scale, shift, gate vectors; c = channel)
+  PRO_IM2COL_ANY = 15,     // internal: PRO_IM2COL by the generic per-element gather (3-channel / uint8 images, k > 5); PRO_IM2COL itself is
+                           //     the granule form (float image, C % 4 == 0: gemm.hip im2col_granule_ok)
 };
 
 // prologue applied to B elements (k-major B only): B = swish(z*b_scale[n]+b_shift[n]) * b_gate[(k/b_hw)*N + n]
-enum : int { BPRO_NONE = 0, BPRO_BN_SWISH_GATE = 1, BPRO_IM2COL = 2 };   // BPRO_IM2COL: B[k=(n,oh,ow)][n=(kh,kw,ci)] gathered (conv wgrad)
+enum : int { BPRO_NONE = 0, BPRO_BN_SWISH_GATE = 1, BPRO_IM2COL = 2, BPRO_IM2COL_ANY = 3 };   // BPRO_IM2COL: B[k=(n,oh,ow)][n=(kh,kw,ci)] gathered (conv wgrad); _ANY: see PRO_IM2COL_ANY
 
 // epilogues
 enum : int {
@@ -79,22 +82,25 @@ __device__ __forceinline__ int64_t map_row(const RowMap& rm, int r) {
 struct ConvDesc {   // geometry of an im2col prologue
   int H, W, C, Ho, Wo, k, stride, pad, act;   // act: 0 none, 2 relu (applied after the optional per-channel affine)
   int src_u8;                                 // source image is uint8 (raw BGR crops), converted on the fly; scalar-gather path only
+  FastDiv dWo, dHo, dC, dk;                   // multiply-shift reciprocals of Wo, Ho, C, k (conv_desc_of)
 };
+
+inline ConvDesc conv_desc_of(int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int act, int src_u8) {
+  return ConvDesc{H, W, C, Ho, Wo, k, stride, pad, act, src_u8, fast_div_of(Wo), fast_div_of(Ho), fast_div_of(C), fast_div_of(k)};
+}
 
 __device__ __forceinline__ float conv_act(float v, int act) { return act == 2 ? fmaxf(v, 0.f) : v; }
 
 // value of the virtual im2col matrix at (pixel row m, column kk) for 4 consecutive kk (kk % 4 == 0)
 __device__ __forceinline__ float4 im2col_gather4(const float* __restrict__ x, const ConvDesc& cd, const float* __restrict__ scale,
                                                  const float* __restrict__ shift, int m, int kk) {
-  const int ow = m % cd.Wo;
-  const int t = m / cd.Wo;
-  const int oh = t % cd.Ho;
-  const int n = t / cd.Ho;
+  const int t = cd.dWo.div(m), ow = m - t * cd.Wo;
+  const int n = cd.dHo.div(t), oh = t - n * cd.Ho;
   const int kt = cd.k * cd.k * cd.C;
   float out[4];
   if ((cd.C & 3) == 0) {
-    const int tap = kk / cd.C, ci = kk - tap * cd.C;
-    const int kh = tap / cd.k, kw = tap - kh * cd.k;
+    const int tap = cd.dC.div(kk), ci = kk - tap * cd.C;
+    const int kh = cd.dk.div(tap), kw = tap - kh * cd.k;
     const int ih = oh * cd.stride + kh - cd.pad, iw = ow * cd.stride + kw - cd.pad;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (kk < kt && ih >= 0 && ih < cd.H && iw >= 0 && iw < cd.W) {
@@ -112,8 +118,8 @@ __device__ __forceinline__ float4 im2col_gather4(const float* __restrict__ x, co
     const int k1 = kk + e;
     float v = 0.f;
     if (k1 < kt) {
-      const int tap = k1 / cd.C, ci = k1 - tap * cd.C;
-      const int kh = tap / cd.k, kw = tap - kh * cd.k;
+      const int tap = cd.dC.div(k1), ci = k1 - tap * cd.C;
+      const int kh = cd.dk.div(tap), kw = tap - kh * cd.k;
       const int ih = oh * cd.stride + kh - cd.pad, iw = ow * cd.stride + kw - cd.pad;
       if (ih >= 0 && ih < cd.H && iw >= 0 && iw < cd.W) {
         const int64_t off = (((int64_t)n * cd.H + ih) * cd.W + iw) * cd.C + ci;
@@ -458,8 +464,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
   else gemm_epilogue_body<TM, TN, EPI, false>(p, acc, m0, n0, wm, wn, lane, split);
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI, int BPRO = BPRO_NONE>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MT_MIN_WAVES)
+template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI, int BPRO = BPRO_NONE, int MINW = MT_MIN_WAVES>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW)
 void gemm_kernel(const GemmArgs p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * TM * 32;
@@ -518,6 +524,61 @@ void gemm_kernel(const GemmArgs p) {
     }
   };
 
+  // ---- im2col prologues, granule form (a float NHWC image with C % 4 == 0: every user but the 3-channel stem, which keeps
+  // im2col_gather4).  The generic gather decomposed (row -> image, oh, ow) and (column -> tap, channel) and tested the window for
+  // every 16-byte load: ~70 VALU instructions per load, 300 per k-step next to 16 MFMAs (Xception's conv2 ran VALU-bound on the
+  // matrix-core kernel).  Here everything that does not change from one k-step to the next is kept per staging unit:
+  //   A side (rows = output pixels, fixed per unit): the window origin's element offset and a bit mask of its in-image taps; a k-step
+  //     costs one tap decomposition per THREAD (all units of a thread share the k granule) and a bit test + an add per unit;
+  //   B side (rows = the contraction = pixels, 16 further per k-step; columns = (tap, channel), fixed per unit): the column's element
+  //     offset, and the pixel's offset / (oh, ow) advanced incrementally.
+  constexpr bool A_IM = PRO == PRO_IM2COL, B_IM = BPRO == BPRO_IM2COL;
+  constexpr int A_ST = A_IM ? A_UNITS : 1, B_ST = B_IM ? B_UNITS : 1;
+  const ConvDesc& cd = p.conv;
+  const bool im_relu = cd.act == 2;
+  int64_t a_pix[A_ST]; uint32_t a_msk[A_ST];
+  int64_t b_pix[B_ST]; int b_col[B_ST], b_ci[B_ST], b_oh[B_ST], b_ow[B_ST], b_tap[B_ST];
+  if constexpr (A_IM) {
+    static_assert(!A_IM || (AL == LAYOUT_KCONTIG && NT % KQ == 0), "im2col A: k-contiguous rows, one k granule per thread");
+    {
+#pragma unroll
+      for (int i = 0; i < A_UNITS; ++i) {
+        const int u = tid + i * NT, m = m0 + u / KQ;
+        a_pix[i] = 0; a_msk[i] = 0;
+        if ((A_EXACT || u < BM * BK / 4) && m < p.M) {
+          const int t = cd.dWo.div(m), ow = m - t * cd.Wo;
+          const int n = cd.dHo.div(t), oh = t - n * cd.Ho;
+          const int ih0 = oh * cd.stride - cd.pad, iw0 = ow * cd.stride - cd.pad;
+          a_pix[i] = (((int64_t)n * cd.H + ih0) * cd.W + iw0) * cd.C;
+          uint32_t msk = 0;
+          for (int kh = 0, t2 = 0; kh < cd.k; ++kh)
+            for (int kw = 0; kw < cd.k; ++kw, ++t2)
+              if ((unsigned)(ih0 + kh) < (unsigned)cd.H && (unsigned)(iw0 + kw) < (unsigned)cd.W) msk |= 1u << t2;
+          a_msk[i] = msk;
+        }
+      }
+    }
+  }
+  if constexpr (B_IM) {
+    static_assert(!B_IM || BL == LAYOUT_KMAJOR, "im2col B: k-major (weight gradients)");
+    {
+      constexpr int QPR = BN / 4;
+#pragma unroll
+      for (int i = 0; i < B_UNITS; ++i) {
+        const int u = tid + i * NT, kk = u / QPR, n = n0 + (u - kk * QPR) * 4;
+        const int tap = cd.dC.div(n), ci = n - tap * cd.C;
+        const int kh = cd.dk.div(tap), kw = tap - kh * cd.k;
+        b_col[i] = (kh * cd.W + kw) * cd.C + ci; b_ci[i] = ci;
+        b_tap[i] = ((B_EXACT || u < BN * BK / 4) && n < p.N && tap < cd.k * cd.k) ? (kh | (kw << 8)) : -1;
+        const int k = k_begin + kk;                       // this unit's pixel in the first k-step; later ones are BK further
+        const int t = cd.dWo.div(k), ow = k - t * cd.Wo;
+        const int img = cd.dHo.div(t), oh = t - img * cd.Ho;
+        b_oh[i] = oh; b_ow[i] = ow;
+        b_pix[i] = (((int64_t)img * cd.H + (oh * cd.stride - cd.pad)) * cd.W + (ow * cd.stride - cd.pad)) * cd.C;
+      }
+    }
+  }
+
   float4 ra[A_UNITS], rb[B_UNITS];
 
   auto load_tiles = [&](int kt) {
@@ -531,6 +592,20 @@ void gemm_kernel(const GemmArgs p) {
           const int row = u / KQ, kq = u % KQ;
           const int m = m0 + row, k = k0 + kq * 4;
           if constexpr (PRO == PRO_IM2COL) {
+            {
+              // (tap, channel) of this thread's k granule: the same for all its units, the compiler keeps one copy
+              const int tap = cd.dC.div(k), ci = k - tap * cd.C;
+              const int kh = cd.dk.div(tap), kw = tap - kh * cd.k;
+              if (k < k_end && tap < cd.k * cd.k && ((a_msk[i] >> tap) & 1u)) {
+                v = *reinterpret_cast<const float4*>(p.A + (a_pix[i] + ((kh * cd.W + kw) * cd.C + ci)));
+                if (p.scale) {
+                  const float4 sc = *reinterpret_cast<const float4*>(p.scale + ci), sh = *reinterpret_cast<const float4*>(p.shift + ci);
+                  v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                }
+                if (im_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+              }
+            }
+          } else if constexpr (PRO == PRO_IM2COL_ANY) {
             if (m < p.M && k < k_end) v = im2col_gather4(p.A, p.conv, p.scale, p.shift, m, k);
           } else if (m < p.M && k < k_end) {
             v = *reinterpret_cast<const float4*>(p.A + map_row(p.a_map, m) * p.lda + k);
@@ -589,6 +664,26 @@ void gemm_kernel(const GemmArgs p) {
           const int kk = u / QPR, nq = u - kk * QPR;
           const int k = k0 + kk, n = n0 + nq * 4;
           if constexpr (BPRO == BPRO_IM2COL) {
+            {
+              const int kh = b_tap[i] & 255, kw = b_tap[i] >> 8;
+              const int ih = b_oh[i] * cd.stride - cd.pad + kh, iw = b_ow[i] * cd.stride - cd.pad + kw;
+              if (k < k_end && b_tap[i] >= 0 && (unsigned)ih < (unsigned)cd.H && (unsigned)iw < (unsigned)cd.W) {
+                v = *reinterpret_cast<const float4*>(p.B + (b_pix[i] + b_col[i]));
+                if (p.b_scale) {
+                  const int ci = b_ci[i];
+                  const float4 sc = *reinterpret_cast<const float4*>(p.b_scale + ci), sh = *reinterpret_cast<const float4*>(p.b_shift + ci);
+                  v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                }
+                if (im_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+              }
+              // next k-step: BK pixels further (load_tiles is called once per k-step, in order)
+              b_ow[i] += BK; b_pix[i] += (int64_t)BK * cd.stride * cd.C;
+              while (b_ow[i] >= cd.Wo) {
+                b_ow[i] -= cd.Wo; b_oh[i] += 1; b_pix[i] += ((int64_t)cd.W - cd.Wo) * cd.stride * cd.C;
+                if (b_oh[i] >= cd.Ho) { b_oh[i] = 0; b_pix[i] += ((int64_t)cd.H - (int64_t)cd.Ho * cd.stride) * cd.W * cd.C; }
+              }
+            }
+          } else if constexpr (BPRO == BPRO_IM2COL_ANY) {
             if (k < k_end && n < p.N) v = im2col_gather4(p.B, p.conv, p.b_scale, p.b_shift, k, n);
           } else if (k < k_end && n < p.N) {
             v = *reinterpret_cast<const float4*>(p.B + map_row(p.b_map, k) * p.ldb + n);

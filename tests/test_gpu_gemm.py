@@ -141,7 +141,7 @@ def test_im2col_conv_matches_torch_conv():
     import torch.nn.functional as F
     lib = L.get()
     for (Cin, Cout, k, s, p, H, relu) in ((3, 32, 3, 2, 0, 37, False), (32, 64, 3, 1, 0, 21, True), (64, 128, 1, 2, 0, 19, False),
-                                          (64, 32, 3, 1, 2, 11, False)):
+                                          (64, 32, 3, 1, 2, 11, False), (8, 24, 5, 2, 2, 13, True), (16, 32, 3, 2, 1, 10, True)):
         n = 2
         x = _rand(n, H, H, Cin, seed=1)
         w = _rand(Cout, Cin, k, k, seed=2, scale=0.2)
@@ -158,6 +158,38 @@ def test_im2col_conv_matches_torch_conv():
             a = a.clamp_min(0)
         ref = F.conv2d(a.permute(0, 3, 1, 2), w.double(), None, s, p).permute(0, 2, 3, 1).reshape(n * Ho * Ho, Cout)
         assert_close(out, ref, 5e-5, f"im2col conv {Cin}->{Cout} k{k} s{s} p{p}")
+
+
+def test_im2col_weight_gradient_matches_torch_conv():
+    """Weight gradient of a dense convolution as a TN GEMM whose B operand is gathered (BPRO_IM2COL) and whose A operand carries the
+    BatchNorm-backward prologue: dW[co][(kh,kw,ci)] = sum_pixels (ka*dy + kb*z + kc)[pix][co] * act(x*sc+sh)[window(pix)][kh,kw,ci].
+    Cases: Xception conv2's 64 x 288 (the one-tile-per-K-range configuration, gemm.hip CFG_WG64) over image rows that wrap inside a
+    k-step, a padded 3x3 (window tests on the B side), a strided 1x1, and the 3-channel per-element gather."""
+    import torch.nn.functional as F
+    for (Cin, Cout, k, s, p, H, relu) in ((32, 64, 3, 1, 0, 23, True), (32, 48, 3, 1, 1, 9, False), (64, 128, 1, 2, 0, 19, True),
+                                          (3, 32, 3, 2, 0, 21, False), (8, 64, 5, 2, 2, 13, True)):
+        n = 3
+        x = _rand(n, H, H, Cin, seed=1)
+        Ho = (H + 2 * p - k) // s + 1
+        M = n * Ho * Ho
+        dy, z = _rand(M, Cout, seed=2), _rand(M, Cout, seed=3)
+        ka, kb, kc = _rand(Cout, seed=4).abs() + 0.5, _rand(Cout, seed=5, scale=0.2), _rand(Cout, seed=6, scale=0.1)
+        sc, sh = _rand(Cin, seed=7).abs() + 0.5, _rand(Cin, seed=8, scale=0.3)
+        K = (k * k * Cin + 3) // 4 * 4
+        dw = torch.zeros(Cout, K, device="cuda")
+        L.gemm(L.OP_TN, dy.cuda(), x.cuda(), dw, Cout, K, M, Cout, K, K, prologue=L.PRO_BN_BWD, epilogue=L.EPI_ATOMIC, split_k=0,
+               A2=z.cuda(), scale=ka.cuda(), shift=kb.cuda(), gate=kc.cuda(), b_prologue=L.BPRO_IM2COL, b_scale=sc.cuda(),
+               b_shift=sh.cuda(), conv=(H, H, Cin, Ho, Ho, k, s, p, 2 if relu else 0))
+        a = x.double() * sc.double() + sh.double()
+        if relu:
+            a = a.clamp_min(0)
+        g = (ka.double() * dy.double() + kb.double() * z.double() + kc.double()).reshape(n, Ho, Ho, Cout).permute(0, 3, 1, 2)
+        a_nchw = a.permute(0, 3, 1, 2).requires_grad_(False)
+        w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+        F.conv2d(a_nchw, w, None, s, p).backward(g)
+        ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin)          # columns in (kh, kw, ci) order
+        assert_close(dw[:, :k * k * Cin], ref, 5e-5, f"im2col wgrad {Cin}->{Cout} k{k} s{s} p{p}")
+        assert float(dw[:, k * k * Cin:].abs().sum()) == 0.0
 
 
 # ---------------------------------------------------------------------------------------------------------------------
