@@ -55,11 +55,8 @@ int launch(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
       else hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, AL, BL, PRO, EPI, BPRO>), grid, dim3(256), 0, s, a);
       break;
     case CFG_WG64:
-      if constexpr ((BPRO == BPRO_IM2COL || BPRO == BPRO_IM2COL_ANY) && EPI == EPI_ATOMIC) {
-        static const bool two = getenv("MT_CONV_WG64") && atoi(getenv("MT_CONV_WG64")) == 2;
-        if (two) hipLaunchKernelGGL((gemm_kernel<2, 3, 1, 3, AL, BL, PRO, EPI, BPRO, 2>), grid, dim3(384), 0, s, a);
-        else hipLaunchKernelGGL((gemm_kernel<2, 3, 1, 3, AL, BL, PRO, EPI, BPRO>), grid, dim3(384), 0, s, a);
-      }
+      if constexpr ((BPRO == BPRO_IM2COL || BPRO == BPRO_IM2COL_ANY) && EPI == EPI_ATOMIC)
+        hipLaunchKernelGGL((gemm_kernel<2, 3, 1, 3, AL, BL, PRO, EPI, BPRO>), grid, dim3(384), 0, s, a);
       else return fail(MT_ERR_UNSUPPORTED, "the 64 x 288 tile is the im2col weight gradient's");
       break;
 

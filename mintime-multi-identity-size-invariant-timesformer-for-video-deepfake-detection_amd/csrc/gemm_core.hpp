@@ -464,8 +464,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
   else gemm_epilogue_body<TM, TN, EPI, false>(p, acc, m0, n0, wm, wn, lane, split);
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI, int BPRO = BPRO_NONE, int MINW = MT_MIN_WAVES>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MINW)
+template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI, int BPRO = BPRO_NONE>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MT_MIN_WAVES)
 void gemm_kernel(const GemmArgs p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * TM * 32;
@@ -537,7 +537,10 @@ void gemm_kernel(const GemmArgs p) {
   const ConvDesc& cd = p.conv;
   const bool im_relu = cd.act == 2;
   int64_t a_pix[A_ST]; uint32_t a_msk[A_ST];
-  int64_t b_pix[B_ST]; int b_col[B_ST], b_ci[B_ST], b_oh[B_ST], b_ow[B_ST], b_tap[B_ST];
+  int64_t b_pix[B_ST]; int b_col[B_ST], b_oh[B_ST], b_ow[B_ST], b_tap[B_ST];
+  float4 b_sc[B_ST], b_sh[B_ST];                              // the column's affine (identity without b_scale): loop-invariant per unit
+  constexpr bool A_KB = B_IM && PRO == PRO_BN_BWD && AL == LAYOUT_KMAJOR && BM <= 64;   // the one-tile weight gradient: ka / kb / kc of the unit's 4 channels kept too
+  float4 a_ka[A_KB ? A_UNITS : 1], a_kb[A_KB ? A_UNITS : 1], a_kc[A_KB ? A_UNITS : 1];
   if constexpr (A_IM) {
     static_assert(!A_IM || (AL == LAYOUT_KCONTIG && NT % KQ == 0), "im2col A: k-contiguous rows, one k granule per thread");
     {
@@ -568,7 +571,11 @@ void gemm_kernel(const GemmArgs p) {
         const int u = tid + i * NT, kk = u / QPR, n = n0 + (u - kk * QPR) * 4;
         const int tap = cd.dC.div(n), ci = n - tap * cd.C;
         const int kh = cd.dk.div(tap), kw = tap - kh * cd.k;
-        b_col[i] = (kh * cd.W + kw) * cd.C + ci; b_ci[i] = ci;
+        b_col[i] = (kh * cd.W + kw) * cd.C + ci;
+        b_sc[i] = make_float4(1.f, 1.f, 1.f, 1.f); b_sh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.b_scale && n < p.N && tap < cd.k * cd.k) {
+          b_sc[i] = *reinterpret_cast<const float4*>(p.b_scale + ci); b_sh[i] = *reinterpret_cast<const float4*>(p.b_shift + ci);
+        }
         b_tap[i] = ((B_EXACT || u < BN * BK / 4) && n < p.N && tap < cd.k * cd.k) ? (kh | (kw << 8)) : -1;
         const int k = k_begin + kk;                       // this unit's pixel in the first k-step; later ones are BK further
         const int t = cd.dWo.div(k), ow = k - t * cd.Wo;
@@ -579,6 +586,18 @@ void gemm_kernel(const GemmArgs p) {
     }
   }
 
+  if constexpr (A_KB) {
+    constexpr int QPRA = BM / 4;
+#pragma unroll
+    for (int i = 0; i < A_UNITS; ++i) {
+      const int u = tid + i * NT, m = m0 + (u % QPRA) * 4;
+      a_ka[i] = a_kb[i] = a_kc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((A_EXACT || u < BM * BK / 4) && m < p.M) {
+        a_ka[i] = *reinterpret_cast<const float4*>(p.scale + m); a_kb[i] = *reinterpret_cast<const float4*>(p.shift + m);
+        a_kc[i] = *reinterpret_cast<const float4*>(p.gate + m);
+      }
+    }
+  }
   float4 ra[A_UNITS], rb[B_UNITS];
 
   auto load_tiles = [&](int kt) {
@@ -639,9 +658,13 @@ void gemm_kernel(const GemmArgs p) {
             v = *reinterpret_cast<const float4*>(p.A + off);
             if constexpr (PRO == PRO_BN_BWD) {      // channel index is the output row m here
               const float4 z2 = *reinterpret_cast<const float4*>(p.A2 + off);
-              const float4 ka = *reinterpret_cast<const float4*>(p.scale + m);
-              const float4 kb = *reinterpret_cast<const float4*>(p.shift + m);
-              const float4 kc = *reinterpret_cast<const float4*>(p.gate + m);
+              float4 ka, kb, kc;
+              if constexpr (A_KB) { ka = a_ka[i]; kb = a_kb[i]; kc = a_kc[i]; }
+              else {
+                ka = *reinterpret_cast<const float4*>(p.scale + m);
+                kb = *reinterpret_cast<const float4*>(p.shift + m);
+                kc = *reinterpret_cast<const float4*>(p.gate + m);
+              }
               v.x = fmaf(ka.x, v.x, fmaf(kb.x, z2.x, kc.x)); v.y = fmaf(ka.y, v.y, fmaf(kb.y, z2.y, kc.y));
               v.z = fmaf(ka.z, v.z, fmaf(kb.z, z2.z, kc.z)); v.w = fmaf(ka.w, v.w, fmaf(kb.w, z2.w, kc.w));
             }
@@ -670,9 +693,8 @@ void gemm_kernel(const GemmArgs p) {
               if (k < k_end && b_tap[i] >= 0 && (unsigned)ih < (unsigned)cd.H && (unsigned)iw < (unsigned)cd.W) {
                 v = *reinterpret_cast<const float4*>(p.B + (b_pix[i] + b_col[i]));
                 if (p.b_scale) {
-                  const int ci = b_ci[i];
-                  const float4 sc = *reinterpret_cast<const float4*>(p.b_scale + ci), sh = *reinterpret_cast<const float4*>(p.b_shift + ci);
-                  v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                  v.x = fmaf(v.x, b_sc[i].x, b_sh[i].x); v.y = fmaf(v.y, b_sc[i].y, b_sh[i].y);
+                  v.z = fmaf(v.z, b_sc[i].z, b_sh[i].z); v.w = fmaf(v.w, b_sc[i].w, b_sh[i].w);
                 }
                 if (im_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
               }

@@ -20,7 +20,7 @@ wp2 = torch.randn(64, 288, device=dev, generator=g) * 0.05
 wp2t = torch.randn(32, 576, device=dev, generator=g) * 0.05
 RELU, NONE = 2, 0
 
-def timed(fn, reps=5):
+def timed(fn, reps=int(os.environ.get("LAB_REPS", "5"))):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
