@@ -9,13 +9,13 @@ using namespace mt;
 
 namespace {
 
-enum { CFG_BIG = 0, CFG_MID = 1, CFG_NARROW = 2, CFG_SMALL = 3, CFG_WG64 = 4 };
+enum { CFG_BIG = 0, CFG_MID = 1, CFG_NARROW = 2, CFG_SMALL = 3, CFG_WG64 = 4, CFG_WG64K = 5 };
 
 struct Cfg { int bm, bn, threads; };
 // CFG_WG64: the weight gradient of a dense 3x3 convolution with <= 64 output channels and 9 x 32 gathered columns (Xception's conv2,
 // reference models/xception.py:164: out[64][288] over 11 M pixel rows): ONE 64 x 288 tile per K range (six wavefronts, 32 x 96 each)
 // -- the 128 x 64 tile computed 64 rows of zeros and re-read the dy / z operand pair once per column tile (5x).
-constexpr Cfg kCfg[5] = {{128, 128, 256}, {128, 64, 256}, {256, 32, 256}, {64, 64, 256}, {64, 288, 384}};
+constexpr Cfg kCfg[6] = {{128, 128, 256}, {128, 64, 256}, {256, 32, 256}, {64, 64, 256}, {64, 288, 384}, {64, 288, 768}};
 
 // Tile choice.  Replaying every GEMM of a B = 32 training step alone under each configuration (round-1 tuning script; results: profiles/r01_gemm_tile_config_sweep.txt, 70
 // shapes) favours 64x64 tiles almost everywhere, but inside the real step -- where the weight-gradient GEMMs of a second stream
@@ -57,6 +57,11 @@ int launch(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
     case CFG_WG64:
       if constexpr ((BPRO == BPRO_IM2COL || BPRO == BPRO_IM2COL_ANY) && EPI == EPI_ATOMIC)
         hipLaunchKernelGGL((gemm_kernel<2, 3, 1, 3, AL, BL, PRO, EPI, BPRO>), grid, dim3(384), 0, s, a);
+      else return fail(MT_ERR_UNSUPPORTED, "the 64 x 288 tile is the im2col weight gradient's");
+      break;
+    case CFG_WG64K:     // the same tile by two K groups of six wavefronts (gemm_core.hpp WAVES_K): 3 wavefronts on every SIMD
+      if constexpr ((BPRO == BPRO_IM2COL || BPRO == BPRO_IM2COL_ANY) && EPI == EPI_ATOMIC)
+        hipLaunchKernelGGL((gemm_kernel<2, 3, 1, 3, AL, BL, PRO, EPI, BPRO, 2>), grid, dim3(768), 0, s, a);
       else return fail(MT_ERR_UNSUPPORTED, "the 64 x 288 tile is the im2col weight gradient's");
       break;
 
@@ -147,7 +152,7 @@ static int gemm_impl(const mt_gemm_desc* d, void* stream) {
   int cfg = pick_cfg(d->op, d->M, d->N, d->prologue, d->epilogue);
   static const bool wg64_off = getenv("MT_CONV_WG64") && atoi(getenv("MT_CONV_WG64")) == 0;      // lab: 0 = the 128 x 64 tile
   if (d->op == MT_OP_TN && d->b_prologue == MT_BPRO_IM2COL && d->epilogue == MT_EPI_ATOMIC && d->M <= 64 && d->N > 192 && d->N <= 288 && !wg64_off)
-    cfg = CFG_WG64;
+    cfg = (det_enabled() || (getenv("MT_CONV_WG64") && atoi(getenv("MT_CONV_WG64")) == 1)) ? CFG_WG64 : CFG_WG64K;   // (deterministic mode writes per-split slabs: one writer per tile)
   const int m_tiles = (d->M + kCfg[cfg].bm - 1) / kCfg[cfg].bm;
   const int n_tiles = (d->N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
   dim3 grid(m_tiles * n_tiles, 1, 1);

@@ -464,10 +464,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
   else gemm_epilogue_body<TM, TN, EPI, false>(p, acc, m0, n0, wm, wn, lane, split);
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI, int BPRO = BPRO_NONE>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, MT_MIN_WAVES)
+// WAVES_K = 2 (split-K weight gradients with the atomic epilogue only): two groups of WAVES_M x WAVES_N wavefronts share the staged
+// tiles, group wk takes MFMA slice group wk of every k-step and adds its own partial tile in the epilogue.  For the one-tile
+// 64 x 288 weight gradient this makes the block 12 wavefronts = 3 per SIMD: a 6-wavefront block sits (2, 2, 1, 1) on the four SIMDs
+// and a second one does not fit beside it at 3 wavefronts per SIMD (measured: one block per CU, run time linear in the block count
+// from 256 blocks on), so half of the matrix pipes ran at half load.
+template <int WAVES_M, int WAVES_N, int TM, int TN, int AL, int BL, int PRO, int EPI, int BPRO = BPRO_NONE, int WAVES_K = 1>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * WAVES_K * 64, MT_MIN_WAVES)
 void gemm_kernel(const GemmArgs p) {
-  constexpr int NT = WAVES_M * WAVES_N * 64;
+  static_assert(WAVES_K == 1 || (WAVES_K == 2 && EPI == EPI_ATOMIC && MT_BK == 16), "K groups: one per MFMA slice group, partial tiles added atomically");
+  constexpr int NT = WAVES_M * WAVES_N * WAVES_K * 64;
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   constexpr int BK = MT_BK;
@@ -495,7 +501,8 @@ void gemm_kernel(const GemmArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave / WAVES_N;
+  const int wk = wave / (WAVES_M * WAVES_N);          // K group (0 unless WAVES_K == 2)
+  const int wm = (wave % (WAVES_M * WAVES_N)) / WAVES_N;
   const int wn = wave % WAVES_N;
 
   int mt_, nt_;
@@ -807,6 +814,19 @@ void gemm_kernel(const GemmArgs p) {
   constexpr int NG = BK / 8;
   static_assert(NG == 2 || NG == 4, "BK must be 16 or 32");
 
+  if constexpr (WAVES_K == 2) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      const bool more = kt + 1 < nk;
+      if (more) load_tiles(kt + 1);
+      float fa[TM][4], fb[TN][4];
+      load_frags(As + buf * A_TILE, Bs + buf * B_TILE, wk, fa, fb);
+      mma_steps(fa, fb, 0, 2);
+      if (more) store_tiles(buf ^ 1);
+      mma_steps(fa, fb, 2, 4);
+      __syncthreads();
+    }
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     const bool more = kt + 1 < nk;

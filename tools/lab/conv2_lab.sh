@@ -1,16 +1,14 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/conv2lab
 o=gpurun_out/conv2lab/out.txt; : > $o
-python - >> $o 2>&1 <<'PY'
-import importlib, sys, torch
-sys.path.insert(0, ".")
-pkg = importlib.import_module("mintime-multi-identity-size-invariant-timesformer-for-video-deepfake-detection_amd")
-L = importlib.import_module(pkg.__name__ + ".lib")
-lib = L.get(); torch.zeros(1, device="cuda")
-import ctypes
-f = lib.mt_debug_wg64_blocks_per_cu; f.restype = ctypes.c_int; f.argtypes = [ctypes.c_int]
-print("blocks per CU: minw3", f(3), "minw2", f(2), "minw4", f(4))
-PY
-MT_CONV_WG64=4 LAB_WHICH=wgrad python tools/lab/conv2_lab.py 2>&1 | grep -v amdgpu.ids >> $o
-MT_CONV_WG64=1 LAB_WHICH=wgrad python tools/lab/conv2_lab.py 2>&1 | grep -v amdgpu.ids >> $o
+python -m pytest tests/test_gpu_gemm.py -x -q -k "im2col" 2>&1 | tail -2 >> $o
+MT_CONV_WG64=1 python -m pytest tests/test_gpu_gemm.py -x -q -k "im2col" 2>&1 | tail -2 >> $o
+MT_CONV_WG64=1 LAB_WHICH=wgrad LAB_SAVE=/tmp/dw1.pt python tools/lab/conv2_lab.py 2>&1 | grep -v amdgpu.ids >> $o
+LAB_WHICH=wgrad LAB_CMP=/tmp/dw1.pt python tools/lab/conv2_lab.py 2>&1 | grep -v amdgpu.ids >> $o
+LAB_N=128 MT_WGRAD_BLOCKS_OLD=256 LAB_WHICH=wgrad python tools/lab/conv2_lab.py 2>&1 | grep -v amdgpu.ids >> $o
+LAB_N=256 MT_WGRAD_BLOCKS_OLD=512 LAB_WHICH=wgrad python tools/lab/conv2_lab.py 2>&1 | grep -v amdgpu.ids >> $o
+for f in 0.7 1.0; do
+  MT_XC_CONV2_WGRAD_SIDE=$f python bench.py --config 5 --steps 5 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c5 side $f', d['ms_per_step'], d['value'])" >> $o
+done
+MT_CONV_WG64=1 python bench.py --config 5 --steps 5 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c5 six-wave tile', d['ms_per_step'], d['value'])" >> $o
 cat $o
