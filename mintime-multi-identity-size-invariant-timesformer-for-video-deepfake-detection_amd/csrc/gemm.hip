@@ -150,9 +150,9 @@ static int gemm_impl(const mt_gemm_desc* d, void* stream) {
     if (rc <= 0) return rc;
   }
   int cfg = pick_cfg(d->op, d->M, d->N, d->prologue, d->epilogue);
-  static const bool wg64_off = getenv("MT_CONV_WG64") && atoi(getenv("MT_CONV_WG64")) == 0;      // lab: 0 = the 128 x 64 tile
-  if (d->op == MT_OP_TN && d->b_prologue == MT_BPRO_IM2COL && d->epilogue == MT_EPI_ATOMIC && d->M <= 64 && d->N > 192 && d->N <= 288 && !wg64_off)
-    cfg = (det_enabled() || (getenv("MT_CONV_WG64") && atoi(getenv("MT_CONV_WG64")) == 1)) ? CFG_WG64 : CFG_WG64K;   // (deterministic mode writes per-split slabs: one writer per tile)
+  static const int wg64_var = getenv("MT_CONV_WG64") ? atoi(getenv("MT_CONV_WG64")) : 2;      // lab: 0 = the 128 x 64 tile, 1 = six wavefronts
+  if (d->op == MT_OP_TN && d->b_prologue == MT_BPRO_IM2COL && d->epilogue == MT_EPI_ATOMIC && d->M <= 64 && d->N > 192 && d->N <= 288 && wg64_var != 0)
+    cfg = (det_enabled() || wg64_var == 1) ? CFG_WG64 : CFG_WG64K;   // (deterministic mode writes per-split slabs: one writer per tile)
   const int m_tiles = (d->M + kCfg[cfg].bm - 1) / kCfg[cfg].bm;
   const int n_tiles = (d->N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
   dim3 grid(m_tiles * n_tiles, 1, 1);
@@ -170,7 +170,8 @@ static int gemm_impl(const mt_gemm_desc* d, void* stream) {
   }
 
   // im2col prologues: the granule form (gemm_core.hpp) for float images with C % 4 == 0 and k <= 5, else the per-element gather
-  const bool im_granule = (d->conv_C & 3) == 0 && !d->conv_src_u8 && d->conv_k * d->conv_k <= 32 && !getenv("MT_IM2COL_ANY");
+  static const bool im_any = getenv("MT_IM2COL_ANY") != nullptr;                  // lab: the per-element gather everywhere
+  const bool im_granule = (d->conv_C & 3) == 0 && !d->conv_src_u8 && d->conv_k * d->conv_k <= 32 && !im_any;
 #define COMBO(OP, AL, BL, PRO, EPI)                                                        \
   if (d->op == OP && d->prologue == PRO && d->epilogue == EPI)                             \
     return launch<AL, BL, PRO, EPI>(cfg, a, grid, s);

@@ -15,7 +15,7 @@ RELU, NONE = 2, 0
 
 # pointwise convolutions with at least this many input channels run on plane operands (MT_XC_PLANES=0: the in-kernel-split loop)
 XC_PLANES = __import__("os").environ.get("MT_XC_PLANES", "1") != "0"
-PLANES_MIN_C = int(__import__("os").environ.get("MT_XC_PLANES_MIN_C", "256"))
+PLANES_MIN_C = int(__import__("os").environ.get("MT_XC_PLANES_MIN_C", "128"))   # (256 until round 6: config 5 185.1 -> 184.3 ms; 64: 185.7)
 DW_PLANES = __import__("os").environ.get("MT_XC_DW_PLANES", "1") != "0"   # 0: depthwise output as fp32 + mt_split_planes_blk (round 4)
 CONV2_WGRAD_SIDE = float(__import__("os").environ.get("MT_XC_CONV2_WGRAD_SIDE", "0.7"))   # share of conv2's weight gradient on the side stream
 XC_STEM = __import__("os").environ.get("MT_XC_STEM", "1") != "0"             # 0: conv1 as an im2col GEMM (round 4)
