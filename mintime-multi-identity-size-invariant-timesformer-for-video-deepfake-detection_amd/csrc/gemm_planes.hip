@@ -182,6 +182,10 @@ static int gemm_planes_impl(const mt_gemm_planes_desc* d, void* stream) {
   a.C = d->C; a.M = d->M; a.N = d->N; a.K = d->K; a.ldc = d->ldc;
   a.a_planes = d->a_planes; a.a_pstride = mt_planes_elems(a_rows, a_cols); a.lda = (a_cols + 15) >> 4;
   a.b_planes = d->b_planes; a.b_pstride = mt_planes_elems(b_rows, b_cols); a.ldb = (b_cols + 15) >> 4;
+  // the loop addresses an operand's three planes by 32-bit byte offsets from one base (gemm_planes.hpp voff): 4 GB per operand
+  if (6 * a.a_pstride > 0xFFFFFFFFll || 6 * a.b_pstride > 0xFFFFFFFFll)
+    return fail(MT_ERR_UNSUPPORTED, "mt_gemm_planes: an operand's planes span %lld bytes (> 4 GB: 32-bit DMA offsets); use mt_gemm for it (lib.planes_fit)",
+                (long long)(6 * (a.a_pstride > a.b_pstride ? a.a_pstride : a.b_pstride)));
   a.bias = d->bias; a.R = d->R; a.ldr = d->ldr; a.C2 = d->C2; a.ldc2 = d->ldc2; a.n_half = d->n_half; a.col_sum = d->col_sum;
   a.hw = 1; a.stats_slots = d->stats_slots != 0 ? d->stats_slots : 1; a.stats = d->stats; a.b_hw = 1; a.e_hw = 1;
   if (epi == MT_EPI_STATS && !d->stats) return fail(MT_ERR_ARG, "mt_gemm_planes: STATS needs stats");

@@ -291,6 +291,13 @@ def streamk_workspace(device=None):
     return ws
 
 
+def planes_fit(rows: int, cols: int) -> bool:
+    """True when a rows x cols plane tensor can be a mt_gemm_planes operand: the loop reaches an operand's three bf16 planes by
+    32-bit byte offsets from one base, so the padded tensor must stay under 4 GB (csrc/gemm_planes.hip raises otherwise)."""
+    rp, cp = (rows + 31) // 32 * 32, (cols + 15) // 16 * 16
+    return 6 * rp * cp <= 0xFFFFFFFF
+
+
 def gemm_planes(op, a_planes, b_planes, M, N, K, Cout=None, ldc=0, epilogue=EPI_STORE, bias=None, R=None, ldr=0, C2=None, ldc2=0,
                 n_half=0, col_sum=None, c_planes=None, split_k=0, streamk=None, stats=None, stats_slots=0):
     """streamk: True lends the stream's workspace (persistent grid sharing the (tile, k-step) list), False = one block per tile,

@@ -15,7 +15,7 @@ RELU, NONE = 2, 0
 
 # pointwise convolutions with at least this many input channels run on plane operands (MT_XC_PLANES=0: the in-kernel-split loop)
 XC_PLANES = __import__("os").environ.get("MT_XC_PLANES", "1") != "0"
-PLANES_MIN_C = int(__import__("os").environ.get("MT_XC_PLANES_MIN_C", "128"))   # (256 until round 6: config 5 185.1 -> 184.3 ms; 64: 185.7)
+PLANES_MIN_C = int(__import__("os").environ.get("MT_XC_PLANES_MIN_C", "256"))   # (128: +0.4 ms in config 5 once the 4 GB operand limit is respected, lib.planes_fit)
 DW_PLANES = __import__("os").environ.get("MT_XC_DW_PLANES", "1") != "0"   # 0: depthwise output as fp32 + mt_split_planes_blk (round 4)
 CONV2_WGRAD_SIDE = float(__import__("os").environ.get("MT_XC_CONV2_WGRAD_SIDE", "0.7"))   # share of conv2's weight gradient on the side stream
 XC_STEM = __import__("os").environ.get("MT_XC_STEM", "1") != "0"             # 0: conv1 as an im2col GEMM (round 4)
@@ -179,7 +179,7 @@ def xception_forward(model, x, params, training, save, plan=None):
         ctx = _BNCtx(dev, co, training, pool)
         z = _new(dev, M, co)
         d = d_p = w_p = None
-        if planes_on and ci >= PLANES_MIN_C and M >= 512:
+        if planes_on and ci >= PLANES_MIN_C and M >= 512 and L.planes_fit(M, max(ci, co)):
             # wide pointwise convolutions on plane operands (csrc/gemm_planes.hpp): forward, data gradient and weight gradient read
             # the same plane tensors by LDS-DMA (728 -> 728 over 100 352 rows: 0.81 -> 0.58 ms).  The weight is split once per
             # forward; the depthwise kernel writes its output as planes and nowhere else (DW_PLANES; round 4: fp32 + a split pass)

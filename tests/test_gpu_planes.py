@@ -393,3 +393,14 @@ def test_dropout_passes_match_torch():
         assert_close(du[:, :nh], a.grad, 1e-5, "da")
         assert_close(du[:, nh:], g.grad, 1e-5, "dg")
         assert torch.equal(L.planes_to_float(du_p, rows, 2 * nh), du)
+
+
+def test_operands_beyond_four_gigabytes_are_refused():
+    """The plane loop reaches an operand's three planes by 32-bit byte offsets from one base: a 6.08 M x 128 activation (Xception's
+    first block at 512 crops) spans 4.67 GB and must be refused loudly, not wrapped (lib.planes_fit is what the engines ask)."""
+    assert L.planes_fit(1548800, 256) and L.planes_fit(25120, 4096)
+    assert not L.planes_fit(6083072, 128)
+    a = torch.zeros(4096, dtype=torch.bfloat16, device="cuda")          # never read: the shape check comes first
+    out = torch.zeros(128, 128, device="cuda")
+    with pytest.raises(L.MintimeHipError, match="4 GB"):
+        L.gemm_planes(L.OP_NT, a, a, 6083072, 128, 128, Cout=out, ldc=128)
