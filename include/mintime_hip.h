@@ -173,6 +173,8 @@ typedef struct {
                                     /* of the stored result into [slots][2][N] fp64 accumulators, like mt_gemm                              */
 } mt_gemm_planes_desc;
 
+/* Limit: an operand's three planes (padded rows x padded columns x 6 bytes) must stay under 4 GB -- the loop reaches them by 32-bit
+ * byte offsets from one base -- or the call returns MT_ERR_UNSUPPORTED (before round 6's end it wrapped silently).                      */
 int mt_gemm_planes(const mt_gemm_planes_desc* d, void* stream);
 
 /* nn.Dropout inside the TimeSformer (size_invariant_timesformer.py:66-70 between GEGLU and net.3, :98-101 behind to_out.0), train mode
