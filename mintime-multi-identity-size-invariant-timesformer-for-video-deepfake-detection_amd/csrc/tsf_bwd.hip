@@ -816,14 +816,21 @@ __device__ __forceinline__ void load_row32(const float* __restrict__ p, float (&
   }
 }
 
-template <int WPB, bool FACT = false>
+// XP (round 6, default): phase B does not recompute P and dS (256 of the 896 MFMAs, plus the row loads of Q and dO) -- phase A leaves
+// P^T and dS^T in LDS as [key][query] with a 65-float row stride (33 KB per wavefront, dynamic LDS: the block's four wavefronts take
+// 133 KB, one block per CU as before), written along rows and read back along columns, both conflict-free.  640 MFMAs per group.
+constexpr int XP_LD = 65;
+template <int WPB, bool FACT = false, bool XP = false>
 __global__ __launch_bounds__(WPB * 64) void attn_space_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                       float* __restrict__ dqkv, int B, int H, int F, int n,
                                                                       float scale, const PlaneRef dp, const DetLog det) {
-  __shared__ float2 stat_all[WPB][64];                      // (logsumexp, delta) per query of the wavefront's group
+  __shared__ float2 stat_all[XP ? 1 : WPB][64];             // (logsumexp, delta) per query of the wavefront's group
+  extern __shared__ __attribute__((aligned(16))) float xp_lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = lane & 31, hf = lane >> 5;
-  float2* stat = stat_all[wave];
+  float2* stat = stat_all[XP ? 0 : wave];
+  float* Pm = xp_lds + (XP ? wave * 2 * 64 * XP_LD : 0);    // P^T [key slot][query slot]
+  float* Sm = Pm + 64 * XP_LD;                              // dS^T
   const int N = 1 + F * n, inner = H * DH, ld = 3 * inner;
   const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
   if (wid >= (int64_t)B * H * F) return;                    // wave-uniform (no block-level barrier below)
@@ -890,11 +897,22 @@ __global__ __launch_bounds__(WPB * 64) void attn_space_bwd_mfma_kernel(const flo
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[i][r] *= inv; delta = fmaf(st[i][r], dpt[i][r], delta); }
     delta += __shfl_xor(delta, 32);
+    if constexpr (XP) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Pm[(32 * i + mfma_slot_row(r, hf)) * XP_LD + q] = st[i][r];
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[i][r] *= dpt[i][r] - delta;          // dS^T (zero on padded keys: P^T is zero there)
-    if (hf == 0) stat[q] = make_float2(mx + __logf(sum), delta);
+    if constexpr (XP) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Sm[(32 * i + mfma_slot_row(r, hf)) * XP_LD + q] = st[i][r];
+    } else if (hf == 0) stat[q] = make_float2(mx + __logf(sum), delta);
     f32x16 dq[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -923,21 +941,23 @@ __global__ __launch_bounds__(WPB * 64) void attn_space_bwd_mfma_kernel(const flo
 #pragma unroll 1
   for (int j = 0; j < 2; ++j) {
     const int key = 32 * j + c;
-    float kb[32], vb[32];
-    load_row32(base + (int64_t)tok_k(key) * ld + inner + hf * 32, kb, 1.0f);
-    load_row32(base + (int64_t)tok_k(key) * ld + 2 * inner + hf * 32, vb, 1.0f);
     f32x16 pp[2], ds[2];                      // P and dS tiles [query tile]
+    if constexpr (!XP) {
+      float kb[32], vb[32];
+      load_row32(base + (int64_t)tok_k(key) * ld + inner + hf * 32, kb, 1.0f);
+      load_row32(base + (int64_t)tok_k(key) * ld + 2 * inner + hf * 32, vb, 1.0f);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float qa[32], da[32];
-      load_row32(base + (int64_t)tok_q(32 * i + c) * ld + hf * 32, qa, scale);
-      load_row32(dobase + (int64_t)tok_q(32 * i + c) * inner + hf * 32, da, 1.0f);
+      for (int i = 0; i < 2; ++i) {
+        float qa[32], da[32];
+        load_row32(base + (int64_t)tok_q(32 * i + c) * ld + hf * 32, qa, scale);
+        load_row32(dobase + (int64_t)tok_q(32 * i + c) * inner + hf * 32, da, 1.0f);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { pp[i][r] = 0.f; ds[i][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { pp[i][r] = 0.f; ds[i][r] = 0.f; }
 #pragma unroll
-      for (int ks = 0; ks < 32; ++ks) {
-        pp[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[ks], kb[ks], pp[i], 0, 0, 0);
-        ds[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[ks], vb[ks], ds[i], 0, 0, 0);
+        for (int ks = 0; ks < 32; ++ks) {
+          pp[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[ks], kb[ks], pp[i], 0, 0, 0);
+          ds[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[ks], vb[ks], ds[i], 0, 0, 0);
+        }
       }
     }
     // dO and scaled Q by columns, in the query order the P / dS accumulators are consumed in
@@ -955,10 +975,16 @@ __global__ __launch_bounds__(WPB * 64) void attn_space_bwd_mfma_kernel(const flo
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int q = 32 * i + mfma_slot_row(r, hf);
-        const float2 sd = stat[q];
-        const float p = (q < n && key <= n) ? __expf(pp[i][r] - sd.x) : 0.f;
-        ds[i][r] = p * (ds[i][r] - sd.y);
-        pp[i][r] = p;
+        if constexpr (XP) {                   // phase A's P^T / dS^T, read along a column (rows of padded keys hold zeros; padded
+          const bool ok = q < n;              // query slots hold copies of the last query: masked here)
+          pp[i][r] = ok ? Pm[key * XP_LD + q] : 0.f;
+          ds[i][r] = ok ? Sm[key * XP_LD + q] : 0.f;
+        } else {
+          const float2 sd = stat[q];
+          const float p = (q < n && key <= n) ? __expf(pp[i][r] - sd.x) : 0.f;
+          ds[i][r] = p * (ds[i][r] - sd.y);
+          pp[i][r] = p;
+        }
       }
     f32x16 dv[2], dk[2];
 #pragma unroll
@@ -1696,8 +1722,15 @@ extern "C" int mt_attn_bwd(const float* qkv, const float* dout, float* dqkv, con
     if (valu) rc = launch_patch_bwd<1, 50, 1, 64, 2>(qkv, dout, dqkv, mask, ident, B, H, F, n, scale, dp, det.log, s);
     else {
       const int64_t waves = (int64_t)B * H * F;
-      if (fact) hipLaunchKernelGGL((attn_space_bwd_mfma_kernel<4, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n, scale, dp, det.log);
-      else hipLaunchKernelGGL((attn_space_bwd_mfma_kernel<4, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n, scale, dp, det.log);
+      static const bool xp = !(getenv("MT_ATTN_SPACE_XP") && atoi(getenv("MT_ATTN_SPACE_XP")) == 0);    // 0: phase B recomputes P / dS (round 5)
+      const dim3 grid((unsigned)((waves + 3) / 4));
+      if (xp) {
+        constexpr size_t lds = (size_t)4 * 2 * 64 * XP_LD * sizeof(float);
+        auto k = fact ? attn_space_bwd_mfma_kernel<4, true, true> : attn_space_bwd_mfma_kernel<4, false, true>;
+        if (ensure_dynamic_lds((const void*)k, lds) != hipSuccess) return fail(MT_ERR_LAUNCH, "mt_attn_bwd(space): %zu bytes of LDS refused", lds);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, qkv, dout, dqkv, B, H, F, n, scale, dp, det.log);
+      } else if (fact) hipLaunchKernelGGL((attn_space_bwd_mfma_kernel<4, true, false>), grid, dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n, scale, dp, det.log);
+      else hipLaunchKernelGGL((attn_space_bwd_mfma_kernel<4, false, false>), grid, dim3(256), 0, s, qkv, dout, dqkv, B, H, F, n, scale, dp, det.log);
       rc = check_launch("mt_attn_bwd(space, mfma)");
     }
   } else if (!time_old) {
