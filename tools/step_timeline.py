@@ -7,9 +7,11 @@ from collections import defaultdict
 ap = argparse.ArgumentParser()
 ap.add_argument("csv")
 ap.add_argument("--start", default="stem_mfma_kernel", help="substring of the kernel that starts a step (the stem kernel)")
-ap.add_argument("--steps-from-end", type=int, default=6,
+ap.add_argument("--steps-from-end", type=int, default=0,
                 help="which step of the trace: bench.py ends with three enqueue-timing steps that follow a synchronize (the host is not "
-                     "ahead there and its launch latency shows as device idle); 6 from the end lies inside the timed region")
+                     "ahead there and its launch latency shows as device idle); 4-9 from the end lie inside the timed region of "
+                     "`bench.py --steps 8`.  0 (default): the one of those six with the median span (a single step can catch a host "
+                     "hiccup of the profiler: one evidence run showed a 2.9 ms gap in step 6 and none in its neighbours)")
 ap.add_argument("--top", type=int, default=40, help="symbols listed per queue")
 a = ap.parse_args()
 rows = sorted(csv.DictReader(open(a.csv)), key=lambda r: int(r["Start_Timestamp"]))
@@ -21,6 +23,12 @@ def short(n):
 
 
 starts = [i for i, r in enumerate(rows) if a.start in r["Kernel_Name"]]
+if a.steps_from_end == 0:
+    cand = [k for k in range(4, 10) if k < len(starts)]
+    spans = sorted((int(rows[starts[-k + 1]]["Start_Timestamp"]) - int(rows[starts[-k]]["Start_Timestamp"]), k) for k in cand)
+    a.steps_from_end = spans[len(spans) // 2][1]
+    print(f"(step {a.steps_from_end} from the end: median span of steps 4-9 from the end, start-to-start spans "
+          f"{[round(sp / 1e6, 2) for sp, _ in sorted(spans, key=lambda x: x[1])]} ms)")
 lo, hi = starts[-a.steps_from_end], starts[-a.steps_from_end + 1]
 seg = rows[lo:hi]
 t0 = int(seg[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in seg)
