@@ -637,3 +637,16 @@ def test_deterministic_switch_round_trips_without_a_gpu():
         assert lib.deterministic() is False
     finally:
         lib.set_deterministic(prev)
+
+
+def test_planes_fit_is_the_four_gigabyte_rule_of_the_plane_loop():
+    """lib.planes_fit mirrors csrc/gemm_planes.hip: three bf16 planes of the padded operand (rows to 32, columns to 16) must stay within
+    32-bit byte offsets.  The cases are the operands of BASELINE configs 3 / 5 and the one that wrapped before the guard existed."""
+    from mintime_amd import lib as L
+    assert L.planes_fit(32 * 785, 4096)                   # TimeSformer feed-forward operand, B = 32
+    assert L.planes_fit(222 * 785, 4096) and not L.planes_fit(223 * 785, 4096)
+    assert L.planes_fit(512 * 55 * 55, 256)               # Xception block 2 at 512 crops
+    assert not L.planes_fit(512 * 109 * 109, 128)         # block 1: 4.67 GB, stays on mt_gemm
+    assert L.planes_fit(1, 1) and L.planes_fit(31, 15) == L.planes_fit(32, 16)
+    rows = (0xFFFFFFFF // (6 * 16)) // 32 * 32
+    assert L.planes_fit(rows, 16) and not L.planes_fit(rows + 1, 16)
